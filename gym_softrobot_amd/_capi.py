@@ -1,0 +1,193 @@
+"""ctypes binding of include/softrod.h (the C-ABI of libsoftrod_hip.so).
+
+This is the binding a gym-softrobot maintainer would add to call the HIP stepper
+from `SoftPendulumEnv.step`.  There is NO CPU fallback: if the
+shared library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+ABI_VERSION = 1
+
+# softrod_feature (include/softrod.h)
+FEAT_GRAVITY = 1 << 0
+FEAT_POINT_FORCE_NODE0_X = 1 << 1
+FEAT_PENDULUM_BC = 1 << 2
+FEAT_ANALYTICAL_DAMPER = 1 << 3
+FEAT_FIXED_BC = 1 << 4
+FEAT_TIP_FORCE = 1 << 5
+FEATURES_SOFTPENDULUM = (
+    FEAT_GRAVITY | FEAT_POINT_FORCE_NODE0_X | FEAT_PENDULUM_BC | FEAT_ANALYTICAL_DAMPER
+)
+
+MATH_LIBM = 0
+MATH_FAST = 1
+
+LANE_STRIDE = 64  # one wavefront row per rod (softrod_state_view.lane_stride)
+
+
+class SoftrodConfig(C.Structure):
+    """Mirror of `struct softrod_config` (include/softrod.h)."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("features", C.c_uint32),
+        ("n_envs", C.c_int32),
+        ("n_elem", C.c_int32),
+        ("n_substeps", C.c_int32),
+        ("math_mode", C.c_int32),
+        ("dt", C.c_double),
+        ("final_time", C.c_double),
+        ("base_length", C.c_double),
+        ("base_radius", C.c_double),
+        ("density", C.c_double),
+        ("youngs_modulus", C.c_double),
+        ("shear_modulus", C.c_double),
+        ("gravity", C.c_double * 3),
+        ("damping_constant", C.c_double),
+        ("tip_force", C.c_double * 3),
+        ("alpha_c", C.c_double),
+        ("eps_length", C.c_double),
+        ("eps_rot_axis", C.c_double),
+        ("acos_shift", C.c_double),
+        ("eps_sin", C.c_double),
+        ("time_two_half_adds", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+    def copy(self) -> "SoftrodConfig":
+        out = SoftrodConfig()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(SoftrodConfig))
+        return out
+
+
+class SoftrodStateView(C.Structure):
+    """Mirror of `struct softrod_state_view`."""
+
+    _fields_ = [
+        ("n_envs", C.c_int32),
+        ("n_elem", C.c_int32),
+        ("lane_stride", C.c_int32),
+        ("reserved", C.c_int32),
+        ("position", C.c_void_p),
+        ("velocity", C.c_void_p),
+        ("director", C.c_void_p),
+        ("omega", C.c_void_p),
+        ("tangents", C.c_void_p),
+        ("time", C.c_void_p),
+    ]
+
+
+def softpendulum_config(
+    n_envs: int = 1,
+    *,
+    final_time: float = 5.0,
+    time_step: float = 1.0e-4,
+    recording_fps: int = 25,
+    n_elems: int = 50,
+    math_mode: int = MATH_FAST,
+) -> SoftrodConfig:
+    """Host-side equivalent of `softrod_config_softpendulum` with the constructor
+    keywords of the reference's SoftPendulumEnv.
+
+    Values: SoftPendulumEnv.__init__ (soft_pendulum.py:59-78) and
+    build_soft_pendulum (build.py:18-26,87-113).  `shear_modulus` is not passed by
+    build.py:54-61, so PyElastica's default applies: E / (2 (1 + 0.5)).
+    """
+    cfg = SoftrodConfig()
+    cfg.struct_size = C.sizeof(SoftrodConfig)
+    cfg.features = FEATURES_SOFTPENDULUM
+    cfg.n_envs = int(n_envs)
+    cfg.n_elem = int(n_elems)
+    cfg.n_substeps = int(1.0 / (recording_fps * time_step))  # soft_pendulum.py:78
+    cfg.math_mode = int(math_mode)
+    cfg.dt = float(time_step)
+    cfg.final_time = float(final_time)
+    cfg.base_length = 1.0
+    cfg.base_radius = 0.05
+    cfg.density = 1000.0
+    cfg.youngs_modulus = 1e6
+    cfg.shear_modulus = 1e6 / (2.0 * (1.0 + 0.5))
+    cfg.gravity[0], cfg.gravity[1], cfg.gravity[2] = 0.0, -9.80665, 0.0
+    cfg.damping_constant = 2e-3
+    cfg.alpha_c = 27.0 / 28.0
+    cfg.eps_length = 1e-14
+    cfg.eps_rot_axis = 1e-14
+    cfg.acos_shift = 1e-10
+    cfg.eps_sin = 1e-14
+    cfg.time_two_half_adds = 1
+    return cfg
+
+
+class SoftrodError(RuntimeError):
+    pass
+
+
+_EXPORTS = {
+    # name: (restype, argtypes)
+    "softrod_abi_version": (C.c_int, []),
+    "softrod_config_softpendulum": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_create": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "softrod_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "softrod_reset_straight": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "softrod_step": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "softrod_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "softrod_substeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "softrod_state_view_get": (C.c_int, [C.c_void_p, C.POINTER(SoftrodStateView)]),
+    "softrod_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "softrod_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "softrod_last_error": (C.c_char_p, [C.c_void_p]),
+    "softrod_destroy": (C.c_int, [C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_EXPORTS)
+
+_lib = None
+
+
+def library_path() -> Path:
+    env = os.environ.get("SOFTROD_HIP_LIB")
+    if env:
+        return Path(env)
+    return Path(__file__).resolve().parent / "csrc" / "libsoftrod_hip.so"
+
+
+def load_library() -> C.CDLL:
+    """dlopen libsoftrod_hip.so and type its entry points.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise SoftrodError(
+            f"{path} not found: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = C.CDLL(str(path))
+    for name, (restype, argtypes) in _EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.softrod_abi_version() != ABI_VERSION:
+        raise SoftrodError("libsoftrod_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, handle=None) -> None:
+    if rc == 0:
+        return
+    msg = ""
+    if handle is not None and _lib is not None:
+        raw = _lib.softrod_last_error(handle)
+        msg = raw.decode() if raw else ""
+    raise SoftrodError(f"softrod call failed with code {rc}: {msg}")

@@ -1,0 +1,201 @@
+/*
+ * softrod.h — C-ABI of the MI355X-native batched Cosserat-rod stepper.
+ *
+ * This is the drop-in boundary for the ONE hot path of skim0119/gym-softrobot
+ * that BASELINE.json names: `env.step()` of SoftPendulum-v0, i.e.
+ *
+ *     for _ in range(self.step_skip):
+ *         self.time = self.do_step(self.simulator, self.time, self.time_step)
+ *                                   (gym_softrobot/envs/soft_pendulum/soft_pendulum.py:183-184)
+ *
+ * where `do_step` is PyElastica's `PositionVerlet().step` (soft_pendulum.py:137-139)
+ * applied to the simulator assembled by `build_soft_pendulum`
+ * (gym_softrobot/envs/soft_pendulum/build.py:29-115), followed by the NaN check,
+ * reward, truncation test and observation of soft_pendulum.py:196-251.
+ *
+ * The reference has no FFI for this path: its "operator API" is a set of Python
+ * classes PyElastica calls back into once per substep (ConstraintBase /
+ * NoForces subclasses, build.py:65-79,94-101) plus the registration DSL
+ * (build.py:62,81-113).  Those per-substep Python callbacks ARE the bottleneck,
+ * so this boundary replaces them with compiled-in, bit-selected features.  Each
+ * entry point below cites the reference interface it stands in for.
+ *
+ * Conventions: every function returns 0 on success or a negative
+ * SOFTROD_E* code and never throws; plain pointers and sizes only (no torch
+ * types).  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Pointers documented "device" must be device-accessible; "host" must be host
+ * memory.  One handle = one device; a handle is not re-entrant, independent
+ * handles are thread-safe.
+ *
+ * The same declarations are implemented by the HIP library
+ * (gym_softrobot_amd/csrc → libsoftrod_hip.so).  The CPU oracle
+ * (oracle/softrod_oracle.c) shares only `softrod_config` and is test
+ * infrastructure, not a fallback.
+ */
+#ifndef SOFTROD_H
+#define SOFTROD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOFTROD_ABI_VERSION 1
+
+/* error codes */
+#define SOFTROD_OK 0
+#define SOFTROD_EINVAL (-1)   /* bad argument / unsupported configuration   */
+#define SOFTROD_ENOMEM (-2)   /* device or host allocation failed           */
+#define SOFTROD_EHIP (-3)     /* a HIP runtime call failed (see last_error) */
+#define SOFTROD_ENODEV (-4)   /* no usable gfx950 device                    */
+
+/*
+ * Feature bits: the compiled-in replacements of the reference's per-substep
+ * Python hooks.  Order of application inside a substep is fixed to the order
+ * PyElastica's PositionVerlet.step gives them (DESIGN.md "substep order").
+ */
+enum softrod_feature {
+    /* GravityForces(acc_gravity)                          build.py:88-91   */
+    SOFTROD_FEAT_GRAVITY = 1u << 0,
+    /* PendulumPointForces.apply_forces: external_forces[0,0] = action
+     * (ASSIGNS, after gravity was added)                  build.py:94-105  */
+    SOFTROD_FEAT_POINT_FORCE_NODE0_X = 1u << 1,
+    /* PendulumBoundaryConditions.constrain_values/rates   build.py:65-85   */
+    SOFTROD_FEAT_PENDULUM_BC = 1u << 2,
+    /* AnalyticalLinearDamper(damping_constant, time_step) build.py:108-113 */
+    SOFTROD_FEAT_ANALYTICAL_DAMPER = 1u << 3,
+    /* PyElastica OneEndFixedBC on node 0 / element 0 (known-answer tests)  */
+    SOFTROD_FEAT_FIXED_BC = 1u << 4,
+    /* constant force on the last node, PyElastica EndpointForces with
+     * start_force = 0 and no ramp (known-answer tests)                      */
+    SOFTROD_FEAT_TIP_FORCE = 1u << 5,
+};
+
+#define SOFTROD_FEATURES_SOFTPENDULUM                                             \
+    (SOFTROD_FEAT_GRAVITY | SOFTROD_FEAT_POINT_FORCE_NODE0_X |                   \
+     SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_ANALYTICAL_DAMPER)
+
+/* math_mode (HIP library only; the oracle always uses libm). */
+#define SOFTROD_MATH_LIBM 0 /* sqrt/sin/cos/acos/pow evaluated as written   */
+#define SOFTROD_MATH_FAST 1 /* range-checked polynomial forms, libm fallback */
+
+/*
+ * Everything that is identical for all rods of a batch.  Defaults are filled by
+ * softrod_config_softpendulum(); the "PyElastica numerics" block holds the
+ * constants SURVEY.md App. A marks (?) so that a session with pyelastica==1.0.0
+ * importable can flip them without touching a kernel.
+ */
+typedef struct softrod_config {
+    uint32_t struct_size; /* = sizeof(softrod_config); ABI guard            */
+    uint32_t features;    /* OR of softrod_feature                          */
+    int32_t n_envs;       /* rods in this handle (batch shard)              */
+    int32_t n_elem;       /* elements per rod (n_elems, soft_pendulum.py:64) */
+    int32_t n_substeps;   /* step_skip = int(1/(fps*dt)), soft_pendulum.py:78 */
+    int32_t math_mode;    /* SOFTROD_MATH_*                                 */
+    double dt;            /* time_step, soft_pendulum.py:62                 */
+    double final_time;    /* soft_pendulum.py:61; truncation is time > it   */
+    /* straight_rod arguments, build.py:18-26,54-61 */
+    double base_length;
+    double base_radius;
+    double density;
+    double youngs_modulus;
+    double shear_modulus; /* build.py passes none -> PyElastica default     */
+    double gravity[3];    /* build.py:87-91                                 */
+    double damping_constant; /* build.py:108                                */
+    double tip_force[3];  /* SOFTROD_FEAT_TIP_FORCE only                    */
+    /* PyElastica numerics (UNVERIFIED recollection) */
+    double alpha_c;       /* 27/28 shear correction                         */
+    double eps_length;    /* 1e-14 added to |dx|                            */
+    double eps_rot_axis;  /* 1e-14 added to |w| before normalising the axis */
+    double acos_shift;    /* 1e-10 subtracted inside arccos of _inv_rotate  */
+    double eps_sin;       /* 1e-14 added inside sin of _inv_rotate          */
+    int32_t time_two_half_adds; /* 1: t += dt/2 twice per substep; 0: += dt */
+    int32_t reserved;
+} softrod_config;
+
+typedef struct softrod_handle softrod_handle;
+
+/*
+ * Borrowed device pointers to the resident state (valid until destroy).
+ * Layout (DESIGN.md "HBM layout"): structure-of-arrays, component-major, one
+ * 64-entry row per rod so that lane k of the rod's wavefront owns node k,
+ * element k and Voronoi vertex k:
+ *     position[(c * n_envs + env) * 64 + node]        c = 0..2
+ *     director[((r*3 + c) * n_envs + env) * 64 + elem]  row r of Q, lab comp. c
+ * Mirrors rod.position_collection / velocity_collection / director_collection /
+ * omega_collection / tangents of the reference (soft_pendulum.py:152-154).
+ */
+typedef struct softrod_state_view {
+    int32_t n_envs, n_elem, lane_stride, reserved;
+    double* position; /* [3][n_envs][64]    */
+    double* velocity; /* [3][n_envs][64]    */
+    double* director; /* [9][n_envs][64]    */
+    double* omega;    /* [3][n_envs][64]    */
+    double* tangents; /* [3][n_envs][64]  as of the last force evaluation   */
+    double* time;     /* [n_envs]  simulated time (soft_pendulum.py:141,184) */
+} softrod_state_view;
+
+/* Fill `cfg` with SoftPendulumEnv.__init__ defaults (soft_pendulum.py:59-78)
+ * and build_soft_pendulum's constants (build.py:18-26,87-113).             */
+int softrod_config_softpendulum(softrod_config* cfg, int n_envs);
+
+/* Replaces: BaseSimulator() + build_soft_pendulum(...) + simulator.finalize()
+ * (soft_pendulum.py:115-138) for a whole batch: allocates resident device
+ * state for cfg->n_envs rods on HIP device `device`.                        */
+int softrod_create(const softrod_config* cfg, int device, softrod_handle** out);
+
+/* Replaces: the state part of SoftPendulumEnv.reset (soft_pendulum.py:108-147)
+ * i.e. CosseratRod.straight_rod with direction=(cos t, sin t, 0),
+ * normal=(sin t, -cos t, 0) (build.py:47-61), time = 0.
+ * theta0: host [n_envs] radians (drawn by the caller exactly as build.py:47-49).
+ * mask:   host [n_envs] (non-zero = reset this rod) or NULL = all.          */
+int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask,
+                  void* stream);
+
+/* General straight rod for known-answer tests: start/direction/normal are host
+ * [n_envs][3] (CosseratRod.straight_rod arguments, build.py:54-61).         */
+int softrod_reset_straight(softrod_handle* h, const double* start,
+                           const double* direction, const double* normal,
+                           void* stream);
+
+/* Replaces: SoftPendulumEnv.step (soft_pendulum.py:176-251) for every rod:
+ * set_action -> n_substeps x PositionVerlet.step -> NaN check -> reward ->
+ * truncation -> get_state.  Asynchronous on `stream`.
+ *   actions     device [n_envs]      float32 (point_force[:] = action, :165-166)
+ *   obs         device [n_envs][4]   float32 [x0, vx0, prev_action, theta] (:149-161)
+ *   reward      device [n_envs]      float64 (:231)
+ *   terminated  device [n_envs]      uint8   (:205-208)
+ *   truncated   device [n_envs]      uint8   (:226-229)                      */
+int softrod_step(softrod_handle* h, const float* actions, float* obs,
+                 double* reward, uint8_t* terminated, uint8_t* truncated,
+                 void* stream);
+
+/* Replaces: get_state() at reset (soft_pendulum.py:145-161).  prev_action is
+ * device [n_envs] float32 or NULL (= zeros).                                */
+int softrod_observe(softrod_handle* h, const float* prev_action, float* obs,
+                    void* stream);
+
+/* Run `n` bare PositionVerlet substeps with a fixed action and no env
+ * epilogue (the inner loop of soft_pendulum.py:183-184 alone); used by the
+ * known-answer tests and by the kernel micro-benchmarks.                    */
+int softrod_substeps(softrod_handle* h, const float* actions, int n, void* stream);
+
+int softrod_state_view_get(softrod_handle* h, softrod_state_view* out);
+
+/* Duration in milliseconds of the most recent softrod_step /
+ * softrod_substeps kernel launch, measured with HIP events recorded on the
+ * launch stream around the kernel (synchronises on the stop event).         */
+int softrod_last_kernel_ms(softrod_handle* h, float* ms);
+/* Enable/disable the event pair above (off by default: zero overhead).      */
+int softrod_set_timing(softrod_handle* h, int enabled);
+
+const char* softrod_last_error(softrod_handle* h);
+int softrod_destroy(softrod_handle* h);
+int softrod_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOFTROD_H */

@@ -1,0 +1,602 @@
+/*
+ * softrod_oracle.c — CPU restatement (plain C, fp64) of the SoftPendulum-v0 hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this; the product path
+ * (gym_softrobot_amd/, libsoftrod_hip.so) never links, imports or calls it.
+ *
+ * PARITY UNPINNED.  The arithmetic of this path does not live in
+ * /root/reference: gym-softrobot delegates it to the third-party package
+ * pyelastica==1.0.0 (uv.lock:845-846, pyproject.toml:22), which is neither
+ * vendored, installed nor installable here, and the reference's own tests hold
+ * no golden numbers for it (tests/envs/test_determinism.py:46-54 compares two
+ * runs with each other only).  What follows restates PyElastica's published
+ * algorithm (Gazzola, Dudte, McCormick, Mahadevan, R. Soc. Open Sci. 5:171628,
+ * 2018) in the operation order of the PyElastica modules named per function
+ * (module names recalled, not on disk), anchored on the reference's call sites:
+ *   - assembly:     gym_softrobot/envs/soft_pendulum/build.py:29-115
+ *   - hot loop:     gym_softrobot/envs/soft_pendulum/soft_pendulum.py:183-184
+ *   - epilogue:     soft_pendulum.py:149-161,196-251
+ * Every constant SURVEY.md App. A marks "(?)" is a field of softrod_config so it
+ * can be flipped once pyelastica is importable.  The only reference-derived
+ * golden vectors that exist (reset observations, App. B) are checked in
+ * tests/test_oracle_golden.py; the physics is pinned by known-answer tests
+ * (tests/test_oracle_physics.py).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: Numba does not
+ * contract a*b+c either).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/softrod.h"
+
+#define NMAX 256 /* max elements per rod the oracle supports */
+
+typedef struct oracle_rod {
+    softrod_config cfg;
+    int n; /* elements */
+    /* state (PyElastica: position_collection (3,n+1), director_collection
+     * (3,3,n) rows = d1,d2,d3 in lab frame, velocity, omega (material frame)) */
+    double x[3][NMAX + 1], v[3][NMAX + 1];
+    double Q[3][3][NMAX], w[3][NMAX];
+    double time;
+    /* constants from CosseratRod.straight_rod (elastica/rod/factory_function.py) */
+    double mass[NMAX + 1];
+    double rest_len[NMAX], rest_vor[NMAX], volume[NMAX];
+    double J[3][NMAX], invJ[3][NMAX];      /* diagonal mass second moment   */
+    double shear[3][NMAX];                 /* diag(ac*G*A, ac*G*A, E*A)     */
+    double bend[3][NMAX];                  /* Voronoi-averaged diag(EI,EI,GI3) */
+    double rest_sigma[3][NMAX], rest_kappa[3][NMAX];
+    double damp_t;                         /* exp(-nu dt)                   */
+    double damp_r[3][NMAX];                /* exp(-nu dt m_e invJ)          */
+    /* caches (as of the last force evaluation) */
+    double len[NMAX], tang[3][NMAX], dil[NMAX], vdil[NMAX], dil_rate[NMAX];
+    double sigma[3][NMAX], kappa[3][NMAX];
+    double n_int[3][NMAX], m_int[3][NMAX]; /* internal_stress / internal_couple */
+    double f_int[3][NMAX + 1], t_int[3][NMAX];
+    double f_ext[3][NMAX + 1], t_ext[3][NMAX];
+    /* boundary condition targets */
+    double fixed_pos[3], fixed_dir[3][3];
+    float prev_action; /* _prev_action, soft_pendulum.py:97-99,165 */
+    double point_force; /* point_force[0], soft_pendulum.py:117,166 */
+} oracle_rod;
+
+/* ------------------------------------------------------------------------- */
+/* CosseratRod.straight_rod -> elastica/rod/factory_function.py allocate()    */
+/* call site: build.py:54-61                                                   */
+/* ------------------------------------------------------------------------- */
+static void straight_rod(oracle_rod* r, const double start[3],
+                         const double direction[3], const double normal_in[3])
+{
+    const softrod_config* c = &r->cfg;
+    const int n = r->n;
+    double end[3], normal[3];
+    for (int i = 0; i < 3; ++i) end[i] = start[i] + direction[i] * c->base_length;
+    /* np.linspace(start, end, n+1): start + k*step with step=(end-start)/n,
+     * last point forced to `end`. */
+    for (int i = 0; i < 3; ++i) {
+        const double step = (end[i] - start[i]) / (double)n;
+        for (int k = 0; k <= n; ++k) r->x[i][k] = start[i] + (double)k * step;
+        r->x[i][n] = end[i];
+    }
+    double nn = sqrt(normal_in[0] * normal_in[0] + normal_in[1] * normal_in[1] +
+                     normal_in[2] * normal_in[2]);
+    for (int i = 0; i < 3; ++i) normal[i] = normal_in[i] / nn;
+
+    for (int k = 0; k < n; ++k) {
+        double d[3];
+        for (int i = 0; i < 3; ++i) d[i] = r->x[i][k + 1] - r->x[i][k];
+        const double l = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        r->rest_len[k] = l;
+        double t[3] = { d[0] / l, d[1] / l, d[2] / l };
+        /* directors rows: d1 = normal, d2 = tangent x normal, d3 = tangent */
+        for (int i = 0; i < 3; ++i) r->Q[0][i][k] = normal[i];
+        r->Q[1][0][k] = t[1] * normal[2] - t[2] * normal[1];
+        r->Q[1][1][k] = t[2] * normal[0] - t[0] * normal[2];
+        r->Q[1][2][k] = t[0] * normal[1] - t[1] * normal[0];
+        for (int i = 0; i < 3; ++i) r->Q[2][i][k] = t[i];
+    }
+    const double radius = c->base_radius;
+    const double A0 = M_PI * radius * radius;
+    const double I1 = A0 * A0 / (4.0 * M_PI);
+    const double I[3] = { I1, I1, 2.0 * I1 };
+    for (int k = 0; k < n; ++k) {
+        for (int i = 0; i < 3; ++i) {
+            r->J[i][k] = I[i] * (c->density * r->rest_len[k]);
+            r->invJ[i][k] = 1.0 / r->J[i][k];
+        }
+        r->shear[0][k] = c->alpha_c * c->shear_modulus * A0;
+        r->shear[1][k] = c->alpha_c * c->shear_modulus * A0;
+        r->shear[2][k] = c->youngs_modulus * A0;
+        r->volume[k] = M_PI * (radius * radius) * r->rest_len[k];
+    }
+    /* element bend matrix, then rest-length-weighted average onto Voronoi */
+    double be[3][NMAX];
+    for (int k = 0; k < n; ++k) {
+        be[0][k] = c->youngs_modulus * I[0];
+        be[1][k] = c->youngs_modulus * I[1];
+        be[2][k] = c->shear_modulus * I[2];
+    }
+    for (int k = 0; k < n - 1; ++k) {
+        for (int i = 0; i < 3; ++i)
+            r->bend[i][k] = (be[i][k + 1] * r->rest_len[k + 1] + be[i][k] * r->rest_len[k]) /
+                            (r->rest_len[k + 1] + r->rest_len[k]);
+        r->rest_vor[k] = 0.5 * (r->rest_len[k + 1] + r->rest_len[k]);
+    }
+    for (int k = 0; k <= n; ++k) r->mass[k] = 0.0;
+    for (int k = 0; k < n; ++k) {
+        r->mass[k] += 0.5 * c->density * r->volume[k];
+        r->mass[k + 1] += 0.5 * c->density * r->volume[k];
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k <= n; ++k) { r->v[i][k] = 0.0; r->f_ext[i][k] = 0.0; r->f_int[i][k] = 0.0; }
+        for (int k = 0; k < n; ++k) {
+            r->w[i][k] = 0.0; r->t_ext[i][k] = 0.0; r->t_int[i][k] = 0.0;
+            r->rest_sigma[i][k] = 0.0; r->rest_kappa[i][k] = 0.0;
+        }
+    }
+    /* AnalyticalLinearDamper.__init__ (elastica/dissipation.py), build.py:108-113.
+     * `damping_constant=` keyword -> per-unit-mass protocol. */
+    r->damp_t = exp(-c->damping_constant * c->dt);
+    for (int k = 0; k < n; ++k) {
+        double me = 0.5 * (r->mass[k + 1] + r->mass[k]);
+        if (k == 0) me += 0.5 * r->mass[0];
+        if (k == n - 1) me += 0.5 * r->mass[n];
+        for (int i = 0; i < 3; ++i)
+            r->damp_r[i][k] = exp(-c->damping_constant * c->dt * me * r->invJ[i][k]);
+    }
+    /* constraint targets: ConstraintBase is handed position[..., idx] and
+     * directors[..., idx] at finalize (build.py:81-85) */
+    for (int i = 0; i < 3; ++i) {
+        r->fixed_pos[i] = r->x[i][0];
+        for (int j = 0; j < 3; ++j) r->fixed_dir[i][j] = r->Q[i][j][0];
+    }
+    r->time = 0.0;
+    r->point_force = 0.0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* elastica/rod/cosserat_rod.py kernels                                        */
+/* ------------------------------------------------------------------------- */
+
+/* _compute_geometry_from_state + _compute_all_dilatations */
+static void compute_all_dilatations(oracle_rod* r)
+{
+    const int n = r->n;
+    for (int k = 0; k < n; ++k) {
+        double d0 = r->x[0][k + 1] - r->x[0][k];
+        double d1 = r->x[1][k + 1] - r->x[1][k];
+        double d2 = r->x[2][k + 1] - r->x[2][k];
+        r->len[k] = sqrt(d0 * d0 + d1 * d1 + d2 * d2) + r->cfg.eps_length;
+        r->tang[0][k] = d0 / r->len[k];
+        r->tang[1][k] = d1 / r->len[k];
+        r->tang[2][k] = d2 / r->len[k];
+        /* radius[k] = sqrt(volume/len/pi): geometry only, not used by the path */
+        r->dil[k] = r->len[k] / r->rest_len[k];
+    }
+    for (int k = 0; k < n - 1; ++k) {
+        const double vl = 0.5 * (r->len[k + 1] + r->len[k]);
+        r->vdil[k] = vl / r->rest_vor[k];
+    }
+}
+
+/* _compute_shear_stretch_strains + _compute_internal_shear_stretch_stresses_from_model */
+static void compute_shear_stress(oracle_rod* r)
+{
+    const int n = r->n;
+    compute_all_dilatations(r);
+    for (int k = 0; k < n; ++k) {
+        for (int i = 0; i < 3; ++i) {
+            double qt = r->Q[i][0][k] * r->tang[0][k];
+            qt += r->Q[i][1][k] * r->tang[1][k];
+            qt += r->Q[i][2][k] * r->tang[2][k];
+            r->sigma[i][k] = r->dil[k] * qt - (i == 2 ? 1.0 : 0.0);
+        }
+        for (int i = 0; i < 3; ++i)
+            r->n_int[i][k] = r->shear[i][k] * (r->sigma[i][k] - r->rest_sigma[i][k]);
+    }
+}
+
+/* _compute_internal_forces: Q^T n / e then the two-point difference kernel */
+static void compute_internal_forces(oracle_rod* r)
+{
+    const int n = r->n;
+    double cs[3][NMAX];
+    compute_shear_stress(r);
+    for (int k = 0; k < n; ++k)
+        for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < 3; ++j) s += r->Q[j][i][k] * r->n_int[j][k];
+            cs[i][k] = s / r->dil[k];
+        }
+    for (int i = 0; i < 3; ++i) {
+        r->f_int[i][0] = cs[i][0];
+        for (int k = 1; k < n; ++k) r->f_int[i][k] = cs[i][k] - cs[i][k - 1];
+        r->f_int[i][n] = -cs[i][n - 1];
+    }
+}
+
+/* elastica/_rotations.py _inv_rotate + _compute_bending_twist_strains */
+static void compute_bending_twist_strains(oracle_rod* r)
+{
+    const int n = r->n;
+    for (int k = 0; k < n - 1; ++k) {
+        double R[3][3]; /* Q_{k+1} Q_k^T */
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = r->Q[i][0][k + 1] * r->Q[j][0][k];
+                s += r->Q[i][1][k + 1] * r->Q[j][1][k];
+                s += r->Q[i][2][k + 1] * r->Q[j][2][k];
+                R[i][j] = s;
+            }
+        double vec[3] = { R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1] };
+        const double trace = (R[0][0] + R[1][1]) + R[2][2];
+        const double theta = acos(0.5 * trace - 0.5 - r->cfg.acos_shift);
+        const double f = -0.5 * theta / sin(theta + r->cfg.eps_sin);
+        for (int i = 0; i < 3; ++i) r->kappa[i][k] = (vec[i] * f) / r->rest_vor[k];
+    }
+}
+
+/* _compute_dilatation_rate (expanded dot-product form, as PyElastica writes it) */
+static void compute_dilatation_rate(oracle_rod* r)
+{
+    const int n = r->n;
+    double rv[NMAX + 1];
+    for (int k = 0; k <= n; ++k)
+        rv[k] = (r->x[0][k] * r->v[0][k] + r->x[1][k] * r->v[1][k]) + r->x[2][k] * r->v[2][k];
+    for (int k = 0; k < n; ++k) {
+        const double rp1v = (r->x[0][k + 1] * r->v[0][k] + r->x[1][k + 1] * r->v[1][k]) +
+                            r->x[2][k + 1] * r->v[2][k];
+        const double rvp1 = (r->x[0][k] * r->v[0][k + 1] + r->x[1][k] * r->v[1][k + 1]) +
+                            r->x[2][k] * r->v[2][k + 1];
+        r->dil_rate[k] = (rv[k] + rv[k + 1] - rvp1 - rp1v) / r->len[k] / r->rest_len[k];
+    }
+}
+
+/* _compute_internal_torques */
+static void compute_internal_torques(oracle_rod* r)
+{
+    const int n = r->n;
+    double c2d[3][NMAX], c3d[3][NMAX]; /* Voronoi-domain quantities */
+    compute_bending_twist_strains(r);
+    for (int k = 0; k < n - 1; ++k)
+        for (int i = 0; i < 3; ++i)
+            r->m_int[i][k] = r->bend[i][k] * (r->kappa[i][k] - r->rest_kappa[i][k]);
+    compute_dilatation_rate(r);
+    for (int k = 0; k < n - 1; ++k) {
+        const double e3 = 1.0 / (r->vdil[k] * r->vdil[k] * r->vdil[k]);
+        const double* kp[3] = { &r->kappa[0][k], &r->kappa[1][k], &r->kappa[2][k] };
+        const double* mm[3] = { &r->m_int[0][k], &r->m_int[1][k], &r->m_int[2][k] };
+        for (int i = 0; i < 3; ++i) c2d[i][k] = r->m_int[i][k] * e3;
+        c3d[0][k] = ((*kp[1]) * (*mm[2]) - (*kp[2]) * (*mm[1])) * r->rest_vor[k] * e3;
+        c3d[1][k] = ((*kp[2]) * (*mm[0]) - (*kp[0]) * (*mm[2])) * r->rest_vor[k] * e3;
+        c3d[2][k] = ((*kp[0]) * (*mm[1]) - (*kp[1]) * (*mm[0])) * r->rest_vor[k] * e3;
+    }
+    for (int k = 0; k < n; ++k) {
+        double d2[3], d3[3];
+        for (int i = 0; i < 3; ++i) {
+            /* difference kernel / trapezoidal kernel, Voronoi -> element */
+            if (k == 0) { d2[i] = c2d[i][0]; d3[i] = 0.5 * c3d[i][0]; }
+            else if (k == n - 1) { d2[i] = -c2d[i][n - 2]; d3[i] = 0.5 * c3d[i][n - 2]; }
+            else { d2[i] = c2d[i][k] - c2d[i][k - 1]; d3[i] = 0.5 * (c3d[i][k] + c3d[i][k - 1]); }
+        }
+        double qt[3], ssc[3], jwe[3], lt[3], ud[3];
+        for (int i = 0; i < 3; ++i) {
+            double s = r->Q[i][0][k] * r->tang[0][k];
+            s += r->Q[i][1][k] * r->tang[1][k];
+            s += r->Q[i][2][k] * r->tang[2][k];
+            qt[i] = s;
+        }
+        ssc[0] = (qt[1] * r->n_int[2][k] - qt[2] * r->n_int[1][k]) * r->rest_len[k];
+        ssc[1] = (qt[2] * r->n_int[0][k] - qt[0] * r->n_int[2][k]) * r->rest_len[k];
+        ssc[2] = (qt[0] * r->n_int[1][k] - qt[1] * r->n_int[0][k]) * r->rest_len[k];
+        for (int i = 0; i < 3; ++i) jwe[i] = (r->J[i][k] * r->w[i][k]) / r->dil[k];
+        lt[0] = jwe[1] * r->w[2][k] - jwe[2] * r->w[1][k];
+        lt[1] = jwe[2] * r->w[0][k] - jwe[0] * r->w[2][k];
+        lt[2] = jwe[0] * r->w[1][k] - jwe[1] * r->w[0][k];
+        for (int i = 0; i < 3; ++i) ud[i] = jwe[i] * r->dil_rate[k] / r->dil[k];
+        for (int i = 0; i < 3; ++i)
+            r->t_int[i][k] = d2[i] + d3[i] + ssc[i] + lt[i] + ud[i];
+    }
+}
+
+/* elastica/_rotations.py _get_rotation_matrix(1.0, prefac*omega) and
+ * elastica/timestepper/symplectic_steppers.py overload_operator_kinematic_numba */
+static void kinematic_step(oracle_rod* r, double prefac)
+{
+    const int n = r->n;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k <= n; ++k) r->x[i][k] += prefac * r->v[i][k];
+    for (int k = 0; k < n; ++k) {
+        double v0 = prefac * r->w[0][k], v1 = prefac * r->w[1][k], v2 = prefac * r->w[2][k];
+        double theta = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+        v0 /= theta + r->cfg.eps_rot_axis;
+        v1 /= theta + r->cfg.eps_rot_axis;
+        v2 /= theta + r->cfg.eps_rot_axis;
+        const double up = sin(theta), usq = 1.0 - cos(theta);
+        double R[3][3];
+        R[0][0] = 1.0 - usq * (v1 * v1 + v2 * v2);
+        R[1][1] = 1.0 - usq * (v0 * v0 + v2 * v2);
+        R[2][2] = 1.0 - usq * (v0 * v0 + v1 * v1);
+        R[0][1] = up * v2 + usq * v0 * v1;
+        R[1][0] = -up * v2 + usq * v0 * v1;
+        R[0][2] = -up * v1 + usq * v0 * v2;
+        R[2][0] = up * v1 + usq * v0 * v2;
+        R[1][2] = up * v0 + usq * v1 * v2;
+        R[2][1] = -up * v0 + usq * v1 * v2;
+        double Qn[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = R[i][0] * r->Q[0][j][k];
+                s += R[i][1] * r->Q[1][j][k];
+                s += R[i][2] * r->Q[2][j][k];
+                Qn[i][j] = s;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) r->Q[i][j][k] = Qn[i][j];
+    }
+}
+
+/* constrain_values: PendulumBoundaryConditions (build.py:71-74) or OneEndFixedBC */
+static void constrain_values(oracle_rod* r)
+{
+    if (r->cfg.features & SOFTROD_FEAT_PENDULUM_BC) {
+        r->x[1][0] = r->fixed_pos[1];
+        r->x[2][0] = r->fixed_pos[2];
+        for (int j = 0; j < 3; ++j) {
+            r->Q[0][j][0] = r->fixed_dir[0][j];
+            r->Q[2][j][0] = r->fixed_dir[2][j]; /* row 1 deliberately untouched */
+        }
+    }
+    if (r->cfg.features & SOFTROD_FEAT_FIXED_BC) {
+        for (int i = 0; i < 3; ++i) {
+            r->x[i][0] = r->fixed_pos[i];
+            for (int j = 0; j < 3; ++j) r->Q[i][j][0] = r->fixed_dir[i][j];
+        }
+    }
+}
+
+/* constrain_rates (build.py:76-79) */
+static void constrain_rates(oracle_rod* r)
+{
+    if (r->cfg.features & SOFTROD_FEAT_PENDULUM_BC) {
+        r->v[1][0] = 0.0; r->v[2][0] = 0.0;
+        r->w[0][0] = 0.0; r->w[2][0] = 0.0;
+    }
+    if (r->cfg.features & SOFTROD_FEAT_FIXED_BC)
+        for (int i = 0; i < 3; ++i) { r->v[i][0] = 0.0; r->w[i][0] = 0.0; }
+}
+
+/* synchronize(): forcing in registration order — GravityForces (build.py:88-91)
+ * then PendulumPointForces which ASSIGNS (build.py:100-101) */
+static void apply_forcing(oracle_rod* r)
+{
+    const int n = r->n;
+    if (r->cfg.features & SOFTROD_FEAT_GRAVITY)
+        for (int i = 0; i < 3; ++i)
+            for (int k = 0; k <= n; ++k) r->f_ext[i][k] += r->cfg.gravity[i] * r->mass[k];
+    if (r->cfg.features & SOFTROD_FEAT_POINT_FORCE_NODE0_X) r->f_ext[0][0] = r->point_force;
+    if (r->cfg.features & SOFTROD_FEAT_TIP_FORCE)
+        for (int i = 0; i < 3; ++i) r->f_ext[i][n] += r->cfg.tip_force[i];
+}
+
+/* _update_accelerations + overload_operator_dynamic_numba (v += dt*a) */
+static void dynamic_step(oracle_rod* r, double dt)
+{
+    const int n = r->n;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k <= n; ++k) {
+            const double a = (r->f_int[i][k] + r->f_ext[i][k]) / r->mass[k];
+            r->v[i][k] += dt * a;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < n; ++k) {
+            const double al = (r->invJ[i][k] * (r->t_int[i][k] + r->t_ext[i][k])) * r->dil[k];
+            r->w[i][k] += dt * al;
+        }
+}
+
+/* AnalyticalLinearDamper.dampen_rates (elastica/dissipation.py) */
+static void dampen_rates(oracle_rod* r)
+{
+    const int n = r->n;
+    if (!(r->cfg.features & SOFTROD_FEAT_ANALYTICAL_DAMPER)) return;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k <= n; ++k) r->v[i][k] = r->v[i][k] * r->damp_t;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < n; ++k) r->w[i][k] = r->w[i][k] * pow(r->damp_r[i][k], r->dil[k]);
+}
+
+/* PositionVerlet().step(simulator, time, dt) — elastica/timestepper/
+ * symplectic_steppers.py SymplecticStepperMethods.do_step; call site
+ * soft_pendulum.py:184 */
+static void position_verlet_step(oracle_rod* r)
+{
+    const double dt = r->cfg.dt;
+    const int n = r->n;
+    kinematic_step(r, 0.5 * dt);
+    if (r->cfg.time_two_half_adds) r->time += 0.5 * dt;
+    constrain_values(r);
+    compute_internal_forces(r);
+    compute_internal_torques(r);
+    apply_forcing(r);
+    dynamic_step(r, dt);
+    /* _feature_group_constrain_rates: Damping registers before Constraints for
+     * the mixin order of BaseSimulator (soft_pendulum.py:34-42); the two
+     * commute exactly for this env (zeros vs. scaling). */
+    dampen_rates(r);
+    constrain_rates(r);
+    kinematic_step(r, 0.5 * dt);
+    if (r->cfg.time_two_half_adds) r->time += 0.5 * dt; else r->time += dt;
+    constrain_values(r);
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k <= n; ++k) r->f_ext[i][k] = 0.0;
+        for (int k = 0; k < n; ++k) r->t_ext[i][k] = 0.0;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* env epilogue: soft_pendulum.py:149-161 (get_state) and :196-251             */
+/* ------------------------------------------------------------------------- */
+static double py_mod(double a, double b)
+{
+    double m = fmod(a, b);
+    if (m != 0.0 && ((m < 0.0) != (b < 0.0))) m += b;
+    return m;
+}
+
+static double wrapped_theta(const oracle_rod* r)
+{
+    const int n = r->n;
+    double tm[2] = { 0.0, 0.0 };
+    for (int k = 0; k < n; ++k) { tm[0] += r->tang[0][k]; tm[1] += r->tang[1][k]; }
+    tm[0] /= (double)n; tm[1] /= (double)n;
+    double theta = atan(tm[0] / tm[1]);
+    return py_mod(theta + M_PI, 2.0 * M_PI) - M_PI;
+}
+
+static void get_state(const oracle_rod* r, float obs[4])
+{
+    obs[0] = (float)r->x[0][0];
+    obs[1] = (float)r->v[0][0];
+    obs[2] = r->prev_action;
+    obs[3] = (float)wrapped_theta(r);
+}
+
+/* ------------------------------------------------------------------------- */
+/* exported API (loaded with ctypes by tests/ and bench.py cpu_baseline)       */
+/* ------------------------------------------------------------------------- */
+oracle_rod* oracle_create(const softrod_config* cfg)
+{
+    if (!cfg || cfg->struct_size != sizeof(softrod_config)) return NULL;
+    if (cfg->n_elem < 2 || cfg->n_elem > NMAX) return NULL;
+    oracle_rod* r = (oracle_rod*)calloc(1, sizeof(oracle_rod));
+    if (!r) return NULL;
+    r->cfg = *cfg;
+    r->n = cfg->n_elem;
+    return r;
+}
+
+void oracle_destroy(oracle_rod* r) { free(r); }
+
+void oracle_reset_straight(oracle_rod* r, const double start[3], const double direction[3],
+                           const double normal[3])
+{
+    straight_rod(r, start, direction, normal);
+    /* CosseratRod.__init__ evaluates strains once at allocation, so
+     * rod.tangents is valid for the reset observation (soft_pendulum.py:145) */
+    compute_shear_stress(r);
+    compute_bending_twist_strains(r);
+}
+
+/* build.py:46-52 */
+void oracle_reset_pendulum(oracle_rod* r, double theta)
+{
+    const double start[3] = { 0.0, 0.0, 0.0 };
+    const double direction[3] = { 1.0 * cos(theta), 1.0 * sin(theta), 0.0 };
+    const double normal[3] = { 1.0 * sin(theta), -1.0 * cos(theta), 0.0 };
+    oracle_reset_straight(r, start, direction, normal);
+}
+
+void oracle_set_prev_action(oracle_rod* r, float a) { r->prev_action = a; }
+void oracle_observe(const oracle_rod* r, float obs[4]) { get_state(r, obs); }
+double oracle_time(const oracle_rod* r) { return r->time; }
+
+void oracle_substeps(oracle_rod* r, float action, int nsub)
+{
+    r->point_force = (double)action;
+    for (int s = 0; s < nsub; ++s) position_verlet_step(r);
+}
+
+/* SoftPendulumEnv.step, soft_pendulum.py:176-251 */
+void oracle_env_step(oracle_rod* r, float action, float obs[4], double* reward,
+                     uint8_t* terminated, uint8_t* truncated)
+{
+    const int n = r->n;
+    r->prev_action = action;          /* :165 */
+    r->point_force = (double)action;  /* :166 (float32 value held in float64) */
+    for (int s = 0; s < r->cfg.n_substeps; ++s) position_verlet_step(r);
+    int invalid = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k <= n; ++k)
+            if (isnan(r->x[i][k]) || isnan(r->v[i][k])) invalid = 1;
+    double survive = 0.0, forward = 0.0;
+    *terminated = 0;
+    if (invalid) { *terminated = 1; survive = -50.0; }
+    else {
+        const double dist = fabs(r->x[0][0]);
+        const double th = wrapped_theta(r);
+        forward = dist * 10 + th * th;
+    }
+    *truncated = (r->time > r->cfg.final_time) ? 1 : 0;
+    *reward = forward - 0.0 + survive;
+    get_state(r, obs);
+}
+
+/* batched driver for the cpu_baseline leg (OpenMP over rods when built with it) */
+void oracle_env_step_batch(oracle_rod** rods, int n_rods, const float* actions, float* obs,
+                           double* reward, uint8_t* terminated, uint8_t* truncated)
+{
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < n_rods; ++e)
+        oracle_env_step(rods[e], actions[e], obs + 4 * e, reward + e, terminated + e,
+                        truncated + e);
+}
+
+/* field access for tests: name in {x,v,Q,w,tangents,kappa,sigma,mass,f_int,t_int,...} */
+int oracle_get(const oracle_rod* r, const char* name, double* out)
+{
+    const int n = r->n;
+#define COPY3(arr, cnt) do { for (int i = 0; i < 3; ++i) for (int k = 0; k < (cnt); ++k) \
+        out[i * (cnt) + k] = r->arr[i][k]; return 3 * (cnt); } while (0)
+    if (!strcmp(name, "x")) COPY3(x, n + 1);
+    if (!strcmp(name, "v")) COPY3(v, n + 1);
+    if (!strcmp(name, "w")) COPY3(w, n);
+    if (!strcmp(name, "tangents")) COPY3(tang, n);
+    if (!strcmp(name, "sigma")) COPY3(sigma, n);
+    if (!strcmp(name, "kappa")) COPY3(kappa, n - 1);
+    if (!strcmp(name, "n_int")) COPY3(n_int, n);
+    if (!strcmp(name, "m_int")) COPY3(m_int, n - 1);
+    if (!strcmp(name, "f_int")) COPY3(f_int, n + 1);
+    if (!strcmp(name, "t_int")) COPY3(t_int, n);
+    if (!strcmp(name, "J")) COPY3(J, n);
+    if (!strcmp(name, "shear")) COPY3(shear, n);
+    if (!strcmp(name, "bend")) COPY3(bend, n - 1);
+    if (!strcmp(name, "damp_r")) COPY3(damp_r, n);
+#undef COPY3
+    if (!strcmp(name, "Q")) {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < n; ++k)
+            out[(i * 3 + j) * n + k] = r->Q[i][j][k];
+        return 9 * n;
+    }
+    if (!strcmp(name, "mass")) { for (int k = 0; k <= n; ++k) out[k] = r->mass[k]; return n + 1; }
+    if (!strcmp(name, "lengths")) { for (int k = 0; k < n; ++k) out[k] = r->len[k]; return n; }
+    if (!strcmp(name, "dilatation")) { for (int k = 0; k < n; ++k) out[k] = r->dil[k]; return n; }
+    if (!strcmp(name, "rest_lengths")) { for (int k = 0; k < n; ++k) out[k] = r->rest_len[k]; return n; }
+    if (!strcmp(name, "damp_t")) { out[0] = r->damp_t; return 1; }
+    return -1;
+}
+
+/* state injection for tests (perturbed initial conditions) */
+int oracle_set(oracle_rod* r, const char* name, const double* in)
+{
+    const int n = r->n;
+#define SET3(arr, cnt) do { for (int i = 0; i < 3; ++i) for (int k = 0; k < (cnt); ++k) \
+        r->arr[i][k] = in[i * (cnt) + k]; return 0; } while (0)
+    if (!strcmp(name, "x")) SET3(x, n + 1);
+    if (!strcmp(name, "v")) SET3(v, n + 1);
+    if (!strcmp(name, "w")) SET3(w, n);
+    if (!strcmp(name, "rest_kappa")) SET3(rest_kappa, n - 1);
+#undef SET3
+    if (!strcmp(name, "Q")) {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < n; ++k)
+            r->Q[i][j][k] = in[(i * 3 + j) * n + k];
+        return 0;
+    }
+    return -1;
+}
+
+size_t oracle_config_size(void) { return sizeof(softrod_config); }

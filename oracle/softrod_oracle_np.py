@@ -1,0 +1,248 @@
+"""NumPy restatement (fp64) of the SoftPendulum-v0 hot path — second, independent oracle.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/ and tools/make_golden.py, never by
+gym_softrobot_amd/.  PARITY UNPINNED for the PyElastica arithmetic (see the header
+of softrod_oracle.c for why); this file exists so that the C oracle is checked
+against a second transcription written in PyElastica's own array style
+((3, n) blocks, whole-array kernels) rather than per-element loops.
+
+Anchors in the reference:
+  assembly   gym_softrobot/envs/soft_pendulum/build.py:29-115
+  hot loop   gym_softrobot/envs/soft_pendulum/soft_pendulum.py:183-184
+  epilogue   gym_softrobot/envs/soft_pendulum/soft_pendulum.py:149-161,196-251
+PyElastica modules restated (pyelastica==1.0.0, uv.lock:845-846; not on disk):
+  elastica/rod/factory_function.py, rod/cosserat_rod.py, _rotations.py,
+  _calculus.py, timestepper/symplectic_steppers.py, external_forces.py,
+  dissipation.py.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _difference(a):
+    """two-point difference kernel: (3, m) -> (3, m+1)."""
+    out = np.empty((3, a.shape[1] + 1))
+    out[:, 0] = a[:, 0]
+    out[:, 1:-1] = a[:, 1:] - a[:, :-1]
+    out[:, -1] = -a[:, -1]
+    return out
+
+
+def _trapezoidal(a):
+    out = np.empty((3, a.shape[1] + 1))
+    out[:, 0] = 0.5 * a[:, 0]
+    out[:, 1:-1] = 0.5 * (a[:, 1:] + a[:, :-1])
+    out[:, -1] = 0.5 * a[:, -1]
+    return out
+
+
+def _matvec(A, v):  # (3,3,n),(3,n)->(3,n)
+    return np.einsum("ijk,jk->ik", A, v)
+
+
+def _cross(a, b):
+    return np.cross(a, b, axis=0)
+
+
+class NumpyRod:
+    """One rod; cfg is any object with the attribute names of softrod_config."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.n = int(cfg.n_elem)
+
+    # -- CosseratRod.straight_rod (build.py:54-61) ---------------------------------
+    def reset_straight(self, start, direction, normal):
+        c, n = self.cfg, self.n
+        start = np.asarray(start, float)
+        direction = np.asarray(direction, float)
+        normal = np.asarray(normal, float)
+        end = start + direction * c.base_length
+        self.x = np.stack([np.linspace(start[i], end[i], n + 1) for i in range(3)])
+        diff = self.x[:, 1:] - self.x[:, :-1]
+        self.rest_len = np.sqrt(np.einsum("ik,ik->k", diff, diff))
+        tang = diff / self.rest_len
+        normal = normal / np.linalg.norm(normal)
+        ncol = np.repeat(normal[:, None], n, axis=1)
+        self.Q = np.zeros((3, 3, n))
+        self.Q[0] = ncol
+        self.Q[1] = _cross(tang, ncol)
+        self.Q[2] = tang
+        radius = np.full(n, c.base_radius)
+        A0 = np.pi * radius * radius
+        I1 = A0 * A0 / (4.0 * np.pi)
+        I0 = np.array([I1, I1, 2.0 * I1])  # (3, n)
+        self.J = I0 * (c.density * self.rest_len)  # diagonal entries
+        self.invJ = 1.0 / self.J
+        G = c.shear_modulus
+        self.shear = np.array([c.alpha_c * G * A0, c.alpha_c * G * A0, c.youngs_modulus * A0])
+        be = np.array([c.youngs_modulus * I0[0], c.youngs_modulus * I0[1], G * I0[2]])
+        rl = self.rest_len
+        self.bend = (be[:, 1:] * rl[1:] + be[:, :-1] * rl[:-1]) / (rl[1:] + rl[:-1])
+        self.volume = np.pi * radius**2 * rl
+        self.mass = np.zeros(n + 1)
+        self.mass[:-1] += 0.5 * c.density * self.volume
+        self.mass[1:] += 0.5 * c.density * self.volume
+        self.rest_vor = 0.5 * (rl[1:] + rl[:-1])
+        self.v = np.zeros((3, n + 1))
+        self.w = np.zeros((3, n))
+        self.rest_sigma = np.zeros((3, n))
+        self.rest_kappa = np.zeros((3, n - 1))
+        self.f_ext = np.zeros((3, n + 1))
+        self.t_ext = np.zeros((3, n))
+        # AnalyticalLinearDamper.__init__ (build.py:108-113)
+        self.damp_t = np.exp(-c.damping_constant * c.dt)
+        me = 0.5 * (self.mass[1:] + self.mass[:-1])
+        me[0] += 0.5 * self.mass[0]
+        me[-1] += 0.5 * self.mass[-1]
+        self.damp_r = np.exp(-c.damping_constant * c.dt * me * self.invJ)
+        self.fixed_pos = self.x[:, 0].copy()
+        self.fixed_dir = self.Q[:, :, 0].copy()
+        self.time = np.float64(0.0)
+        self.point_force = 0.0
+        self.prev_action = np.float32(0.0)
+        self._shear_stress()
+        self._kappa()
+
+    def reset_pendulum(self, theta):  # build.py:46-52
+        direction = np.array([1.0 * np.cos(theta), 1.0 * np.sin(theta), 0.0])
+        normal = np.array([1.0 * np.sin(theta), -1.0 * np.cos(theta), 0.0])
+        self.reset_straight(np.zeros(3), direction, normal)
+
+    # -- cosserat_rod.py kernels ---------------------------------------------------
+    def _shear_stress(self):
+        c = self.cfg
+        d = self.x[:, 1:] - self.x[:, :-1]
+        self.len = np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + c.eps_length
+        self.tang = d / self.len
+        self.dil = self.len / self.rest_len
+        self.vdil = 0.5 * (self.len[1:] + self.len[:-1]) / self.rest_vor
+        z = np.array([0.0, 0.0, 1.0]).reshape(3, 1)
+        self.sigma = self.dil * _matvec(self.Q, self.tang) - z
+        self.n_int = self.shear * (self.sigma - self.rest_sigma)
+
+    def _kappa(self):
+        c = self.cfg
+        Q = self.Q
+        R = np.einsum("imk,jmk->ijk", Q[:, :, 1:], Q[:, :, :-1])  # Q_{k+1} Q_k^T
+        vec = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        trace = R[0, 0] + R[1, 1] + R[2, 2]
+        theta = np.arccos(0.5 * trace - 0.5 - c.acos_shift)
+        self.kappa = vec * (-0.5 * theta / np.sin(theta + c.eps_sin)) / self.rest_vor
+
+    def _forces_and_torques(self):
+        self._shear_stress()
+        cs = np.einsum("jik,jk->ik", self.Q, self.n_int) / self.dil
+        self.f_int = _difference(cs)
+        self._kappa()
+        self.m_int = self.bend * (self.kappa - self.rest_kappa)
+        x, v = self.x, self.v
+        rv = np.einsum("ik,ik->k", x, v)
+        rp1v = np.einsum("ik,ik->k", x[:, 1:], v[:, :-1])
+        rvp1 = np.einsum("ik,ik->k", x[:, :-1], v[:, 1:])
+        self.dil_rate = (rv[:-1] + rv[1:] - rvp1 - rp1v) / self.len / self.rest_len
+        e3 = 1.0 / self.vdil**3
+        c2d = _difference(self.m_int * e3)
+        c3d = _trapezoidal(_cross(self.kappa, self.m_int) * self.rest_vor * e3)
+        ssc = _cross(_matvec(self.Q, self.tang), self.n_int) * self.rest_len
+        jwe = self.J * self.w / self.dil
+        lt = _cross(jwe, self.w)
+        ud = jwe * self.dil_rate / self.dil
+        self.t_int = c2d + c3d + ssc + lt + ud
+
+    # -- symplectic_steppers.py ------------------------------------------------------
+    def _kinematic(self, prefac):
+        c = self.cfg
+        self.x = self.x + prefac * self.v
+        ax = prefac * self.w
+        theta = np.sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2])
+        u = ax / (theta + c.eps_rot_axis)
+        up, usq = np.sin(theta), 1.0 - np.cos(theta)
+        R = np.empty((3, 3, self.n))
+        R[0, 0] = 1.0 - usq * (u[1] * u[1] + u[2] * u[2])
+        R[1, 1] = 1.0 - usq * (u[0] * u[0] + u[2] * u[2])
+        R[2, 2] = 1.0 - usq * (u[0] * u[0] + u[1] * u[1])
+        R[0, 1] = up * u[2] + usq * u[0] * u[1]
+        R[1, 0] = -up * u[2] + usq * u[0] * u[1]
+        R[0, 2] = -up * u[1] + usq * u[0] * u[2]
+        R[2, 0] = up * u[1] + usq * u[0] * u[2]
+        R[1, 2] = up * u[0] + usq * u[1] * u[2]
+        R[2, 1] = -up * u[0] + usq * u[1] * u[2]
+        self.Q = np.einsum("imk,mjk->ijk", R, self.Q)
+
+    def _constrain_values(self):
+        f = self.cfg.features
+        if f & 4:  # PENDULUM_BC, build.py:71-74
+            self.x[1:, 0] = self.fixed_pos[1:]
+            self.Q[0, :, 0] = self.fixed_dir[0, :]
+            self.Q[2, :, 0] = self.fixed_dir[2, :]
+        if f & 16:  # FIXED_BC
+            self.x[:, 0] = self.fixed_pos
+            self.Q[:, :, 0] = self.fixed_dir
+
+    def _constrain_rates(self):
+        f = self.cfg.features
+        if f & 4:  # build.py:76-79
+            self.v[1:, 0] = 0
+            self.w[0, 0] = 0
+            self.w[2, 0] = 0
+        if f & 16:
+            self.v[:, 0] = 0
+            self.w[:, 0] = 0
+
+    def substep(self):
+        c = self.cfg
+        dt = c.dt
+        self._kinematic(0.5 * dt)
+        if c.time_two_half_adds:
+            self.time = self.time + 0.5 * dt
+        self._constrain_values()
+        self._forces_and_torques()
+        g = np.asarray(list(c.gravity), float)
+        if c.features & 1:
+            self.f_ext += g[:, None] * self.mass[None, :]
+        if c.features & 2:
+            self.f_ext[0, 0] = self.point_force  # assigns: build.py:101
+        if c.features & 32:
+            self.f_ext[:, -1] += np.asarray(list(c.tip_force), float)
+        acc = (self.f_int + self.f_ext) / self.mass
+        alpha = (self.invJ * (self.t_int + self.t_ext)) * self.dil
+        self.v = self.v + dt * acc
+        self.w = self.w + dt * alpha
+        if c.features & 8:
+            self.v = self.v * self.damp_t
+            self.w = self.w * np.power(self.damp_r, self.dil)
+        self._constrain_rates()
+        self._kinematic(0.5 * dt)
+        self.time = self.time + (0.5 * dt if c.time_two_half_adds else dt)
+        self._constrain_values()
+        self.f_ext[:] = 0.0
+        self.t_ext[:] = 0.0
+
+    # -- env epilogue (soft_pendulum.py) ---------------------------------------------
+    def theta(self):
+        tm = np.mean(self.tang, axis=1)
+        th = np.arctan(tm[0] / tm[1])
+        return ((th + np.pi) % (2 * np.pi)) - np.pi
+
+    def get_state(self):  # :149-161
+        return np.hstack(
+            [self.x[0, 0], self.v[0, 0], np.array([self.prev_action]), self.theta()]
+        ).astype(np.float32)
+
+    def env_step(self, action):  # :176-251
+        a32 = np.float32(action)
+        self.prev_action = a32
+        self.point_force = float(a32)
+        for _ in range(int(self.cfg.n_substeps)):
+            self.substep()
+        invalid = bool(np.isnan(np.concatenate([self.x, self.v])).any())
+        terminated, survive, forward = False, 0.0, 0.0
+        if invalid:
+            terminated, survive = True, -50.0
+        else:
+            th = self.theta()
+            forward = np.abs(self.x[0, 0]) * 10 + th**2
+        truncated = bool(self.time > self.cfg.final_time)
+        return self.get_state(), forward - 0.0 + survive, terminated, truncated
