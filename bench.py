@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of N parallel SoftPendulum-v0 on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one env.step() of every env of the job: 4096 envs x 50 elements per GPU
+(BASELINE.json configs[1]; with N GPUs the batch is 4096*N envs sharded contiguously,
+configs[3] at N=8 — weak scaling), i.e. per GPU 4096 x 400 PositionVerlet substeps in
+one kernel launch, plus (N>1) one packed RCCL all-gather of the per-env outputs.
+Inputs (state, pre-staged float32 actions) are resident in HBM when the timed region
+starts.  Rank 0 prints ONE JSON line.
+
+roofline: algorithmic bytes per launch = rods x substeps x 2*(18n+6)*8 B (SURVEY.md
+§8(d): every substep reads+writes x, v, Q, omega once) divided by the step kernel's
+average duration, measured with HIP events recorded on the launch stream around every
+timed launch (softrod_set_timing / softrod_kernel_times_ms).  The kernel is
+register-resident (HBM is touched once per env.step), so measured `traffic` is far below
+the algorithmic figure — see DESIGN.md "roofline".
+
+cpu_baseline: the repo's fp64 C oracle (a port/restatement, NOT PyElastica — see
+oracle/softrod_oracle.c) timed on this box's host cores with OpenMP over rods, rank 0,
+N=1 only, on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+ENVS_PER_GPU = 4096
+N_ELEM = 50
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_rod_substep(n_elem: int, sizeof_real: int = 8) -> int:
+    return 2 * (18 * n_elem + 6) * sizeof_real  # 14 496 B for n = 50, fp64
+
+
+def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
+    """Time the C oracle (OpenMP over rods) on a bounded sample: 16 rods per core,
+    env.steps until ~budget_s of wall time (at least 2 steps)."""
+    import numpy as np
+
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    from gym_softrobot_amd.seeding import initial_angle, np_random
+    from oracle import oracle_c
+
+    oracle_c.build()
+    n_rods = 16 * cores
+    batch = oracle_c.OracleBatch(cfg, n_rods, omp=True)
+    batch.reset([initial_angle(np_random(i)[0]) for i in range(n_rods)])
+    acts = np.random.default_rng(1).uniform(-22, 22, (64, n_rods)).astype(np.float32)
+    batch.env_step(acts[0])  # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 2 or (time.perf_counter() - t0 < budget_s and steps < 60):
+        batch.env_step(acts[1 + steps])
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_rods * steps / dt,
+        "unit": "env-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n_rods} rods x {steps} env.steps (400 substeps, 50 elements, fp64 C oracle, "
+                  f"OpenMP {cores} threads, {dt:.1f} s)",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--math-mode", choices=["fast", "libm"], default="fast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.distributed import ShardedVecEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_local = args.envs_per_gpu
+    n_total = n_local * world
+    K, W = args.steps, args.warmup
+    math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
+    local = gsa.make_vec("SoftPendulum-v0", n_local, device=local_rank, math_mode=math_mode)
+    env = ShardedVecEnv(local, n_total)
+    env.reset(seed=0)  # global env i seeded i
+    lo, hi = env.lo, env.hi
+    # the truncation flag first fires on env.step #126; keep the window inside one episode
+    # by re-resetting (untimed) if a longer run was requested
+    T = W + K
+    acts = np.random.default_rng(1).uniform(-22, 22, (T, n_total, 1)).astype(np.float32)
+    acts_dev = torch.from_numpy(acts[:, lo:hi, 0].copy()).to(local.backend.device)
+
+    for t in range(W):
+        env.step(acts_dev[t])
+    local.backend.set_timing(K)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(W, T):
+        obs, rew, term, trunc, _ = env.step(acts_dev[t])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=local.backend.device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    kt = local.backend.kernel_times_ms()
+    assert len(kt) == K
+    n_bad = int((~torch.isfinite(obs).all(dim=1)).sum().item())
+
+    if rank == 0:
+        cfg = local.cfg
+        nsub = int(cfg.n_substeps)
+        bytes_per_launch = n_local * nsub * algorithmic_bytes_per_rod_substep(int(cfg.n_elem))
+        kernel_ms = float(np.mean(kt))
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists():  # measured with rocprofv3 --pmc (separate passes), see profiles/README.md
+            try:
+                traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "env_steps_per_sec",
+            "value": n_total * K / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"SoftPendulum-v0, {n_local} envs x {int(cfg.n_elem)} elements per GPU "
+                            f"(BASELINE configs[1]; x{world} GPUs)",
+                "envs_total": n_total,
+                "substeps_per_env_step": nsub,
+                "math_mode": args.math_mode,
+                "sharding": "contiguous env blocks per rank; one packed all_gather per step" if world > 1 else "single GPU",
+                "rod_substeps_per_sec": n_total * K * nsub / elapsed,
+                "non_finite_envs_at_end": n_bad,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "softrod_step_kernel",
+                "kernel_ms_avg": kernel_ms,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "note": "algorithmic bytes = rods x substeps x 2(18n+6) x 8 B (SURVEY 8d); the kernel keeps "
+                        "the state in registers for all substeps, so real HBM traffic is ~1/400 of that",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = len(os.sched_getaffinity(0))
+            line["cpu_baseline"] = cpu_baseline(cfg, cores)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

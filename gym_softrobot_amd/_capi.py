@@ -143,8 +143,9 @@ _EXPORTS = {
     "softrod_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "softrod_substeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "softrod_state_view_get": (C.c_int, [C.c_void_p, C.POINTER(SoftrodStateView)]),
-    "softrod_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "softrod_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "softrod_kernel_times_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "softrod_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "softrod_last_error": (C.c_char_p, [C.c_void_p]),
     "softrod_destroy": (C.c_int, [C.c_void_p]),
 }

@@ -1,0 +1,180 @@
+"""Device backend: one `softrod_handle` (include/softrod.h) per GPU, fed with torch-ROCm
+tensors.  torch is plumbing only (device memory, streams); all arithmetic of the hot
+path happens in libsoftrod_hip.so.  There is no CPU fallback here by design."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import LANE_STRIDE, SoftrodConfig, SoftrodStateView, check, load_library
+
+
+class _DevArray:
+    """Borrowed device memory exposed through __cuda_array_interface__ (zero-copy)."""
+
+    def __init__(self, ptr: int, shape, typestr: str, owner):
+        self._owner = owner  # keeps the handle alive
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape),
+            "typestr": typestr,
+            "data": (int(ptr), False),
+            "version": 2,
+            "strides": None,
+        }
+
+
+class HipRodBackend:
+    """Resident batch of rods on one MI355X."""
+
+    def __init__(self, cfg: SoftrodConfig, device: int = 0):
+        if not torch.cuda.is_available():
+            raise _capi.SoftrodError(
+                "HipRodBackend needs a ROCm device (torch.cuda.is_available() is False); "
+                "the hot path has no CPU fallback"
+            )
+        self._lib = load_library()
+        self.cfg = cfg.copy()
+        self.n_envs = int(cfg.n_envs)
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self._h = C.c_void_p()
+        check(self._lib.softrod_create(C.byref(self.cfg), self.device_index, C.byref(self._h)))
+        n = self.n_envs
+        with torch.cuda.device(self.device):
+            self.obs = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+            self.reward = torch.empty((n,), dtype=torch.float64, device=self.device)
+            self.terminated = torch.empty((n,), dtype=torch.uint8, device=self.device)
+            self.truncated = torch.empty((n,), dtype=torch.uint8, device=self.device)
+
+    # -- lifetime -------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.softrod_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _actions(self, actions) -> torch.Tensor:
+        a = torch.as_tensor(actions, dtype=torch.float32, device=self.device).reshape(-1)
+        if a.numel() != self.n_envs:
+            raise ValueError(f"expected {self.n_envs} actions, got {a.numel()}")
+        return a.contiguous()
+
+    # -- C-ABI calls ----------------------------------------------------------------
+    def reset(self, theta0: np.ndarray, mask: Optional[np.ndarray] = None) -> None:
+        th = np.ascontiguousarray(theta0, dtype=np.float64).reshape(self.n_envs)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.n_envs)
+        check(
+            self._lib.softrod_reset(
+                self._h, th.ctypes.data, m.ctypes.data if m is not None else None, self._stream()
+            ),
+            self._h,
+        )
+
+    def reset_straight(self, start, direction, normal) -> None:
+        arrs = [
+            np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float64), (self.n_envs, 3)))
+            for v in (start, direction, normal)
+        ]
+        check(
+            self._lib.softrod_reset_straight(
+                self._h, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, self._stream()
+            ),
+            self._h,
+        )
+
+    def observe(self, prev_action: Optional[torch.Tensor] = None) -> torch.Tensor:
+        pa = None
+        if prev_action is not None:
+            pa = self._actions(prev_action)
+        check(
+            self._lib.softrod_observe(
+                self._h, pa.data_ptr() if pa is not None else None, self.obs.data_ptr(), self._stream()
+            ),
+            self._h,
+        )
+        return self.obs
+
+    def step(self, actions) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        a = self._actions(actions)
+        check(
+            self._lib.softrod_step(
+                self._h, a.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
+                self.terminated.data_ptr(), self.truncated.data_ptr(), self._stream(),
+            ),
+            self._h,
+        )
+        return self.obs, self.reward, self.terminated, self.truncated
+
+    def substeps(self, actions, n: int) -> None:
+        a = self._actions(actions) if actions is not None else None
+        check(
+            self._lib.softrod_substeps(
+                self._h, a.data_ptr() if a is not None else None, int(n), self._stream()
+            ),
+            self._h,
+        )
+
+    def set_timing(self, n_launches: int) -> None:
+        """Record HIP events around the next `n_launches` kernels (0 = off)."""
+        check(self._lib.softrod_set_timing(self._h, int(n_launches)), self._h)
+
+    def kernel_times_ms(self) -> np.ndarray:
+        """Durations of the launches timed since set_timing (synchronises)."""
+        cap = 1 << 16
+        out = np.zeros(cap, np.float32)
+        cnt = C.c_int()
+        check(self._lib.softrod_kernel_times_ms(self._h, out.ctypes.data, cap, C.byref(cnt)), self._h)
+        return out[: cnt.value].copy()
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        check(self._lib.softrod_last_kernel_ms(self._h, C.byref(ms)), self._h)
+        return float(ms.value)
+
+    def state(self) -> Dict[str, torch.Tensor]:
+        """Zero-copy torch views of the resident SoA state (softrod_state_view)."""
+        v = SoftrodStateView()
+        check(self._lib.softrod_state_view_get(self._h, C.byref(v)), self._h)
+        n, s = self.n_envs, LANE_STRIDE
+
+        def view(ptr, comps):
+            return torch.as_tensor(_DevArray(ptr, (comps, n, s), "<f8", self), device=self.device)
+
+        return {
+            "position": view(v.position, 3),
+            "velocity": view(v.velocity, 3),
+            "director": view(v.director, 9),
+            "omega": view(v.omega, 3),
+            "tangents": view(v.tangents, 3),
+            "time": torch.as_tensor(_DevArray(v.time, (n,), "<f8", self), device=self.device),
+        }
+
+    def state_numpy(self) -> Dict[str, np.ndarray]:
+        """Host copy in the reference's per-rod shapes: x,v (N,3,n+1); Q (N,3,3,n); w (N,3,n)."""
+        st = self.state()
+        ne = int(self.cfg.n_elem)
+        torch.cuda.synchronize(self.device)
+        out = {
+            "x": st["position"][:, :, : ne + 1].permute(1, 0, 2).cpu().numpy(),
+            "v": st["velocity"][:, :, : ne + 1].permute(1, 0, 2).cpu().numpy(),
+            "w": st["omega"][:, :, :ne].permute(1, 0, 2).cpu().numpy(),
+            "tangents": st["tangents"][:, :, :ne].permute(1, 0, 2).cpu().numpy(),
+            "time": st["time"].cpu().numpy(),
+        }
+        q = st["director"][:, :, :ne].permute(1, 0, 2).cpu().numpy()
+        out["Q"] = q.reshape(self.n_envs, 3, 3, ne)
+        return out

@@ -1,0 +1,367 @@
+// softrod_capi.hip — host side of the C-ABI declared in include/softrod.h.
+//
+// Owns the resident device state of one batch shard and launches the kernels of
+// softrod_kernels.hpp.  No CPU implementation of the physics lives here: the only
+// host arithmetic is the rod *allocation* (CosseratRod.straight_rod constants and the
+// initial frame of each rod, build.py:46-61), which the reference also performs once
+// per reset on the host.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "softrod_kernels.hpp"
+
+using namespace softrod;
+
+struct softrod_handle {
+    softrod_config cfg;
+    int device = 0;
+    RodParams P{};
+    StatePtrs S{};
+    double* d_init = nullptr;     // [N][18] staging for reset
+    uint8_t* d_mask = nullptr;    // [N]
+    double* h_init = nullptr;     // pinned
+    uint8_t* h_mask = nullptr;    // pinned
+    std::vector<hipEvent_t> ev_start, ev_stop;  // timing ring (softrod_set_timing)
+    int timed = 0;                  // launches recorded since set_timing
+    hipEvent_t ev_reset = nullptr;  // guards reuse of the pinned staging buffers
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err;  // errors raised before a handle exists
+
+int fail(softrod_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_err = msg;
+    return code;
+}
+
+#define SR_HIP(h, call)                                                                 \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(h, SOFTROD_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Constants of a uniform straight rod — CosseratRod.straight_rod
+// (elastica/rod/factory_function.py allocate(), called at build.py:54-61) and
+// AnalyticalLinearDamper.__init__ (build.py:108-113).
+void fill_params(const softrod_config& c, RodParams& P) {
+    std::memset(&P, 0, sizeof(P));
+    P.n_envs = c.n_envs;
+    P.n_elem = c.n_elem;
+    P.time_two_half_adds = c.time_two_half_adds;
+    P.features = c.features;
+    P.dt = c.dt;
+    P.half_dt = 0.5 * c.dt;
+    P.final_time = c.final_time;
+    const int n = c.n_elem;
+    const double rest_len = c.base_length / (double)n;
+    P.rest_len = rest_len;
+    P.inv_rest_len = 1.0 / rest_len;
+    P.rest_vor = 0.5 * (rest_len + rest_len);
+    P.inv_rest_vor = 1.0 / P.rest_vor;
+    const double r = c.base_radius;
+    const double A0 = M_PI * r * r;
+    const double I1 = A0 * A0 / (4.0 * M_PI);
+    const double I[3] = {I1, I1, 2.0 * I1};
+    for (int i = 0; i < 3; ++i) {
+        P.J[i] = I[i] * (c.density * rest_len);
+        P.invJ[i] = 1.0 / P.J[i];
+    }
+    P.shear[0] = c.alpha_c * c.shear_modulus * A0;
+    P.shear[1] = c.alpha_c * c.shear_modulus * A0;
+    P.shear[2] = c.youngs_modulus * A0;
+    P.bend[0] = c.youngs_modulus * I[0];
+    P.bend[1] = c.youngs_modulus * I[1];
+    P.bend[2] = c.shear_modulus * I[2];
+    const double volume = M_PI * (r * r) * rest_len;
+    P.mass_node = c.density * volume;  // two half-element contributions
+    for (int i = 0; i < 3; ++i) { P.gravity[i] = c.gravity[i]; P.tip_force[i] = c.tip_force[i]; }
+    P.damp_t = std::exp(-c.damping_constant * c.dt);
+    // element mass seen by the damper: 0.5(m_k+m_{k+1}), ends augmented by half their
+    // outer node -> rho*V for every element of a uniform rod
+    const double me = P.mass_node;
+    for (int i = 0; i < 3; ++i) {
+        P.damp_logr[i] = -c.damping_constant * c.dt * me * P.invJ[i];
+        P.damp_r[i] = std::exp(P.damp_logr[i]);
+    }
+    P.eps_length = c.eps_length;
+    P.eps_rot_axis = c.eps_rot_axis;
+    P.acos_shift = c.acos_shift;
+    P.eps_sin = c.eps_sin;
+}
+
+int launch_step(softrod_handle* h, const float* actions, float* obs, double* reward,
+                uint8_t* term, uint8_t* trunc, int n_sub, int epilogue, hipStream_t st) {
+    const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
+    const bool timing = h->timed < (int)h->ev_start.size();
+    if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
+    if (h->cfg.math_mode == SOFTROD_MATH_FAST)
+        hipLaunchKernelGGL(softrod_step_kernel<SOFTROD_MATH_FAST>, grid, block, 0, st, h->P, h->S,
+                           actions, obs, reward, term, trunc, n_sub, epilogue);
+    else
+        hipLaunchKernelGGL(softrod_step_kernel<SOFTROD_MATH_LIBM>, grid, block, 0, st, h->P, h->S,
+                           actions, obs, reward, term, trunc, n_sub, epilogue);
+    SR_HIP(h, hipGetLastError());
+    if (timing) {
+        SR_HIP(h, hipEventRecord(h->ev_stop[h->timed], st));
+        ++h->timed;
+    }
+    return SOFTROD_OK;
+}
+
+int upload_and_reset(softrod_handle* h, hipStream_t st, bool use_mask) {
+    const size_t N = (size_t)h->cfg.n_envs;
+    SR_HIP(h, hipMemcpyAsync(h->d_init, h->h_init, N * 18 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (use_mask)
+        SR_HIP(h, hipMemcpyAsync(h->d_mask, h->h_mask, N, hipMemcpyHostToDevice, st));
+    ResetArgs A{h->d_init, use_mask ? h->d_mask : nullptr};
+    hipLaunchKernelGGL(softrod_reset_kernel, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
+    SR_HIP(h, hipGetLastError());
+    SR_HIP(h, hipEventRecord(h->ev_reset, st));
+    return SOFTROD_OK;
+}
+
+// host part of straight_rod for one rod: start, step, end, Q rows
+void straight_init(const softrod_config& c, const double start[3], const double direction[3],
+                   const double normal_in[3], double out[18]) {
+    const int n = c.n_elem;
+    double end[3], normal[3], t[3], d[3];
+    for (int i = 0; i < 3; ++i) end[i] = start[i] + direction[i] * c.base_length;
+    const double nn = std::sqrt(normal_in[0] * normal_in[0] + normal_in[1] * normal_in[1] +
+                                normal_in[2] * normal_in[2]);
+    for (int i = 0; i < 3; ++i) normal[i] = normal_in[i] / nn;
+    for (int i = 0; i < 3; ++i) {
+        out[i] = start[i];
+        out[3 + i] = (end[i] - start[i]) / (double)n;
+        out[6 + i] = end[i];
+        d[i] = (start[i] + 1.0 * out[3 + i]) - start[i];  // x[1]-x[0] as linspace produces it
+    }
+    const double l = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    for (int i = 0; i < 3; ++i) t[i] = d[i] / l;
+    for (int i = 0; i < 3; ++i) out[9 + i] = normal[i];
+    out[12] = t[1] * normal[2] - t[2] * normal[1];
+    out[13] = t[2] * normal[0] - t[0] * normal[2];
+    out[14] = t[0] * normal[1] - t[1] * normal[0];
+    for (int i = 0; i < 3; ++i) out[15 + i] = t[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int softrod_abi_version(void) { return SOFTROD_ABI_VERSION; }
+
+int softrod_config_softpendulum(softrod_config* cfg, int n_envs) {
+    if (!cfg || n_envs < 1) return SOFTROD_EINVAL;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (uint32_t)sizeof(softrod_config);
+    cfg->features = SOFTROD_FEATURES_SOFTPENDULUM;
+    cfg->n_envs = n_envs;
+    cfg->n_elem = 50;                                   // soft_pendulum.py:64
+    cfg->dt = 1.0e-4;                                   // :62
+    cfg->n_substeps = (int)(1.0 / (25 * cfg->dt));      // :78 (recording_fps = 25, :63)
+    cfg->math_mode = SOFTROD_MATH_FAST;
+    cfg->final_time = 5.0;                              // :61
+    cfg->base_length = 1.0;                             // build.py:23-26
+    cfg->base_radius = 0.05;
+    cfg->density = 1000.0;                              // build.py:18-22
+    cfg->youngs_modulus = 1e6;
+    cfg->shear_modulus = 1e6 / (2.0 * (1.0 + 0.5));     // PyElastica default (none passed)
+    cfg->gravity[0] = 0.0; cfg->gravity[1] = -9.80665; cfg->gravity[2] = 0.0;  // build.py:87-91
+    cfg->damping_constant = 2e-3;                       // build.py:108
+    cfg->alpha_c = 27.0 / 28.0;
+    cfg->eps_length = 1e-14;
+    cfg->eps_rot_axis = 1e-14;
+    cfg->acos_shift = 1e-10;
+    cfg->eps_sin = 1e-14;
+    cfg->time_two_half_adds = 1;
+    return SOFTROD_OK;
+}
+
+int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) {
+    if (!cfg || !out) return fail(nullptr, SOFTROD_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(softrod_config))
+        return fail(nullptr, SOFTROD_EINVAL, "softrod_config.struct_size mismatch");
+    if (cfg->n_envs < 1 || cfg->n_elem < 2 || cfg->n_elem > kLanes - 1)
+        return fail(nullptr, SOFTROD_EINVAL, "need n_envs >= 1 and 2 <= n_elem <= 63");
+    if (cfg->n_substeps < 0 || !(cfg->dt > 0.0))
+        return fail(nullptr, SOFTROD_EINVAL, "need n_substeps >= 0 and dt > 0");
+    if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
+        return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, SOFTROD_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(nullptr, SOFTROD_EINVAL, "device out of range");
+    softrod_handle* h = new (std::nothrow) softrod_handle;
+    if (!h) return fail(nullptr, SOFTROD_ENOMEM, "host allocation failed");
+    h->cfg = *cfg;
+    h->device = device;
+    fill_params(h->cfg, h->P);
+    const size_t N = (size_t)cfg->n_envs;
+    const size_t rowb = N * kLanes * sizeof(double);
+    int rc = SOFTROD_OK;
+    auto alloc = [&](void** p, size_t bytes) {
+        if (rc != SOFTROD_OK) return;
+        if (hipMalloc(p, bytes) != hipSuccess) { rc = SOFTROD_ENOMEM; return; }
+        if (hipMemset(*p, 0, bytes) != hipSuccess) rc = SOFTROD_EHIP;
+    };
+    if (hipSetDevice(device) != hipSuccess) rc = SOFTROD_EHIP;
+    alloc((void**)&h->S.pos, 3 * rowb);
+    alloc((void**)&h->S.vel, 3 * rowb);
+    alloc((void**)&h->S.dir, 9 * rowb);
+    alloc((void**)&h->S.omg, 3 * rowb);
+    alloc((void**)&h->S.tan, 3 * rowb);
+    alloc((void**)&h->S.time, N * sizeof(double));
+    alloc((void**)&h->S.bc, 12 * N * sizeof(double));
+    alloc((void**)&h->S.prev_action, N * sizeof(float));
+    alloc((void**)&h->d_init, N * 18 * sizeof(double));
+    alloc((void**)&h->d_mask, N);
+    if (rc == SOFTROD_OK && hipHostMalloc((void**)&h->h_init, N * 18 * sizeof(double)) != hipSuccess) rc = SOFTROD_ENOMEM;
+    if (rc == SOFTROD_OK && hipHostMalloc((void**)&h->h_mask, N) != hipSuccess) rc = SOFTROD_ENOMEM;
+    if (rc == SOFTROD_OK && hipEventCreateWithFlags(&h->ev_reset, hipEventDisableTiming) != hipSuccess)
+        rc = SOFTROD_EHIP;
+    if (rc != SOFTROD_OK) {
+        softrod_destroy(h);
+        return fail(nullptr, rc, "device allocation failed");
+    }
+    *out = h;
+    return SOFTROD_OK;
+}
+
+int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask, void* stream) {
+    if (!h || !theta0) return fail(h, SOFTROD_EINVAL, "null argument");
+    SR_HIP(h, hipSetDevice(h->device));
+    SR_HIP(h, hipEventSynchronize(h->ev_reset));  // previous upload out of the pinned buffers
+    const int N = h->cfg.n_envs;
+    for (int e = 0; e < N; ++e) {
+        if (mask) h->h_mask[e] = mask[e];
+        if (mask && !mask[e]) continue;
+        const double th = theta0[e];
+        // build.py:46-52
+        const double start[3] = {0.0, 0.0, 0.0};
+        const double direction[3] = {1.0 * std::cos(th), 1.0 * std::sin(th), 0.0};
+        const double normal[3] = {1.0 * std::sin(th), -1.0 * std::cos(th), 0.0};
+        straight_init(h->cfg, start, direction, normal, h->h_init + (size_t)e * 18);
+    }
+    return upload_and_reset(h, (hipStream_t)stream, mask != nullptr);
+}
+
+int softrod_reset_straight(softrod_handle* h, const double* start, const double* direction,
+                           const double* normal, void* stream) {
+    if (!h || !start || !direction || !normal) return fail(h, SOFTROD_EINVAL, "null argument");
+    SR_HIP(h, hipSetDevice(h->device));
+    SR_HIP(h, hipEventSynchronize(h->ev_reset));
+    const int N = h->cfg.n_envs;
+    for (int e = 0; e < N; ++e)
+        straight_init(h->cfg, start + 3 * e, direction + 3 * e, normal + 3 * e, h->h_init + (size_t)e * 18);
+    return upload_and_reset(h, (hipStream_t)stream, false);
+}
+
+int softrod_step(softrod_handle* h, const float* actions, float* obs, double* reward,
+                 uint8_t* terminated, uint8_t* truncated, void* stream) {
+    if (!h || !actions || !obs || !reward || !terminated || !truncated)
+        return fail(h, SOFTROD_EINVAL, "null argument");
+    SR_HIP(h, hipSetDevice(h->device));
+    return launch_step(h, actions, obs, reward, terminated, truncated, h->cfg.n_substeps, 1,
+                       (hipStream_t)stream);
+}
+
+int softrod_substeps(softrod_handle* h, const float* actions, int n, void* stream) {
+    if (!h || n < 0) return fail(h, SOFTROD_EINVAL, "bad argument");
+    SR_HIP(h, hipSetDevice(h->device));
+    return launch_step(h, actions, nullptr, nullptr, nullptr, nullptr, n, 0, (hipStream_t)stream);
+}
+
+int softrod_observe(softrod_handle* h, const float* prev_action, float* obs, void* stream) {
+    if (!h || !obs) return fail(h, SOFTROD_EINVAL, "null argument");
+    SR_HIP(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(softrod_observe_kernel, dim3((unsigned)h->cfg.n_envs), dim3(kLanes), 0,
+                       (hipStream_t)stream, h->P, h->S, prev_action, obs);
+    SR_HIP(h, hipGetLastError());
+    return SOFTROD_OK;
+}
+
+int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
+    if (!h || !out) return fail(h, SOFTROD_EINVAL, "null argument");
+    out->n_envs = h->cfg.n_envs;
+    out->n_elem = h->cfg.n_elem;
+    out->lane_stride = kLanes;
+    out->reserved = 0;
+    out->position = h->S.pos;
+    out->velocity = h->S.vel;
+    out->director = h->S.dir;
+    out->omega = h->S.omg;
+    out->tangents = h->S.tan;
+    out->time = h->S.time;
+    return SOFTROD_OK;
+}
+
+int softrod_set_timing(softrod_handle* h, int n_launches) {
+    if (!h || n_launches < 0 || n_launches > (1 << 20)) return fail(h, SOFTROD_EINVAL, "bad argument");
+    SR_HIP(h, hipSetDevice(h->device));
+    while ((int)h->ev_start.size() < n_launches) {
+        hipEvent_t a = nullptr, b = nullptr;
+        SR_HIP(h, hipEventCreate(&a));
+        SR_HIP(h, hipEventCreate(&b));
+        h->ev_start.push_back(a);
+        h->ev_stop.push_back(b);
+    }
+    while ((int)h->ev_start.size() > n_launches) {
+        (void)hipEventDestroy(h->ev_start.back());
+        (void)hipEventDestroy(h->ev_stop.back());
+        h->ev_start.pop_back();
+        h->ev_stop.pop_back();
+    }
+    h->timed = 0;
+    return SOFTROD_OK;
+}
+
+int softrod_kernel_times_ms(softrod_handle* h, float* out_ms, int cap, int* count) {
+    if (!h || !out_ms || !count || cap < 0) return fail(h, SOFTROD_EINVAL, "bad argument");
+    SR_HIP(h, hipSetDevice(h->device));
+    const int n = h->timed < cap ? h->timed : cap;
+    for (int i = 0; i < n; ++i) {
+        SR_HIP(h, hipEventSynchronize(h->ev_stop[i]));
+        SR_HIP(h, hipEventElapsedTime(out_ms + i, h->ev_start[i], h->ev_stop[i]));
+    }
+    *count = n;
+    return SOFTROD_OK;
+}
+
+int softrod_last_kernel_ms(softrod_handle* h, float* ms) {
+    if (!h || !ms) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (h->timed < 1) return fail(h, SOFTROD_EINVAL, "timing not enabled or no timed launch yet");
+    SR_HIP(h, hipSetDevice(h->device));
+    SR_HIP(h, hipEventSynchronize(h->ev_stop[h->timed - 1]));
+    SR_HIP(h, hipEventElapsedTime(ms, h->ev_start[h->timed - 1], h->ev_stop[h->timed - 1]));
+    return SOFTROD_OK;
+}
+
+const char* softrod_last_error(softrod_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int softrod_destroy(softrod_handle* h) {
+    if (!h) return SOFTROD_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
+                    h->S.prev_action, h->d_init, h->d_mask};
+    for (void* p : bufs) (void)hipFree(p);
+    if (h->h_init) (void)hipHostFree(h->h_init);
+    if (h->h_mask) (void)hipHostFree(h->h_mask);
+    for (hipEvent_t e : h->ev_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_stop) (void)hipEventDestroy(e);
+    if (h->ev_reset) (void)hipEventDestroy(h->ev_reset);
+    delete h;
+    return SOFTROD_OK;
+}
+
+}  // extern "C"

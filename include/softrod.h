@@ -184,12 +184,18 @@ int softrod_substeps(softrod_handle* h, const float* actions, int n, void* strea
 
 int softrod_state_view_get(softrod_handle* h, softrod_state_view* out);
 
-/* Duration in milliseconds of the most recent softrod_step /
- * softrod_substeps kernel launch, measured with HIP events recorded on the
- * launch stream around the kernel (synchronises on the stop event).         */
+/* Kernel timing with HIP events recorded on the launch stream around each
+ * softrod_step / softrod_substeps kernel (no host synchronisation at record
+ * time, so it can stay on inside a timed region).
+ *   softrod_set_timing(h, n)      n > 0: keep event pairs for the next n launches
+ *                                 (ring restarts at 0); n = 0: off (default).
+ *   softrod_kernel_times_ms(...)  synchronises on the recorded events and writes
+ *                                 the per-launch durations, oldest first; *count
+ *                                 receives how many were written (<= cap).
+ *   softrod_last_kernel_ms(...)   duration of the most recent timed launch.    */
+int softrod_set_timing(softrod_handle* h, int n_launches);
+int softrod_kernel_times_ms(softrod_handle* h, float* out_ms, int cap, int* count);
 int softrod_last_kernel_ms(softrod_handle* h, float* ms);
-/* Enable/disable the event pair above (off by default: zero overhead).      */
-int softrod_set_timing(softrod_handle* h, int enabled);
 
 const char* softrod_last_error(softrod_handle* h);
 int softrod_destroy(softrod_handle* h);

@@ -37,6 +37,7 @@ def _load(omp: bool) -> C.CDLL:
     lib.oracle_destroy.argtypes = [C.c_void_p]
     lib.oracle_reset_pendulum.argtypes = [C.c_void_p, C.c_double]
     lib.oracle_reset_straight.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_refresh_strains.argtypes = [C.c_void_p]
     lib.oracle_set_prev_action.argtypes = [C.c_void_p, C.c_float]
     lib.oracle_observe.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_time.restype = C.c_double
@@ -87,6 +88,9 @@ class OracleRod:
     def reset_straight(self, start, direction, normal) -> None:
         a = [np.ascontiguousarray(v, dtype=np.float64) for v in (start, direction, normal)]
         self._lib.oracle_reset_straight(self._h, *[v.ctypes.data for v in a])
+
+    def refresh_strains(self) -> None:
+        self._lib.oracle_refresh_strains(self._h)
 
     def set_prev_action(self, a: float) -> None:
         self._lib.oracle_set_prev_action(self._h, float(a))

@@ -501,6 +501,14 @@ void oracle_reset_pendulum(oracle_rod* r, double theta)
     oracle_reset_straight(r, start, direction, normal);
 }
 
+/* re-evaluate the strain caches at the CURRENT configuration (tests: energy audits);
+ * the stepping path itself leaves them stale by half a substep, as PyElastica does */
+void oracle_refresh_strains(oracle_rod* r)
+{
+    compute_shear_stress(r);
+    compute_bending_twist_strains(r);
+}
+
 void oracle_set_prev_action(oracle_rod* r, float a) { r->prev_action = a; }
 void oracle_observe(const oracle_rod* r, float obs[4]) { get_state(r, obs); }
 double oracle_time(const oracle_rod* r) { return r->time; }

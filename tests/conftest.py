@@ -1,0 +1,32 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_built():
+    from oracle import oracle_c
+
+    oracle_c.build()
+    return oracle_c
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """Builds (if needed) and loads libsoftrod_hip.so; never falls back."""
+    from gym_softrobot_amd import _capi
+
+    if not _capi.library_path().exists():
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _capi.load_library()

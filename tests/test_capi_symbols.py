@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads without a GPU and
+exports every entry point include/softrod.h declares; the ctypes mirror of
+softrod_config is layout-identical to the C struct; calls fail loudly (no fallback)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from gym_softrobot_amd import _capi
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared():
+    text = (ROOT / "include" / "softrod.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(softrod_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(hip_lib):
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(hip_lib, n), f"{n} declared in include/softrod.h but not exported"
+    assert set(names) == set(_capi.EXPORTED_SYMBOLS)
+
+
+def test_config_layout_and_defaults_match_c(hip_lib):
+    c = _capi.SoftrodConfig()
+    assert hip_lib.softrod_config_softpendulum(C.byref(c), 7) == 0
+    py = _capi.softpendulum_config(7)
+    assert c.struct_size == C.sizeof(_capi.SoftrodConfig)
+    assert bytes(c) == bytes(py)
+    assert py.n_substeps == 400 and py.n_elem == 50      # soft_pendulum.py:64,78
+    assert py.shear_modulus == pytest.approx(1e6 / 3.0)
+
+
+def test_create_rejects_bad_config_and_never_falls_back(hip_lib):
+    h = C.c_void_p()
+    cfg = _capi.softpendulum_config(4)
+    cfg.struct_size = 8
+    assert hip_lib.softrod_create(C.byref(cfg), 0, C.byref(h)) == -1
+    cfg = _capi.softpendulum_config(4)
+    cfg.n_elem = 64  # one rod per 64-lane wavefront: at most 63 elements
+    assert hip_lib.softrod_create(C.byref(cfg), 0, C.byref(h)) == -1
+    assert not h.value
+
+
+def test_backend_refuses_to_run_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import gym_softrobot_amd as gsa
+
+    with pytest.raises(_capi.SoftrodError):
+        gsa.make_vec("SoftPendulum-v0", 2)
+    with pytest.raises(_capi.SoftrodError):
+        gsa.make("SoftPendulum-v0")

@@ -1,0 +1,268 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (ctypes -> libsoftrod_hip.so),
+against the fp64 CPU oracle on the same seeds and actions.  Tolerance: rtol 1e-5 on
+observations/rewards (BASELINE.json north_star), exact on flags.  Both math modes of the
+kernel are held to the same bar."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).parent / "golden"
+RTOL = 1e-5
+
+
+def _theta(seed):
+    from gym_softrobot_amd.seeding import initial_angle, np_random
+
+    rng, _ = np_random(seed)
+    return initial_angle(rng)
+
+
+@pytest.fixture(scope="module")
+def torch_gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch
+
+
+def _make(n, math_mode, **kw):
+    import gym_softrobot_amd as gsa
+
+    return gsa.make_vec("SoftPendulum-v0", n, device=0, math_mode=math_mode, **kw)
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+def test_reset_observation_golden(torch_gpu, hip_lib, math_mode):
+    vectors = json.loads((GOLD / "softpendulum_reset.json").read_text())
+    env = _make(len(vectors), math_mode)
+    obs, info = env.reset(seed=[v["seed"] for v in vectors])
+    obs = obs.cpu().numpy()
+    assert obs.dtype == np.float32 and info == {}
+    for o, v in zip(obs, vectors):
+        np.testing.assert_array_equal(o[:3], 0.0)
+        assert abs(float(o[3]) - v["obs"][3]) <= 2 * np.spacing(np.float32(abs(v["obs"][3])))
+    env.close()
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+def test_rollout_matches_oracle(torch_gpu, hip_lib, oracle_built, math_mode):
+    n, T = 16, 6
+    env = _make(n, math_mode)
+    env.reset(seed=0)
+    acts = np.random.default_rng(1).uniform(-22, 22, (T, n)).astype(np.float32)
+    rods = []
+    for i in range(n):
+        r = oracle_built.OracleRod(env.cfg)
+        r.reset_pendulum(_theta(i))
+        rods.append(r)
+    worst = 0.0
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(acts[t])
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        term, trunc = term.cpu().numpy(), trunc.cpu().numpy()
+        for i, r in enumerate(rods):
+            o, rw, te, tr = r.env_step(acts[t, i])
+            np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=1e-7)
+            np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-9)
+            assert bool(term[i]) == te and bool(trunc[i]) == tr
+            worst = max(worst, np.max(np.abs(obs[i] - o) / (np.abs(o) + 1e-3)))
+    print(f"math_mode={math_mode}: worst |dobs|/(|obs|+1e-3) over {T} steps = {worst:.3e}")
+    # full state after T steps
+    st = env.backend.state_numpy()
+    for i, r in enumerate(rods):
+        np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(st["v"][i], r.get("v"), rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(st["Q"][i], r.get("Q"), rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(st["w"][i], r.get("w"), rtol=RTOL, atol=1e-5)
+        assert st["time"][i] == r.time
+    env.close()
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+def test_golden_oracle_rollout_fixture(torch_gpu, hip_lib, math_mode):
+    # committed fixture (tools/make_golden.py): does not need the oracle at run time
+    z = np.load(GOLD / "softpendulum_oracle_rollout.npz")
+    seeds = [int(s) for s in z["seeds"]]
+    env = _make(len(seeds), math_mode)
+    env.reset(seed=seeds)
+    for t in range(z["actions"].shape[0]):
+        obs, rew, term, trunc, _ = env.step(z["actions"][t])
+        np.testing.assert_allclose(obs.cpu().numpy(), z["obs"][t], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(rew.cpu().numpy(), z["reward"][t], rtol=RTOL, atol=1e-9)
+        assert not term.any() and not trunc.any()
+    x = env.backend.state_numpy()["x"]
+    np.testing.assert_allclose(x, z["x_final"], rtol=RTOL, atol=1e-8)
+    env.close()
+
+
+def test_fast_and_libm_modes_agree(torch_gpu, hip_lib):
+    n, T = 64, 10
+    acts = np.random.default_rng(3).uniform(-22, 22, (T, n)).astype(np.float32)
+    outs = []
+    for mode in (0, 1):
+        env = _make(n, mode)
+        env.reset(seed=100)
+        for t in range(T):
+            obs, rew, *_ = env.step(acts[t])
+        outs.append((obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), env.backend.state_numpy()))
+        env.close()
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(outs[0][2]["x"], outs[1][2]["x"], rtol=RTOL, atol=1e-8)
+
+
+def test_bitwise_determinism_and_batch_independence(torch_gpu, hip_lib):
+    # K7 (tests/envs/test_determinism.py:46-54 of the reference) and K8
+    n, T = 32, 3
+    acts = np.random.default_rng(0).uniform(-22, 22, (T, n)).astype(np.float32)
+
+    def run(idx):
+        env = _make(len(idx), 1)
+        env.reset(seed=[int(i) for i in idx])
+        res = []
+        for t in range(T):
+            o, r, te, tr, _ = env.step(acts[t, idx])
+            res.append((o.cpu().numpy().copy(), r.cpu().numpy().copy()))
+        st = env.backend.state_numpy()
+        env.close()
+        return res, st
+
+    full1, st1 = run(np.arange(n))
+    full2, st2 = run(np.arange(n))
+    for (o1, r1), (o2, r2) in zip(full1, full2):
+        np.testing.assert_array_equal(o1, o2)
+        np.testing.assert_array_equal(r1, r2)
+    for k in ("x", "v", "Q", "w"):
+        np.testing.assert_array_equal(st1[k], st2[k])
+    sub = np.array([5, 17, 31])
+    part, stp = run(sub)
+    for (o1, r1), (o2, r2) in zip(full1, part):
+        np.testing.assert_array_equal(o1[sub], o2)
+        np.testing.assert_array_equal(r1[sub], r2)
+    np.testing.assert_array_equal(st1["x"][sub], stp["x"])
+
+
+def test_single_env_facade_api(torch_gpu, hip_lib, oracle_built):
+    # mirrors tests/envs/test_envs.py:27-47 and test_determinism.py of the reference
+    import gym_softrobot_amd as gsa
+
+    env = gsa.make("SoftPendulum-v0")
+    ob, info = env.reset(seed=0)
+    assert isinstance(info, dict) and env.observation_space.contains(ob)
+    assert ob.dtype == env.observation_space.dtype
+    env.action_space.seed(0)
+    a = env.action_space.sample()
+    o, r, te, tr, inf = env.step(a)
+    assert env.observation_space.contains(o) and o.dtype == np.float32
+    assert np.isscalar(r) and isinstance(te, bool) and isinstance(tr, bool)
+    assert set(inf) == {"time", "TimeLimit.truncated"}
+    rod = oracle_built.OracleRod(env._vec.cfg)
+    rod.reset_pendulum(_theta(0))
+    oo, rr, _, _ = rod.env_step(a[0])
+    np.testing.assert_allclose(o, oo, rtol=RTOL, atol=1e-7)
+    assert r == pytest.approx(rr, rel=RTOL)
+    assert inf["time"] == rod.time
+    # _prev_action survives reset (soft_pendulum.py:97-99): obs[2] of the next reset
+    ob2, _ = env.reset(seed=0)
+    assert ob2[2] == np.float32(a[0]) and ob2[3] == ob[3]
+    env.close()
+
+
+def test_truncation_fires_on_step_126(torch_gpu, hip_lib):
+    env = _make(4, 1)
+    env.reset(seed=3)
+    zero = np.zeros(4, np.float32)
+    fired = None
+    for k in range(1, 128):
+        _, _, term, trunc, info = env.step(zero)
+        if trunc.any().item() and fired is None:
+            fired = k
+            assert trunc.all().item() and info["TimeLimit.truncated"].all()
+    assert fired == 126  # SURVEY.md App. B; soft_pendulum.py:226-229
+    env.close()
+
+
+def test_nan_state_terminates_with_penalty(torch_gpu, hip_lib):
+    env = _make(3, 1)
+    env.reset(seed=0)
+    st = env.backend.state()
+    st["velocity"][0, 1, 7] = float("nan")  # poison env 1, node 7
+    obs, rew, term, trunc, _ = env.step(np.zeros(3, np.float32))
+    term, rew = term.cpu().numpy(), rew.cpu().numpy()
+    assert term.tolist() == [False, True, False]
+    assert rew[1] == -50.0 and rew[0] >= 0.0   # soft_pendulum.py:205-208,231
+    env.close()
+
+
+def test_masked_reset_leaves_other_envs_untouched(torch_gpu, hip_lib):
+    env = _make(4, 1)
+    env.reset(seed=0)
+    env.step(np.full(4, 5.0, np.float32))
+    before = env.backend.state_numpy()
+    mask = np.array([False, True, False, True])
+    obs, _ = env.reset(mask=mask)
+    after = env.backend.state_numpy()
+    np.testing.assert_array_equal(before["x"][~mask], after["x"][~mask])
+    assert np.all(after["v"][mask] == 0.0) and np.all(after["time"][mask] == 0.0)
+    assert np.all(after["time"][~mask] > 0.0)
+    env.close()
+
+
+def test_full_size_batch_properties(torch_gpu, hip_lib, oracle_built):
+    # BASELINE config 2: 4096 envs x 50 elements.  Size-independent properties + spot
+    # parity of a few rods against the oracle.
+    n = 4096
+    env = _make(n, 1)
+    env.reset(seed=0)
+    acts = np.random.default_rng(1).uniform(-22, 22, (2, n)).astype(np.float32)
+    for t in range(2):
+        obs, rew, term, trunc, _ = env.step(acts[t])
+    obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+    assert np.isfinite(obs).all() and not term.any().item() and not trunc.any().item()
+    np.testing.assert_array_equal(obs[:, 2], acts[1])
+    np.testing.assert_allclose(rew, 10 * np.abs(obs[:, 0].astype(np.float64)) + obs[:, 3].astype(np.float64) ** 2, rtol=1e-5, atol=1e-6)
+    st = env.backend.state_numpy()
+    Q = st["Q"]
+    QQt = np.einsum("eimk,ejmk->eijk", Q, Q)
+    assert np.abs(QQt - np.eye(3)[None, :, :, None]).max() < 1e-11   # K5
+    assert np.abs(st["x"][:, 1:, 0]).max() == 0.0                      # BC: y0 = z0 = 0
+    assert np.abs(st["x"][:, 2, :]).max() < 1e-12                      # planar motion
+    for i in (0, 1, 777, 4095):
+        r = oracle_built.OracleRod(env.cfg)
+        r.reset_pendulum(_theta(i))
+        for t in range(2):
+            o, rw, _, _ = r.env_step(acts[t, i])
+        np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-8)
+    env.close()
+
+
+def test_known_answer_cantilever_on_gpu(torch_gpu, hip_lib):
+    # K2 on the HIP path itself (FIXED_BC + TIP_FORCE features), discrete-chain formula
+    import torch
+
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    n_el, F = 40, 0.02
+    cfg = _capi.softpendulum_config(2, n_elems=n_el, math_mode=1)
+    cfg.dt = 2e-4
+    cfg.features = _capi.FEAT_FIXED_BC | _capi.FEAT_TIP_FORCE | _capi.FEAT_ANALYTICAL_DAMPER
+    cfg.damping_constant = 0.8
+    cfg.tip_force[1] = F
+    be = HipRodBackend(cfg, 0)
+    be.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    be.substeps(None, 50000)
+    st = be.state_numpy()
+    E, G, r, L = 1e6, 1e6 / 3.0, 0.05, 1.0
+    A = np.pi * r * r
+    I = A * A / (4 * np.pi)
+    expect = F * L**3 / (3 * E * I) * (1 - 1 / n_el) * (1 - 1 / (2 * n_el)) + F * L / (27.0 / 28.0 * G * A)
+    assert np.abs(st["v"]).max() < 1e-8
+    assert st["x"][0, 1, -1] == pytest.approx(expect, rel=2e-4)
+    assert st["x"][1, 1, -1] == st["x"][0, 1, -1]
+    be.close()

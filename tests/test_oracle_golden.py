@@ -1,0 +1,135 @@
+"""Pins the oracle: (i) the reference-derived reset vectors (SURVEY.md App. B — the only
+golden values gym-softrobot's own code determines without PyElastica), (ii) agreement of
+the two independent restatements (C loops vs NumPy array style), (iii) regression pins
+of the C oracle's own rollout (labelled as such in tools/make_golden.py)."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from gym_softrobot_amd._capi import softpendulum_config
+from gym_softrobot_amd.seeding import initial_angle, np_random
+
+GOLD = Path(__file__).parent / "golden"
+
+
+def _theta(seed):
+    rng, _ = np_random(seed)
+    return initial_angle(rng)
+
+
+def test_reset_observation_golden(oracle_built):
+    vectors = json.loads((GOLD / "softpendulum_reset.json").read_text())
+    cfg = softpendulum_config(1)
+    for v in vectors:
+        th = _theta(v["seed"])
+        assert th == v["theta0"]  # bit-exact: PCG64 stream + deg2rad
+        rod = oracle_built.OracleRod(cfg)
+        rod.reset_pendulum(th)
+        obs = rod.observe()
+        assert obs.dtype == np.float32
+        np.testing.assert_array_equal(obs[:3], np.zeros(3, np.float32))
+        # float32 of an fp64 value that agrees to ~1e-16: allow one float32 ulp
+        assert abs(float(obs[3]) - v["obs"][3]) <= np.spacing(np.float32(abs(v["obs"][3])))
+
+
+def test_survey_appendix_b_values(oracle_built):
+    # SURVEY.md App. B table (seed -> obs0[3]) as independently computed by the survey
+    expect = {0: -0.02390432, 1: -0.00206326, 42: -0.04781435, 123: -0.0318264}
+    cfg = softpendulum_config(1)
+    for seed, th_obs in expect.items():
+        rod = oracle_built.OracleRod(cfg)
+        rod.reset_pendulum(_theta(seed))
+        assert rod.observe()[3] == pytest.approx(th_obs, abs=5e-9)
+
+
+def test_derived_constants_match_survey(oracle_built):
+    # App. B derived numbers: element mass, EA, ac*G*A (with G = E/3 here), EI, J1, c_t
+    cfg = softpendulum_config(1)
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_pendulum(_theta(0))
+    mass = rod.get("mass")
+    assert mass[1] == pytest.approx(0.15707963, rel=1e-7)
+    assert mass[0] == pytest.approx(0.07853982, rel=1e-7)
+    assert mass.sum() == pytest.approx(7.853982, rel=1e-7)
+    shear = rod.get("shear")
+    assert shear[2, 0] == pytest.approx(7853.9816, rel=1e-7)
+    assert shear[0, 0] == pytest.approx(27.0 / 28.0 * (1e6 / 3.0) * np.pi * 0.05**2, rel=1e-12)
+    bend = rod.get("bend")
+    assert bend[0, 0] == pytest.approx(4.9087385, rel=1e-7)
+    assert rod.get("J")[0, 0] == pytest.approx(9.8174770e-5, rel=1e-7)
+    assert rod.get("damp_t")[0] == pytest.approx(0.99999980000002, rel=1e-14)
+
+
+def test_c_and_numpy_restatements_agree(oracle_built):
+    from oracle.softrod_oracle_np import NumpyRod
+
+    cfg = softpendulum_config(1)
+    cfg.n_substeps = 60
+    th = _theta(42)
+    c = oracle_built.OracleRod(cfg)
+    p = NumpyRod(cfg)
+    c.reset_pendulum(th)
+    p.reset_pendulum(th)
+    for name, arr in (("x", p.x), ("Q", p.Q), ("mass", p.mass), ("bend", p.bend), ("damp_r", p.damp_r)):
+        np.testing.assert_array_equal(c.get(name), arr)
+    for a in (7.5, -20.0, 3.25):
+        oc = c.env_step(a)
+        op = p.env_step(a)
+        np.testing.assert_allclose(oc[0], op[0], rtol=1e-6, atol=1e-9)
+        assert oc[1] == pytest.approx(op[1], rel=1e-9)
+        assert oc[2:] == op[2:]
+    np.testing.assert_allclose(c.get("x"), p.x, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(c.get("Q"), p.Q, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(c.get("w"), p.w, rtol=0, atol=1e-9)
+    assert c.time == float(p.time)
+
+
+def test_oracle_regression_rollout(oracle_built):
+    z = np.load(GOLD / "softpendulum_oracle_rollout.npz")
+    cfg = softpendulum_config(1)
+    for j, seed in enumerate(z["seeds"]):
+        rod = oracle_built.OracleRod(cfg)
+        rod.reset_pendulum(_theta(int(seed)))
+        for t in range(z["actions"].shape[0]):
+            obs, rew, term, trunc = rod.env_step(z["actions"][t, j])
+            np.testing.assert_allclose(obs, z["obs"][t, j], rtol=1e-6, atol=1e-7)
+            assert rew == pytest.approx(z["reward"][t, j], rel=1e-9)
+            assert not term and not trunc
+        np.testing.assert_allclose(rod.get("x"), z["x_final"][j], rtol=0, atol=1e-10)
+
+
+def test_oracle_determinism(oracle_built):
+    # mirrors tests/envs/test_determinism.py:46-54 of the reference
+    cfg = softpendulum_config(1)
+    outs = []
+    for _ in range(2):
+        rod = oracle_built.OracleRod(cfg)
+        rod.reset_pendulum(_theta(0))
+        outs.append([rod.env_step(a) for a in (1.5, -3.0, 21.0)])
+    for (o1, r1, t1, x1), (o2, r2, t2, x2) in zip(*outs):
+        np.testing.assert_array_equal(o1, o2)
+        assert r1 == r2 and t1 == t2 and x1 == x2
+
+
+def test_truncation_step_and_time(oracle_built):
+    # soft_pendulum.py:226-229 strict '>' on a float64 accumulated by two half-adds per
+    # substep -> fires on env.step #126; with one add per substep #125.
+    from gym_softrobot_amd.envs.soft_pendulum import _time_table
+
+    cfg = softpendulum_config(1)
+    tab = _time_table(cfg, 126)
+    assert tab[125] == 4.999999999995016 and not tab[125] > 5.0
+    assert tab[126] > 5.0
+    cfg.time_two_half_adds = 0
+    tab1 = _time_table(cfg, 126)
+    assert tab1[125] > 5.0 and not tab1[124] > 5.0
+    # the oracle accumulates the same float64
+    cfg = softpendulum_config(1)
+    cfg.n_elem = 4
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_pendulum(_theta(0))
+    for k in range(1, 4):
+        rod.env_step(0.0)
+        assert rod.time == tab[k]
