@@ -167,6 +167,16 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7 (same soname as /opt/rocm's).  The first one
+    # mapped wins symbol resolution, and a process with BOTH runtimes breaks (streams and
+    # device state are per runtime; observed on the MI355X box as hipGetDeviceCount
+    # failing).  The Python host path always runs next to torch, so make sure torch's
+    # runtime is the one libsoftrod_hip.so binds to.  A pure C/C++ host never imports
+    # torch and binds to the system ROCm runtime instead.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
     path = library_path()
     if not path.exists():
         raise SoftrodError(
@@ -188,7 +198,7 @@ def check(rc: int, handle=None) -> None:
     if rc == 0:
         return
     msg = ""
-    if handle is not None and _lib is not None:
-        raw = _lib.softrod_last_error(handle)
+    if _lib is not None:
+        raw = _lib.softrod_last_error(handle)  # NULL handle -> this thread's last error
         msg = raw.decode() if raw else ""
     raise SoftrodError(f"softrod call failed with code {rc}: {msg}")

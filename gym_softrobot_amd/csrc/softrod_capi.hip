@@ -198,8 +198,11 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
-        return fail(nullptr, SOFTROD_ENODEV, "no HIP device visible");
+    const hipError_t cnt_err = hipGetDeviceCount(&ndev);
+    if (cnt_err != hipSuccess || ndev < 1)
+        return fail(nullptr, SOFTROD_ENODEV,
+                    std::string("no HIP device visible: hipGetDeviceCount -> ") +
+                        hipGetErrorString(cnt_err) + ", count " + std::to_string(ndev));
     if (device < 0 || device >= ndev) return fail(nullptr, SOFTROD_EINVAL, "device out of range");
     softrod_handle* h = new (std::nothrow) softrod_handle;
     if (!h) return fail(nullptr, SOFTROD_ENOMEM, "host allocation failed");

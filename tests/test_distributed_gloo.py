@@ -1,0 +1,108 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes run the sharded env (oracle-backed test
+double as the local stepper) and must reproduce the single-process batch bit-for-bit
+after the packed all-gather."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, T, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.distributed import ShardedVecEnv, shard_bounds
+    from tests.oracle_backend import OracleBackend
+
+    lo, hi = shard_bounds(total, world, rank)
+    cfg = _capi.softpendulum_config(hi - lo)
+    cfg.n_substeps = 40  # keep the CPU suite quick; the sharding logic does not depend on it
+    local = gsa.VecSoftPendulumEnv(hi - lo, backend=OracleBackend(cfg))
+    local.cfg.n_substeps = 40
+    env = ShardedVecEnv(local, total)
+    obs0, _ = env.reset(seed=7)
+    acts = np.random.default_rng(5).uniform(-22, 22, (T, total)).astype(np.float32)
+    out = [obs0.clone().numpy()]
+    for t in range(T):
+        o, r, te, tr, _ = env.step(acts[t])
+        out.append((o.clone().numpy(), r.clone().numpy(), te.clone().numpy(), tr.clone().numpy()))
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single(total, T):
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from tests.oracle_backend import OracleBackend
+
+    cfg = _capi.softpendulum_config(total)
+    cfg.n_substeps = 40
+    env = gsa.VecSoftPendulumEnv(total, backend=OracleBackend(cfg), numpy_output=True)
+    obs0, _ = env.reset(seed=7)
+    acts = np.random.default_rng(5).uniform(-22, 22, (T, total)).astype(np.float32)
+    out = [obs0.copy()]
+    for t in range(T):
+        o, r, te, tr, _ = env.step(acts[t])
+        out.append((o.copy(), r.copy(), te.copy(), tr.copy()))
+    return out
+
+
+def test_pack_unpack_roundtrip_is_bit_exact():
+    from gym_softrobot_amd.distributed import pack_outputs, unpack_outputs
+
+    n = 9
+    g = torch.Generator().manual_seed(0)
+    obs = torch.randn((n, 4), generator=g)
+    rew = torch.randn(n, dtype=torch.float64, generator=g) * 1e3
+    rew[3] = -50.0
+    term = (torch.arange(n) % 3 == 0).to(torch.uint8)
+    trunc = (torch.arange(n) % 2 == 0)
+    o, r, te, tr = unpack_outputs(pack_outputs(obs, rew, term, trunc))
+    assert torch.equal(o, obs) and torch.equal(r, rew)
+    assert torch.equal(te, term.bool()) and torch.equal(tr, trunc)
+
+
+def test_shard_bounds():
+    from gym_softrobot_amd.distributed import shard_bounds
+
+    assert [shard_bounds(32768, 8, r) for r in (0, 7)] == [(0, 4096), (28672, 32768)]
+    with pytest.raises(ValueError):
+        shard_bounds(10, 4, 0)
+
+
+def test_world2_gloo_matches_single_process(oracle_built):
+    total, T, world = 6, 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _single(total, T)
+    np.testing.assert_array_equal(got[0], ref[0])
+    for g, r in zip(got[1:], ref[1:]):
+        for a, b in zip(g, r):
+            np.testing.assert_array_equal(a, b)

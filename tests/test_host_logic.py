@@ -1,0 +1,108 @@
+"""Host-side logic of the env classes (no GPU): seeding, spaces, API conformance in the
+shape of the reference's tests/envs/test_envs.py and test_determinism.py, run on the
+oracle-backed test double."""
+import numpy as np
+import pytest
+
+import gym_softrobot_amd as gsa
+from gym_softrobot_amd import _capi
+from gym_softrobot_amd.seeding import initial_angle, np_random
+from gym_softrobot_amd.spaces import Box
+
+from .oracle_backend import OracleBackend
+
+
+def _env(**kw):
+    cfg = _capi.softpendulum_config(1, **{k: v for k, v in kw.items() if k in ("n_elems",)})
+    return gsa.SoftPendulumEnv(backend=OracleBackend(cfg), **kw)
+
+
+def test_registry_lists_softpendulum():
+    assert "SoftPendulum-v0" in gsa.registered()
+    with pytest.raises(KeyError):
+        gsa.make("OctoFlat-v0")
+
+
+def test_seeding_matches_gymnasium_convention():
+    rng, s = np_random(0)
+    assert s == 0 and rng.random() == 0.6369616873214543
+    assert initial_angle(np_random(0)[0]) == np.deg2rad(90 + (0.6369616873214543 - 0.5) * 10)
+    with pytest.raises(ValueError):
+        np_random(-1)
+
+
+def test_spaces_match_reference():
+    env = _env()
+    assert isinstance(env.action_space, Box) and env.action_space.shape == (1,)
+    assert env.action_space.dtype == np.float32
+    assert float(env.action_space.low[0]) == -22.0 and float(env.action_space.high[0]) == 22.0
+    assert env.observation_space.shape == (4,) and env.observation_space.dtype == np.float32
+    assert env.step_skip == 400 and env.total_steps == 50000
+    with pytest.raises(ValueError):
+        gsa.SoftPendulumEnv(render_mode="human", backend=OracleBackend(_capi.softpendulum_config(1)))
+
+
+def test_env_api_conformance(oracle_built):
+    # tests/envs/test_envs.py:27-47 of the reference
+    env = _env()
+    ob, info = env.reset()
+    assert isinstance(info, dict) and env.observation_space.contains(ob)
+    assert ob.dtype == env.observation_space.dtype
+    a = env.action_space.sample()
+    observation, reward, terminated, truncated, _info = env.step(a)
+    assert env.observation_space.contains(observation)
+    assert np.isscalar(reward) and isinstance(terminated, bool) and isinstance(truncated, bool)
+    assert observation.dtype == np.float32
+    assert set(_info) == {"time", "TimeLimit.truncated"}
+    assert _info["time"] == pytest.approx(0.04, rel=1e-9)
+    env.close()
+
+
+def test_env_determinism(oracle_built):
+    # tests/envs/test_determinism.py:12-54 of the reference
+    runs = []
+    for _ in range(2):
+        env = _env()
+        ob0, _ = env.reset(seed=0)
+        env.action_space.seed(0)
+        acts = [env.action_space.sample() for _ in range(3)]
+        runs.append((ob0, acts, [env.step(a) for a in acts]))
+        env.close()
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    for a1, a2 in zip(runs[0][1], runs[1][1]):
+        np.testing.assert_array_equal(a1, a2)
+    for (o1, r1, t1, x1, _), (o2, r2, t2, x2, _) in zip(runs[0][2], runs[1][2]):
+        np.testing.assert_array_equal(o1, o2)
+        assert r1 == r2 and t1 == t2 and x1 == x2
+
+
+def test_reset_continues_rng_stream_and_keeps_prev_action(oracle_built):
+    env = _env()
+    ob_a, _ = env.reset(seed=5)
+    env.step(np.array([3.5], np.float32))
+    ob_b, _ = env.reset()  # no seed: next draw of the same stream (soft_pendulum.py:114,123)
+    rng, _ = np_random(5)
+    th1, th2 = initial_angle(rng), initial_angle(rng)
+    assert th1 != th2
+    assert ob_b[2] == np.float32(3.5)  # _prev_action survives reset (soft_pendulum.py:97-99)
+    assert ob_a[3] != ob_b[3]
+    env.close()
+
+
+def test_vec_env_seeds_are_seed_plus_index(oracle_built):
+    n = 3
+    cfg = _capi.softpendulum_config(n)
+    vec = gsa.VecSoftPendulumEnv(n, backend=OracleBackend(cfg), numpy_output=True)
+    obs, _ = vec.reset(seed=10)
+    for i in range(n):
+        single = _env()
+        o, _ = single.reset(seed=10 + i)
+        np.testing.assert_array_equal(obs[i], o)
+    acts = np.array([1.0, -2.0, 3.0], np.float32)
+    o, r, te, tr, info = vec.step(acts)
+    assert o.shape == (n, 4) and r.shape == (n,) and r.dtype == np.float64
+    assert te.dtype == bool and tr.dtype == bool and info["time"].shape == (n,)
+    # masked reset only touches the masked env and its step counter
+    vec.reset(mask=np.array([False, True, False]))
+    assert vec._steps.tolist() == [1, 0, 1]
+    vec.close()

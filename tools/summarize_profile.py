@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_gpu.sh output directory into one JSON document:
+per-kernel time from `rocprofv3 --kernel-trace --stats`, and per-launch HBM bytes of the
+step kernel from the FETCH_SIZE / WRITE_SIZE PMC passes.
+
+Units (MI355X_MICROARCH.md §HBM, cdna_hip_programming.md §7): FETCH_SIZE and WRITE_SIZE
+are in KiB; on gfx950 FETCH_SIZE under-reports a wide coalesced read stream by exactly 2x
+(calibrated for 16 B/lane; this kernel loads 8 B/lane, uncalibrated) — both the raw and
+the 2x-corrected read figure are reported and the corrected one is used for `traffic`.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+KERNEL = "softrod_step_kernel"
+
+
+def read_csv(path):
+    with open(path, newline="") as f:
+        return list(csv.DictReader(f))
+
+
+def kernel_stats(root):
+    out = []
+    for p in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        for r in read_csv(p):
+            out.append({
+                "name": r.get("Name", "")[:120],
+                "calls": int(float(r.get("Calls", 0))),
+                "total_ns": float(r.get("TotalDurationNs", 0)),
+                "avg_ns": float(r.get("AverageNs", 0)),
+                "min_ns": float(r.get("MinNs", 0)),
+                "max_ns": float(r.get("MaxNs", 0)),
+                "pct": float(r.get("Percentage", 0)),
+            })
+    out.sort(key=lambda r: -r["total_ns"])
+    return out
+
+
+def counters(root, sub):
+    """-> {counter_name: [per-dispatch values of the step kernel]} and register info"""
+    vals = defaultdict(list)
+    regs = {}
+    for p in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in read_csv(p):
+            if KERNEL not in r.get("Kernel_Name", ""):
+                continue
+            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            regs = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+                                          "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
+    return vals, regs
+
+
+def main(root):
+    doc = {"dir": os.path.basename(root.rstrip("/"))}
+    ks = kernel_stats(root)
+    doc["kernel_stats"] = ks[:8]
+    step = [k for k in ks if KERNEL in k["name"]]
+    if step:
+        doc["step_kernel_avg_ms"] = step[0]["avg_ns"] / 1e6
+        doc["step_kernel_calls"] = step[0]["calls"]
+    fetch, regs = counters(root, "pmc_fetch")
+    write, _ = counters(root, "pmc_write")
+    sq, _ = counters(root, "pmc_sq")
+    doc["registers"] = regs
+    if fetch.get("FETCH_SIZE"):
+        f = fetch["FETCH_SIZE"]
+        doc["FETCH_SIZE_KiB_per_launch_raw"] = sum(f) / len(f)
+    if write.get("WRITE_SIZE"):
+        w = write["WRITE_SIZE"]
+        doc["WRITE_SIZE_KiB_per_launch_raw"] = sum(w) / len(w)
+    if "FETCH_SIZE_KiB_per_launch_raw" in doc and "WRITE_SIZE_KiB_per_launch_raw" in doc:
+        rd = doc["FETCH_SIZE_KiB_per_launch_raw"] * 1024.0
+        wr = doc["WRITE_SIZE_KiB_per_launch_raw"] * 1024.0
+        doc["hbm_bytes_per_launch_raw"] = rd + wr
+        doc["hbm_bytes_per_launch"] = 2.0 * rd + wr  # gfx950 FETCH_SIZE x2 correction
+    if sq:
+        doc["sq_per_launch"] = {k: sum(v) / len(v) for k, v in sq.items()}
+    for name in ("bench_trace.log", "bench_pmc_fetch.log"):
+        p = os.path.join(root, name)
+        if os.path.exists(p):
+            for line in open(p):
+                if line.startswith("{"):
+                    try:
+                        b = json.loads(line)
+                        doc.setdefault("bench_lines", {})[name] = {
+                            "value": b["value"], "ms_per_step": b["ms_per_step"],
+                            "kernel_ms_avg": b["roofline"]["kernel_ms_avg"],
+                            "frac": b["roofline"]["frac"],
+                        }
+                    except Exception:  # noqa: BLE001
+                        pass
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
