@@ -104,10 +104,10 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
     if (h->cfg.math_mode == SOFTROD_MATH_FAST)
-        hipLaunchKernelGGL(softrod_step_kernel<SOFTROD_MATH_FAST>, grid, block, 0, st, h->P, h->S,
+        hipLaunchKernelGGL(softrod_step_fast_kernel, grid, block, 0, st, h->P, h->S,
                            actions, obs, reward, term, trunc, n_sub, epilogue);
     else
-        hipLaunchKernelGGL(softrod_step_kernel<SOFTROD_MATH_LIBM>, grid, block, 0, st, h->P, h->S,
+        hipLaunchKernelGGL(softrod_step_libm_kernel, grid, block, 0, st, h->P, h->S,
                            actions, obs, reward, term, trunc, n_sub, epilogue);
     SR_HIP(h, hipGetLastError());
     if (timing) {

@@ -9,6 +9,14 @@
 // Q[k+1]Q[k]^T, 1/2(a[k]+a[k-1])) is a DPP wave shift (v_mov_b32_dpp wave_shl:1 /
 // wave_shr:1, 2 per fp64 value) — no LDS round trip, no barrier.
 //
+// Two step kernels share this file's state layout:
+//   softrod_step_libm_kernel  SOFTROD_MATH_LIBM: the substep exactly as PyElastica
+//                             writes it (sqrt / sincos / acos / pow / divisions, two
+//                             half kinematic steps, constrain_values after each) — the
+//                             on-device reference the fast kernel is tested against.
+//   softrod_step_fast_kernel  SOFTROD_MATH_FAST (default): same mathematics,
+//                             reorganised for the fp64 VALU (softrod_fast.hpp).
+//
 // The arithmetic restates PyElastica's PositionVerlet substep for the simulator that
 // build_soft_pendulum assembles (gym_softrobot/envs/soft_pendulum/build.py:29-115);
 // the order of operations is documented in DESIGN.md "substep order" and mirrored by
@@ -57,27 +65,27 @@ struct StatePtrs {
 // cross-lane: full-wave shift by one lane (GFX9 DPP wave_shl / wave_shr)
 // ---------------------------------------------------------------------------------
 #ifdef SOFTROD_USE_BPERMUTE
-__device__ __forceinline__ double from_next(double x, int lane) {
+__device__ __forceinline__ double from_next(double x) {
     double y = __shfl_down(x, 1);
-    return lane == 63 ? 0.0 : y;
+    return (threadIdx.x & 63) == 63 ? 0.0 : y;
 }
-__device__ __forceinline__ double from_prev(double x, int lane) {
+__device__ __forceinline__ double from_prev(double x) {
     double y = __shfl_up(x, 1);
-    return lane == 0 ? 0.0 : y;
+    return (threadIdx.x & 63) == 0 ? 0.0 : y;
 }
 #else
 // lane k receives lane k+1's value; lane 63 receives 0.
-__device__ __forceinline__ double from_next(double x, int) {
+__device__ __forceinline__ double from_next(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true);  // wave_shl:1, bound_ctrl:0 -> 0
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // lane k receives lane k-1's value; lane 0 receives 0.
-__device__ __forceinline__ double from_prev(double x, int) {
+__device__ __forceinline__ double from_prev(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);  // wave_shr:1, bound_ctrl:0 -> 0
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 #endif
@@ -89,29 +97,6 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 
 // ---------------------------------------------------------------------------------
-// fast-path scalar helpers (SOFTROD_MATH_FAST)
-// ---------------------------------------------------------------------------------
-// 1/x: v_rcp_f64 seed (~2^-25) + two Newton steps -> <= 1 ulp for normal x.
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    return r;
-}
-// 1/sqrt(x): v_rsq_f64 seed + two Newton steps.
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    double r = __builtin_amdgcn_rsq(x);
-    double hx = 0.5 * x;
-    double e = fma(-hx * r, r, 0.5);
-    r = fma(r, e, r);
-    e = fma(-hx * r, r, 0.5);
-    r = fma(r, e, r);
-    return r;
-}
-
-// ---------------------------------------------------------------------------------
 // per-lane register state
 // ---------------------------------------------------------------------------------
 struct LaneState {
@@ -119,58 +104,6 @@ struct LaneState {
     double Q[9], w[3];  // element k: Q row-major (rows d1,d2,d3 in lab frame), omega local
     double t[3];        // tangent of element k at the last force evaluation
 };
-
-// Kinematic update (PyElastica overload_operator_kinematic_numba + _get_rotation_matrix):
-//   x += h v ;  Q <- R(h w) Q  with R the transposed Rodrigues matrix.
-template <int MATH>
-__device__ __forceinline__ void kinematic_step(const RodParams& P, double h, LaneState& L) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) L.x[i] = fma(h, L.v[i], L.x[i]);
-    double a0 = h * L.w[0], a1 = h * L.w[1], a2 = h * L.w[2];
-    double R[9];
-    const double t2 = a0 * a0 + a1 * a1 + a2 * a2;
-    bool fast = false;
-    if (MATH == SOFTROD_MATH_FAST) fast = !__any(t2 >= 0.01);
-    if (MATH == SOFTROD_MATH_FAST && fast) {
-        // sin(th)/th and (1-cos(th))/th^2 as Taylor polynomials in th^2 < 0.01
-        // (truncation < 2e-22); the 1e-14 of the axis normalisation is dropped
-        // (relative effect on the rotation increment < 1e-14/th).
-        const double sc = fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, -1.0 / 39916800.0, 1.0 / 362880.0),
-                                                   -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
-        const double cc = fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, -1.0 / 479001600.0, 1.0 / 3628800.0),
-                                                   -1.0 / 40320.0), 1.0 / 720.0), -1.0 / 24.0), 0.5);
-        const double s0 = sc * a0, s1 = sc * a1, s2 = sc * a2;
-        const double c01 = cc * a0 * a1, c02 = cc * a0 * a2, c12 = cc * a1 * a2;
-        R[0] = 1.0 - cc * (a1 * a1 + a2 * a2);
-        R[4] = 1.0 - cc * (a0 * a0 + a2 * a2);
-        R[8] = 1.0 - cc * (a0 * a0 + a1 * a1);
-        R[1] = s2 + c01;  R[3] = -s2 + c01;
-        R[2] = -s1 + c02; R[6] = s1 + c02;
-        R[5] = s0 + c12;  R[7] = -s0 + c12;
-    } else {
-        const double th = sqrt(t2);
-        const double den = th + P.eps_rot_axis;
-        a0 /= den; a1 /= den; a2 /= den;
-        double up, cs;
-        sincos(th, &up, &cs);
-        const double usq = 1.0 - cs;
-        R[0] = 1.0 - usq * (a1 * a1 + a2 * a2);
-        R[4] = 1.0 - usq * (a0 * a0 + a2 * a2);
-        R[8] = 1.0 - usq * (a0 * a0 + a1 * a1);
-        R[1] = up * a2 + usq * a0 * a1;  R[3] = -up * a2 + usq * a0 * a1;
-        R[2] = -up * a1 + usq * a0 * a2; R[6] = up * a1 + usq * a0 * a2;
-        R[5] = up * a0 + usq * a1 * a2;  R[7] = -up * a0 + usq * a1 * a2;
-    }
-    double Qn[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            Qn[i * 3 + j] = R[i * 3 + 0] * L.Q[0 * 3 + j] + R[i * 3 + 1] * L.Q[1 * 3 + j] +
-                            R[i * 3 + 2] * L.Q[2 * 3 + j];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) L.Q[i] = Qn[i];
-}
 
 struct BcTargets {
     double pos[3];
@@ -218,36 +151,55 @@ __device__ __forceinline__ void constrain_rates(const RodParams& P, int lane, La
     }
 }
 
+// =================================================================================
+// SOFTROD_MATH_LIBM: the substep as written by PyElastica
+// =================================================================================
+
+// overload_operator_kinematic_numba + _get_rotation_matrix:
+//   x += h v ;  Q <- R(h w) Q  with R the transposed Rodrigues matrix.
+__device__ __forceinline__ void libm_kinematic_step(const RodParams& P, double h, LaneState& L) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) L.x[i] += h * L.v[i];
+    double a0 = h * L.w[0], a1 = h * L.w[1], a2 = h * L.w[2];
+    const double th = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+    const double den = th + P.eps_rot_axis;
+    a0 /= den; a1 /= den; a2 /= den;
+    double up, cs;
+    sincos(th, &up, &cs);
+    const double usq = 1.0 - cs;
+    double R[9];
+    R[0] = 1.0 - usq * (a1 * a1 + a2 * a2);
+    R[4] = 1.0 - usq * (a0 * a0 + a2 * a2);
+    R[8] = 1.0 - usq * (a0 * a0 + a1 * a1);
+    R[1] = up * a2 + usq * a0 * a1;  R[3] = -up * a2 + usq * a0 * a1;
+    R[2] = -up * a1 + usq * a0 * a2; R[6] = up * a1 + usq * a0 * a2;
+    R[5] = up * a0 + usq * a1 * a2;  R[7] = -up * a0 + usq * a1 * a2;
+    double Qn[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Qn[i * 3 + j] = R[i * 3 + 0] * L.Q[0 * 3 + j] + R[i * 3 + 1] * L.Q[1 * 3 + j] +
+                            R[i * 3 + 2] * L.Q[2 * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) L.Q[i] = Qn[i];
+}
+
 // Internal forces/torques + forcing + dynamic update + damper + rate constraints:
 // steps (3)-(6) of the substep (DESIGN.md "substep order").
-template <int MATH>
-__device__ __forceinline__ void dynamic_step(const RodParams& P, int lane, double action,
-                                             double inv_mass, double mass, LaneState& L) {
+__device__ __forceinline__ void libm_dynamic_step(const RodParams& P, int lane, double action,
+                                                  double mass, LaneState& L) {
     const int n = P.n_elem;
     const bool node_valid = lane <= n;
     const bool elem_valid = lane < n;
     const bool vor_valid = lane < n - 1;
 
     // ---- geometry: lengths, tangents, dilatation (_compute_all_dilatations) ----
-    const double xn0 = from_next(L.x[0], lane), xn1 = from_next(L.x[1], lane),
-                 xn2 = from_next(L.x[2], lane);
+    const double xn0 = from_next(L.x[0]), xn1 = from_next(L.x[1]), xn2 = from_next(L.x[2]);
     const double d0 = xn0 - L.x[0], d1 = xn1 - L.x[1], d2 = xn2 - L.x[2];
-    const double dd = d0 * d0 + d1 * d1 + d2 * d2;
-    double len, e, inv_e, inv_len;
-    if (MATH == SOFTROD_MATH_FAST) {
-        const double r = fast_rsqrt(dd);
-        len = fma(dd, r, P.eps_length);
-        inv_len = fma(-P.eps_length * r, r, r);  // 1/(|d|+eps) to first order in eps
-        L.t[0] = d0 * inv_len; L.t[1] = d1 * inv_len; L.t[2] = d2 * inv_len;
-        e = len * P.inv_rest_len;
-        inv_e = P.rest_len * inv_len;
-    } else {
-        len = sqrt(dd) + P.eps_length;
-        inv_len = 1.0 / len;
-        L.t[0] = d0 / len; L.t[1] = d1 / len; L.t[2] = d2 / len;
-        e = len / P.rest_len;
-        inv_e = 1.0 / e;
-    }
+    const double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2) + P.eps_length;
+    L.t[0] = d0 / len; L.t[1] = d1 / len; L.t[2] = d2 / len;
+    const double e = len / P.rest_len;
 
     // ---- shear/stretch: sigma = e Q t - z ; n = S sigma ----
     const double qt0 = L.Q[0] * L.t[0] + L.Q[1] * L.t[1] + L.Q[2] * L.t[2];
@@ -258,28 +210,21 @@ __device__ __forceinline__ void dynamic_step(const RodParams& P, int lane, doubl
     const double n2 = P.shear[2] * (e * qt2 - 1.0);
 
     // ---- internal force: difference of Q^T n / e ----
-    double cs0, cs1, cs2;
-    if (MATH == SOFTROD_MATH_FAST) {
-        cs0 = (L.Q[0] * n0 + L.Q[3] * n1 + L.Q[6] * n2) * inv_e;
-        cs1 = (L.Q[1] * n0 + L.Q[4] * n1 + L.Q[7] * n2) * inv_e;
-        cs2 = (L.Q[2] * n0 + L.Q[5] * n1 + L.Q[8] * n2) * inv_e;
-    } else {
-        cs0 = (L.Q[0] * n0 + L.Q[3] * n1 + L.Q[6] * n2) / e;
-        cs1 = (L.Q[1] * n0 + L.Q[4] * n1 + L.Q[7] * n2) / e;
-        cs2 = (L.Q[2] * n0 + L.Q[5] * n1 + L.Q[8] * n2) / e;
-    }
+    double cs0 = (L.Q[0] * n0 + L.Q[3] * n1 + L.Q[6] * n2) / e;
+    double cs1 = (L.Q[1] * n0 + L.Q[4] * n1 + L.Q[7] * n2) / e;
+    double cs2 = (L.Q[2] * n0 + L.Q[5] * n1 + L.Q[8] * n2) / e;
     cs0 = elem_valid ? cs0 : 0.0;
     cs1 = elem_valid ? cs1 : 0.0;
     cs2 = elem_valid ? cs2 : 0.0;
-    const double f0 = cs0 - from_prev(cs0, lane);
-    const double f1 = cs1 - from_prev(cs1, lane);
-    const double f2 = cs2 - from_prev(cs2, lane);
+    const double f0 = cs0 - from_prev(cs0);
+    const double f1 = cs1 - from_prev(cs1);
+    const double f2 = cs2 - from_prev(cs2);
 
     // ---- bend/twist: kappa = -log(Q_{k+1} Q_k^T)/D  (_inv_rotate) ----
     double Qn[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) Qn[i] = from_next(L.Q[i], lane);
-    const double len_n = from_next(len, lane);
+    for (int i = 0; i < 9; ++i) Qn[i] = from_next(L.Q[i]);
+    const double len_n = from_next(len);
 #define SR_ROWDOT(i, j) (Qn[3 * (i)] * L.Q[3 * (j)] + Qn[3 * (i) + 1] * L.Q[3 * (j) + 1] + \
                          Qn[3 * (i) + 2] * L.Q[3 * (j) + 2])
     const double vec0 = SR_ROWDOT(2, 1) - SR_ROWDOT(1, 2);
@@ -287,41 +232,12 @@ __device__ __forceinline__ void dynamic_step(const RodParams& P, int lane, doubl
     const double vec2 = SR_ROWDOT(1, 0) - SR_ROWDOT(0, 1);
     const double trace = (SR_ROWDOT(0, 0) + SR_ROWDOT(1, 1)) + SR_ROWDOT(2, 2);
 #undef SR_ROWDOT
-    const double carg = 0.5 * trace - 0.5 - P.acos_shift;
-    double fk;  // kappa = vec * fk
-    bool fastk = false;
-    const double sarg = 1.0 - carg;
-    if (MATH == SOFTROD_MATH_FAST) fastk = !__any(vor_valid && !(sarg < 0.02));
-    if (MATH == SOFTROD_MATH_FAST && fastk) {
-        // theta/sin(theta) with cos(theta) = 1 - s, y = s/2 = sin^2(theta/2):
-        //   asin(sqrt y)/(sqrt y sqrt(1-y)) = sum_k (2k)!!/(2k+1)!! y^k ; y < 0.01,
-        //   9 terms -> truncation < 4e-19.  eps_sin (1e-14) is dropped.
-        const double y = 0.5 * sarg;
-        double g = 32768.0 / 109395.0;                     // k = 8
-        g = fma(g, y, 2048.0 / 6435.0);                    // k = 7
-        g = fma(g, y, 1024.0 / 3003.0);                    // k = 6
-        g = fma(g, y, 256.0 / 693.0);                      // k = 5
-        g = fma(g, y, 128.0 / 315.0);                      // k = 4
-        g = fma(g, y, 16.0 / 35.0);                        // k = 3
-        g = fma(g, y, 8.0 / 15.0);                         // k = 2
-        g = fma(g, y, 2.0 / 3.0);                          // k = 1
-        g = fma(g, y, 1.0);
-        fk = -0.5 * g * P.inv_rest_vor;
-    } else {
-        const double theta = acos(carg);
-        fk = (-0.5 * theta / sin(theta + P.eps_sin)) / P.rest_vor;
-    }
+    const double theta = acos(0.5 * trace - 0.5 - P.acos_shift);
+    const double fk = (-0.5 * theta / sin(theta + P.eps_sin)) / P.rest_vor;
     const double k0 = vec0 * fk, k1 = vec1 * fk, k2 = vec2 * fk;
     const double m0 = P.bend[0] * k0, m1 = P.bend[1] * k1, m2 = P.bend[2] * k2;
-    double e3;
-    if (MATH == SOFTROD_MATH_FAST) {
-        const double vd = 0.5 * (len_n + len) * P.inv_rest_vor;
-        const double rv = fast_rcp(vd);
-        e3 = rv * rv * rv;
-    } else {
-        const double vd = 0.5 * (len_n + len) / P.rest_vor;
-        e3 = 1.0 / (vd * vd * vd);
-    }
+    const double vd = 0.5 * (len_n + len) / P.rest_vor;
+    const double e3 = 1.0 / (vd * vd * vd);
     double c20 = m0 * e3, c21 = m1 * e3, c22 = m2 * e3;
     const double dv3 = P.rest_vor * e3;
     double c30 = (k1 * m2 - k2 * m1) * dv3;
@@ -330,9 +246,9 @@ __device__ __forceinline__ void dynamic_step(const RodParams& P, int lane, doubl
     c20 = vor_valid ? c20 : 0.0; c21 = vor_valid ? c21 : 0.0; c22 = vor_valid ? c22 : 0.0;
     c30 = vor_valid ? c30 : 0.0; c31 = vor_valid ? c31 : 0.0; c32 = vor_valid ? c32 : 0.0;
     // difference + trapezoid, Voronoi -> element (zeros beyond both ends do the end rules)
-    double tq0 = (c20 - from_prev(c20, lane)) + 0.5 * (c30 + from_prev(c30, lane));
-    double tq1 = (c21 - from_prev(c21, lane)) + 0.5 * (c31 + from_prev(c31, lane));
-    double tq2 = (c22 - from_prev(c22, lane)) + 0.5 * (c32 + from_prev(c32, lane));
+    double tq0 = (c20 - from_prev(c20)) + 0.5 * (c30 + from_prev(c30));
+    double tq1 = (c21 - from_prev(c21)) + 0.5 * (c31 + from_prev(c31));
+    double tq2 = (c22 - from_prev(c22)) + 0.5 * (c32 + from_prev(c32));
 
     // shear/stretch couple (Q t) x n * l_rest
     tq0 += (qt1 * n2 - qt2 * n1) * P.rest_len;
@@ -340,32 +256,17 @@ __device__ __forceinline__ void dynamic_step(const RodParams& P, int lane, doubl
     tq2 += (qt0 * n1 - qt1 * n0) * P.rest_len;
 
     // transport (J w / e) x w and unsteady dilatation (J w / e) (de/dt) / e
-    const double vn0 = from_next(L.v[0], lane), vn1 = from_next(L.v[1], lane),
-                 vn2 = from_next(L.v[2], lane);
-    double jw0, jw1, jw2, dil_rate;
-    {
-        const double rv = (L.x[0] * L.v[0] + L.x[1] * L.v[1]) + L.x[2] * L.v[2];
-        const double rvn = (xn0 * vn0 + xn1 * vn1) + xn2 * vn2;
-        const double rp1v = (xn0 * L.v[0] + xn1 * L.v[1]) + xn2 * L.v[2];
-        const double rvp1 = (L.x[0] * vn0 + L.x[1] * vn1) + L.x[2] * vn2;
-        const double num = rv + rvn - rvp1 - rp1v;
-        if (MATH == SOFTROD_MATH_FAST) {
-            dil_rate = num * inv_len * P.inv_rest_len;
-            jw0 = P.J[0] * L.w[0] * inv_e; jw1 = P.J[1] * L.w[1] * inv_e; jw2 = P.J[2] * L.w[2] * inv_e;
-        } else {
-            dil_rate = num / len / P.rest_len;
-            jw0 = P.J[0] * L.w[0] / e; jw1 = P.J[1] * L.w[1] / e; jw2 = P.J[2] * L.w[2] / e;
-        }
-    }
+    const double vn0 = from_next(L.v[0]), vn1 = from_next(L.v[1]), vn2 = from_next(L.v[2]);
+    const double rv = (L.x[0] * L.v[0] + L.x[1] * L.v[1]) + L.x[2] * L.v[2];
+    const double rvn = (xn0 * vn0 + xn1 * vn1) + xn2 * vn2;
+    const double rp1v = (xn0 * L.v[0] + xn1 * L.v[1]) + xn2 * L.v[2];
+    const double rvp1 = (L.x[0] * vn0 + L.x[1] * vn1) + L.x[2] * vn2;
+    const double dil_rate = (rv + rvn - rvp1 - rp1v) / len / P.rest_len;
+    const double jw0 = P.J[0] * L.w[0] / e, jw1 = P.J[1] * L.w[1] / e, jw2 = P.J[2] * L.w[2] / e;
     tq0 += jw1 * L.w[2] - jw2 * L.w[1];
     tq1 += jw2 * L.w[0] - jw0 * L.w[2];
     tq2 += jw0 * L.w[1] - jw1 * L.w[0];
-    if (MATH == SOFTROD_MATH_FAST) {
-        const double s = dil_rate * inv_e;
-        tq0 = fma(jw0, s, tq0); tq1 = fma(jw1, s, tq1); tq2 = fma(jw2, s, tq2);
-    } else {
-        tq0 += jw0 * dil_rate / e; tq1 += jw1 * dil_rate / e; tq2 += jw2 * dil_rate / e;
-    }
+    tq0 += jw0 * dil_rate / e; tq1 += jw1 * dil_rate / e; tq2 += jw2 * dil_rate / e;
 
     // ---- forcing (synchronize): gravity, then the point force ASSIGNS F_ext[0,0] ----
     double fe0 = 0.0, fe1 = 0.0, fe2 = 0.0;
@@ -381,12 +282,7 @@ __device__ __forceinline__ void dynamic_step(const RodParams& P, int lane, doubl
     }
 
     // ---- accelerations and rate update (v += dt a ; w += dt alpha) ----
-    double a0, a1, a2;
-    if (MATH == SOFTROD_MATH_FAST) {
-        a0 = (f0 + fe0) * inv_mass; a1 = (f1 + fe1) * inv_mass; a2 = (f2 + fe2) * inv_mass;
-    } else {
-        a0 = (f0 + fe0) / mass; a1 = (f1 + fe1) / mass; a2 = (f2 + fe2) / mass;
-    }
+    const double a0 = (f0 + fe0) / mass, a1 = (f1 + fe1) / mass, a2 = (f2 + fe2) / mass;
     const double al0 = (P.invJ[0] * tq0) * e, al1 = (P.invJ[1] * tq1) * e, al2 = (P.invJ[2] * tq2) * e;
     L.v[0] += node_valid ? P.dt * a0 : 0.0;
     L.v[1] += node_valid ? P.dt * a1 : 0.0;
@@ -398,26 +294,9 @@ __device__ __forceinline__ void dynamic_step(const RodParams& P, int lane, doubl
     // ---- AnalyticalLinearDamper.dampen_rates, then constrain_rates ----
     if (P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER) {
         L.v[0] *= P.damp_t; L.v[1] *= P.damp_t; L.v[2] *= P.damp_t;
-        bool fastd = false;
-        double x0 = 0, x1 = 0, x2 = 0;
-        if (MATH == SOFTROD_MATH_FAST) {
-            x0 = e * P.damp_logr[0]; x1 = e * P.damp_logr[1]; x2 = e * P.damp_logr[2];
-            const double mx = fmax(fabs(x0), fmax(fabs(x1), fabs(x2)));
-            fastd = !__any(elem_valid && !(mx < 0.01));
-        }
-        if (MATH == SOFTROD_MATH_FAST && fastd) {
-            // exp(x), |x| < 0.01, degree-7 Taylor (truncation < 3e-21)
-#define SR_EXP(x) fma(x, fma(x, fma(x, fma(x, fma(x, fma(x, fma(x, 1.0 / 5040.0, 1.0 / 720.0), \
-                  1.0 / 120.0), 1.0 / 24.0), 1.0 / 6.0), 0.5), 1.0), 1.0)
-            L.w[0] *= SR_EXP(x0);
-            L.w[1] *= (P.damp_logr[1] == P.damp_logr[0]) ? SR_EXP(x0) : SR_EXP(x1);
-            L.w[2] *= SR_EXP(x2);
-#undef SR_EXP
-        } else {
-            L.w[0] *= pow(P.damp_r[0], e);
-            L.w[1] *= pow(P.damp_r[1], e);
-            L.w[2] *= pow(P.damp_r[2], e);
-        }
+        L.w[0] *= pow(P.damp_r[0], e);
+        L.w[1] *= pow(P.damp_r[1], e);
+        L.w[2] *= pow(P.damp_r[2], e);
     }
     constrain_rates(P, lane, L);
 }
@@ -449,6 +328,13 @@ __device__ __forceinline__ void store_state(const StatePtrs& S, size_t N, size_t
     for (int c = 0; c < 9; ++c) S.dir[c * N * kLanes + row] = L.Q[c];
 }
 
+__device__ __forceinline__ void load_bc(const StatePtrs& S, size_t N, int rod, BcTargets& B) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) B.pos[i] = S.bc[(size_t)i * N + rod];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) B.Q[i] = S.bc[(size_t)(3 + i) * N + rod];
+}
+
 // theta = wrap(arctan(mean t_x / mean t_y)), soft_pendulum.py:154-156
 __device__ __forceinline__ double wrapped_theta(const RodParams& P, int lane, const LaneState& L) {
     const bool elem_valid = lane < P.n_elem;
@@ -462,52 +348,13 @@ __device__ __forceinline__ double wrapped_theta(const RodParams& P, int lane, co
     return m - M_PI;
 }
 
-// ---------------------------------------------------------------------------------
-// THE kernel: one env.step (or `n_sub` bare substeps) for every rod of the shard.
-// grid = n_envs blocks of one wavefront.
-// ---------------------------------------------------------------------------------
-template <int MATH>
-__global__ void __launch_bounds__(kLanes)
-softrod_step_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
-                    float* __restrict__ obs, double* __restrict__ reward,
-                    uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                    const int n_sub, const int epilogue) {
-    const int rod = blockIdx.x;
-    const int lane = threadIdx.x;
-    const size_t N = (size_t)P.n_envs;
-    const size_t row = (size_t)rod * kLanes + lane;
-
-    LaneState L;
-    load_state(S, N, row, L);
-    BcTargets B;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) B.pos[i] = S.bc[(size_t)i * N + rod];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) B.Q[i] = S.bc[(size_t)(3 + i) * N + rod];
-
-    const float act32 = actions ? actions[rod] : 0.0f;
-    const double action = (double)act32;  // point_force[:] = action (float32 -> float64)
-    double time = S.time[rod];
-    const int n = P.n_elem;
-    const double mass = (lane == 0 || lane == n) ? 0.5 * P.mass_node : P.mass_node;
-    const double inv_mass = 1.0 / mass;
-
-    for (int s = 0; s < n_sub; ++s) {
-        kinematic_step<MATH>(P, P.half_dt, L);
-        if (P.time_two_half_adds) time += P.half_dt;
-        constrain_values(P, B, lane, L);
-        dynamic_step<MATH>(P, lane, action, inv_mass, mass, L);
-        kinematic_step<MATH>(P, P.half_dt, L);
-        time += P.time_two_half_adds ? P.half_dt : P.dt;
-        constrain_values(P, B, lane, L);
-    }
-
-    store_state(S, N, row, L);
-    if (lane == 0) S.time[rod] = time;
-    if (!epilogue) return;
-
-    // ---- env epilogue: soft_pendulum.py:196-251 ----
-    const bool node_valid = lane <= n;
+// env epilogue: NaN check, reward, truncation, observation (soft_pendulum.py:196-251)
+__device__ __forceinline__ void env_epilogue(const RodParams& P, const StatePtrs& S, int rod, int lane,
+                                             const LaneState& L, double time, float act32,
+                                             float* __restrict__ obs, double* __restrict__ reward,
+                                             uint8_t* __restrict__ terminated,
+                                             uint8_t* __restrict__ truncated) {
+    const bool node_valid = lane <= P.n_elem;
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) bad = bad || isnan(L.x[c]) || isnan(L.v[c]);
@@ -526,6 +373,46 @@ softrod_step_kernel(const RodParams P, const StatePtrs S, const float* __restric
         obs[4 * rod + 2] = act32;
         obs[4 * rod + 3] = (float)th;
     }
+}
+
+// ---------------------------------------------------------------------------------
+// LIBM kernel: one env.step (or `n_sub` bare substeps) for every rod of the shard.
+// grid = n_envs blocks of one wavefront.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kLanes)
+softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
+                         float* __restrict__ obs, double* __restrict__ reward,
+                         uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+                         const int n_sub, const int epilogue) {
+    const int rod = blockIdx.x;
+    const int lane = threadIdx.x;
+    const size_t N = (size_t)P.n_envs;
+    const size_t row = (size_t)rod * kLanes + lane;
+
+    LaneState L;
+    load_state(S, N, row, L);
+    BcTargets B;
+    load_bc(S, N, rod, B);
+
+    const float act32 = actions ? actions[rod] : 0.0f;
+    const double action = (double)act32;  // point_force[:] = action (float32 -> float64)
+    double time = S.time[rod];
+    const int n = P.n_elem;
+    const double mass = (lane == 0 || lane == n) ? 0.5 * P.mass_node : P.mass_node;
+
+    for (int s = 0; s < n_sub; ++s) {
+        libm_kinematic_step(P, P.half_dt, L);
+        if (P.time_two_half_adds) time += P.half_dt;
+        constrain_values(P, B, lane, L);
+        libm_dynamic_step(P, lane, action, mass, L);
+        libm_kinematic_step(P, P.half_dt, L);
+        time += P.time_two_half_adds ? P.half_dt : P.dt;
+        constrain_values(P, B, lane, L);
+    }
+
+    store_state(S, N, row, L);
+    if (lane == 0) S.time[rod] = time;
+    if (epilogue) env_epilogue(P, S, rod, lane, L, time, act32, obs, reward, terminated, truncated);
 }
 
 // get_state() outside a step (reset observation), soft_pendulum.py:145-161
@@ -566,10 +453,10 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
     LaneState L;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        // np.linspace(start, end, n+1): start + k*step, last point = end
+        // np.linspace(start, end, n+1): start + k*step, last point = end.  Lanes beyond the
+        // rod keep marching so that |dx| stays finite and non-zero there.
         double xv = in[c] + (double)lane * in[3 + c];
         if (lane == n) xv = in[6 + c];
-        // lanes beyond the rod keep marching so |dx| stays finite and non-zero there
         L.x[c] = xv;
         L.v[c] = 0.0;
         L.w[c] = 0.0;
@@ -577,8 +464,7 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) L.Q[c] = in[9 + c];
     // CosseratRod.__init__ evaluates the strains once, so rod.tangents is valid at reset
-    const double xn0 = from_next(L.x[0], lane), xn1 = from_next(L.x[1], lane),
-                 xn2 = from_next(L.x[2], lane);
+    const double xn0 = from_next(L.x[0]), xn1 = from_next(L.x[1]), xn2 = from_next(L.x[2]);
     const double d0 = xn0 - L.x[0], d1 = xn1 - L.x[1], d2 = xn2 - L.x[2];
     const double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2) + P.eps_length;
     L.t[0] = d0 / len; L.t[1] = d1 / len; L.t[2] = d2 / len;
@@ -593,3 +479,5 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
 }
 
 }  // namespace softrod
+
+#include "softrod_fast.hpp"
