@@ -266,3 +266,123 @@ def test_known_answer_cantilever_on_gpu(torch_gpu, hip_lib):
     assert st["x"][0, 1, -1] == pytest.approx(expect, rel=2e-4)
     assert st["x"][1, 1, -1] == st["x"][0, 1, -1]
     be.close()
+
+
+# ---- range-reduction paths of the fast kernel (softrod_fast.hpp) -------------------------
+def _backend(cfg):
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    return HipRodBackend(cfg, 0)
+
+
+def _inject(be, name, arr):
+    """arr: (comps, k) for every rod -> resident SoA rows."""
+    import torch
+
+    st = be.state()
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(st[name].device)
+    st[name][:, :, : arr.shape[1]] = t[:, None, :]
+
+
+def test_fast_kernel_large_bending_angles(torch_gpu, hip_lib, oracle_built):
+    # neighbouring elements > 0.1 rad apart -> half-angle recursion in theta_over_sin
+    from gym_softrobot_amd import _capi
+
+    n_el = 10
+    cfg = _capi.softpendulum_config(2, n_elems=n_el, math_mode=1)
+    cfg.features = _capi.FEAT_FIXED_BC | _capi.FEAT_TIP_FORCE | _capi.FEAT_ANALYTICAL_DAMPER
+    cfg.damping_constant = 0.8
+    cfg.dt = 2e-4
+    cfg.tip_force[1] = 20.0
+    be = _backend(cfg)
+    be.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    be.substeps(None, 20000)
+    rod.substeps(0.0, 20000)
+    st = be.state_numpy()
+    rod.refresh_strains()
+    ang = np.abs(rod.get("kappa")).max() * (1.0 / n_el)
+    assert ang > 0.15, ang                      # the slow branch really ran
+    np.testing.assert_allclose(st["x"][0], rod.get("x"), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(st["Q"][1], rod.get("Q"), rtol=1e-7, atol=1e-9)
+    be.close()
+
+
+def test_fast_kernel_large_rotation_rates(torch_gpu, hip_lib, oracle_built):
+    # |omega| dt > 0.03 rad -> angle halving + double-angle rebuild in sinc_cosc
+    from gym_softrobot_amd import _capi
+
+    n_el = 12
+    cfg = _capi.softpendulum_config(1, n_elems=n_el, math_mode=1)
+    cfg.features = 0
+    cfg.damping_constant = 0.0
+    be = _backend(cfg)
+    be.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    w = np.zeros((3, n_el))
+    w[2] = 900.0            # fast spin about the rod axis: 0.09 rad per substep
+    w[0] = 40.0 * np.sin(np.linspace(0, np.pi, n_el))
+    rod.set("w", w)
+    _inject(be, "omega", w)
+    be.substeps(None, 40)
+    rod.substeps(0.0, 40)
+    st = be.state_numpy()
+    np.testing.assert_allclose(st["Q"][0], rod.get("Q"), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(st["w"][0], rod.get("w"), rtol=1e-8, atol=1e-7)
+    np.testing.assert_allclose(st["x"][0], rod.get("x"), rtol=0, atol=1e-11)
+    be.close()
+
+
+def test_fast_kernel_strong_damping_and_free_features(torch_gpu, hip_lib, oracle_built):
+    # |e * log c_r| > 1e-3 -> halving + squaring in exp_pair; also a feature set without BC
+    from gym_softrobot_amd import _capi
+
+    n_el = 16
+    cfg = _capi.softpendulum_config(1, n_elems=n_el, math_mode=1)
+    cfg.features = _capi.FEAT_GRAVITY | _capi.FEAT_ANALYTICAL_DAMPER
+    cfg.damping_constant = 3.0
+    be = _backend(cfg)
+    d, nrm = [np.cos(0.4), np.sin(0.4), 0.0], [np.sin(0.4), -np.cos(0.4), 0.0]
+    be.reset_straight([0.1, 0.2, 0.3], d, nrm)
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_straight([0.1, 0.2, 0.3], d, nrm)
+    w = np.zeros((3, n_el))
+    w[1] = 3.0 * np.cos(np.linspace(0, 3, n_el))
+    w[0] = 1.0
+    rod.set("w", w)
+    _inject(be, "omega", w)
+    be.substeps(None, 500)
+    rod.substeps(0.0, 500)
+    st = be.state_numpy()
+    np.testing.assert_allclose(st["x"][0], rod.get("x"), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(st["v"][0], rod.get("v"), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(st["w"][0], rod.get("w"), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(st["Q"][0], rod.get("Q"), rtol=0, atol=1e-10)
+    be.close()
+
+
+def test_odd_rod_sizes_and_substep_counts(torch_gpu, hip_lib, oracle_built):
+    # edge sizes: the smallest rod, the largest one wavefront holds (63 elements), and
+    # substep counts 0 / 1 (first and last kinematic half-steps coincide)
+    from gym_softrobot_amd import _capi
+
+    for n_el, nsub in ((2, 7), (63, 30), (50, 1), (50, 0)):
+        for mode in (0, 1):
+            cfg = _capi.softpendulum_config(2, n_elems=n_el, math_mode=mode)
+            be = _backend(cfg)
+            th = np.deg2rad([91.0, 88.5])
+            be.reset(th)
+            be.substeps(np.array([4.0, -9.0], np.float32), nsub)
+            st = be.state_numpy()
+            for i in range(2):
+                rod = oracle_built.OracleRod(cfg)
+                rod.reset_pendulum(th[i])
+                rod.substeps([4.0, -9.0][i], nsub)
+                np.testing.assert_allclose(st["x"][i], rod.get("x"), rtol=1e-9, atol=1e-12)
+                # velocities far ahead of the elastic wave front are ~1e-10 of the scale
+                np.testing.assert_allclose(st["v"][i], rod.get("v"), rtol=1e-7, atol=1e-10)
+                np.testing.assert_allclose(st["Q"][i], rod.get("Q"), rtol=0, atol=1e-11)
+                assert st["time"][i] == rod.time
+            be.close()
