@@ -184,7 +184,7 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "softrod_step_kernel",
+                "kernel": "softrod_step_fast_kernel" if args.math_mode == "fast" else "softrod_step_libm_kernel",
                 "kernel_ms_avg": kernel_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "algorithmic bytes = rods x substeps x 2(18n+6) x 8 B (SURVEY 8d); the kernel keeps "

@@ -15,7 +15,7 @@ import os
 import sys
 from collections import defaultdict
 
-KERNEL = "softrod_step_kernel"
+KERNEL = "softrod_step_"
 
 
 def read_csv(path):
