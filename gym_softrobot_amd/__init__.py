@@ -1,22 +1,26 @@
 """gym_softrobot_amd — MI355X-native batched Cosserat-rod stepper behind the
-Gymnasium surface of gym-softrobot's SoftPendulum-v0."""
+Gymnasium surface of gym-softrobot's SoftPendulum-v0 / SoftPendulum3D-v0."""
 from . import _capi
-from .envs import SoftPendulumEnv, VecSoftPendulumEnv
+from .envs import SoftPendulum3DEnv, SoftPendulumEnv, VecSoftPendulum3DEnv, VecSoftPendulumEnv
 from .registration import make, register, registered
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
-# gym_softrobot/__init__.py:74-76
+# gym_softrobot/__init__.py:74-80
 register(id="SoftPendulum-v0", entry_point=SoftPendulumEnv)
+register(id="SoftPendulum3D-v0", entry_point=SoftPendulum3DEnv)
+
+_VEC = {"SoftPendulum-v0": VecSoftPendulumEnv, "SoftPendulum3D-v0": VecSoftPendulum3DEnv}
 
 
 def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
     """N parallel envs on one GPU (the batched form of `make`)."""
-    if id != "SoftPendulum-v0":
-        raise KeyError(f"no batched implementation registered for {id!r}")
-    return VecSoftPendulumEnv(num_envs, **kwargs)
+    if id not in _VEC:
+        raise KeyError(f"no batched implementation registered for {id!r}; have {sorted(_VEC)}")
+    return _VEC[id](num_envs, **kwargs)
 
 
 __all__ = [
-    "SoftPendulumEnv", "VecSoftPendulumEnv", "make", "make_vec", "register", "registered", "_capi",
+    "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
+    "make", "make_vec", "register", "registered", "_capi",
 ]

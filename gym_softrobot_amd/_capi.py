@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -19,14 +19,39 @@ FEAT_PENDULUM_BC = 1 << 2
 FEAT_ANALYTICAL_DAMPER = 1 << 3
 FEAT_FIXED_BC = 1 << 4
 FEAT_TIP_FORCE = 1 << 5
+FEAT_MOVING_BASE_BC = 1 << 6
+FEAT_LAPLACE_FILTER = 1 << 7
 FEATURES_SOFTPENDULUM = (
     FEAT_GRAVITY | FEAT_POINT_FORCE_NODE0_X | FEAT_PENDULUM_BC | FEAT_ANALYTICAL_DAMPER
 )
+FEATURES_SOFTPENDULUM3D = (
+    FEAT_GRAVITY | FEAT_MOVING_BASE_BC | FEAT_ANALYTICAL_DAMPER | FEAT_LAPLACE_FILTER
+)
+
+ENV_NONE = 0
+ENV_SOFTPENDULUM = 1
+ENV_SOFTPENDULUM3D = 2
 
 MATH_LIBM = 0
 MATH_FAST = 1
 
 LANE_STRIDE = 64  # one wavefront row per rod (softrod_state_view.lane_stride)
+
+_ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2}
+_OBS_DIM = {ENV_NONE: 4, ENV_SOFTPENDULUM: 4, ENV_SOFTPENDULUM3D: 9}
+_AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1}
+
+
+def action_dim(env_kind: int) -> int:
+    return _ACTION_DIM[int(env_kind)]
+
+
+def obs_dim(env_kind: int) -> int:
+    return _OBS_DIM[int(env_kind)]
+
+
+def aux_dim(env_kind: int) -> int:
+    return _AUX_DIM[int(env_kind)]
 
 
 class SoftrodConfig(C.Structure):
@@ -39,6 +64,8 @@ class SoftrodConfig(C.Structure):
         ("n_elem", C.c_int32),
         ("n_substeps", C.c_int32),
         ("math_mode", C.c_int32),
+        ("env_kind", C.c_int32),
+        ("filter_order", C.c_int32),
         ("dt", C.c_double),
         ("final_time", C.c_double),
         ("base_length", C.c_double),
@@ -49,13 +76,15 @@ class SoftrodConfig(C.Structure):
         ("gravity", C.c_double * 3),
         ("damping_constant", C.c_double),
         ("tip_force", C.c_double * 3),
+        ("base_step", C.c_double),
+        ("base_limit", C.c_double),
         ("alpha_c", C.c_double),
         ("eps_length", C.c_double),
         ("eps_rot_axis", C.c_double),
         ("acos_shift", C.c_double),
         ("eps_sin", C.c_double),
         ("time_two_half_adds", C.c_int32),
-        ("reserved", C.c_int32),
+        ("damp_before_constrain", C.c_int32),
     ]
 
     def copy(self) -> "SoftrodConfig":
@@ -78,7 +107,25 @@ class SoftrodStateView(C.Structure):
         ("omega", C.c_void_p),
         ("tangents", C.c_void_p),
         ("time", C.c_void_p),
+        ("control", C.c_void_p),
     ]
+
+
+def _common(cfg: SoftrodConfig, n_envs, final_time, time_step, recording_fps, n_elems, math_mode):
+    cfg.struct_size = C.sizeof(SoftrodConfig)
+    cfg.n_envs = int(n_envs)
+    cfg.n_elem = int(n_elems)
+    cfg.n_substeps = int(1.0 / (recording_fps * time_step))  # soft_pendulum.py:78
+    cfg.math_mode = int(math_mode)
+    cfg.dt = float(time_step)
+    cfg.final_time = float(final_time)
+    cfg.alpha_c = 27.0 / 28.0
+    cfg.eps_length = 1e-14
+    cfg.eps_rot_axis = 1e-14
+    cfg.acos_shift = 1e-10
+    cfg.eps_sin = 1e-14
+    cfg.time_two_half_adds = 1
+    cfg.damp_before_constrain = 1
 
 
 def softpendulum_config(
@@ -98,14 +145,9 @@ def softpendulum_config(
     build.py:54-61, so PyElastica's default applies: E / (2 (1 + 0.5)).
     """
     cfg = SoftrodConfig()
-    cfg.struct_size = C.sizeof(SoftrodConfig)
+    _common(cfg, n_envs, final_time, time_step, recording_fps, n_elems, math_mode)
     cfg.features = FEATURES_SOFTPENDULUM
-    cfg.n_envs = int(n_envs)
-    cfg.n_elem = int(n_elems)
-    cfg.n_substeps = int(1.0 / (recording_fps * time_step))  # soft_pendulum.py:78
-    cfg.math_mode = int(math_mode)
-    cfg.dt = float(time_step)
-    cfg.final_time = float(final_time)
+    cfg.env_kind = ENV_SOFTPENDULUM
     cfg.base_length = 1.0
     cfg.base_radius = 0.05
     cfg.density = 1000.0
@@ -113,12 +155,35 @@ def softpendulum_config(
     cfg.shear_modulus = 1e6 / (2.0 * (1.0 + 0.5))
     cfg.gravity[0], cfg.gravity[1], cfg.gravity[2] = 0.0, -9.80665, 0.0
     cfg.damping_constant = 2e-3
-    cfg.alpha_c = 27.0 / 28.0
-    cfg.eps_length = 1e-14
-    cfg.eps_rot_axis = 1e-14
-    cfg.acos_shift = 1e-10
-    cfg.eps_sin = 1e-14
-    cfg.time_two_half_adds = 1
+    return cfg
+
+
+def softpendulum3d_config(
+    n_envs: int = 1,
+    *,
+    final_time: float = 5.0,
+    time_step: float = 1.0e-4,
+    recording_fps: int = 25,
+    n_elems: int = 50,
+    math_mode: int = MATH_FAST,
+) -> SoftrodConfig:
+    """`softrod_config_softpendulum3d`: SoftPendulum3DEnv.__init__
+    (soft_pendulum_3d.py:28-58) and build_soft_pendulum_3d
+    (soft_pendulum_3d/build.py:43-86)."""
+    cfg = SoftrodConfig()
+    _common(cfg, n_envs, final_time, time_step, recording_fps, n_elems, math_mode)
+    cfg.features = FEATURES_SOFTPENDULUM3D
+    cfg.env_kind = ENV_SOFTPENDULUM3D
+    cfg.filter_order = 7
+    cfg.base_length = 1.0
+    cfg.base_radius = 0.1
+    cfg.density = 4000.0
+    cfg.youngs_modulus = 1e6
+    cfg.shear_modulus = 1e6 / (2.0 * (1.0 + 0.5))
+    cfg.gravity[0], cfg.gravity[1], cfg.gravity[2] = 0.0, 0.0, -9.80665
+    cfg.damping_constant = 1.0
+    cfg.base_step = 1e-3
+    cfg.base_limit = 0.5
     return cfg
 
 
@@ -126,28 +191,27 @@ class SoftrodError(RuntimeError):
     pass
 
 
+_VP = C.c_void_p
 _EXPORTS = {
     # name: (restype, argtypes)
     "softrod_abi_version": (C.c_int, []),
+    "softrod_action_dim": (C.c_int, [C.c_int]),
+    "softrod_obs_dim": (C.c_int, [C.c_int]),
+    "softrod_aux_dim": (C.c_int, [C.c_int]),
     "softrod_config_softpendulum": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_config_softpendulum3d": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_create": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.POINTER(C.c_void_p)]),
-    "softrod_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "softrod_reset_straight": (
-        C.c_int,
-        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
-    ),
-    "softrod_step": (
-        C.c_int,
-        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
-    ),
-    "softrod_observe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "softrod_substeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "softrod_state_view_get": (C.c_int, [C.c_void_p, C.POINTER(SoftrodStateView)]),
-    "softrod_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
-    "softrod_kernel_times_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
-    "softrod_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
-    "softrod_last_error": (C.c_char_p, [C.c_void_p]),
-    "softrod_destroy": (C.c_int, [C.c_void_p]),
+    "softrod_reset": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "softrod_reset_straight": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "softrod_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "softrod_observe": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "softrod_substeps": (C.c_int, [_VP, _VP, C.c_int, _VP]),
+    "softrod_state_view_get": (C.c_int, [_VP, C.POINTER(SoftrodStateView)]),
+    "softrod_set_timing": (C.c_int, [_VP, C.c_int]),
+    "softrod_kernel_times_ms": (C.c_int, [_VP, _VP, C.c_int, C.POINTER(C.c_int)]),
+    "softrod_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "softrod_last_error": (C.c_char_p, [_VP]),
+    "softrod_destroy": (C.c_int, [_VP]),
 }
 
 EXPORTED_SYMBOLS = tuple(_EXPORTS)

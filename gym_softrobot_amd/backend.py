@@ -39,16 +39,23 @@ class HipRodBackend:
         self._lib = load_library()
         self.cfg = cfg.copy()
         self.n_envs = int(cfg.n_envs)
+        self.action_dim = _capi.action_dim(cfg.env_kind)
+        self.obs_dim = _capi.obs_dim(cfg.env_kind)
+        self.aux_dim = _capi.aux_dim(cfg.env_kind)
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
         self._h = C.c_void_p()
         check(self._lib.softrod_create(C.byref(self.cfg), self.device_index, C.byref(self._h)))
         n = self.n_envs
         with torch.cuda.device(self.device):
-            self.obs = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+            self.obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=self.device)
             self.reward = torch.empty((n,), dtype=torch.float64, device=self.device)
             self.terminated = torch.empty((n,), dtype=torch.uint8, device=self.device)
             self.truncated = torch.empty((n,), dtype=torch.uint8, device=self.device)
+            self.aux = (
+                torch.empty((n, self.aux_dim), dtype=torch.float64, device=self.device)
+                if self.aux_dim else None
+            )
 
     # -- lifetime -------------------------------------------------------------------
     def close(self) -> None:
@@ -67,8 +74,8 @@ class HipRodBackend:
 
     def _actions(self, actions) -> torch.Tensor:
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.device).reshape(-1)
-        if a.numel() != self.n_envs:
-            raise ValueError(f"expected {self.n_envs} actions, got {a.numel()}")
+        if a.numel() != self.n_envs * self.action_dim:
+            raise ValueError(f"expected {self.n_envs}x{self.action_dim} actions, got {a.numel()}")
         return a.contiguous()
 
     # -- C-ABI calls ----------------------------------------------------------------
@@ -84,14 +91,18 @@ class HipRodBackend:
             self._h,
         )
 
-    def reset_straight(self, start, direction, normal) -> None:
+    def reset_straight(self, start, direction, normal, mask: Optional[np.ndarray] = None) -> None:
         arrs = [
             np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float64), (self.n_envs, 3)))
             for v in (start, direction, normal)
         ]
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.n_envs)
         check(
             self._lib.softrod_reset_straight(
-                self._h, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, self._stream()
+                self._h, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                m.ctypes.data if m is not None else None, self._stream(),
             ),
             self._h,
         )
@@ -113,7 +124,8 @@ class HipRodBackend:
         check(
             self._lib.softrod_step(
                 self._h, a.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(),
-                self.terminated.data_ptr(), self.truncated.data_ptr(), self._stream(),
+                self.terminated.data_ptr(), self.truncated.data_ptr(),
+                self.aux.data_ptr() if self.aux is not None else None, self._stream(),
             ),
             self._h,
         )
@@ -161,6 +173,7 @@ class HipRodBackend:
             "omega": view(v.omega, 3),
             "tangents": view(v.tangents, 3),
             "time": torch.as_tensor(_DevArray(v.time, (n,), "<f8", self), device=self.device),
+            "control": torch.as_tensor(_DevArray(v.control, (4, n), "<f8", self), device=self.device),
         }
 
     def state_numpy(self) -> Dict[str, np.ndarray]:
@@ -174,6 +187,7 @@ class HipRodBackend:
             "w": st["omega"][:, :, :ne].permute(1, 0, 2).cpu().numpy(),
             "tangents": st["tangents"][:, :, :ne].permute(1, 0, 2).cpu().numpy(),
             "time": st["time"].cpu().numpy(),
+            "control": st["control"].permute(1, 0).cpu().numpy(),
         }
         q = st["director"][:, :, :ne].permute(1, 0, 2).cpu().numpy()
         out["Q"] = q.reshape(self.n_envs, 3, 3, ne)

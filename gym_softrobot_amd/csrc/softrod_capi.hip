@@ -58,6 +58,9 @@ void fill_params(const softrod_config& c, RodParams& P) {
     P.n_elem = c.n_elem;
     P.time_two_half_adds = c.time_two_half_adds;
     P.features = c.features;
+    P.env_kind = c.env_kind;
+    P.filter_order = c.filter_order;
+    P.damp_before_constrain = c.damp_before_constrain;
     P.dt = c.dt;
     P.half_dt = 0.5 * c.dt;
     P.final_time = c.final_time;
@@ -96,19 +99,23 @@ void fill_params(const softrod_config& c, RodParams& P) {
     P.eps_rot_axis = c.eps_rot_axis;
     P.acos_shift = c.acos_shift;
     P.eps_sin = c.eps_sin;
+    P.base_limit = c.base_limit;
+    P.step_time = (double)c.n_substeps * c.dt;  // step_skip * time_step, soft_pendulum_3d.py:110-112
+    P.base_step = (float)c.base_step;
 }
 
 int launch_step(softrod_handle* h, const float* actions, float* obs, double* reward,
-                uint8_t* term, uint8_t* trunc, int n_sub, int epilogue, hipStream_t st) {
+                uint8_t* term, uint8_t* trunc, double* aux, int n_sub, int epilogue,
+                hipStream_t st) {
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
     if (h->cfg.math_mode == SOFTROD_MATH_FAST)
         hipLaunchKernelGGL(softrod_step_fast_kernel, grid, block, 0, st, h->P, h->S,
-                           actions, obs, reward, term, trunc, n_sub, epilogue);
+                           actions, obs, reward, term, trunc, aux, n_sub, epilogue);
     else
         hipLaunchKernelGGL(softrod_step_libm_kernel, grid, block, 0, st, h->P, h->S,
-                           actions, obs, reward, term, trunc, n_sub, epilogue);
+                           actions, obs, reward, term, trunc, aux, n_sub, epilogue);
     SR_HIP(h, hipGetLastError());
     if (timing) {
         SR_HIP(h, hipEventRecord(h->ev_stop[h->timed], st));
@@ -153,23 +160,39 @@ void straight_init(const softrod_config& c, const double start[3], const double 
     for (int i = 0; i < 3; ++i) out[15 + i] = t[i];
 }
 
-}  // namespace
-
-extern "C" {
-
-int softrod_abi_version(void) { return SOFTROD_ABI_VERSION; }
-
-int softrod_config_softpendulum(softrod_config* cfg, int n_envs) {
-    if (!cfg || n_envs < 1) return SOFTROD_EINVAL;
+void config_common(softrod_config* cfg, int n_envs) {
     std::memset(cfg, 0, sizeof(*cfg));
     cfg->struct_size = (uint32_t)sizeof(softrod_config);
-    cfg->features = SOFTROD_FEATURES_SOFTPENDULUM;
     cfg->n_envs = n_envs;
     cfg->n_elem = 50;                                   // soft_pendulum.py:64
     cfg->dt = 1.0e-4;                                   // :62
     cfg->n_substeps = (int)(1.0 / (25 * cfg->dt));      // :78 (recording_fps = 25, :63)
     cfg->math_mode = SOFTROD_MATH_FAST;
     cfg->final_time = 5.0;                              // :61
+    cfg->alpha_c = 27.0 / 28.0;
+    cfg->eps_length = 1e-14;
+    cfg->eps_rot_axis = 1e-14;
+    cfg->acos_shift = 1e-10;
+    cfg->eps_sin = 1e-14;
+    cfg->time_two_half_adds = 1;
+    cfg->damp_before_constrain = 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int softrod_abi_version(void) { return SOFTROD_ABI_VERSION; }
+
+int softrod_action_dim(int env_kind) { return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 2 : 1; }
+int softrod_obs_dim(int env_kind) { return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 9 : 4; }
+int softrod_aux_dim(int env_kind) { return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 1 : 0; }
+
+int softrod_config_softpendulum(softrod_config* cfg, int n_envs) {
+    if (!cfg || n_envs < 1) return SOFTROD_EINVAL;
+    config_common(cfg, n_envs);
+    cfg->features = SOFTROD_FEATURES_SOFTPENDULUM;
+    cfg->env_kind = SOFTROD_ENV_SOFTPENDULUM;
     cfg->base_length = 1.0;                             // build.py:23-26
     cfg->base_radius = 0.05;
     cfg->density = 1000.0;                              // build.py:18-22
@@ -177,12 +200,24 @@ int softrod_config_softpendulum(softrod_config* cfg, int n_envs) {
     cfg->shear_modulus = 1e6 / (2.0 * (1.0 + 0.5));     // PyElastica default (none passed)
     cfg->gravity[0] = 0.0; cfg->gravity[1] = -9.80665; cfg->gravity[2] = 0.0;  // build.py:87-91
     cfg->damping_constant = 2e-3;                       // build.py:108
-    cfg->alpha_c = 27.0 / 28.0;
-    cfg->eps_length = 1e-14;
-    cfg->eps_rot_axis = 1e-14;
-    cfg->acos_shift = 1e-10;
-    cfg->eps_sin = 1e-14;
-    cfg->time_two_half_adds = 1;
+    return SOFTROD_OK;
+}
+
+int softrod_config_softpendulum3d(softrod_config* cfg, int n_envs) {
+    if (!cfg || n_envs < 1) return SOFTROD_EINVAL;
+    config_common(cfg, n_envs);
+    cfg->features = SOFTROD_FEATURES_SOFTPENDULUM3D;
+    cfg->env_kind = SOFTROD_ENV_SOFTPENDULUM3D;
+    cfg->filter_order = 7;                              // soft_pendulum_3d/build.py:82-85
+    cfg->base_length = 1.0;                             // soft_pendulum_3d/build.py:55-64
+    cfg->base_radius = 0.1;
+    cfg->density = 4000.0;
+    cfg->youngs_modulus = 1e6;
+    cfg->shear_modulus = 1e6 / (2.0 * (1.0 + 0.5));
+    cfg->gravity[0] = 0.0; cfg->gravity[1] = 0.0; cfg->gravity[2] = -9.80665;  // :73-76
+    cfg->damping_constant = 1.0;                        // :77-81
+    cfg->base_step = 1e-3;                              // soft_pendulum_3d.py:57
+    cfg->base_limit = 0.5;                              // :58
     return SOFTROD_OK;
 }
 
@@ -197,6 +232,19 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "need n_substeps >= 0 and dt > 0");
     if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
+    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_SOFTPENDULUM3D)
+        return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
+    if ((cfg->features & SOFTROD_FEAT_LAPLACE_FILTER) && (cfg->filter_order < 1 || cfg->n_elem < 3))
+        return fail(nullptr, SOFTROD_EINVAL, "LaplaceDissipationFilter needs filter_order >= 1");
+    if (cfg->math_mode == SOFTROD_MATH_FAST && !cfg->damp_before_constrain &&
+        (cfg->features & SOFTROD_FEAT_LAPLACE_FILTER))
+        return fail(nullptr, SOFTROD_EINVAL,
+                    "the fast kernel fuses dampers before constrain_rates; use SOFTROD_MATH_LIBM");
+    {
+        const unsigned bcs = cfg->features & (SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_FIXED_BC |
+                                              SOFTROD_FEAT_MOVING_BASE_BC);
+        if (bcs & (bcs - 1)) return fail(nullptr, SOFTROD_EINVAL, "at most one boundary condition");
+    }
     int ndev = 0;
     const hipError_t cnt_err = hipGetDeviceCount(&ndev);
     if (cnt_err != hipSuccess || ndev < 1)
@@ -225,7 +273,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     alloc((void**)&h->S.tan, 3 * rowb);
     alloc((void**)&h->S.time, N * sizeof(double));
     alloc((void**)&h->S.bc, 12 * N * sizeof(double));
-    alloc((void**)&h->S.prev_action, N * sizeof(float));
+    alloc((void**)&h->S.ctrl, 4 * N * sizeof(double));
     alloc((void**)&h->d_init, N * 18 * sizeof(double));
     alloc((void**)&h->d_mask, N);
     if (rc == SOFTROD_OK && hipHostMalloc((void**)&h->h_init, N * 18 * sizeof(double)) != hipSuccess) rc = SOFTROD_ENOMEM;
@@ -259,33 +307,41 @@ int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask, 
 }
 
 int softrod_reset_straight(softrod_handle* h, const double* start, const double* direction,
-                           const double* normal, void* stream) {
+                           const double* normal, const uint8_t* mask, void* stream) {
     if (!h || !start || !direction || !normal) return fail(h, SOFTROD_EINVAL, "null argument");
     SR_HIP(h, hipSetDevice(h->device));
     SR_HIP(h, hipEventSynchronize(h->ev_reset));
     const int N = h->cfg.n_envs;
-    for (int e = 0; e < N; ++e)
+    for (int e = 0; e < N; ++e) {
+        if (mask) h->h_mask[e] = mask[e];
+        if (mask && !mask[e]) continue;
         straight_init(h->cfg, start + 3 * e, direction + 3 * e, normal + 3 * e, h->h_init + (size_t)e * 18);
-    return upload_and_reset(h, (hipStream_t)stream, false);
+    }
+    return upload_and_reset(h, (hipStream_t)stream, mask != nullptr);
 }
 
 int softrod_step(softrod_handle* h, const float* actions, float* obs, double* reward,
-                 uint8_t* terminated, uint8_t* truncated, void* stream) {
+                 uint8_t* terminated, uint8_t* truncated, double* aux, void* stream) {
     if (!h || !actions || !obs || !reward || !terminated || !truncated)
         return fail(h, SOFTROD_EINVAL, "null argument");
+    if (h->cfg.env_kind == SOFTROD_ENV_NONE)
+        return fail(h, SOFTROD_EINVAL, "env_kind NONE has no step epilogue; use softrod_substeps");
     SR_HIP(h, hipSetDevice(h->device));
-    return launch_step(h, actions, obs, reward, terminated, truncated, h->cfg.n_substeps, 1,
+    return launch_step(h, actions, obs, reward, terminated, truncated, aux, h->cfg.n_substeps, 1,
                        (hipStream_t)stream);
 }
 
 int softrod_substeps(softrod_handle* h, const float* actions, int n, void* stream) {
     if (!h || n < 0) return fail(h, SOFTROD_EINVAL, "bad argument");
+    if (actions && h->cfg.env_kind == SOFTROD_ENV_SOFTPENDULUM3D)
+        return fail(h, SOFTROD_EINVAL, "softrod_substeps takes no actions for this env_kind");
     SR_HIP(h, hipSetDevice(h->device));
-    return launch_step(h, actions, nullptr, nullptr, nullptr, nullptr, n, 0, (hipStream_t)stream);
+    return launch_step(h, actions, nullptr, nullptr, nullptr, nullptr, nullptr, n, 0, (hipStream_t)stream);
 }
 
 int softrod_observe(softrod_handle* h, const float* prev_action, float* obs, void* stream) {
     if (!h || !obs) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no observation");
     SR_HIP(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(softrod_observe_kernel, dim3((unsigned)h->cfg.n_envs), dim3(kLanes), 0,
                        (hipStream_t)stream, h->P, h->S, prev_action, obs);
@@ -305,6 +361,7 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->omega = h->S.omg;
     out->tangents = h->S.tan;
     out->time = h->S.time;
+    out->control = h->S.ctrl;
     return SOFTROD_OK;
 }
 
@@ -356,7 +413,7 @@ int softrod_destroy(softrod_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.prev_action, h->d_init, h->d_mask};
+                    h->S.ctrl, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

@@ -50,6 +50,7 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // Per-lane constants (VGPRs), built once per launch.  Lane-validity masks and the
 // loop-invariant parts of the rate update live here.
 struct FastConst {
+    double hx;        // 1, or 0 for a node whose position the BC holds against its velocity
     double hq;        // 1, or 0 for an element whose director the BC holds
     double cf;        // damp_t*dt/m_k            (0 beyond the last node)
     double ca[3];     // damp_t*dt*F_ext,i/m_k    (gravity, action, tip force)
@@ -116,9 +117,10 @@ __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid, doubl
 
 // x += h v ;  Q <- R(h w) Q   (h = dt/2 at the ends of a launch, dt in between)
 __device__ __forceinline__ void fast_kinematic_step(double h, const FastConst& C, LaneState& L) {
-    L.x[0] = fma(h, L.v[0], L.x[0]);
-    L.x[1] = fma(h, L.v[1], L.x[1]);
-    L.x[2] = fma(h, L.v[2], L.x[2]);
+    const double hp = h * C.hx;
+    L.x[0] = fma(hp, L.v[0], L.x[0]);
+    L.x[1] = fma(hp, L.v[1], L.x[1]);
+    L.x[2] = fma(hp, L.v[2], L.x[2]);
     const double hh = h * C.hq;
     const double a0 = hh * L.w[0], a1 = hh * L.w[1], a2 = hh * L.w[2];
     const double q0 = a0 * a0, q1 = a1 * a1, q2 = a2 * a2;
@@ -141,8 +143,8 @@ __device__ __forceinline__ void fast_kinematic_step(double h, const FastConst& C
 }
 
 // forces, torques, rate update, damper, constrain_rates — steps (3)-(6) of the substep.
-__device__ __forceinline__ void fast_dynamic_step(const RodParams& P, const FastConst& C, int lane,
-                                                  LaneState& L) {
+__device__ __forceinline__ void fast_dynamic_step(const RodParams& P, const FastConst& C,
+                                                  const BcTargets& B, int lane, LaneState& L) {
     const int n = P.n_elem;
     const bool elem_valid = lane < n;
     const bool vor_valid = lane < n - 1;
@@ -234,14 +236,20 @@ __device__ __forceinline__ void fast_dynamic_step(const RodParams& P, const Fast
         w0 *= ex0; w1 *= ex0; w2 *= ex2;
     }
     L.w[0] = w0; L.w[1] = w1; L.w[2] = w2;
-    constrain_rates(P, lane, L);
+    if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates(P, lane, L);
+    constrain_rates(P, B, lane, L);
 }
 
-__global__ void __launch_bounds__(kLanes)
+// SOFTROD_FAST_WAVES: minimum waves per SIMD the register allocator must leave room for
+// (2nd __launch_bounds__ argument = waves per EU on gfx950); tuned in profiles/README.md.
+#ifndef SOFTROD_FAST_WAVES
+#define SOFTROD_FAST_WAVES 3
+#endif
+__global__ void __launch_bounds__(kLanes, SOFTROD_FAST_WAVES)
 softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                         const int n_sub, const int epilogue) {
+                         double* __restrict__ aux, const int n_sub, const int epilogue) {
     const int rod = blockIdx.x;
     const int lane = threadIdx.x;
     const size_t N = (size_t)P.n_envs;
@@ -250,31 +258,43 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
 
     LaneState L;
     load_state(S, N, row, L);
-    {   // (re)establish the boundary-condition invariant once
-        BcTargets B;
-        load_bc(S, N, rod, B);
-        constrain_rates(P, lane, L);
+    BcTargets B;
+    load_bc(S, N, rod, B);
+    EnvAction A;
+    env_set_action(P, S, N, rod, lane, actions, A, B);
+    {   // (re)establish the boundary-condition invariant once.  The imposed base velocity
+        // of MOVING_BASE_BC is NOT applied here: the reference keeps the previous step's
+        // base velocity until the first constrain_rates of the new step.
+        BcTargets B0 = B;
+        if (P.features & SOFTROD_FEAT_MOVING_BASE_BC) {
+            const double v0x = __shfl(L.v[0], 0), v0y = __shfl(L.v[1], 0), v0z = __shfl(L.v[2], 0);
+            B0.vel[0] = v0x; B0.vel[1] = v0y; B0.vel[2] = v0z;
+        }
+        constrain_rates(P, B0, lane, L);
         constrain_values(P, B, lane, L);
     }
-    const float act32 = actions ? actions[rod] : 0.0f;
     double time = S.time[rod];
 
     FastConst C;
     {
-        const bool held = (lane == 0) && (P.features & (SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_FIXED_BC));
+        const bool l0 = (lane == 0);
+        const bool held_q = l0 && (P.features & (SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_FIXED_BC |
+                                                 SOFTROD_FEAT_MOVING_BASE_BC));
+        const bool held_x = l0 && (P.features & (SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC));
         const bool node_valid = lane <= n, elem_valid = lane < n, vor_valid = lane < n - 1;
         const double mass = (lane == 0 || lane == n) ? 0.5 * P.mass_node : P.mass_node;
         const bool damp = (P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER) != 0;
         const double ct = damp ? P.damp_t : 1.0;
-        C.hq = held ? 0.0 : 1.0;
+        C.hx = held_x ? 0.0 : 1.0;
+        C.hq = held_q ? 0.0 : 1.0;
         const double cdm = node_valid ? ct * P.dt / mass : 0.0;
         C.cf = cdm;
         double fe0 = 0.0, fe1 = 0.0, fe2 = 0.0;
         if (P.features & SOFTROD_FEAT_GRAVITY) {
             fe0 = P.gravity[0] * mass; fe1 = P.gravity[1] * mass; fe2 = P.gravity[2] * mass;
         }
-        // PendulumPointForces ASSIGNS external_forces[0,0] (build.py:101)
-        if (P.features & SOFTROD_FEAT_POINT_FORCE_NODE0_X) fe0 = (lane == 0) ? (double)act32 : fe0;
+        // PendulumPointForces ASSIGNS external_forces[0,0] (soft_pendulum/build.py:101)
+        if (P.features & SOFTROD_FEAT_POINT_FORCE_NODE0_X) fe0 = l0 ? A.force : fe0;
         if ((P.features & SOFTROD_FEAT_TIP_FORCE) && lane == n) {
             fe0 += P.tip_force[0]; fe1 += P.tip_force[1]; fe2 += P.tip_force[2];
         }
@@ -293,7 +313,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
         fast_kinematic_step(P.half_dt, C, L);
         if (P.time_two_half_adds) time += P.half_dt;
         for (int s = 0; s < n_sub; ++s) {
-            fast_dynamic_step(Pk, C, lane, L);
+            fast_dynamic_step(Pk, C, B, lane, L);
             const bool last = (s == n_sub - 1);
             fast_kinematic_step(last ? P.half_dt : P.dt, C, L);
             time += P.time_two_half_adds ? P.half_dt : P.dt;          // end of substep s
@@ -303,7 +323,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
 
     store_state(S, N, row, L);
     if (lane == 0) S.time[rod] = time;
-    if (epilogue) env_epilogue(P, S, rod, lane, L, time, act32, obs, reward, terminated, truncated);
+    if (epilogue) env_epilogue(P, S, N, rod, lane, L, time, A, obs, reward, terminated, truncated, aux);
 }
 
 }  // namespace softrod

@@ -6,8 +6,9 @@
 // loop of `env.step` (soft_pendulum.py:183-184: step_skip x PositionVerlet.step) runs
 // register-resident: HBM is read once and written once per env.step.  Every
 // nearest-neighbour stencil of the discretisation (x[k+1]-x[k], n[k]-n[k-1],
-// Q[k+1]Q[k]^T, 1/2(a[k]+a[k-1])) is a DPP wave shift (v_mov_b32_dpp wave_shl:1 /
-// wave_shr:1, 2 per fp64 value) — no LDS round trip, no barrier.
+// Q[k+1]Q[k]^T, 1/2(a[k]+a[k-1]), the Laplace filter) is a DPP wave shift
+// (v_mov_b32_dpp wave_shl:1 / wave_shr:1, 2 per fp64 value) — no LDS round trip, no
+// barrier.
 //
 // Two step kernels share this file's state layout:
 //   softrod_step_libm_kernel  SOFTROD_MATH_LIBM: the substep exactly as PyElastica
@@ -17,8 +18,9 @@
 //   softrod_step_fast_kernel  SOFTROD_MATH_FAST (default): same mathematics,
 //                             reorganised for the fp64 VALU (softrod_fast.hpp).
 //
-// The arithmetic restates PyElastica's PositionVerlet substep for the simulator that
-// build_soft_pendulum assembles (gym_softrobot/envs/soft_pendulum/build.py:29-115);
+// The arithmetic restates PyElastica's PositionVerlet substep for the simulators that
+// build_soft_pendulum (gym_softrobot/envs/soft_pendulum/build.py:29-115) and
+// build_soft_pendulum_3d (gym_softrobot/envs/soft_pendulum_3d/build.py:43-86) assemble;
 // the order of operations is documented in DESIGN.md "substep order" and mirrored by
 // the CPU oracle (oracle/softrod_oracle.c), against which tests/ check this file.
 #pragma once
@@ -35,6 +37,7 @@ constexpr int kLanes = 64;
 struct RodParams {
     int n_envs, n_elem, time_two_half_adds;
     unsigned features;
+    int env_kind, filter_order, damp_before_constrain, pad0;
     double dt, half_dt, final_time;
     double rest_len, inv_rest_len;   // uniform straight rod: all elements alike
     double rest_vor, inv_rest_vor;
@@ -48,6 +51,8 @@ struct RodParams {
     double damp_r[3];                // exp(-nu*dt*m_e/J_i)
     double damp_logr[3];             // -nu*dt*m_e/J_i  (fast path: exp(e*logr))
     double eps_length, eps_rot_axis, acos_shift, eps_sin;
+    double base_limit, step_time;    // SoftPendulum3D set_action
+    float base_step, pad1;
 };
 
 struct StatePtrs {
@@ -57,8 +62,8 @@ struct StatePtrs {
     double* omg;   // [3][N][64]
     double* tan;   // [3][N][64]  tangents as of the last force evaluation
     double* time;  // [N]
-    double* bc;    // [12][N]     pendulum/fixed BC targets: pos0[3], Q0[9] of element 0
-    float* prev_action;  // [N]
+    double* bc;    // [12][N]     BC targets: pos0[3], Q0[9] of node/element 0
+    double* ctrl;  // [4][N]      moving-base controller: position x,y ; velocity x,y
 };
 
 // ---------------------------------------------------------------------------------
@@ -108,11 +113,21 @@ struct LaneState {
 struct BcTargets {
     double pos[3];
     double Q[9];
+    double vel[3];      // imposed base velocity (moving base), else 0
 };
 
-// constrain_values: PendulumBoundaryConditions (build.py:71-74) resets y,z of node 0 and
-// director rows 0 and 2 of element 0 (row 1 is deliberately left alone); FIXED_BC is
-// PyElastica's OneEndFixedBC.
+// Per-env action handling done once per env.step before the substeps.
+struct EnvAction {
+    float a[2];         // raw action (float32), as many as the env has
+    double force;       // SoftPendulum: point_force[0] (float32 value held in float64)
+};
+
+// constrain_values.
+//   PENDULUM_BC   soft_pendulum/build.py:71-74: y,z of node 0 and director rows 0 and 2 of
+//                 element 0 are reset (row 1 is deliberately left alone);
+//   FIXED_BC      PyElastica OneEndFixedBC;
+//   MOVING_BASE   soft_pendulum_3d/build.py:31-34: node 0 = (controller x, y, fixed height),
+//                 element 0 director fixed.  (B.pos already holds the commanded position.)
 __device__ __forceinline__ void constrain_values(const RodParams& P, const BcTargets& B, int lane,
                                                  LaneState& L) {
     const bool l0 = (lane == 0);
@@ -125,7 +140,7 @@ __device__ __forceinline__ void constrain_values(const RodParams& P, const BcTar
             L.Q[6 + j] = l0 ? B.Q[6 + j] : L.Q[6 + j];
         }
     }
-    if (P.features & SOFTROD_FEAT_FIXED_BC) {
+    if (P.features & (SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) L.x[j] = l0 ? B.pos[j] : L.x[j];
 #pragma unroll
@@ -133,8 +148,9 @@ __device__ __forceinline__ void constrain_values(const RodParams& P, const BcTar
     }
 }
 
-// constrain_rates (build.py:76-79)
-__device__ __forceinline__ void constrain_rates(const RodParams& P, int lane, LaneState& L) {
+// constrain_rates (soft_pendulum/build.py:76-79, soft_pendulum_3d/build.py:36-39)
+__device__ __forceinline__ void constrain_rates(const RodParams& P, const BcTargets& B, int lane,
+                                                LaneState& L) {
     const bool l0 = (lane == 0);
     if (P.features & SOFTROD_FEAT_PENDULUM_BC) {
         L.v[1] = l0 ? 0.0 : L.v[1];
@@ -142,12 +158,36 @@ __device__ __forceinline__ void constrain_rates(const RodParams& P, int lane, La
         L.w[0] = l0 ? 0.0 : L.w[0];
         L.w[2] = l0 ? 0.0 : L.w[2];
     }
-    if (P.features & SOFTROD_FEAT_FIXED_BC) {
+    if (P.features & (SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            L.v[j] = l0 ? 0.0 : L.v[j];
+            L.v[j] = l0 ? B.vel[j] : L.v[j];
             L.w[j] = l0 ? 0.0 : L.w[j];
         }
+    }
+}
+
+// LaplaceDissipationFilter.dampen_rates (elastica/dissipation.py nb_filter_rate):
+//   f <- rate ; repeat order times { f_interior <- (2 f_k - f_{k-1} - f_{k+1})/4 ; f_ends <- 0 } ;
+//   rate <- rate - f.      `q` is 0.25 on interior entries of the array and 0 elsewhere.
+__device__ __forceinline__ double laplace_filter(double rate, double q, int order) {
+    double f = rate;
+    for (int i = 0; i < order; ++i) f = ((-from_next(f) - from_prev(f)) + 2.0 * f) * q;
+    return rate - f;
+}
+
+__device__ __forceinline__ void laplace_filter_rates(const RodParams& P, int lane, LaneState& L) {
+    const int n = P.n_elem;
+    const double qn = (lane >= 1 && lane <= n - 1) ? 0.25 : 0.0;   // nodes 1..n-1 of 0..n
+    const double qe = (lane >= 1 && lane <= n - 2) ? 0.25 : 0.0;   // elements 1..n-2 of 0..n-1
+    // the ends keep f = 0, i.e. are not filtered; entries beyond the rod hold rate 0
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double vq = (lane <= n) ? L.v[c] : 0.0, wq = (lane < n) ? L.w[c] : 0.0;
+        const double vf = laplace_filter(vq, qn, P.filter_order);
+        const double wf = laplace_filter(wq, qe, P.filter_order);
+        L.v[c] = (lane <= n) ? vf : L.v[c];
+        L.w[c] = (lane < n) ? wf : L.w[c];
     }
 }
 
@@ -185,10 +225,10 @@ __device__ __forceinline__ void libm_kinematic_step(const RodParams& P, double h
     for (int i = 0; i < 9; ++i) L.Q[i] = Qn[i];
 }
 
-// Internal forces/torques + forcing + dynamic update + damper + rate constraints:
+// Internal forces/torques + forcing + dynamic update + dampers + rate constraints:
 // steps (3)-(6) of the substep (DESIGN.md "substep order").
-__device__ __forceinline__ void libm_dynamic_step(const RodParams& P, int lane, double action,
-                                                  double mass, LaneState& L) {
+__device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTargets& B, int lane,
+                                                  double action, double mass, LaneState& L) {
     const int n = P.n_elem;
     const bool node_valid = lane <= n;
     const bool elem_valid = lane < n;
@@ -291,14 +331,16 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, int lane, 
     L.w[1] += elem_valid ? P.dt * al1 : 0.0;
     L.w[2] += elem_valid ? P.dt * al2 : 0.0;
 
-    // ---- AnalyticalLinearDamper.dampen_rates, then constrain_rates ----
+    // ---- dampers (registration order) and constrain_rates ----
+    if (!P.damp_before_constrain) constrain_rates(P, B, lane, L);
     if (P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER) {
         L.v[0] *= P.damp_t; L.v[1] *= P.damp_t; L.v[2] *= P.damp_t;
         L.w[0] *= pow(P.damp_r[0], e);
         L.w[1] *= pow(P.damp_r[1], e);
         L.w[2] *= pow(P.damp_r[2], e);
     }
-    constrain_rates(P, lane, L);
+    if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates(P, lane, L);
+    if (P.damp_before_constrain) constrain_rates(P, B, lane, L);
 }
 
 // ---------------------------------------------------------------------------------
@@ -333,6 +375,45 @@ __device__ __forceinline__ void load_bc(const StatePtrs& S, size_t N, int rod, B
     for (int i = 0; i < 3; ++i) B.pos[i] = S.bc[(size_t)i * N + rod];
 #pragma unroll
     for (int i = 0; i < 9; ++i) B.Q[i] = S.bc[(size_t)(3 + i) * N + rod];
+    B.vel[0] = B.vel[1] = B.vel[2] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------
+// env prologue: set_action
+// ---------------------------------------------------------------------------------
+//   SoftPendulum     point_force[:] = action                       soft_pendulum.py:163-166
+//   SoftPendulum3D   clipped base displacement -> controller        soft_pendulum_3d.py:99-113
+// All lanes compute the same wave-uniform values; lane 0 persists the controller.
+__device__ __forceinline__ void env_set_action(const RodParams& P, const StatePtrs& S, size_t N,
+                                               int rod, int lane, const float* __restrict__ actions,
+                                               EnvAction& A, BcTargets& B) {
+    A.a[0] = A.a[1] = 0.0f;
+    A.force = 0.0;
+    if (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) {
+        if (actions) { A.a[0] = actions[2 * rod]; A.a[1] = actions[2 * rod + 1]; }
+        if (P.features & SOFTROD_FEAT_MOVING_BASE_BC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double pos = S.ctrl[(size_t)i * N + rod];
+                double vel = S.ctrl[(size_t)(2 + i) * N + rod];
+                double next = pos;
+                if (actions) {
+                    const float disp = P.base_step * A.a[i];   // float32, as base_step * action
+                    next = fmin(fmax(pos + (double)disp, -P.base_limit), P.base_limit);  // np.clip
+                    vel = (next - pos) / P.step_time;
+                    if (lane == 0) {
+                        S.ctrl[(size_t)i * N + rod] = next;
+                        S.ctrl[(size_t)(2 + i) * N + rod] = vel;
+                    }
+                }
+                B.pos[i] = next;
+                B.vel[i] = vel;
+            }
+        }
+    } else {
+        if (actions) A.a[0] = actions[rod];
+        A.force = (double)A.a[0];  // float32 value held in float64
+    }
 }
 
 // theta = wrap(arctan(mean t_x / mean t_y)), soft_pendulum.py:154-156
@@ -348,30 +429,92 @@ __device__ __forceinline__ double wrapped_theta(const RodParams& P, int lane, co
     return m - M_PI;
 }
 
-// env epilogue: NaN check, reward, truncation, observation (soft_pendulum.py:196-251)
-__device__ __forceinline__ void env_epilogue(const RodParams& P, const StatePtrs& S, int rod, int lane,
-                                             const LaneState& L, double time, float act32,
-                                             float* __restrict__ obs, double* __restrict__ reward,
-                                             uint8_t* __restrict__ terminated,
-                                             uint8_t* __restrict__ truncated) {
-    const bool node_valid = lane <= P.n_elem;
+// _tilt_angle, soft_pendulum_3d.py:88-91
+__device__ __forceinline__ double tilt_angle(const RodParams& P, int lane, const LaneState& L) {
+    const bool elem_valid = lane < P.n_elem;
+    double tm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tm[c] = wave_sum(elem_valid ? L.t[c] : 0.0) / (double)P.n_elem;
+    const double nrm = sqrt(tm[0] * tm[0] + tm[1] * tm[1] + tm[2] * tm[2]);
+    const double tz = tm[2] / nrm;
+    return acos(fmin(fmax(tz, -1.0), 1.0));
+}
+
+__device__ __forceinline__ bool state_has_nan(const RodParams& P, int lane, const LaneState& L) {
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) bad = bad || isnan(L.x[c]) || isnan(L.v[c]);
-    const bool invalid = __any(node_valid && bad);
-    const double th = wrapped_theta(P, lane, L);
-    if (lane == 0) {
-        S.prev_action[rod] = act32;
-        double forward = 0.0, survive = 0.0;
-        if (invalid) survive = -50.0;
-        else forward = fabs(L.x[0]) * 10.0 + th * th;
-        reward[rod] = forward - 0.0 + survive;
-        terminated[rod] = invalid ? 1 : 0;
-        truncated[rod] = (time > P.final_time) ? 1 : 0;
-        obs[4 * rod + 0] = (float)L.x[0];
-        obs[4 * rod + 1] = (float)L.v[0];
-        obs[4 * rod + 2] = act32;
-        obs[4 * rod + 3] = (float)th;
+    return __any((lane <= P.n_elem) && bad);
+}
+
+// observation only (get_state at reset)
+__device__ __forceinline__ void env_observe(const RodParams& P, int rod, int lane, const LaneState& L,
+                                            const float* pa, float* __restrict__ obs) {
+    if (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) {
+        const double tilt = tilt_angle(P, lane, L);
+        if (lane == 0) {
+            float* o = obs + 9 * (size_t)rod;
+            o[0] = (float)L.x[0]; o[1] = (float)L.x[1]; o[2] = (float)L.x[2];
+            o[3] = (float)L.v[0]; o[4] = (float)L.v[1]; o[5] = (float)L.v[2];
+            o[6] = pa[0]; o[7] = pa[1];
+            o[8] = (float)tilt;
+        }
+    } else {
+        const double th = wrapped_theta(P, lane, L);
+        if (lane == 0) {
+            float* o = obs + 4 * (size_t)rod;
+            o[0] = (float)L.x[0];
+            o[1] = (float)L.v[0];
+            o[2] = pa[0];
+            o[3] = (float)th;
+        }
+    }
+}
+
+// env epilogue: NaN check, reward, truncation, observation
+//   SoftPendulum    soft_pendulum.py:196-251       SoftPendulum3D  soft_pendulum_3d.py:130-174
+__device__ __forceinline__ void env_epilogue(const RodParams& P, const StatePtrs& S, size_t N, int rod,
+                                             int lane, const LaneState& L, double time,
+                                             const EnvAction& A, float* __restrict__ obs,
+                                             double* __restrict__ reward,
+                                             uint8_t* __restrict__ terminated,
+                                             uint8_t* __restrict__ truncated,
+                                             double* __restrict__ aux) {
+    const bool invalid = state_has_nan(P, lane, L);
+    if (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) {
+        const double tilt = tilt_angle(P, lane, L);
+        if (lane == 0) {
+            const double bx = S.ctrl[(size_t)0 * N + rod], by = S.ctrl[(size_t)1 * N + rod];
+            const double base_distance = sqrt(bx * bx + by * by);
+            // 1e-3 * np.dot(action, action) stays float32 (NumPy 2 weak-scalar promotion)
+            const float ctl = 1e-3f * (A.a[0] * A.a[0] + A.a[1] * A.a[1]);
+            double r = -(tilt * tilt + 0.1 * (base_distance * base_distance) + (double)ctl);
+            if (invalid) r = -50.0;
+            reward[rod] = r;
+            terminated[rod] = invalid ? 1 : 0;
+            truncated[rod] = (time >= P.final_time) ? 1 : 0;   // '>=' here, '>' in SoftPendulum
+            if (aux) aux[rod] = tilt;
+            float* o = obs + 9 * (size_t)rod;
+            o[0] = (float)L.x[0]; o[1] = (float)L.x[1]; o[2] = (float)L.x[2];
+            o[3] = (float)L.v[0]; o[4] = (float)L.v[1]; o[5] = (float)L.v[2];
+            o[6] = A.a[0]; o[7] = A.a[1];
+            o[8] = (float)tilt;
+        }
+    } else {
+        const double th = wrapped_theta(P, lane, L);
+        if (lane == 0) {
+            double forward = 0.0, survive = 0.0;
+            if (invalid) survive = -50.0;
+            else forward = fabs(L.x[0]) * 10.0 + th * th;
+            reward[rod] = forward - 0.0 + survive;
+            terminated[rod] = invalid ? 1 : 0;
+            truncated[rod] = (time > P.final_time) ? 1 : 0;
+            float* o = obs + 4 * (size_t)rod;
+            o[0] = (float)L.x[0];
+            o[1] = (float)L.v[0];
+            o[2] = A.a[0];
+            o[3] = (float)th;
+        }
     }
 }
 
@@ -383,7 +526,7 @@ __global__ void __launch_bounds__(kLanes)
 softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                         const int n_sub, const int epilogue) {
+                         double* __restrict__ aux, const int n_sub, const int epilogue) {
     const int rod = blockIdx.x;
     const int lane = threadIdx.x;
     const size_t N = (size_t)P.n_envs;
@@ -393,9 +536,9 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
     load_state(S, N, row, L);
     BcTargets B;
     load_bc(S, N, rod, B);
+    EnvAction A;
+    env_set_action(P, S, N, rod, lane, actions, A, B);
 
-    const float act32 = actions ? actions[rod] : 0.0f;
-    const double action = (double)act32;  // point_force[:] = action (float32 -> float64)
     double time = S.time[rod];
     const int n = P.n_elem;
     const double mass = (lane == 0 || lane == n) ? 0.5 * P.mass_node : P.mass_node;
@@ -404,7 +547,7 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
         libm_kinematic_step(P, P.half_dt, L);
         if (P.time_two_half_adds) time += P.half_dt;
         constrain_values(P, B, lane, L);
-        libm_dynamic_step(P, lane, action, mass, L);
+        libm_dynamic_step(P, B, lane, A.force, mass, L);
         libm_kinematic_step(P, P.half_dt, L);
         time += P.time_two_half_adds ? P.half_dt : P.dt;
         constrain_values(P, B, lane, L);
@@ -412,7 +555,7 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
 
     store_state(S, N, row, L);
     if (lane == 0) S.time[rod] = time;
-    if (epilogue) env_epilogue(P, S, rod, lane, L, time, act32, obs, reward, terminated, truncated);
+    if (epilogue) env_epilogue(P, S, N, rod, lane, L, time, A, obs, reward, terminated, truncated, aux);
 }
 
 // get_state() outside a step (reset observation), soft_pendulum.py:145-161
@@ -424,13 +567,11 @@ softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __rest
     const size_t N = (size_t)P.n_envs;
     LaneState L;
     load_state(S, N, (size_t)rod * kLanes + lane, L);
-    const double th = wrapped_theta(P, lane, L);
-    if (lane == 0) {
-        obs[4 * rod + 0] = (float)L.x[0];
-        obs[4 * rod + 1] = (float)L.v[0];
-        obs[4 * rod + 2] = prev_action ? prev_action[rod] : 0.0f;
-        obs[4 * rod + 3] = (float)th;
-    }
+    const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2 : 1;
+    float pa[2] = {0.0f, 0.0f};
+    if (prev_action)
+        for (int i = 0; i < adim; ++i) pa[i] = prev_action[adim * (size_t)rod + i];
+    env_observe(P, rod, lane, L, pa, obs);
 }
 
 // Reset: expand the host-computed straight-rod description of each masked rod
@@ -475,6 +616,9 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
         for (int i = 0; i < 3; ++i) S.bc[(size_t)i * N + rod] = in[i];
 #pragma unroll
         for (int i = 0; i < 9; ++i) S.bc[(size_t)(3 + i) * N + rod] = in[9 + i];
+        // MovingBaseController() is rebuilt by reset (soft_pendulum_3d.py:66)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.ctrl[(size_t)i * N + rod] = 0.0;
     }
 }
 

@@ -1,3 +1,4 @@
 from .soft_pendulum import SoftPendulumEnv, VecSoftPendulumEnv
+from .soft_pendulum_3d import SoftPendulum3DEnv, VecSoftPendulum3DEnv
 
-__all__ = ["SoftPendulumEnv", "VecSoftPendulumEnv"]
+__all__ = ["SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv"]

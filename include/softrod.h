@@ -11,7 +11,9 @@
  * where `do_step` is PyElastica's `PositionVerlet().step` (soft_pendulum.py:137-139)
  * applied to the simulator assembled by `build_soft_pendulum`
  * (gym_softrobot/envs/soft_pendulum/build.py:29-115), followed by the NaN check,
- * reward, truncation test and observation of soft_pendulum.py:196-251.
+ * reward, truncation test and observation of soft_pendulum.py:196-251 — and for
+ * the identical loops of the envs SURVEY.md §8 lists next to it
+ * (soft_pendulum_3d.py:127-128, octopus/arm_single_env.py:247-248).
  *
  * The reference has no FFI for this path: its "operator API" is a set of Python
  * classes PyElastica calls back into once per substep (ConstraintBase /
@@ -42,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 1
+#define SOFTROD_ABI_VERSION 2
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -55,37 +57,55 @@ extern "C" {
  * Feature bits: the compiled-in replacements of the reference's per-substep
  * Python hooks.  Order of application inside a substep is fixed to the order
  * PyElastica's PositionVerlet.step gives them (DESIGN.md "substep order").
+ * File names below are relative to gym_softrobot/envs/.
  */
 enum softrod_feature {
-    /* GravityForces(acc_gravity)                          build.py:88-91   */
+    /* GravityForces(acc_gravity)                  soft_pendulum/build.py:88-91 */
     SOFTROD_FEAT_GRAVITY = 1u << 0,
     /* PendulumPointForces.apply_forces: external_forces[0,0] = action
-     * (ASSIGNS, after gravity was added)                  build.py:94-105  */
+     * (ASSIGNS, after gravity was added)          soft_pendulum/build.py:94-105 */
     SOFTROD_FEAT_POINT_FORCE_NODE0_X = 1u << 1,
-    /* PendulumBoundaryConditions.constrain_values/rates   build.py:65-85   */
+    /* PendulumBoundaryConditions                  soft_pendulum/build.py:65-85 */
     SOFTROD_FEAT_PENDULUM_BC = 1u << 2,
-    /* AnalyticalLinearDamper(damping_constant, time_step) build.py:108-113 */
+    /* AnalyticalLinearDamper(damping_constant, time_step)
+     *                                             soft_pendulum/build.py:108-113 */
     SOFTROD_FEAT_ANALYTICAL_DAMPER = 1u << 3,
-    /* PyElastica OneEndFixedBC on node 0 / element 0 (known-answer tests)  */
+    /* PyElastica OneEndFixedBC on node 0 / element 0 (known-answer tests)      */
     SOFTROD_FEAT_FIXED_BC = 1u << 4,
     /* constant force on the last node, PyElastica EndpointForces with
-     * start_force = 0 and no ramp (known-answer tests)                      */
+     * start_force = 0 and no ramp (known-answer tests)                          */
     SOFTROD_FEAT_TIP_FORCE = 1u << 5,
+    /* MovingBaseConstraint: node 0 pinned to the commanded base position,
+     * element 0 director fixed, base velocity imposed
+     *                                             soft_pendulum_3d/build.py:23-40 */
+    SOFTROD_FEAT_MOVING_BASE_BC = 1u << 6,
+    /* LaplaceDissipationFilter(filter_order)      soft_pendulum_3d/build.py:82-85 */
+    SOFTROD_FEAT_LAPLACE_FILTER = 1u << 7,
 };
 
 #define SOFTROD_FEATURES_SOFTPENDULUM                                             \
     (SOFTROD_FEAT_GRAVITY | SOFTROD_FEAT_POINT_FORCE_NODE0_X |                   \
      SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_ANALYTICAL_DAMPER)
+#define SOFTROD_FEATURES_SOFTPENDULUM3D                                           \
+    (SOFTROD_FEAT_GRAVITY | SOFTROD_FEAT_MOVING_BASE_BC |                        \
+     SOFTROD_FEAT_ANALYTICAL_DAMPER | SOFTROD_FEAT_LAPLACE_FILTER)
+
+/* env_kind: which env's set_action / NaN check / reward / observation the step
+ * kernel's prologue and epilogue implement.                                     */
+#define SOFTROD_ENV_NONE 0           /* bare rod: softrod_substeps only            */
+#define SOFTROD_ENV_SOFTPENDULUM 1   /* soft_pendulum/soft_pendulum.py:149-251     */
+#define SOFTROD_ENV_SOFTPENDULUM3D 2 /* soft_pendulum_3d/soft_pendulum_3d.py:93-174 */
 
 /* math_mode (HIP library only; the oracle always uses libm). */
 #define SOFTROD_MATH_LIBM 0 /* sqrt/sin/cos/acos/pow evaluated as written   */
-#define SOFTROD_MATH_FAST 1 /* range-checked polynomial forms, libm fallback */
+#define SOFTROD_MATH_FAST 1 /* range-checked polynomial forms, no libm      */
 
 /*
  * Everything that is identical for all rods of a batch.  Defaults are filled by
- * softrod_config_softpendulum(); the "PyElastica numerics" block holds the
- * constants SURVEY.md App. A marks (?) so that a session with pyelastica==1.0.0
- * importable can flip them without touching a kernel.
+ * softrod_config_softpendulum() / softrod_config_softpendulum3d(); the
+ * "PyElastica numerics" block holds the constants SURVEY.md App. A marks (?) so
+ * that a session with pyelastica==1.0.0 importable can flip them without
+ * touching a kernel.
  */
 typedef struct softrod_config {
     uint32_t struct_size; /* = sizeof(softrod_config); ABI guard            */
@@ -94,8 +114,10 @@ typedef struct softrod_config {
     int32_t n_elem;       /* elements per rod (n_elems, soft_pendulum.py:64) */
     int32_t n_substeps;   /* step_skip = int(1/(fps*dt)), soft_pendulum.py:78 */
     int32_t math_mode;    /* SOFTROD_MATH_*                                 */
+    int32_t env_kind;     /* SOFTROD_ENV_*                                  */
+    int32_t filter_order; /* LaplaceDissipationFilter order                 */
     double dt;            /* time_step, soft_pendulum.py:62                 */
-    double final_time;    /* soft_pendulum.py:61; truncation is time > it   */
+    double final_time;    /* soft_pendulum.py:61                            */
     /* straight_rod arguments, build.py:18-26,54-61 */
     double base_length;
     double base_radius;
@@ -105,6 +127,9 @@ typedef struct softrod_config {
     double gravity[3];    /* build.py:87-91                                 */
     double damping_constant; /* build.py:108                                */
     double tip_force[3];  /* SOFTROD_FEAT_TIP_FORCE only                    */
+    /* SoftPendulum3D set_action, soft_pendulum_3d.py:57-58,99-113 */
+    double base_step;     /* 1e-3 (applied in float32, as the reference)    */
+    double base_limit;    /* 0.5                                            */
     /* PyElastica numerics (UNVERIFIED recollection) */
     double alpha_c;       /* 27/28 shear correction                         */
     double eps_length;    /* 1e-14 added to |dx|                            */
@@ -112,8 +137,14 @@ typedef struct softrod_config {
     double acos_shift;    /* 1e-10 subtracted inside arccos of _inv_rotate  */
     double eps_sin;       /* 1e-14 added inside sin of _inv_rotate          */
     int32_t time_two_half_adds; /* 1: t += dt/2 twice per substep; 0: += dt */
-    int32_t reserved;
+    int32_t damp_before_constrain; /* 1: dampen_rates then constrain_rates
+                                      (mixin order of BaseSimulator)          */
 } softrod_config;
+
+/* Per-env I/O widths implied by env_kind. */
+int softrod_action_dim(int env_kind); /* 1, 2                               */
+int softrod_obs_dim(int env_kind);    /* 4, 9                               */
+int softrod_aux_dim(int env_kind);    /* 0, 1 (info["tilt"], float64)       */
 
 typedef struct softrod_handle softrod_handle;
 
@@ -135,11 +166,16 @@ typedef struct softrod_state_view {
     double* omega;    /* [3][n_envs][64]    */
     double* tangents; /* [3][n_envs][64]  as of the last force evaluation   */
     double* time;     /* [n_envs]  simulated time (soft_pendulum.py:141,184) */
+    double* control;  /* [4][n_envs]  MovingBaseController position x,y and
+                         velocity x,y (soft_pendulum_3d/build.py:15-20)      */
 } softrod_state_view;
 
 /* Fill `cfg` with SoftPendulumEnv.__init__ defaults (soft_pendulum.py:59-78)
  * and build_soft_pendulum's constants (build.py:18-26,87-113).             */
 int softrod_config_softpendulum(softrod_config* cfg, int n_envs);
+/* Same for SoftPendulum3DEnv (soft_pendulum_3d.py:28-58) and
+ * build_soft_pendulum_3d (soft_pendulum_3d/build.py:43-86).                 */
+int softrod_config_softpendulum3d(softrod_config* cfg, int n_envs);
 
 /* Replaces: BaseSimulator() + build_soft_pendulum(...) + simulator.finalize()
  * (soft_pendulum.py:115-138) for a whole batch: allocates resident device
@@ -154,32 +190,38 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out);
 int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask,
                   void* stream);
 
-/* General straight rod for known-answer tests: start/direction/normal are host
- * [n_envs][3] (CosseratRod.straight_rod arguments, build.py:54-61).         */
+/* General straight rod (CosseratRod.straight_rod arguments, build.py:54-61):
+ * start/direction/normal are host [n_envs][3]; mask as above.  Also clears the
+ * moving-base controller of the reset rods (soft_pendulum_3d.py:67).  Used by
+ * SoftPendulum3D (direction = (sin tilt, 0, cos tilt), normal = +y,
+ * soft_pendulum_3d/build.py:51-53) and by the known-answer tests.           */
 int softrod_reset_straight(softrod_handle* h, const double* start,
                            const double* direction, const double* normal,
-                           void* stream);
+                           const uint8_t* mask, void* stream);
 
-/* Replaces: SoftPendulumEnv.step (soft_pendulum.py:176-251) for every rod:
- * set_action -> n_substeps x PositionVerlet.step -> NaN check -> reward ->
- * truncation -> get_state.  Asynchronous on `stream`.
- *   actions     device [n_envs]      float32 (point_force[:] = action, :165-166)
- *   obs         device [n_envs][4]   float32 [x0, vx0, prev_action, theta] (:149-161)
- *   reward      device [n_envs]      float64 (:231)
- *   terminated  device [n_envs]      uint8   (:205-208)
- *   truncated   device [n_envs]      uint8   (:226-229)                      */
+/* Replaces: Env.step for every rod (soft_pendulum.py:176-251,
+ * soft_pendulum_3d.py:115-174): set_action -> n_substeps x PositionVerlet.step
+ * -> NaN check -> reward -> truncation -> get_state.  Asynchronous on `stream`.
+ *   actions     device [n_envs][action_dim] float32
+ *   obs         device [n_envs][obs_dim]    float32
+ *   reward      device [n_envs]             float64
+ *   terminated  device [n_envs]             uint8
+ *   truncated   device [n_envs]             uint8
+ *   aux         device [n_envs][aux_dim]    float64 or NULL (info extras)    */
 int softrod_step(softrod_handle* h, const float* actions, float* obs,
                  double* reward, uint8_t* terminated, uint8_t* truncated,
-                 void* stream);
+                 double* aux, void* stream);
 
-/* Replaces: get_state() at reset (soft_pendulum.py:145-161).  prev_action is
- * device [n_envs] float32 or NULL (= zeros).                                */
+/* Replaces: get_state() at reset (soft_pendulum.py:145-161,
+ * soft_pendulum_3d.py:93-98).  prev_action is device [n_envs][action_dim]
+ * float32 or NULL (= zeros).                                                */
 int softrod_observe(softrod_handle* h, const float* prev_action, float* obs,
                     void* stream);
 
-/* Run `n` bare PositionVerlet substeps with a fixed action and no env
- * epilogue (the inner loop of soft_pendulum.py:183-184 alone); used by the
- * known-answer tests and by the kernel micro-benchmarks.                    */
+/* Run `n` bare PositionVerlet substeps with fixed per-env forcing inputs and no
+ * env epilogue (the inner loop of soft_pendulum.py:183-184 alone); `actions`
+ * (device [n_envs] float32 or NULL) feeds SOFTROD_FEAT_POINT_FORCE_NODE0_X.
+ * Used by the known-answer tests and by the kernel micro-benchmarks.        */
 int softrod_substeps(softrod_handle* h, const float* actions, int n, void* stream);
 
 int softrod_state_view_get(softrod_handle* h, softrod_state_view* out);

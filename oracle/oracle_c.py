@@ -45,6 +45,10 @@ def _load(omp: bool) -> C.CDLL:
     lib.oracle_substeps.argtypes = [C.c_void_p, C.c_float, C.c_int]
     lib.oracle_env_step.argtypes = [C.c_void_p, C.c_float] + [C.c_void_p] * 4
     lib.oracle_env_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    lib.oracle_reset_pendulum3d.argtypes = [C.c_void_p, C.c_double]
+    lib.oracle_observe3d.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_clear_prev_action3d.argtypes = [C.c_void_p]
+    lib.oracle_env_step3d.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.oracle_get.restype = C.c_int
     lib.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.oracle_set.restype = C.c_int
@@ -63,6 +67,7 @@ _SHAPES = {
     "shear": lambda n: (3, n), "bend": lambda n: (3, n - 1), "damp_r": lambda n: (3, n),
     "mass": lambda n: (n + 1,), "lengths": lambda n: (n,), "dilatation": lambda n: (n,),
     "rest_lengths": lambda n: (n,), "damp_t": lambda n: (1,), "rest_kappa": lambda n: (3, n - 1),
+    "control": lambda n: (4,),
 }
 
 
@@ -117,6 +122,28 @@ class OracleRod:
             term.ctypes.data, trunc.ctypes.data,
         )
         return obs, float(rew[0]), bool(term[0]), bool(trunc[0])
+
+    # -- SoftPendulum3D-v0 --------------------------------------------------------
+    def reset_pendulum3d(self, tilt: float) -> None:
+        self._lib.oracle_reset_pendulum3d(self._h, float(tilt))
+
+    def observe3d(self) -> np.ndarray:
+        obs = np.empty(9, np.float32)
+        self._lib.oracle_observe3d(self._h, obs.ctypes.data)
+        return obs
+
+    def env_step3d(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(2)
+        obs = np.empty(9, np.float32)
+        rew = np.empty(1, np.float64)
+        tilt = np.empty(1, np.float64)
+        term = np.empty(1, np.uint8)
+        trunc = np.empty(1, np.uint8)
+        self._lib.oracle_env_step3d(
+            self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
+            trunc.ctypes.data, tilt.ctypes.data,
+        )
+        return obs, float(rew[0]), bool(term[0]), bool(trunc[0]), float(tilt[0])
 
     def get(self, name: str) -> np.ndarray:
         shape = _SHAPES[name](self.n)

@@ -62,6 +62,9 @@ typedef struct oracle_rod {
     double fixed_pos[3], fixed_dir[3][3];
     float prev_action; /* _prev_action, soft_pendulum.py:97-99,165 */
     double point_force; /* point_force[0], soft_pendulum.py:117,166 */
+    /* MovingBaseController, soft_pendulum_3d/build.py:15-20 */
+    double ctrl_pos[3], ctrl_vel[3];
+    float prev_action2[2]; /* SoftPendulum3DEnv._prev_action */
 } oracle_rod;
 
 /* ------------------------------------------------------------------------- */
@@ -156,6 +159,7 @@ static void straight_rod(oracle_rod* r, const double start[3],
     }
     r->time = 0.0;
     r->point_force = 0.0;
+    for (int i = 0; i < 3; ++i) { r->ctrl_pos[i] = 0.0; r->ctrl_vel[i] = 0.0; }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -357,6 +361,13 @@ static void constrain_values(oracle_rod* r)
             for (int j = 0; j < 3; ++j) r->Q[i][j][0] = r->fixed_dir[i][j];
         }
     }
+    /* MovingBaseConstraint.constrain_values, soft_pendulum_3d/build.py:31-34 */
+    if (r->cfg.features & SOFTROD_FEAT_MOVING_BASE_BC) {
+        for (int i = 0; i < 3; ++i) r->x[i][0] = r->ctrl_pos[i];
+        r->x[2][0] = r->fixed_pos[2];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) r->Q[i][j][0] = r->fixed_dir[i][j];
+    }
 }
 
 /* constrain_rates (build.py:76-79) */
@@ -368,6 +379,12 @@ static void constrain_rates(oracle_rod* r)
     }
     if (r->cfg.features & SOFTROD_FEAT_FIXED_BC)
         for (int i = 0; i < 3; ++i) { r->v[i][0] = 0.0; r->w[i][0] = 0.0; }
+    /* MovingBaseConstraint.constrain_rates, soft_pendulum_3d/build.py:36-39 */
+    if (r->cfg.features & SOFTROD_FEAT_MOVING_BASE_BC) {
+        for (int i = 0; i < 3; ++i) r->v[i][0] = r->ctrl_vel[i];
+        r->v[2][0] = 0.0;
+        for (int i = 0; i < 3; ++i) r->w[i][0] = 0.0;
+    }
 }
 
 /* synchronize(): forcing in registration order — GravityForces (build.py:88-91)
@@ -410,6 +427,29 @@ static void dampen_rates(oracle_rod* r)
         for (int k = 0; k < n; ++k) r->w[i][k] = r->w[i][k] * pow(r->damp_r[i][k], r->dil[k]);
 }
 
+/* LaplaceDissipationFilter.dampen_rates -> nb_filter_rate (elastica/dissipation.py),
+ * registered at soft_pendulum_3d/build.py:82-85: applied to velocity (n+1 entries)
+ * and omega (n entries) */
+static void filter_rate(double* rate, int m, int order)
+{
+    double f[NMAX + 1], g[NMAX + 1];
+    for (int k = 0; k < m; ++k) f[k] = rate[k];
+    for (int it = 0; it < order; ++it) {
+        for (int k = 1; k < m - 1; ++k) g[k] = (-f[k + 1] - f[k - 1] + 2.0 * f[k]) / 4.0;
+        for (int k = 1; k < m - 1; ++k) f[k] = g[k];
+        f[0] = 0.0;
+        f[m - 1] = 0.0;
+    }
+    for (int k = 0; k < m; ++k) rate[k] = rate[k] - f[k];
+}
+
+static void laplace_filter(oracle_rod* r)
+{
+    if (!(r->cfg.features & SOFTROD_FEAT_LAPLACE_FILTER)) return;
+    for (int i = 0; i < 3; ++i) filter_rate(r->v[i], r->n + 1, r->cfg.filter_order);
+    for (int i = 0; i < 3; ++i) filter_rate(r->w[i], r->n, r->cfg.filter_order);
+}
+
 /* PositionVerlet().step(simulator, time, dt) — elastica/timestepper/
  * symplectic_steppers.py SymplecticStepperMethods.do_step; call site
  * soft_pendulum.py:184 */
@@ -427,8 +467,15 @@ static void position_verlet_step(oracle_rod* r)
     /* _feature_group_constrain_rates: Damping registers before Constraints for
      * the mixin order of BaseSimulator (soft_pendulum.py:34-42); the two
      * commute exactly for this env (zeros vs. scaling). */
-    dampen_rates(r);
-    constrain_rates(r);
+    if (r->cfg.damp_before_constrain) {
+        dampen_rates(r);   /* dampers in registration order: analytical, then Laplace */
+        laplace_filter(r);
+        constrain_rates(r);
+    } else {
+        constrain_rates(r);
+        dampen_rates(r);
+        laplace_filter(r);
+    }
     kinematic_step(r, 0.5 * dt);
     if (r->cfg.time_two_half_adds) r->time += 0.5 * dt; else r->time += dt;
     constrain_values(r);
@@ -544,6 +591,82 @@ void oracle_env_step(oracle_rod* r, float action, float obs[4], double* reward,
     get_state(r, obs);
 }
 
+/* ---- SoftPendulum3D-v0: soft_pendulum_3d/soft_pendulum_3d.py ---- */
+static double tilt_angle(const oracle_rod* r) /* :88-91 */
+{
+    const int n = r->n;
+    double tm[3] = { 0.0, 0.0, 0.0 };
+    for (int k = 0; k < n; ++k) for (int i = 0; i < 3; ++i) tm[i] += r->tang[i][k];
+    for (int i = 0; i < 3; ++i) tm[i] /= (double)n;
+    const double nrm = sqrt(tm[0] * tm[0] + tm[1] * tm[1] + tm[2] * tm[2]);
+    double tz = tm[2] / nrm;
+    if (tz < -1.0) tz = -1.0;
+    if (tz > 1.0) tz = 1.0;
+    return acos(tz);
+}
+
+static void get_state3d(const oracle_rod* r, float obs[9]) /* :93-98 */
+{
+    for (int i = 0; i < 3; ++i) { obs[i] = (float)r->x[i][0]; obs[3 + i] = (float)r->v[i][0]; }
+    obs[6] = r->prev_action2[0];
+    obs[7] = r->prev_action2[1];
+    obs[8] = (float)tilt_angle(r);
+}
+
+void oracle_observe3d(const oracle_rod* r, float obs[9]) { get_state3d(r, obs); }
+void oracle_clear_prev_action3d(oracle_rod* r) { r->prev_action2[0] = r->prev_action2[1] = 0.0f; }
+
+/* build_soft_pendulum_3d, soft_pendulum_3d/build.py:51-64 */
+void oracle_reset_pendulum3d(oracle_rod* r, double tilt)
+{
+    const double start[3] = { 0.0, 0.0, 0.0 };
+    const double direction[3] = { sin(tilt), 0.0, cos(tilt) };
+    const double normal[3] = { 0.0, 1.0, 0.0 };
+    oracle_reset_straight(r, start, direction, normal);
+    oracle_clear_prev_action3d(r); /* soft_pendulum_3d.py:68 */
+}
+
+/* SoftPendulum3DEnv.step, soft_pendulum_3d.py:115-174 (action validity is checked by
+ * the caller, :116-117) */
+void oracle_env_step3d(oracle_rod* r, const float action[2], float obs[9], double* reward,
+                       uint8_t* terminated, uint8_t* truncated, double* tilt_out)
+{
+    const int n = r->n;
+    /* set_action, :99-113 */
+    double next[3] = { r->ctrl_pos[0], r->ctrl_pos[1], r->ctrl_pos[2] };
+    for (int i = 0; i < 2; ++i) {
+        const float disp = (float)r->cfg.base_step * action[i]; /* float32 product */
+        double v = next[i] + (double)disp;
+        if (v < -r->cfg.base_limit) v = -r->cfg.base_limit; /* np.clip */
+        if (v > r->cfg.base_limit) v = r->cfg.base_limit;
+        next[i] = v;
+    }
+    const double step_time = (double)r->cfg.n_substeps * r->cfg.dt;
+    for (int i = 0; i < 3; ++i) {
+        const double actual = next[i] - r->ctrl_pos[i];
+        r->ctrl_pos[i] = next[i];
+        r->ctrl_vel[i] = actual / step_time;
+    }
+    r->prev_action2[0] = action[0];
+    r->prev_action2[1] = action[1];
+    for (int s = 0; s < r->cfg.n_substeps; ++s) position_verlet_step(r);
+    int invalid = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k <= n; ++k)
+            if (isnan(r->x[i][k]) || isnan(r->v[i][k])) invalid = 1;
+    const double tilt = tilt_angle(r);
+    const double bd = sqrt(r->ctrl_pos[0] * r->ctrl_pos[0] + r->ctrl_pos[1] * r->ctrl_pos[1]);
+    /* 1e-3 * np.dot(action, action): float32 under NumPy 2 promotion rules */
+    const float ctl = 1e-3f * (action[0] * action[0] + action[1] * action[1]);
+    double rew = -(tilt * tilt + 0.1 * (bd * bd) + (double)ctl);
+    *terminated = invalid ? 1 : 0;
+    *truncated = (r->time >= r->cfg.final_time) ? 1 : 0;
+    if (invalid) rew = -50.0;
+    *reward = rew;
+    *tilt_out = tilt;
+    get_state3d(r, obs);
+}
+
 /* batched driver for the cpu_baseline leg (OpenMP over rods when built with it) */
 void oracle_env_step_batch(oracle_rod** rods, int n_rods, const float* actions, float* obs,
                            double* reward, uint8_t* terminated, uint8_t* truncated)
@@ -585,6 +708,11 @@ int oracle_get(const oracle_rod* r, const char* name, double* out)
     if (!strcmp(name, "dilatation")) { for (int k = 0; k < n; ++k) out[k] = r->dil[k]; return n; }
     if (!strcmp(name, "rest_lengths")) { for (int k = 0; k < n; ++k) out[k] = r->rest_len[k]; return n; }
     if (!strcmp(name, "damp_t")) { out[0] = r->damp_t; return 1; }
+    if (!strcmp(name, "control")) {
+        out[0] = r->ctrl_pos[0]; out[1] = r->ctrl_pos[1];
+        out[2] = r->ctrl_vel[0]; out[3] = r->ctrl_vel[1];
+        return 4;
+    }
     return -1;
 }
 

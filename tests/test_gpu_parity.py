@@ -386,3 +386,93 @@ def test_odd_rod_sizes_and_substep_counts(torch_gpu, hip_lib, oracle_built):
                 np.testing.assert_allclose(st["Q"][i], rod.get("Q"), rtol=0, atol=1e-11)
                 assert st["time"][i] == rod.time
             be.close()
+
+
+# ---- SoftPendulum3D-v0 (moving base, Laplace filter, strong damper) --------------------------
+def _tilt(seed):
+    from gym_softrobot_amd.envs.soft_pendulum_3d import initial_tilt
+    from gym_softrobot_amd.seeding import np_random
+
+    return initial_tilt(np_random(seed)[0])
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+def test_softpendulum3d_rollout_matches_oracle(torch_gpu, hip_lib, oracle_built, math_mode):
+    import gym_softrobot_amd as gsa
+
+    n, T = 8, 5
+    env = gsa.make_vec("SoftPendulum3D-v0", n, device=0, math_mode=math_mode)
+    obs0, _ = env.reset(seed=0)
+    obs0 = obs0.cpu().numpy().copy()
+    acts = np.random.default_rng(2).uniform(-1, 1, (T, n, 2)).astype(np.float32)
+    rods = []
+    for i in range(n):
+        r = oracle_built.OracleRod(env.cfg)
+        r.reset_pendulum3d(_tilt(i))
+        np.testing.assert_allclose(obs0[i], r.observe3d(), rtol=1e-6, atol=1e-9)
+        rods.append(r)
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(acts[t])
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        tilt = info["tilt"].cpu().numpy()
+        for i, r in enumerate(rods):
+            o, rw, te, tr, tl = r.env_step3d(acts[t, i])
+            np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=1e-7)
+            np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-9)
+            np.testing.assert_allclose(tilt[i], tl, rtol=RTOL, atol=1e-9)
+            assert bool(term[i]) == te and bool(trunc[i]) == tr
+    st = env.backend.state_numpy()
+    for i, r in enumerate(rods):
+        np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(st["v"][i], r.get("v"), rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(st["Q"][i], r.get("Q"), rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(st["w"][i], r.get("w"), rtol=RTOL, atol=1e-5)
+        np.testing.assert_allclose(st["control"][i], r.get("control"), rtol=1e-12, atol=0)
+        assert st["time"][i] == r.time
+    env.close()
+
+
+def test_softpendulum3d_single_env_and_truncation(torch_gpu, hip_lib):
+    import gym_softrobot_amd as gsa
+
+    env = gsa.make("SoftPendulum3D-v0")
+    ob, info = env.reset(seed=0)
+    assert env.observation_space.contains(ob) and ob.dtype == np.float32 and info == {}
+    with pytest.raises(ValueError):
+        env.step(np.array([2.0, 0.0], np.float32))
+    fired = None
+    a = np.array([0.2, -0.1], np.float32)
+    for k in range(1, 128):
+        ob, r, te, tr, inf = env.step(a)
+        assert isinstance(r, float) and isinstance(te, bool) and isinstance(tr, bool)
+        assert not te
+        if tr and fired is None:
+            fired = k
+    assert fired == 126  # time >= 5.0 on the float64 accumulated by half-steps (t_125 < 5)
+    # base walked to the limit and stayed: 0.2e-3 * 125 = 0.025 < 0.5 -> not clipped yet
+    assert ob[0] == pytest.approx(127 * float(np.float32(1e-3) * np.float32(0.2)), rel=1e-5)
+    env.close()
+
+
+def test_softpendulum3d_determinism_and_masked_reset(torch_gpu, hip_lib):
+    import gym_softrobot_amd as gsa
+
+    acts = np.random.default_rng(4).uniform(-1, 1, (3, 6, 2)).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        env = gsa.make_vec("SoftPendulum3D-v0", 6, device=0)
+        env.reset(seed=9)
+        for t in range(3):
+            o, r, *_ = env.step(acts[t])
+        outs.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), env.backend.state_numpy()))
+        if len(outs) == 2:
+            mask = np.array([True, False, False, True, False, False])
+            o2, _ = env.reset(mask=mask)
+            st = env.backend.state_numpy()
+            assert np.all(st["control"][mask] == 0.0) and np.all(st["control"][~mask, :2] != 0.0)
+            assert np.all(o2.cpu().numpy()[mask, 6:8] == 0.0)   # _prev_action cleared on reset
+            np.testing.assert_array_equal(o2.cpu().numpy()[~mask, 6:8], acts[2][~mask])
+        env.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2]["x"], outs[1][2]["x"])
