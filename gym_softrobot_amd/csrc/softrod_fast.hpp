@@ -236,8 +236,19 @@ __device__ __forceinline__ void fast_dynamic_step(const RodParams& P, const Fast
         w0 *= ex0; w1 *= ex0; w2 *= ex2;
     }
     L.w[0] = w0; L.w[1] = w1; L.w[2] = w2;
-    if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates(P, lane, L);
-    constrain_rates(P, B, lane, L);
+    // The analytical damper is fused into the update above.  Where constrain_rates is
+    // registered BEFORE the dampers (operator order of the env's build function), the
+    // imposed rates are damped like every other entry: targets scaled by c_t (held omega
+    // targets are 0 either way), then the Laplace filter runs on the constrained field.
+    if (P.damp_before_constrain) {
+        if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates(P, lane, L);
+        constrain_rates(P, B, lane, L);
+    } else {
+        BcTargets Bs = B;
+        Bs.vel[0] *= P.damp_t; Bs.vel[1] *= P.damp_t; Bs.vel[2] *= P.damp_t;
+        constrain_rates(P, Bs, lane, L);
+        if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates(P, lane, L);
+    }
 }
 
 // SOFTROD_FAST_WAVES: minimum waves per SIMD the register allocator must leave room for

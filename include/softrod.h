@@ -137,8 +137,13 @@ typedef struct softrod_config {
     double acos_shift;    /* 1e-10 subtracted inside arccos of _inv_rotate  */
     double eps_sin;       /* 1e-14 added inside sin of _inv_rotate          */
     int32_t time_two_half_adds; /* 1: t += dt/2 twice per substep; 0: += dt */
-    int32_t damp_before_constrain; /* 1: dampen_rates then constrain_rates
-                                      (mixin order of BaseSimulator)          */
+    int32_t damp_before_constrain; /* order inside PyElastica's constrain_rates
+                                      operator group.  0 (default): registration
+                                      order of the build function — constrain()
+                                      before dampen() (build.py:81-113,
+                                      soft_pendulum_3d/build.py:66-85), pyelastica
+                                      1.0 OperatorGroupFIFO; 1: dampers first
+                                      (mixin-__init__ order of pyelastica 0.3.x) */
 } softrod_config;
 
 /* Per-env I/O widths implied by env_kind. */
