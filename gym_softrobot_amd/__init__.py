@@ -1,16 +1,28 @@
 """gym_softrobot_amd — MI355X-native batched Cosserat-rod stepper behind the
 Gymnasium surface of gym-softrobot's SoftPendulum-v0 / SoftPendulum3D-v0."""
 from . import _capi
-from .envs import SoftPendulum3DEnv, SoftPendulumEnv, VecSoftPendulum3DEnv, VecSoftPendulumEnv
+from .envs import (
+    ArmSingleEnv,
+    SoftPendulum3DEnv,
+    SoftPendulumEnv,
+    VecArmSingleEnv,
+    VecSoftPendulum3DEnv,
+    VecSoftPendulumEnv,
+)
 from .registration import make, register, registered
 
 __version__ = "0.2.0"
 
-# gym_softrobot/__init__.py:74-80
+# gym_softrobot/__init__.py:27-30,74-80
 register(id="SoftPendulum-v0", entry_point=SoftPendulumEnv)
 register(id="SoftPendulum3D-v0", entry_point=SoftPendulum3DEnv)
+register(id="OctoArmSingle-v0", entry_point=ArmSingleEnv)
 
-_VEC = {"SoftPendulum-v0": VecSoftPendulumEnv, "SoftPendulum3D-v0": VecSoftPendulum3DEnv}
+_VEC = {
+    "SoftPendulum-v0": VecSoftPendulumEnv,
+    "SoftPendulum3D-v0": VecSoftPendulum3DEnv,
+    "OctoArmSingle-v0": VecArmSingleEnv,
+}
 
 
 def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
@@ -22,5 +34,5 @@ def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
 
 __all__ = [
     "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
-    "make", "make_vec", "register", "registered", "_capi",
+    "ArmSingleEnv", "VecArmSingleEnv", "make", "make_vec", "register", "registered", "_capi",
 ]

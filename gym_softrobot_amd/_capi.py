@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -21,6 +21,8 @@ FEAT_FIXED_BC = 1 << 4
 FEAT_TIP_FORCE = 1 << 5
 FEAT_MOVING_BASE_BC = 1 << 6
 FEAT_LAPLACE_FILTER = 1 << 7
+FEAT_PLANE_CONTACT_ANISO = 1 << 8
+FEAT_REST_KAPPA_ACTION = 1 << 9
 FEATURES_SOFTPENDULUM = (
     FEAT_GRAVITY | FEAT_POINT_FORCE_NODE0_X | FEAT_PENDULUM_BC | FEAT_ANALYTICAL_DAMPER
 )
@@ -28,18 +30,23 @@ FEATURES_SOFTPENDULUM3D = (
     FEAT_GRAVITY | FEAT_MOVING_BASE_BC | FEAT_ANALYTICAL_DAMPER | FEAT_LAPLACE_FILTER
 )
 
+FEATURES_ARM_SINGLE = (
+    FEAT_GRAVITY | FEAT_PLANE_CONTACT_ANISO | FEAT_ANALYTICAL_DAMPER | FEAT_REST_KAPPA_ACTION
+)
+
 ENV_NONE = 0
 ENV_SOFTPENDULUM = 1
 ENV_SOFTPENDULUM3D = 2
+ENV_ARM_SINGLE = 3
 
 MATH_LIBM = 0
 MATH_FAST = 1
 
 LANE_STRIDE = 64  # one wavefront row per rod (softrod_state_view.lane_stride)
 
-_ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2}
-_OBS_DIM = {ENV_NONE: 4, ENV_SOFTPENDULUM: 4, ENV_SOFTPENDULUM3D: 9}
-_AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1}
+_ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2, ENV_ARM_SINGLE: 7}
+_OBS_DIM = {ENV_NONE: 4, ENV_SOFTPENDULUM: 4, ENV_SOFTPENDULUM3D: 9, ENV_ARM_SINGLE: 25}
+_AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1, ENV_ARM_SINGLE: 0}
 
 
 def action_dim(env_kind: int) -> int:
@@ -85,6 +92,20 @@ class SoftrodConfig(C.Structure):
         ("eps_sin", C.c_double),
         ("time_two_half_adds", C.c_int32),
         ("damp_before_constrain", C.c_int32),
+        ("contact_before_forcing", C.c_int32),
+        ("reserved1", C.c_int32),
+        ("plane_origin", C.c_double * 3),
+        ("plane_normal", C.c_double * 3),
+        ("contact_k", C.c_double),
+        ("contact_nu", C.c_double),
+        ("slip_velocity_tol", C.c_double),
+        ("surface_tol", C.c_double),
+        ("kinetic_mu", C.c_double * 3),
+        ("static_mu", C.c_double * 3),
+        ("control_penalty_coeff", C.c_double),
+        ("target", C.c_double * 2),
+        ("kappa_range", C.c_double * 2),
+        ("kappa_rate_range", C.c_double * 2),
     ]
 
     def copy(self) -> "SoftrodConfig":
@@ -108,6 +129,9 @@ class SoftrodStateView(C.Structure):
         ("tangents", C.c_void_p),
         ("time", C.c_void_p),
         ("control", C.c_void_p),
+        ("kappa", C.c_void_p),
+        ("rest_kappa", C.c_void_p),
+        ("env_memory", C.c_void_p),
     ]
 
 
@@ -187,6 +211,61 @@ def softpendulum3d_config(
     return cfg
 
 
+def arm_single_config(
+    n_envs: int = 1,
+    *,
+    final_time: float = 10.0,
+    time_step: float = 7.0e-5,
+    recording_fps: int = 20,
+    n_elems: int = 50,
+    control_penalty_coeff: float = 0.001,
+    math_mode: int = MATH_FAST,
+) -> SoftrodConfig:
+    """`softrod_config_arm_single`: ArmSingleEnv.__init__ (octopus/arm_single_env.py:55-113)
+    and build_arm (octopus/build.py:30-49,220-292)."""
+    cfg = SoftrodConfig()
+    _common(cfg, n_envs, final_time, time_step, recording_fps, n_elems, math_mode)
+    cfg.features = FEATURES_ARM_SINGLE
+    cfg.env_kind = ENV_ARM_SINGLE
+    L0, r0 = 0.35, 0.35 * 0.02                      # octopus/build.py:46-49
+    cfg.base_length = L0
+    cfg.base_radius = r0
+    cfg.density = 1000.0                            # :30-33
+    cfg.youngs_modulus = 1e6
+    cfg.shear_modulus = 1e6 / (2.0 * (1.0 + 0.5))
+    g = -9.81                                       # :237
+    cfg.gravity[0], cfg.gravity[1], cfg.gravity[2] = 0.0, 0.0, g
+    cfg.damping_constant = 1e-2                     # :285
+    cfg.plane_origin[0], cfg.plane_origin[1], cfg.plane_origin[2] = 0.0, 0.0, -r0   # :244
+    cfg.plane_normal[0], cfg.plane_normal[1], cfg.plane_normal[2] = 0.0, 0.0, 1.0   # :233
+    cfg.contact_k = 1e2
+    cfg.contact_nu = 1e1
+    cfg.slip_velocity_tol = 1e-8
+    cfg.surface_tol = 1e-4
+    period, froude = 2.0, 0.1
+    mu = L0 / (period * period * abs(g) * froude)   # :247
+    for i, f in enumerate((1.0, 1.5, 2.0)):          # friction_symmetry False, multiplier 1
+        cfg.kinetic_mu[i] = mu * f
+        cfg.static_mu[i] = 2 * (mu * f)
+    cfg.control_penalty_coeff = float(control_penalty_coeff)
+    cfg.target[0], cfg.target[1] = 1.0, 0.0         # arm_single_env.py:165
+    cfg.kappa_range[0], cfg.kappa_range[1] = -49.33508476187419, 49.33545827754751
+    cfg.kappa_rate_range[0], cfg.kappa_rate_range[1] = -21.063520620377012, 24.664591289161944
+    return cfg
+
+
+def action_basis(n_elems: int, n_action: int = 7):
+    """W with rest_kappa[0,:] = W @ action: set_action's cubic `interp1d`
+    (octopus/arm_single_env.py:226-235) applied to unit vectors."""
+    import numpy as np
+    from scipy.interpolate import interp1d
+
+    x = np.linspace(0, 1, n_action)
+    xs = np.linspace(0, 1, n_elems - 1)
+    cols = [interp1d(x, np.eye(n_action)[j], kind="cubic", axis=-1)(xs) for j in range(n_action)]
+    return np.ascontiguousarray(np.stack(cols, axis=1), dtype=np.float64)
+
+
 class SoftrodError(RuntimeError):
     pass
 
@@ -200,6 +279,8 @@ _EXPORTS = {
     "softrod_aux_dim": (C.c_int, [C.c_int]),
     "softrod_config_softpendulum": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_softpendulum3d": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_config_arm_single": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_set_action_basis": (C.c_int, [_VP, _VP]),
     "softrod_create": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "softrod_reset": (C.c_int, [_VP, _VP, _VP, _VP]),
     "softrod_reset_straight": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),

@@ -46,6 +46,9 @@ class HipRodBackend:
         self.device = torch.device("cuda", self.device_index)
         self._h = C.c_void_p()
         check(self._lib.softrod_create(C.byref(self.cfg), self.device_index, C.byref(self._h)))
+        if self.cfg.features & _capi.FEAT_REST_KAPPA_ACTION:
+            basis = _capi.action_basis(int(cfg.n_elem), self.action_dim)
+            check(self._lib.softrod_set_action_basis(self._h, basis.ctypes.data), self._h)
         n = self.n_envs
         with torch.cuda.device(self.device):
             self.obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=self.device)
@@ -174,6 +177,9 @@ class HipRodBackend:
             "tangents": view(v.tangents, 3),
             "time": torch.as_tensor(_DevArray(v.time, (n,), "<f8", self), device=self.device),
             "control": torch.as_tensor(_DevArray(v.control, (4, n), "<f8", self), device=self.device),
+            "kappa": view(v.kappa, 3),
+            "rest_kappa": view(v.rest_kappa, 3),
+            "env_memory": torch.as_tensor(_DevArray(v.env_memory, (n, s), "<f8", self), device=self.device),
         }
 
     def state_numpy(self) -> Dict[str, np.ndarray]:
@@ -188,6 +194,8 @@ class HipRodBackend:
             "tangents": st["tangents"][:, :, :ne].permute(1, 0, 2).cpu().numpy(),
             "time": st["time"].cpu().numpy(),
             "control": st["control"].permute(1, 0).cpu().numpy(),
+            "kappa": st["kappa"][:, :, : ne - 1].permute(1, 0, 2).cpu().numpy(),
+            "rest_kappa": st["rest_kappa"][:, :, : ne - 1].permute(1, 0, 2).cpu().numpy(),
         }
         q = st["director"][:, :, :ne].permute(1, 0, 2).cpu().numpy()
         out["Q"] = q.reshape(self.n_envs, 3, 3, ne)

@@ -25,6 +25,8 @@ struct softrod_handle {
     StatePtrs S{};
     double* d_init = nullptr;     // [N][18] staging for reset
     uint8_t* d_mask = nullptr;    // [N]
+    double* d_basis = nullptr;    // [(n_elem-1)][7] action basis (zero until set)
+    bool basis_set = false;
     double* h_init = nullptr;     // pinned
     uint8_t* h_mask = nullptr;    // pinned
     std::vector<hipEvent_t> ev_start, ev_stop;  // timing ring (softrod_set_timing)
@@ -102,6 +104,31 @@ void fill_params(const softrod_config& c, RodParams& P) {
     P.base_limit = c.base_limit;
     P.step_time = (double)c.n_substeps * c.dt;  // step_skip * time_step, soft_pendulum_3d.py:110-112
     P.base_step = (float)c.base_step;
+    // OctoArmSingle-v0
+    P.control_penalty_coeff = (float)c.control_penalty_coeff;
+    P.contact_before_forcing = c.contact_before_forcing;
+    P.n_action = 7;
+    {   // mass.sum() in the order compute_position_center_of_mass adds it
+        double ms = 0.0;
+        for (int k = 0; k <= n; ++k) ms += (k == 0 || k == n) ? 0.5 * P.mass_node : P.mass_node;
+        P.mass_total = ms;
+    }
+    for (int i = 0; i < 2; ++i) {
+        P.target[i] = c.target[i];
+        P.kappa_range[i] = c.kappa_range[i];
+        P.kappa_rate_range[i] = c.kappa_rate_range[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        P.plane_origin[i] = c.plane_origin[i];
+        P.plane_normal[i] = c.plane_normal[i];
+        P.kin_mu[i] = c.kinetic_mu[i];
+        P.stat_mu[i] = c.static_mu[i];
+    }
+    P.contact_k = c.contact_k;
+    P.contact_nu = c.contact_nu;
+    P.slip_tol = c.slip_velocity_tol;
+    P.surface_tol = c.surface_tol;
+    P.r0_sqrt_rest_len = r * std::sqrt(rest_len);   // radius = sqrt(V/(pi l)) = r0 sqrt(l_rest/l)
 }
 
 int launch_step(softrod_handle* h, const float* actions, float* obs, double* reward,
@@ -110,10 +137,24 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
-    if (h->cfg.math_mode == SOFTROD_MATH_FAST)
-        hipLaunchKernelGGL(softrod_step_fast_kernel, grid, block, 0, st, h->P, h->S,
-                           actions, obs, reward, term, trunc, aux, n_sub, epilogue);
-    else
+    if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
+        // instantiations specialised for the registered envs' feature sets; anything else
+        // (known-answer tests, custom feature mixes) takes the run-time-mask instantiation
+        const unsigned f = h->cfg.features;
+        const int e = h->cfg.env_kind;
+#define SR_LAUNCH(FEATS, ENV)                                                                   \
+        hipLaunchKernelGGL((softrod_step_fast_kernel<FEATS, ENV>), grid, block, 0, st, h->P, h->S, \
+                           actions, obs, reward, term, trunc, aux, n_sub, epilogue)
+        if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM)
+            SR_LAUNCH(SOFTROD_FEATURES_SOFTPENDULUM, SOFTROD_ENV_SOFTPENDULUM);
+        else if (f == SOFTROD_FEATURES_SOFTPENDULUM3D && e == SOFTROD_ENV_SOFTPENDULUM3D)
+            SR_LAUNCH(SOFTROD_FEATURES_SOFTPENDULUM3D, SOFTROD_ENV_SOFTPENDULUM3D);
+        else if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE)
+            SR_LAUNCH(SOFTROD_FEATURES_ARM_SINGLE, SOFTROD_ENV_ARM_SINGLE);
+        else
+            SR_LAUNCH(kRuntimeFeatures, kRuntimeEnv);
+#undef SR_LAUNCH
+    } else
         hipLaunchKernelGGL(softrod_step_libm_kernel, grid, block, 0, st, h->P, h->S,
                            actions, obs, reward, term, trunc, aux, n_sub, epilogue);
     SR_HIP(h, hipGetLastError());
@@ -184,8 +225,12 @@ extern "C" {
 
 int softrod_abi_version(void) { return SOFTROD_ABI_VERSION; }
 
-int softrod_action_dim(int env_kind) { return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 2 : 1; }
-int softrod_obs_dim(int env_kind) { return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 9 : 4; }
+int softrod_action_dim(int env_kind) {
+    return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 2 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 7 : 1;
+}
+int softrod_obs_dim(int env_kind) {
+    return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 9 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 25 : 4;
+}
 int softrod_aux_dim(int env_kind) { return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 1 : 0; }
 
 int softrod_config_softpendulum(softrod_config* cfg, int n_envs) {
@@ -221,6 +266,43 @@ int softrod_config_softpendulum3d(softrod_config* cfg, int n_envs) {
     return SOFTROD_OK;
 }
 
+int softrod_config_arm_single(softrod_config* cfg, int n_envs) {
+    if (!cfg || n_envs < 1) return SOFTROD_EINVAL;
+    config_common(cfg, n_envs);
+    cfg->features = SOFTROD_FEATURES_ARM_SINGLE;
+    cfg->env_kind = SOFTROD_ENV_ARM_SINGLE;
+    cfg->dt = 7.0e-5;                                   // octopus/arm_single_env.py:58
+    cfg->n_substeps = (int)(1.0 / (20 * cfg->dt));      // recording_fps = 20 (:59) -> 714 (:77)
+    cfg->final_time = 10.0;                             // :57
+    const double L0 = 0.35, r0 = 0.35 * 0.02;           // octopus/build.py:46-49
+    cfg->base_length = L0;
+    cfg->base_radius = r0;
+    cfg->density = 1000.0;                              // :30-33
+    cfg->youngs_modulus = 1e6;
+    cfg->shear_modulus = 1e6 / (2.0 * (1.0 + 0.5));
+    const double g = -9.81;                             // :237
+    cfg->gravity[0] = 0.0; cfg->gravity[1] = 0.0; cfg->gravity[2] = g;
+    cfg->damping_constant = 1e-2;                       // :285
+    cfg->plane_origin[0] = 0.0; cfg->plane_origin[1] = 0.0; cfg->plane_origin[2] = -r0;  // :244
+    cfg->plane_normal[0] = 0.0; cfg->plane_normal[1] = 0.0; cfg->plane_normal[2] = 1.0;  // :233
+    cfg->contact_k = 1e2;                               // :241
+    cfg->contact_nu = 1e1;                              // :242
+    cfg->slip_velocity_tol = 1e-8;                      // :245
+    cfg->surface_tol = 1e-4;
+    const double period = 2.0, froude = 0.1;
+    const double mu = L0 / (period * period * std::fabs(g) * froude);   // :247
+    const double fac[3] = {1.0, 1.5, 2.0};               // forward, backward, sideways (:253-256)
+    for (int i = 0; i < 3; ++i) {
+        cfg->kinetic_mu[i] = mu * fac[i];
+        cfg->static_mu[i] = 2 * (mu * fac[i]);          // :257
+    }
+    cfg->control_penalty_coeff = 0.001;                 // arm_single_env.py:62
+    cfg->target[0] = 1.0; cfg->target[1] = 0.0;         // :165
+    cfg->kappa_range[0] = -49.33508476187419; cfg->kappa_range[1] = 49.33545827754751;          // :111
+    cfg->kappa_rate_range[0] = -21.063520620377012; cfg->kappa_rate_range[1] = 24.664591289161944;  // :113
+    return SOFTROD_OK;
+}
+
 int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) {
     if (!cfg || !out) return fail(nullptr, SOFTROD_EINVAL, "null argument");
     *out = nullptr;
@@ -232,7 +314,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "need n_substeps >= 0 and dt > 0");
     if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
-    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_SOFTPENDULUM3D)
+    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_ARM_SINGLE)
         return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
     if ((cfg->features & SOFTROD_FEAT_LAPLACE_FILTER) && (cfg->filter_order < 1 || cfg->n_elem < 3))
         return fail(nullptr, SOFTROD_EINVAL, "LaplaceDissipationFilter needs filter_order >= 1");
@@ -270,6 +352,11 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     alloc((void**)&h->S.time, N * sizeof(double));
     alloc((void**)&h->S.bc, 12 * N * sizeof(double));
     alloc((void**)&h->S.ctrl, 4 * N * sizeof(double));
+    alloc((void**)&h->S.kap, 3 * rowb);
+    alloc((void**)&h->S.rkap, 3 * rowb);
+    alloc((void**)&h->S.envmem, rowb);
+    alloc((void**)&h->d_basis, (size_t)kLanes * 7 * sizeof(double));
+    h->S.basis = h->d_basis;
     alloc((void**)&h->d_init, N * 18 * sizeof(double));
     alloc((void**)&h->d_mask, N);
     if (rc == SOFTROD_OK && hipHostMalloc((void**)&h->h_init, N * 18 * sizeof(double)) != hipSuccess) rc = SOFTROD_ENOMEM;
@@ -316,10 +403,21 @@ int softrod_reset_straight(softrod_handle* h, const double* start, const double*
     return upload_and_reset(h, (hipStream_t)stream, mask != nullptr);
 }
 
+int softrod_set_action_basis(softrod_handle* h, const double* basis) {
+    if (!h || !basis) return fail(h, SOFTROD_EINVAL, "null argument");
+    SR_HIP(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)(h->cfg.n_elem - 1) * 7 * sizeof(double);
+    SR_HIP(h, hipMemcpy(h->d_basis, basis, bytes, hipMemcpyHostToDevice));
+    h->basis_set = true;
+    return SOFTROD_OK;
+}
+
 int softrod_step(softrod_handle* h, const float* actions, float* obs, double* reward,
                  uint8_t* terminated, uint8_t* truncated, double* aux, void* stream) {
     if (!h || !actions || !obs || !reward || !terminated || !truncated)
         return fail(h, SOFTROD_EINVAL, "null argument");
+    if ((h->cfg.features & SOFTROD_FEAT_REST_KAPPA_ACTION) && !h->basis_set)
+        return fail(h, SOFTROD_EINVAL, "softrod_set_action_basis must be called before softrod_step");
     if (h->cfg.env_kind == SOFTROD_ENV_NONE)
         return fail(h, SOFTROD_EINVAL, "env_kind NONE has no step epilogue; use softrod_substeps");
     SR_HIP(h, hipSetDevice(h->device));
@@ -329,7 +427,7 @@ int softrod_step(softrod_handle* h, const float* actions, float* obs, double* re
 
 int softrod_substeps(softrod_handle* h, const float* actions, int n, void* stream) {
     if (!h || n < 0) return fail(h, SOFTROD_EINVAL, "bad argument");
-    if (actions && h->cfg.env_kind == SOFTROD_ENV_SOFTPENDULUM3D)
+    if (actions && h->cfg.env_kind != SOFTROD_ENV_SOFTPENDULUM && h->cfg.env_kind != SOFTROD_ENV_NONE)
         return fail(h, SOFTROD_EINVAL, "softrod_substeps takes no actions for this env_kind");
     SR_HIP(h, hipSetDevice(h->device));
     return launch_step(h, actions, nullptr, nullptr, nullptr, nullptr, nullptr, n, 0, (hipStream_t)stream);
@@ -358,6 +456,9 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->tangents = h->S.tan;
     out->time = h->S.time;
     out->control = h->S.ctrl;
+    out->kappa = h->S.kap;
+    out->rest_kappa = h->S.rkap;
+    out->env_memory = h->S.envmem;
     return SOFTROD_OK;
 }
 
@@ -409,7 +510,7 @@ int softrod_destroy(softrod_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->d_init, h->d_mask};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->d_basis, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

@@ -143,6 +143,7 @@ __device__ __forceinline__ void fast_kinematic_step(double h, const FastConst& C
 }
 
 // forces, torques, rate update, damper, constrain_rates — steps (3)-(6) of the substep.
+template <unsigned F>
 __device__ __forceinline__ void fast_dynamic_step(const RodParams& P, const FastConst& C,
                                                   const BcTargets& B, int lane, LaneState& L) {
     const int n = P.n_elem;
@@ -195,15 +196,31 @@ __device__ __forceinline__ void fast_dynamic_step(const RodParams& P, const Fast
     const double vd = (len_n + len) * (0.5 * P.inv_rest_vor);
     const double rvd = fast_rcp(vd);
     const double e3 = rvd * rvd * rvd;
-    // couples / eps^3: c2 = B kappa, c3 = (kappa x B kappa) D ; with B = diag(b, b, b + bd)
-    // kappa x B kappa = bd k2 (k1, -k0, 0)
-    const double c20 = C.b01 * k0 * e3, c21 = C.b01 * k1 * e3, c22 = (C.b01 + C.bd) * k2 * e3;
-    const double hz = 0.5 * P.rest_vor * C.bd * k2 * e3;   // (1/2) |c3| factor
-    const double h30 = k1 * hz, h31 = -k0 * hz;             // (1/2) c3
-    // element k: (c2_k - c2_{k-1}) + 1/2 (c3_k + c3_{k-1}) = (c2 + h3)_k - (c2 - h3)_{k-1}
-    double tq0 = (c20 + h30) - from_prev(c20 - h30);
-    double tq1 = (c21 + h31) - from_prev(c21 - h31);
-    double tq2 = c22 - from_prev(c22);
+    double tq0, tq1, tq2;
+    if (F == kRuntimeFeatures) { L.kap[0] = k0; L.kap[1] = k1; L.kap[2] = k2; }
+    if (has<F>(P, SOFTROD_FEAT_REST_KAPPA_ACTION)) {
+        // intrinsic curvature: m = B (kappa - kappa_rest), general cross product
+        L.kap[0] = k0; L.kap[1] = k1; L.kap[2] = k2;
+        const double m0 = C.b01 * (k0 - L.rk[0]), m1 = C.b01 * (k1 - L.rk[1]),
+                     m2 = (C.b01 + C.bd) * (k2 - L.rk[2]);
+        const double c20 = m0 * e3, c21 = m1 * e3, c22 = m2 * e3;
+        const double hd = 0.5 * P.rest_vor * e3;
+        const double h30 = (k1 * m2 - k2 * m1) * hd, h31 = (k2 * m0 - k0 * m2) * hd,
+                     h32 = (k0 * m1 - k1 * m0) * hd;
+        tq0 = (c20 + h30) - from_prev(c20 - h30);
+        tq1 = (c21 + h31) - from_prev(c21 - h31);
+        tq2 = (c22 + h32) - from_prev(c22 - h32);
+    } else {
+        // couples / eps^3: c2 = B kappa, c3 = (kappa x B kappa) D ; with B = diag(b, b, b + bd)
+        // kappa x B kappa = bd k2 (k1, -k0, 0)
+        const double c20 = C.b01 * k0 * e3, c21 = C.b01 * k1 * e3, c22 = (C.b01 + C.bd) * k2 * e3;
+        const double hz = 0.5 * P.rest_vor * C.bd * k2 * e3;   // (1/2) |c3| factor
+        const double h30 = k1 * hz, h31 = -k0 * hz;             // (1/2) c3
+        // element k: (c2_k - c2_{k-1}) + 1/2 (c3_k + c3_{k-1}) = (c2 + h3)_k - (c2 - h3)_{k-1}
+        tq0 = (c20 + h30) - from_prev(c20 - h30);
+        tq1 = (c21 + h31) - from_prev(c21 - h31);
+        tq2 = c22 - from_prev(c22);
+    }
 
     // shear/stretch couple (Q t) x n l_rest = len (Q t) x (n/e)
     tq0 = fma(len, fma(qt1, np2, -qt2 * np1), tq0);
@@ -223,14 +240,34 @@ __device__ __forceinline__ void fast_dynamic_step(const RodParams& P, const Fast
     tq1 = fma(js01, L.w[1], tq1);
     tq2 = fma(js2, L.w[2], tq2);
 
+    // ---- plane contact + anisotropic friction (after the forcing operators) ----
+    double fc0 = f0, fc1 = f1, fc2 = f2;
+    if (has<F>(P, SOFTROD_FEAT_PLANE_CONTACT_ANISO)) {
+        const bool node_valid = lane <= n;
+        const double mass = (lane == 0 || lane == n) ? 0.5 * P.mass_node : P.mass_node;
+        const double mass_next = (lane + 1 == n) ? 0.5 * P.mass_node : P.mass_node;
+        // nodal internal + external force so far (gravity; no point/tip force with contact)
+        double Fg[3] = {f0, f1, f2};
+        if (has<F>(P, SOFTROD_FEAT_GRAVITY) && !P.contact_before_forcing) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) Fg[i] += node_valid ? P.gravity[i] * mass : 0.0;
+        }
+        const double xn[3] = {xn0, xn1, xn2}, vn[3] = {vn0, vn1, vn2};
+        double tq[3] = {tq0, tq1, tq2}, fc[3];
+        plane_contact(contact_params(P), lane, n, mass, mass_next, L.x, xn, L.v, vn, L.t, L.Q, L.w,
+                      len, Fg, tq, fc);
+        fc0 += fc[0]; fc1 += fc[1]; fc2 += fc[2];
+        tq0 = tq[0]; tq1 = tq[1]; tq2 = tq[2];
+    }
+
     // ---- rate update fused with the analytical damper ----
     //   v <- c_t (v + dt (f + f_ext)/m)          w <- (w + dt e tau/J) c_r^e
-    L.v[0] = fma(P.damp_t, L.v[0], fma(C.cf, f0, C.ca[0]));
-    L.v[1] = fma(P.damp_t, L.v[1], fma(C.cf, f1, C.ca[1]));
-    L.v[2] = fma(P.damp_t, L.v[2], fma(C.cf, f2, C.ca[2]));
+    L.v[0] = fma(P.damp_t, L.v[0], fma(C.cf, fc0, C.ca[0]));
+    L.v[1] = fma(P.damp_t, L.v[1], fma(C.cf, fc1, C.ca[1]));
+    L.v[2] = fma(P.damp_t, L.v[2], fma(C.cf, fc2, C.ca[2]));
     const double ce01 = C.cw01 * e, ce2 = C.cw2 * e;
     double w0 = fma(ce01, tq0, L.w[0]), w1 = fma(ce01, tq1, L.w[1]), w2 = fma(ce2, tq2, L.w[2]);
-    if (P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER) {
+    if (has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) {
         double ex0, ex2;
         exp_pair(e * P.damp_logr[0], e * P.damp_logr[2], elem_valid, ex0, ex2);
         w0 *= ex0; w1 *= ex0; w2 *= ex2;
@@ -241,13 +278,13 @@ __device__ __forceinline__ void fast_dynamic_step(const RodParams& P, const Fast
     // imposed rates are damped like every other entry: targets scaled by c_t (held omega
     // targets are 0 either way), then the Laplace filter runs on the constrained field.
     if (P.damp_before_constrain) {
-        if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates(P, lane, L);
-        constrain_rates(P, B, lane, L);
+        if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) laplace_filter_rates(P, lane, L);
+        constrain_rates<F>(P, B, lane, L);
     } else {
         BcTargets Bs = B;
         Bs.vel[0] *= P.damp_t; Bs.vel[1] *= P.damp_t; Bs.vel[2] *= P.damp_t;
-        constrain_rates(P, Bs, lane, L);
-        if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates(P, lane, L);
+        constrain_rates<F>(P, Bs, lane, L);
+        if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) laplace_filter_rates(P, lane, L);
     }
 }
 
@@ -256,7 +293,10 @@ __device__ __forceinline__ void fast_dynamic_step(const RodParams& P, const Fast
 #ifndef SOFTROD_FAST_WAVES
 #define SOFTROD_FAST_WAVES 3
 #endif
-__global__ void __launch_bounds__(kLanes, SOFTROD_FAST_WAVES)
+// The contact instantiation needs more live values per lane; it trades a wave of occupancy
+// for not spilling.
+template <unsigned F, int E>
+__global__ void __launch_bounds__(kLanes, ((F != kRuntimeFeatures && (F & SOFTROD_FEAT_PLANE_CONTACT_ANISO)) ? 2 : SOFTROD_FAST_WAVES))
 softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
@@ -268,45 +308,45 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     const int n = P.n_elem;
 
     LaneState L;
-    load_state(S, N, row, L);
+    load_state<F>(S, N, row, L);
     BcTargets B;
     load_bc(S, N, rod, B);
     EnvAction A;
-    env_set_action(P, S, N, rod, lane, actions, A, B);
+    env_set_action<F, E>(P, S, N, rod, lane, actions, A, B, L);
     {   // (re)establish the boundary-condition invariant once.  The imposed base velocity
         // of MOVING_BASE_BC is NOT applied here: the reference keeps the previous step's
         // base velocity until the first constrain_rates of the new step.
         BcTargets B0 = B;
-        if (P.features & SOFTROD_FEAT_MOVING_BASE_BC) {
+        if (has<F>(P, SOFTROD_FEAT_MOVING_BASE_BC)) {
             const double v0x = __shfl(L.v[0], 0), v0y = __shfl(L.v[1], 0), v0z = __shfl(L.v[2], 0);
             B0.vel[0] = v0x; B0.vel[1] = v0y; B0.vel[2] = v0z;
         }
-        constrain_rates(P, B0, lane, L);
-        constrain_values(P, B, lane, L);
+        constrain_rates<F>(P, B0, lane, L);
+        constrain_values<F>(P, B, lane, L);
     }
     double time = S.time[rod];
 
     FastConst C;
     {
         const bool l0 = (lane == 0);
-        const bool held_q = l0 && (P.features & (SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_FIXED_BC |
-                                                 SOFTROD_FEAT_MOVING_BASE_BC));
-        const bool held_x = l0 && (P.features & (SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC));
+        const bool held_q = l0 && has<F>(P, SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_FIXED_BC |
+                                            SOFTROD_FEAT_MOVING_BASE_BC);
+        const bool held_x = l0 && has<F>(P, SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC);
         const bool node_valid = lane <= n, elem_valid = lane < n, vor_valid = lane < n - 1;
         const double mass = (lane == 0 || lane == n) ? 0.5 * P.mass_node : P.mass_node;
-        const bool damp = (P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER) != 0;
+        const bool damp = has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER);
         const double ct = damp ? P.damp_t : 1.0;
         C.hx = held_x ? 0.0 : 1.0;
         C.hq = held_q ? 0.0 : 1.0;
         const double cdm = node_valid ? ct * P.dt / mass : 0.0;
         C.cf = cdm;
         double fe0 = 0.0, fe1 = 0.0, fe2 = 0.0;
-        if (P.features & SOFTROD_FEAT_GRAVITY) {
+        if (has<F>(P, SOFTROD_FEAT_GRAVITY)) {
             fe0 = P.gravity[0] * mass; fe1 = P.gravity[1] * mass; fe2 = P.gravity[2] * mass;
         }
         // PendulumPointForces ASSIGNS external_forces[0,0] (soft_pendulum/build.py:101)
-        if (P.features & SOFTROD_FEAT_POINT_FORCE_NODE0_X) fe0 = l0 ? A.force : fe0;
-        if ((P.features & SOFTROD_FEAT_TIP_FORCE) && lane == n) {
+        if (has<F>(P, SOFTROD_FEAT_POINT_FORCE_NODE0_X)) fe0 = l0 ? A.force : fe0;
+        if (has<F>(P, SOFTROD_FEAT_TIP_FORCE) && lane == n) {
             fe0 += P.tip_force[0]; fe1 += P.tip_force[1]; fe2 += P.tip_force[2];
         }
         C.ca[0] = cdm * fe0; C.ca[1] = cdm * fe1; C.ca[2] = cdm * fe2;
@@ -318,13 +358,13 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
         C.bd = vor_valid ? P.bend[2] - P.bend[0] : 0.0;
     }
     RodParams Pk = P;
-    if (!(P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
+    if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
 
     if (n_sub > 0) {
         fast_kinematic_step(P.half_dt, C, L);
         if (P.time_two_half_adds) time += P.half_dt;
         for (int s = 0; s < n_sub; ++s) {
-            fast_dynamic_step(Pk, C, B, lane, L);
+            fast_dynamic_step<F>(Pk, C, B, lane, L);
             const bool last = (s == n_sub - 1);
             fast_kinematic_step(last ? P.half_dt : P.dt, C, L);
             time += P.time_two_half_adds ? P.half_dt : P.dt;          // end of substep s
@@ -332,9 +372,10 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
         }
     }
 
-    store_state(S, N, row, L);
+    store_state<F>(S, N, row, L);
     if (lane == 0) S.time[rod] = time;
-    if (epilogue) env_epilogue(P, S, N, rod, lane, L, time, A, obs, reward, terminated, truncated, aux);
+    if (epilogue)
+        env_epilogue<E>(P, S, N, rod, lane, L, time, A, obs, reward, terminated, truncated, aux);
 }
 
 }  // namespace softrod

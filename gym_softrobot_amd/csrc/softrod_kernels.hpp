@@ -33,6 +33,12 @@ namespace softrod {
 
 constexpr int kLanes = 64;
 
+// Compile-time feature sets: the step kernels are instantiated for the feature masks of
+// the registered envs (so that unused features cost neither instructions nor registers)
+// plus one instantiation that reads the mask at run time (known-answer tests).
+constexpr unsigned kRuntimeFeatures = 0xFFFFFFFFu;
+constexpr int kRuntimeEnv = -1;
+
 // Wave-uniform parameters: passed by value, so they land in SGPRs (kernarg segment).
 struct RodParams {
     int n_envs, n_elem, time_two_half_adds;
@@ -52,7 +58,15 @@ struct RodParams {
     double damp_logr[3];             // -nu*dt*m_e/J_i  (fast path: exp(e*logr))
     double eps_length, eps_rot_axis, acos_shift, eps_sin;
     double base_limit, step_time;    // SoftPendulum3D set_action
-    float base_step, pad1;
+    float base_step, control_penalty_coeff;
+    // OctoArmSingle-v0
+    int contact_before_forcing, n_action;
+    double mass_total;               // sum of nodal masses (center of mass)
+    double target[2], kappa_range[2], kappa_rate_range[2];
+    double plane_origin[3], plane_normal[3];
+    double contact_k, contact_nu, slip_tol, surface_tol;
+    double kin_mu[3], stat_mu[3];
+    double r0_sqrt_rest_len;         // radius_k = r0 sqrt(l_rest / l_k)  (volume preserving)
 };
 
 struct StatePtrs {
@@ -64,6 +78,11 @@ struct StatePtrs {
     double* time;  // [N]
     double* bc;    // [12][N]     BC targets: pos0[3], Q0[9] of node/element 0
     double* ctrl;  // [4][N]      moving-base controller: position x,y ; velocity x,y
+                   //             (ArmSingle: [0..1] = prev_com_state)
+    double* kap;   // [3][N][64]  kappa as of the last force evaluation
+    double* rkap;  // [3][N][64]  rest_kappa
+    double* envmem;       // [N][64]  ArmSingle prev_kappa_state
+    const double* basis;  // [(n_elem-1)][n_action]  rest_kappa[0,:] = basis @ action
 };
 
 // ---------------------------------------------------------------------------------
@@ -101,6 +120,17 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;  // fixed butterfly -> bitwise deterministic
 }
 
+template <unsigned F>
+__device__ __forceinline__ bool has(const RodParams& P, unsigned bit) {
+    if constexpr (F == kRuntimeFeatures) return (P.features & bit) != 0;
+    else return (F & bit) != 0;
+}
+template <int E>
+__device__ __forceinline__ int env_of(const RodParams& P) {
+    if constexpr (E == kRuntimeEnv) return P.env_kind;
+    else return E;
+}
+
 // ---------------------------------------------------------------------------------
 // per-lane register state
 // ---------------------------------------------------------------------------------
@@ -108,6 +138,8 @@ struct LaneState {
     double x[3], v[3];  // node k
     double Q[9], w[3];  // element k: Q row-major (rows d1,d2,d3 in lab frame), omega local
     double t[3];        // tangent of element k at the last force evaluation
+    double kap[3];      // kappa of Voronoi vertex k at the last force evaluation
+    double rk[3];       // rest_kappa of Voronoi vertex k
 };
 
 struct BcTargets {
@@ -118,7 +150,7 @@ struct BcTargets {
 
 // Per-env action handling done once per env.step before the substeps.
 struct EnvAction {
-    float a[2];         // raw action (float32), as many as the env has
+    float a[7];         // raw action (float32), as many as the env has
     double force;       // SoftPendulum: point_force[0] (float32 value held in float64)
 };
 
@@ -128,10 +160,11 @@ struct EnvAction {
 //   FIXED_BC      PyElastica OneEndFixedBC;
 //   MOVING_BASE   soft_pendulum_3d/build.py:31-34: node 0 = (controller x, y, fixed height),
 //                 element 0 director fixed.  (B.pos already holds the commanded position.)
+template <unsigned F>
 __device__ __forceinline__ void constrain_values(const RodParams& P, const BcTargets& B, int lane,
                                                  LaneState& L) {
     const bool l0 = (lane == 0);
-    if (P.features & SOFTROD_FEAT_PENDULUM_BC) {
+    if (has<F>(P, SOFTROD_FEAT_PENDULUM_BC)) {
         L.x[1] = l0 ? B.pos[1] : L.x[1];
         L.x[2] = l0 ? B.pos[2] : L.x[2];
 #pragma unroll
@@ -140,7 +173,7 @@ __device__ __forceinline__ void constrain_values(const RodParams& P, const BcTar
             L.Q[6 + j] = l0 ? B.Q[6 + j] : L.Q[6 + j];
         }
     }
-    if (P.features & (SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC)) {
+    if (has<F>(P, SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) L.x[j] = l0 ? B.pos[j] : L.x[j];
 #pragma unroll
@@ -149,16 +182,17 @@ __device__ __forceinline__ void constrain_values(const RodParams& P, const BcTar
 }
 
 // constrain_rates (soft_pendulum/build.py:76-79, soft_pendulum_3d/build.py:36-39)
+template <unsigned F>
 __device__ __forceinline__ void constrain_rates(const RodParams& P, const BcTargets& B, int lane,
                                                 LaneState& L) {
     const bool l0 = (lane == 0);
-    if (P.features & SOFTROD_FEAT_PENDULUM_BC) {
+    if (has<F>(P, SOFTROD_FEAT_PENDULUM_BC)) {
         L.v[1] = l0 ? 0.0 : L.v[1];
         L.v[2] = l0 ? 0.0 : L.v[2];
         L.w[0] = l0 ? 0.0 : L.w[0];
         L.w[2] = l0 ? 0.0 : L.w[2];
     }
-    if (P.features & (SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC)) {
+    if (has<F>(P, SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             L.v[j] = l0 ? B.vel[j] : L.v[j];
@@ -189,6 +223,22 @@ __device__ __forceinline__ void laplace_filter_rates(const RodParams& P, int lan
         L.v[c] = (lane <= n) ? vf : L.v[c];
         L.w[c] = (lane < n) ? wf : L.w[c];
     }
+}
+
+}  // namespace softrod
+#include "softrod_contact.hpp"
+namespace softrod {
+
+__device__ __forceinline__ ContactParams contact_params(const RodParams& P) {
+    ContactParams C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        C.origin[i] = P.plane_origin[i]; C.normal[i] = P.plane_normal[i];
+        C.kin_mu[i] = P.kin_mu[i]; C.stat_mu[i] = P.stat_mu[i];
+    }
+    C.k = P.contact_k; C.nu = P.contact_nu; C.slip_tol = P.slip_tol; C.surface_tol = P.surface_tol;
+    C.r0_sqrt_rest_len = P.r0_sqrt_rest_len;
+    return C;
 }
 
 // =================================================================================
@@ -275,7 +325,9 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     const double theta = acos(0.5 * trace - 0.5 - P.acos_shift);
     const double fk = (-0.5 * theta / sin(theta + P.eps_sin)) / P.rest_vor;
     const double k0 = vec0 * fk, k1 = vec1 * fk, k2 = vec2 * fk;
-    const double m0 = P.bend[0] * k0, m1 = P.bend[1] * k1, m2 = P.bend[2] * k2;
+    L.kap[0] = k0; L.kap[1] = k1; L.kap[2] = k2;
+    const double m0 = P.bend[0] * (k0 - L.rk[0]), m1 = P.bend[1] * (k1 - L.rk[1]),
+                 m2 = P.bend[2] * (k2 - L.rk[2]);
     const double vd = 0.5 * (len_n + len) / P.rest_vor;
     const double e3 = 1.0 / (vd * vd * vd);
     double c20 = m0 * e3, c21 = m1 * e3, c22 = m2 * e3;
@@ -308,10 +360,23 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     tq2 += jw0 * L.w[1] - jw1 * L.w[0];
     tq0 += jw0 * dil_rate / e; tq1 += jw1 * dil_rate / e; tq2 += jw2 * dil_rate / e;
 
-    // ---- forcing (synchronize): gravity, then the point force ASSIGNS F_ext[0,0] ----
+    // ---- synchronize(): operators in registration order.  Forcing: gravity, then the
+    // point force ASSIGNS F_ext[0,0]; contact (octopus/build.py:274-283) after it unless
+    // contact_before_forcing. ----
     double fe0 = 0.0, fe1 = 0.0, fe2 = 0.0;
+    const bool has_contact = (P.features & SOFTROD_FEAT_PLANE_CONTACT_ANISO) != 0;
+    const double mass_next = (lane + 1 == n) ? 0.5 * P.mass_node : P.mass_node;
+    const double xn[3] = {xn0, xn1, xn2}, vn[3] = {vn0, vn1, vn2};
+    if (has_contact && P.contact_before_forcing) {
+        const double F[3] = {f0, f1, f2};
+        double tq[3] = {tq0, tq1, tq2}, fc[3];
+        plane_contact(contact_params(P), lane, n, mass, mass_next, L.x, xn, L.v, vn, L.t, L.Q, L.w,
+                      len, F, tq, fc);
+        fe0 = fc[0]; fe1 = fc[1]; fe2 = fc[2];
+        tq0 = tq[0]; tq1 = tq[1]; tq2 = tq[2];
+    }
     if (P.features & SOFTROD_FEAT_GRAVITY) {
-        fe0 = P.gravity[0] * mass; fe1 = P.gravity[1] * mass; fe2 = P.gravity[2] * mass;
+        fe0 += P.gravity[0] * mass; fe1 += P.gravity[1] * mass; fe2 += P.gravity[2] * mass;
     }
     if (P.features & SOFTROD_FEAT_POINT_FORCE_NODE0_X) fe0 = (lane == 0) ? action : fe0;
     if (P.features & SOFTROD_FEAT_TIP_FORCE) {
@@ -319,6 +384,15 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
         fe0 += tip ? P.tip_force[0] : 0.0;
         fe1 += tip ? P.tip_force[1] : 0.0;
         fe2 += tip ? P.tip_force[2] : 0.0;
+    }
+    if (has_contact && !P.contact_before_forcing) {
+        const double F[3] = {f0 + (node_valid ? fe0 : 0.0), f1 + (node_valid ? fe1 : 0.0),
+                             f2 + (node_valid ? fe2 : 0.0)};
+        double tq[3] = {tq0, tq1, tq2}, fc[3];
+        plane_contact(contact_params(P), lane, n, mass, mass_next, L.x, xn, L.v, vn, L.t, L.Q, L.w,
+                      len, F, tq, fc);
+        fe0 += fc[0]; fe1 += fc[1]; fe2 += fc[2];
+        tq0 = tq[0]; tq1 = tq[1]; tq2 = tq[2];
     }
 
     // ---- accelerations and rate update (v += dt a ; w += dt alpha) ----
@@ -332,7 +406,7 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     L.w[2] += elem_valid ? P.dt * al2 : 0.0;
 
     // ---- dampers (registration order) and constrain_rates ----
-    if (!P.damp_before_constrain) constrain_rates(P, B, lane, L);
+    if (!P.damp_before_constrain) constrain_rates<kRuntimeFeatures>(P, B, lane, L);
     if (P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER) {
         L.v[0] *= P.damp_t; L.v[1] *= P.damp_t; L.v[2] *= P.damp_t;
         L.w[0] *= pow(P.damp_r[0], e);
@@ -340,12 +414,15 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
         L.w[2] *= pow(P.damp_r[2], e);
     }
     if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates(P, lane, L);
-    if (P.damp_before_constrain) constrain_rates(P, B, lane, L);
+    if (P.damp_before_constrain) constrain_rates<kRuntimeFeatures>(P, B, lane, L);
 }
 
 // ---------------------------------------------------------------------------------
 // global <-> register state
 // ---------------------------------------------------------------------------------
+// kappa / rest_kappa rows are only touched by feature sets that use them (intrinsic
+// curvature actuation) and by the run-time-mask instantiations.
+template <unsigned F = kRuntimeFeatures>
 __device__ __forceinline__ void load_state(const StatePtrs& S, size_t N, size_t row, LaneState& L) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -356,8 +433,19 @@ __device__ __forceinline__ void load_state(const StatePtrs& S, size_t N, size_t 
     }
 #pragma unroll
     for (int c = 0; c < 9; ++c) L.Q[c] = S.dir[c * N * kLanes + row];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (F == kRuntimeFeatures || (F & SOFTROD_FEAT_REST_KAPPA_ACTION)) {
+            L.kap[c] = S.kap[c * N * kLanes + row];
+            L.rk[c] = S.rkap[c * N * kLanes + row];
+        } else {
+            L.kap[c] = 0.0;
+            L.rk[c] = 0.0;
+        }
+    }
 }
 
+template <unsigned F = kRuntimeFeatures>
 __device__ __forceinline__ void store_state(const StatePtrs& S, size_t N, size_t row, const LaneState& L) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -368,6 +456,10 @@ __device__ __forceinline__ void store_state(const StatePtrs& S, size_t N, size_t
     }
 #pragma unroll
     for (int c = 0; c < 9; ++c) S.dir[c * N * kLanes + row] = L.Q[c];
+    if (F == kRuntimeFeatures || (F & SOFTROD_FEAT_REST_KAPPA_ACTION)) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) S.kap[c * N * kLanes + row] = L.kap[c];
+    }
 }
 
 __device__ __forceinline__ void load_bc(const StatePtrs& S, size_t N, int rod, BcTargets& B) {
@@ -383,15 +475,19 @@ __device__ __forceinline__ void load_bc(const StatePtrs& S, size_t N, int rod, B
 // ---------------------------------------------------------------------------------
 //   SoftPendulum     point_force[:] = action                       soft_pendulum.py:163-166
 //   SoftPendulum3D   clipped base displacement -> controller        soft_pendulum_3d.py:99-113
+//   ArmSingle        rest_kappa[0,:] = interp1d(cubic)(action)      octopus/arm_single_env.py:226-235
 // All lanes compute the same wave-uniform values; lane 0 persists the controller.
+template <unsigned F, int E>
 __device__ __forceinline__ void env_set_action(const RodParams& P, const StatePtrs& S, size_t N,
                                                int rod, int lane, const float* __restrict__ actions,
-                                               EnvAction& A, BcTargets& B) {
-    A.a[0] = A.a[1] = 0.0f;
+                                               EnvAction& A, BcTargets& B, LaneState& L) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
     A.force = 0.0;
-    if (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) {
+    const int env = env_of<E>(P);
+    if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
         if (actions) { A.a[0] = actions[2 * rod]; A.a[1] = actions[2 * rod + 1]; }
-        if (P.features & SOFTROD_FEAT_MOVING_BASE_BC) {
+        if (has<F>(P, SOFTROD_FEAT_MOVING_BASE_BC)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const double pos = S.ctrl[(size_t)i * N + rod];
@@ -408,6 +504,21 @@ __device__ __forceinline__ void env_set_action(const RodParams& P, const StatePt
                 }
                 B.pos[i] = next;
                 B.vel[i] = vel;
+            }
+        }
+    } else if (env == SOFTROD_ENV_ARM_SINGLE) {
+        if (actions) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) A.a[i] = actions[7 * (size_t)rod + i];
+            if (has<F>(P, SOFTROD_FEAT_REST_KAPPA_ACTION)) {
+                double rk0 = 0.0;
+                if (lane < P.n_elem - 1) {
+                    const double* wrow = S.basis + (size_t)lane * 7;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) rk0 += wrow[j] * (double)A.a[j];
+                }
+                L.rk[0] = rk0;
+                S.rkap[(size_t)rod * kLanes + lane] = rk0;   // rest_kappa[0, :] = action
             }
         }
     } else {
@@ -447,10 +558,68 @@ __device__ __forceinline__ bool state_has_nan(const RodParams& P, int lane, cons
     return __any((lane <= P.n_elem) && bad);
 }
 
+// compute_position_center_of_mass()[:2]
+__device__ __forceinline__ void center_of_mass_xy(const RodParams& P, int lane, const LaneState& L,
+                                                  double com[2]) {
+    const int n = P.n_elem;
+    const double mass = (lane == 0 || lane == n) ? 0.5 * P.mass_node : P.mass_node;
+    const double m = (lane <= n) ? mass : 0.0;
+    com[0] = wave_sum(m * L.x[0]) / P.mass_total;
+    com[1] = wave_sum(m * L.x[1]) / P.mass_total;
+}
+
+// ArmSingleEnv.get_state (octopus/arm_single_env.py:186-219): 7-bin means of kappa[0] and of
+// its change since the previous call, change of the centre of mass, previous action, target.
+// Mutates prev_kappa_state / prev_com_state exactly like the reference.
+__device__ __forceinline__ void arm_get_state(const RodParams& P, const StatePtrs& S, size_t N,
+                                              int rod, int lane, const LaneState& L, const float* pa,
+                                              float* __restrict__ obs) {
+    const int nv = P.n_elem - 1;
+    const bool vor_valid = lane < nv;
+    const size_t mrow = (size_t)rod * kLanes + lane;
+    const double kap = L.kap[0];
+    const double prev = S.envmem[mrow];
+    const double rate = kap - prev;
+    if (vor_valid) S.envmem[mrow] = kap;
+    double mk[7], mr[7];
+    int lo = 0;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        const int sz = nv / 7 + (b < nv % 7 ? 1 : 0);   // np.array_split sizes (7 x 7 for nv = 49)
+        const bool in = vor_valid && lane >= lo && lane < lo + sz;
+        mk[b] = wave_sum(in ? kap : 0.0) / (double)sz;
+        mr[b] = wave_sum(in ? rate : 0.0) / (double)sz;
+        lo += sz;
+    }
+    double com[2];
+    center_of_mass_xy(P, lane, L, com);
+    if (lane == 0) {
+        const double pc0 = S.ctrl[(size_t)0 * N + rod], pc1 = S.ctrl[(size_t)1 * N + rod];
+        S.ctrl[(size_t)0 * N + rod] = com[0];
+        S.ctrl[(size_t)1 * N + rod] = com[1];
+        float* o = obs + 25 * (size_t)rod;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            o[b] = (float)((mk[b] - P.kappa_range[0]) / (P.kappa_range[1] - P.kappa_range[0]));
+            o[7 + b] = (float)((mr[b] - P.kappa_rate_range[0]) /
+                               (P.kappa_rate_range[1] - P.kappa_rate_range[0]));
+        }
+        o[14] = (float)(com[0] - pc0);
+        o[15] = (float)(com[1] - pc1);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) o[16 + i] = pa[i];
+        o[23] = (float)P.target[0];
+        o[24] = (float)P.target[1];
+    }
+}
+
 // observation only (get_state at reset)
-__device__ __forceinline__ void env_observe(const RodParams& P, int rod, int lane, const LaneState& L,
-                                            const float* pa, float* __restrict__ obs) {
-    if (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) {
+template <int E>
+__device__ __forceinline__ void env_observe(const RodParams& P, const StatePtrs& S, size_t N, int rod,
+                                            int lane, const LaneState& L, const float* pa,
+                                            float* __restrict__ obs) {
+    const int env = env_of<E>(P);
+    if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
         const double tilt = tilt_angle(P, lane, L);
         if (lane == 0) {
             float* o = obs + 9 * (size_t)rod;
@@ -459,6 +628,8 @@ __device__ __forceinline__ void env_observe(const RodParams& P, int rod, int lan
             o[6] = pa[0]; o[7] = pa[1];
             o[8] = (float)tilt;
         }
+    } else if (env == SOFTROD_ENV_ARM_SINGLE) {
+        arm_get_state(P, S, N, rod, lane, L, pa, obs);
     } else {
         const double th = wrapped_theta(P, lane, L);
         if (lane == 0) {
@@ -473,6 +644,8 @@ __device__ __forceinline__ void env_observe(const RodParams& P, int rod, int lan
 
 // env epilogue: NaN check, reward, truncation, observation
 //   SoftPendulum    soft_pendulum.py:196-251       SoftPendulum3D  soft_pendulum_3d.py:130-174
+//   ArmSingle       octopus/arm_single_env.py:252-316
+template <int E>
 __device__ __forceinline__ void env_epilogue(const RodParams& P, const StatePtrs& S, size_t N, int rod,
                                              int lane, const LaneState& L, double time,
                                              const EnvAction& A, float* __restrict__ obs,
@@ -481,7 +654,8 @@ __device__ __forceinline__ void env_epilogue(const RodParams& P, const StatePtrs
                                              uint8_t* __restrict__ truncated,
                                              double* __restrict__ aux) {
     const bool invalid = state_has_nan(P, lane, L);
-    if (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) {
+    const int env = env_of<E>(P);
+    if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
         const double tilt = tilt_angle(P, lane, L);
         if (lane == 0) {
             const double bx = S.ctrl[(size_t)0 * N + rod], by = S.ctrl[(size_t)1 * N + rod];
@@ -500,6 +674,33 @@ __device__ __forceinline__ void env_epilogue(const RodParams& P, const StatePtrs
             o[6] = A.a[0]; o[7] = A.a[1];
             o[8] = (float)tilt;
         }
+    } else if (env == SOFTROD_ENV_ARM_SINGLE) {
+        // invalid also when ||omega||_F > 250 (:261-271)
+        const bool ev = lane < P.n_elem;
+        const double wn = wave_sum(ev ? L.w[0] * L.w[0] + L.w[1] * L.w[1] + L.w[2] * L.w[2] : 0.0);
+        const bool bad = invalid || (sqrt(wn) > 250.0);
+        double com[2];
+        center_of_mass_xy(P, lane, L, com);
+        if (lane == 0) {
+            // control penalty in float32 (np.square/mean of the float32 action, weak scalar)
+            float sq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sq += A.a[i] * A.a[i];
+            const float pen = P.control_penalty_coeff * (sq / 7.0f);
+            double forward = 0.0, survive = 0.0;
+            bool term = false;
+            if (bad) { term = true; survive = -1.0; }
+            else {
+                const double dx = com[0] - P.target[0], dy = com[1] - P.target[1];
+                const double dist = sqrt(dx * dx + dy * dy);
+                forward = exp(-dist / 0.35) - 0.096;
+                if (dist < 0.1) { survive = 5.0; term = true; }
+            }
+            reward[rod] = forward - (double)pen + survive;
+            terminated[rod] = term ? 1 : 0;
+            truncated[rod] = (time > P.final_time) ? 1 : 0;
+        }
+        arm_get_state(P, S, N, rod, lane, L, A.a, obs);
     } else {
         const double th = wrapped_theta(P, lane, L);
         if (lane == 0) {
@@ -537,7 +738,7 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
     BcTargets B;
     load_bc(S, N, rod, B);
     EnvAction A;
-    env_set_action(P, S, N, rod, lane, actions, A, B);
+    env_set_action<kRuntimeFeatures, kRuntimeEnv>(P, S, N, rod, lane, actions, A, B, L);
 
     double time = S.time[rod];
     const int n = P.n_elem;
@@ -546,16 +747,17 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
     for (int s = 0; s < n_sub; ++s) {
         libm_kinematic_step(P, P.half_dt, L);
         if (P.time_two_half_adds) time += P.half_dt;
-        constrain_values(P, B, lane, L);
+        constrain_values<kRuntimeFeatures>(P, B, lane, L);
         libm_dynamic_step(P, B, lane, A.force, mass, L);
         libm_kinematic_step(P, P.half_dt, L);
         time += P.time_two_half_adds ? P.half_dt : P.dt;
-        constrain_values(P, B, lane, L);
+        constrain_values<kRuntimeFeatures>(P, B, lane, L);
     }
 
     store_state(S, N, row, L);
     if (lane == 0) S.time[rod] = time;
-    if (epilogue) env_epilogue(P, S, N, rod, lane, L, time, A, obs, reward, terminated, truncated, aux);
+    if (epilogue)
+        env_epilogue<kRuntimeEnv>(P, S, N, rod, lane, L, time, A, obs, reward, terminated, truncated, aux);
 }
 
 // get_state() outside a step (reset observation), soft_pendulum.py:145-161
@@ -567,11 +769,12 @@ softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __rest
     const size_t N = (size_t)P.n_envs;
     LaneState L;
     load_state(S, N, (size_t)rod * kLanes + lane, L);
-    const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2 : 1;
-    float pa[2] = {0.0f, 0.0f};
+    const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2
+                   : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : 1;
+    float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (prev_action)
         for (int i = 0; i < adim; ++i) pa[i] = prev_action[adim * (size_t)rod + i];
-    env_observe(P, rod, lane, L, pa, obs);
+    env_observe<kRuntimeEnv>(P, S, N, rod, lane, L, pa, obs);
 }
 
 // Reset: expand the host-computed straight-rod description of each masked rod
@@ -601,6 +804,8 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
         L.x[c] = xv;
         L.v[c] = 0.0;
         L.w[c] = 0.0;
+        L.kap[c] = 0.0;   // a straight rod: kappa = 0 at allocation
+        L.rk[c] = 0.0;
     }
 #pragma unroll
     for (int c = 0; c < 9; ++c) L.Q[c] = in[9 + c];
@@ -610,15 +815,21 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
     const double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2) + P.eps_length;
     L.t[0] = d0 / len; L.t[1] = d1 / len; L.t[2] = d2 / len;
     store_state(S, N, row, L);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) S.rkap[c * N * kLanes + row] = 0.0;
+    S.envmem[row] = 0.0;   // prev_kappa_state = kappa[0] at reset (arm_single_env.py:172)
+    double com[2] = {0.0, 0.0};
+    if (P.env_kind == SOFTROD_ENV_ARM_SINGLE) center_of_mass_xy(P, lane, L, com);
     if (lane == 0) {
         S.time[rod] = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) S.bc[(size_t)i * N + rod] = in[i];
 #pragma unroll
         for (int i = 0; i < 9; ++i) S.bc[(size_t)(3 + i) * N + rod] = in[9 + i];
-        // MovingBaseController() is rebuilt by reset (soft_pendulum_3d.py:66)
+        // MovingBaseController() is rebuilt by reset (soft_pendulum_3d.py:66);
+        // ArmSingle: prev_com_state = centre of mass at reset (arm_single_env.py:173)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S.ctrl[(size_t)i * N + rod] = 0.0;
+        for (int i = 0; i < 4; ++i) S.ctrl[(size_t)i * N + rod] = (i < 2) ? com[i] : 0.0;
     }
 }
 

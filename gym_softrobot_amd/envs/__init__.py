@@ -1,4 +1,8 @@
+from .arm_single import ArmSingleEnv, VecArmSingleEnv
 from .soft_pendulum import SoftPendulumEnv, VecSoftPendulumEnv
 from .soft_pendulum_3d import SoftPendulum3DEnv, VecSoftPendulum3DEnv
 
-__all__ = ["SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv"]
+__all__ = [
+    "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
+    "ArmSingleEnv", "VecArmSingleEnv",
+]

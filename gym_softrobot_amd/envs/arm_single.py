@@ -1,0 +1,211 @@
+"""OctoArmSingle-v0 on the MI355X batched Cosserat-rod stepper.
+
+Mirrors gym_softrobot/envs/octopus/arm_single_env.py:41-316 and build_arm
+(gym_softrobot/envs/octopus/build.py:220-292): one arm lying on a frictional plane,
+actuated by its rest curvature (7 cubic-spline knots), reaching for a target with its
+centre of mass.  GravityForces, RodPlaneContactWithAnisotropicFriction and
+AnalyticalLinearDamper are compiled-in features (SOFTROD_FEATURES_ARM_SINGLE); the
+cubic `interp1d` of `set_action` is a constant basis matrix applied in the kernel
+prologue.  `n_elems` other than 50 generalise the reference's hard-coded 7x7 binning of
+the curvature observation (:193-194) to np.array_split-style bins.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from .. import _capi
+from ..spaces import Box
+from .soft_pendulum import _GymEnv, _time_table
+
+
+class VecArmSingleEnv:
+    """N parallel OctoArmSingle-v0 envs resident on one GPU (see VecSoftPendulumEnv)."""
+
+    metadata = {"render_modes": ["rgb_array", "human"], "render_fps": 20}
+
+    def __init__(
+        self,
+        num_envs: int,
+        final_time: float = 10.0,
+        time_step: float = 7.0e-5,
+        recording_fps: int = 20,
+        n_elems: int = 50,
+        n_action: int = 7,
+        control_penalty_coeff: float = 0.001,
+        config_generate_video: bool = False,
+        policy_mode: str = "centralized",
+        render_mode: Optional[str] = None,
+        *,
+        device: int = 0,
+        math_mode: int = _capi.MATH_FAST,
+        numpy_output: bool = False,
+        backend=None,
+    ):
+        if render_mode not in {None, *self.metadata["render_modes"]}:
+            raise ValueError(f"Unsupported render mode: {render_mode}")
+        if config_generate_video:
+            raise NotImplementedError("diagnostic callbacks/video are outside the hot path (DESIGN.md)")
+        if n_action != 7:
+            raise NotImplementedError("the observation layout of the reference fixes n_action = 7")
+        self.render_mode = render_mode
+        self.num_envs = int(num_envs)
+        self.final_time = final_time
+        self.time_step = time_step
+        self.total_steps = int(self.final_time / self.time_step)
+        self.recording_fps = recording_fps
+        self.step_skip = int(1.0 / (recording_fps * time_step))
+        self.control_penalty_coeff = control_penalty_coeff
+        self.n_elems = n_elems
+        self.n_seg = n_elems - 1
+        self.policy_mode = policy_mode
+        self.n_action = n_action
+        self.numpy_output = numpy_output
+        self.single_action_space = Box(-22.0, 22.0, shape=(7,), dtype=np.float32)
+        self.single_observation_space = Box(-np.inf, np.inf, shape=(25,), dtype=np.float32)
+        self.action_space = Box(-22.0, 22.0, shape=(self.num_envs, 7), dtype=np.float32)
+        self.observation_space = Box(-np.inf, np.inf, shape=(self.num_envs, 25), dtype=np.float32)
+
+        self.cfg = _capi.arm_single_config(
+            self.num_envs, final_time=final_time, time_step=time_step, recording_fps=recording_fps,
+            n_elems=n_elems, control_penalty_coeff=control_penalty_coeff, math_mode=math_mode,
+        )
+        if backend is None:
+            from ..backend import HipRodBackend
+
+            backend = HipRodBackend(self.cfg, device=device)
+        self.backend = backend
+        import torch
+
+        # _prev_action survives reset (arm_single_env.py:97-99)
+        self._prev_action = torch.zeros((self.num_envs, 7), dtype=torch.float32, device=self.backend.device)
+        self._steps = np.zeros(self.num_envs, np.int64)
+        self._time_tab = _time_table(self.cfg, 8)
+
+    def _times(self) -> np.ndarray:
+        kmax = int(self._steps.max()) if self.num_envs else 0
+        if kmax >= len(self._time_tab):
+            self._time_tab = _time_table(self.cfg, max(2 * kmax, 16))
+        return self._time_tab[self._steps]
+
+    def _out(self, t):
+        return t.cpu().numpy() if self.numpy_output else t
+
+    def reset(
+        self,
+        *,
+        seed: Optional[Union[int, Sequence[Optional[int]]]] = None,
+        options: Optional[dict] = None,
+        mask: Optional[np.ndarray] = None,
+    ):
+        # build_arm draws nothing from the RNG: every reset starts from the same straight arm
+        n = self.num_envs
+        m = np.ones(n, bool) if mask is None else np.asarray(mask, bool).reshape(n)
+        start = np.zeros((n, 3))
+        direction = np.tile(np.array([1.0, 0.0, 0.0]), (n, 1))   # octopus/build.py:236-238
+        normal = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1))
+        self.backend.reset_straight(start, direction, normal, None if mask is None else m.astype(np.uint8))
+        self._steps[m] = 0
+        obs = self.backend.observe(self._prev_action)
+        return self._out(obs), {}
+
+    def step(self, actions):
+        import torch
+
+        a = torch.as_tensor(actions, dtype=torch.float32, device=self.backend.device)
+        a = a.reshape(self.num_envs, 7)
+        obs, reward, term, trunc = self.backend.step(a)
+        self._prev_action = a.detach().clone()
+        self._steps += 1
+        times = self._times()
+        infos = {"time": times, "TimeLimit.truncated": times > self.final_time}
+        return (
+            self._out(obs),
+            self._out(reward),
+            self._out(term.bool()),
+            self._out(trunc.bool()),
+            infos,
+        )
+
+    def close(self):
+        if self.backend is not None and hasattr(self.backend, "close"):
+            self.backend.close()
+
+
+class ArmSingleEnv(_GymEnv):
+    """Drop-in for gym_softrobot's ArmSingleEnv (octopus/arm_single_env.py:41-316), N = 1."""
+
+    metadata = {"render_modes": ["rgb_array", "human"], "render_fps": 20}
+
+    def __init__(
+        self,
+        final_time=10.0,
+        time_step=7.0e-5,
+        recording_fps=20,
+        n_elems=50,
+        n_action=7,
+        control_penalty_coeff=0.001,
+        config_generate_video=False,
+        policy_mode="centralized",
+        render_mode: Optional[str] = None,
+        *,
+        device: int = 0,
+        math_mode: int = _capi.MATH_FAST,
+        backend=None,
+    ):
+        super().__init__()
+        if render_mode not in {None, *self.metadata["render_modes"]}:
+            raise ValueError(f"Unsupported render mode: {render_mode}")
+        self.render_mode = render_mode
+        self._vec = VecArmSingleEnv(
+            1, final_time, time_step, recording_fps, n_elems, n_action, control_penalty_coeff,
+            config_generate_video, policy_mode, None, device=device, math_mode=math_mode,
+            numpy_output=True, backend=backend,
+        )
+        self.final_time = final_time
+        self.time_step = time_step
+        self.total_steps = self._vec.total_steps
+        self.recording_fps = recording_fps
+        self.step_skip = self._vec.step_skip
+        self.control_penalty_coeff = control_penalty_coeff
+        self.n_elems = n_elems
+        self.n_seg = n_elems - 1
+        self.policy_mode = policy_mode
+        self.n_action = n_action
+        self.action_space = Box(-22.0, 22.0, shape=(7,), dtype=np.float32)
+        self.observation_space = Box(-np.inf, np.inf, shape=(25,), dtype=np.float32)
+        self.reward_range = 10.0
+        self.kappa_range = [-49.33508476187419, 49.33545827754751]
+        self.kappa_rate_range = [-21.063520620377012, 24.664591289161944]
+        self._target = np.array([1.0, 0.0])
+        self.time = np.float64(0.0)
+        self.counter = 0
+
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
+        super().reset(seed=seed)
+        obs, _ = self._vec.reset()
+        self.time = np.float64(0.0)
+        self.counter = 0
+        return np.asarray(obs[0], dtype=np.float32).copy(), {}
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float32).reshape(1, 7)
+        obs, reward, term, trunc, infos = self._vec.step(a)
+        self.time = np.float64(infos["time"][0])
+        self.counter += 1
+        return (
+            np.asarray(obs[0], dtype=np.float32).copy(),
+            float(reward[0]),
+            bool(term[0]),
+            bool(trunc[0]),
+            {"time": self.time, "TimeLimit.truncated": bool(infos["TimeLimit.truncated"][0])},
+        )
+
+    def render(self):
+        if self.render_mode is None:
+            return None
+        raise NotImplementedError("rendering is outside the hot path (DESIGN.md, out of scope)")
+
+    def close(self):
+        self._vec.close()

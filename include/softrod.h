@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 2
+#define SOFTROD_ABI_VERSION 3
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -81,6 +81,12 @@ enum softrod_feature {
     SOFTROD_FEAT_MOVING_BASE_BC = 1u << 6,
     /* LaplaceDissipationFilter(filter_order)      soft_pendulum_3d/build.py:82-85 */
     SOFTROD_FEAT_LAPLACE_FILTER = 1u << 7,
+    /* Plane + RodPlaneContactWithAnisotropicFriction(k, nu, slip_velocity_tol,
+     * static_mu_array, kinetic_mu_array)          octopus/build.py:236-283    */
+    SOFTROD_FEAT_PLANE_CONTACT_ANISO = 1u << 8,
+    /* set_action: rest_kappa[0, :] = cubic interp1d of the action
+     *                                             octopus/arm_single_env.py:226-235 */
+    SOFTROD_FEAT_REST_KAPPA_ACTION = 1u << 9,
 };
 
 #define SOFTROD_FEATURES_SOFTPENDULUM                                             \
@@ -89,12 +95,16 @@ enum softrod_feature {
 #define SOFTROD_FEATURES_SOFTPENDULUM3D                                           \
     (SOFTROD_FEAT_GRAVITY | SOFTROD_FEAT_MOVING_BASE_BC |                        \
      SOFTROD_FEAT_ANALYTICAL_DAMPER | SOFTROD_FEAT_LAPLACE_FILTER)
+#define SOFTROD_FEATURES_ARM_SINGLE                                               \
+    (SOFTROD_FEAT_GRAVITY | SOFTROD_FEAT_PLANE_CONTACT_ANISO |                   \
+     SOFTROD_FEAT_ANALYTICAL_DAMPER | SOFTROD_FEAT_REST_KAPPA_ACTION)
 
 /* env_kind: which env's set_action / NaN check / reward / observation the step
  * kernel's prologue and epilogue implement.                                     */
 #define SOFTROD_ENV_NONE 0           /* bare rod: softrod_substeps only            */
 #define SOFTROD_ENV_SOFTPENDULUM 1   /* soft_pendulum/soft_pendulum.py:149-251     */
 #define SOFTROD_ENV_SOFTPENDULUM3D 2 /* soft_pendulum_3d/soft_pendulum_3d.py:93-174 */
+#define SOFTROD_ENV_ARM_SINGLE 3     /* octopus/arm_single_env.py:186-316           */
 
 /* math_mode (HIP library only; the oracle always uses libm). */
 #define SOFTROD_MATH_LIBM 0 /* sqrt/sin/cos/acos/pow evaluated as written   */
@@ -144,12 +154,29 @@ typedef struct softrod_config {
                                       soft_pendulum_3d/build.py:66-85), pyelastica
                                       1.0 OperatorGroupFIFO; 1: dampers first
                                       (mixin-__init__ order of pyelastica 0.3.x) */
+    /* ---- OctoArmSingle-v0 (octopus/build.py:220-292, arm_single_env.py) ---- */
+    int32_t contact_before_forcing; /* order inside synchronize(): 0 (default) =
+                                       registration order, gravity then contact
+                                       (octopus/build.py:236-283)              */
+    int32_t reserved1;
+    double plane_origin[3];   /* (0, 0, -r0)            octopus/build.py:244   */
+    double plane_normal[3];   /* (0, 0, 1)              octopus/build.py:233   */
+    double contact_k;         /* 1e2                    :241                    */
+    double contact_nu;        /* 1e1                    :242                    */
+    double slip_velocity_tol; /* 1e-8                   :245                    */
+    double surface_tol;       /* PyElastica class default 1e-4                  */
+    double kinetic_mu[3];     /* forward, backward, sideways   :248-256         */
+    double static_mu[3];      /* 2 x kinetic                   :257             */
+    double control_penalty_coeff; /* 0.001              arm_single_env.py:62    */
+    double target[2];         /* (1, 0)                 arm_single_env.py:165   */
+    double kappa_range[2];    /* arm_single_env.py:111                          */
+    double kappa_rate_range[2]; /* :113                                         */
 } softrod_config;
 
 /* Per-env I/O widths implied by env_kind. */
-int softrod_action_dim(int env_kind); /* 1, 2                               */
-int softrod_obs_dim(int env_kind);    /* 4, 9                               */
-int softrod_aux_dim(int env_kind);    /* 0, 1 (info["tilt"], float64)       */
+int softrod_action_dim(int env_kind); /* 1, 2, 7                            */
+int softrod_obs_dim(int env_kind);    /* 4, 9, 25                           */
+int softrod_aux_dim(int env_kind);    /* 0, 1 (info["tilt"], float64), 0    */
 
 typedef struct softrod_handle softrod_handle;
 
@@ -173,6 +200,12 @@ typedef struct softrod_state_view {
     double* time;     /* [n_envs]  simulated time (soft_pendulum.py:141,184) */
     double* control;  /* [4][n_envs]  MovingBaseController position x,y and
                          velocity x,y (soft_pendulum_3d/build.py:15-20)      */
+    double* kappa;    /* [3][n_envs][64]  rod.kappa as of the last force
+                         evaluation (arm_single_env.py:189)                  */
+    double* rest_kappa; /* [3][n_envs][64]  rod.rest_kappa (:235)            */
+    double* env_memory; /* [n_envs][64]  env-side memory between steps:
+                         prev_kappa_state[0..n-2], prev_com_state at 60,61
+                         (arm_single_env.py:172-173,190-198)                 */
 } softrod_state_view;
 
 /* Fill `cfg` with SoftPendulumEnv.__init__ defaults (soft_pendulum.py:59-78)
@@ -181,6 +214,17 @@ int softrod_config_softpendulum(softrod_config* cfg, int n_envs);
 /* Same for SoftPendulum3DEnv (soft_pendulum_3d.py:28-58) and
  * build_soft_pendulum_3d (soft_pendulum_3d/build.py:43-86).                 */
 int softrod_config_softpendulum3d(softrod_config* cfg, int n_envs);
+/* Same for ArmSingleEnv (octopus/arm_single_env.py:55-113) and build_arm
+ * (octopus/build.py:220-292).                                               */
+int softrod_config_arm_single(softrod_config* cfg, int n_envs);
+
+/* Replaces the constant part of set_action's
+ *   interp1d(linspace(0,1,n_action), action, kind="cubic")(linspace(0,1,n_seg))
+ * (octopus/arm_single_env.py:226-235): cubic not-a-knot interpolation through fixed
+ * knots evaluated at fixed abscissae is linear in the action, rest_kappa[0,:] = W a.
+ * basis: host [n_elem-1][action_dim] float64 (row-major), computed by the caller
+ * with the same scipy call on unit vectors.                                  */
+int softrod_set_action_basis(softrod_handle* h, const double* basis);
 
 /* Replaces: BaseSimulator() + build_soft_pendulum(...) + simulator.finalize()
  * (soft_pendulum.py:115-138) for a whole batch: allocates resident device

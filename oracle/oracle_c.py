@@ -49,6 +49,8 @@ def _load(omp: bool) -> C.CDLL:
     lib.oracle_observe3d.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_clear_prev_action3d.argtypes = [C.c_void_p]
     lib.oracle_env_step3d.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.oracle_reset_arm.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_env_step_arm.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.oracle_get.restype = C.c_int
     lib.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.oracle_set.restype = C.c_int
@@ -67,7 +69,7 @@ _SHAPES = {
     "shear": lambda n: (3, n), "bend": lambda n: (3, n - 1), "damp_r": lambda n: (3, n),
     "mass": lambda n: (n + 1,), "lengths": lambda n: (n,), "dilatation": lambda n: (n,),
     "rest_lengths": lambda n: (n,), "damp_t": lambda n: (1,), "rest_kappa": lambda n: (3, n - 1),
-    "control": lambda n: (4,),
+    "control": lambda n: (4,), "radius": lambda n: (n,),
 }
 
 
@@ -144,6 +146,30 @@ class OracleRod:
             trunc.ctypes.data, tilt.ctypes.data,
         )
         return obs, float(rew[0]), bool(term[0]), bool(trunc[0]), float(tilt[0])
+
+    # -- OctoArmSingle-v0 -----------------------------------------------------------
+    def reset_arm(self) -> np.ndarray:
+        obs = np.empty(25, np.float32)
+        self._lib.oracle_reset_arm(self._h, obs.ctypes.data)
+        return obs
+
+    def env_step_arm(self, action):
+        """set_action's interp1d (arm_single_env.py:226-235) is evaluated here with
+        scipy, exactly as the reference does, and handed to the C oracle."""
+        from scipy.interpolate import interp1d
+
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(7)
+        rk = interp1d(np.linspace(0, 1, 7), a, kind="cubic", axis=-1)(np.linspace(0, 1, self.n - 1))
+        rk = np.ascontiguousarray(rk, dtype=np.float64)
+        obs = np.empty(25, np.float32)
+        rew = np.empty(1, np.float64)
+        term = np.empty(1, np.uint8)
+        trunc = np.empty(1, np.uint8)
+        self._lib.oracle_env_step_arm(
+            self._h, a.ctypes.data, rk.ctypes.data, obs.ctypes.data, rew.ctypes.data,
+            term.ctypes.data, trunc.ctypes.data,
+        )
+        return obs, float(rew[0]), bool(term[0]), bool(trunc[0])
 
     def get(self, name: str) -> np.ndarray:
         shape = _SHAPES[name](self.n)

@@ -62,6 +62,11 @@ typedef struct oracle_rod {
     double fixed_pos[3], fixed_dir[3][3];
     float prev_action; /* _prev_action, soft_pendulum.py:97-99,165 */
     double point_force; /* point_force[0], soft_pendulum.py:117,166 */
+    double radius[NMAX];   /* rod.radius, refreshed with the geometry (volume preserving) */
+    /* ArmSingleEnv memory: prev_kappa_state, prev_com_state, _prev_action
+     * (octopus/arm_single_env.py:97-99,172-173,190-198) */
+    double prev_kappa[NMAX], prev_com[2];
+    float prev_action7[7];
     /* MovingBaseController, soft_pendulum_3d/build.py:15-20 */
     double ctrl_pos[3], ctrl_vel[3];
     float prev_action2[2]; /* SoftPendulum3DEnv._prev_action */
@@ -178,7 +183,7 @@ static void compute_all_dilatations(oracle_rod* r)
         r->tang[0][k] = d0 / r->len[k];
         r->tang[1][k] = d1 / r->len[k];
         r->tang[2][k] = d2 / r->len[k];
-        /* radius[k] = sqrt(volume/len/pi): geometry only, not used by the path */
+        r->radius[k] = sqrt(r->volume[k] / r->len[k] / M_PI); /* used by plane contact only */
         r->dil[k] = r->len[k] / r->rest_len[k];
     }
     for (int k = 0; k < n - 1; ++k) {
@@ -387,6 +392,193 @@ static void constrain_rates(oracle_rod* r)
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* RodPlaneContactWithAnisotropicFriction.apply_contact (pyelastica 1.0.0      */
+/* elastica/contact_forces.py -> _contact_functions.py: the normal-force        */
+/* kernel `_calculate_contact_forces_rod_plane` (Gazzola et al. 2018 eq. 4.8)  */
+/* and `anisotropic_friction`), registered at octopus/build.py:274-283.         */
+/* RECALLED, not on disk: second-largest parity risk after the stepper.        */
+/* ------------------------------------------------------------------------- */
+static void node_to_element_force(const oracle_rod* r, double out[3][NMAX])
+{
+    const int n = r->n;
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < n; ++k) {
+            const double a = r->f_int[i][k] + r->f_ext[i][k];
+            const double b = r->f_int[i][k + 1] + r->f_ext[i][k + 1];
+            out[i][k] = 0.0;
+            out[i][k] += 0.5 * (a + b);
+        }
+        out[i][0] += 0.5 * (r->f_int[i][0] + r->f_ext[i][0]);
+        out[i][n - 1] += 0.5 * (r->f_int[i][n] + r->f_ext[i][n]);
+    }
+}
+
+static void elements_to_nodes(oracle_rod* r, const double e[3][NMAX])
+{
+    const int n = r->n;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < n; ++k) {
+            r->f_ext[i][k] += 0.5 * e[i][k];
+            r->f_ext[i][k + 1] += 0.5 * e[i][k];
+        }
+}
+
+static double sign_of(double x) { return (x > 0.0) - (x < 0.0); }
+
+/* find_slipping_elements: 1 below the threshold, linear ramp to 0 at 2x threshold */
+static double slip_function(const double vec[3], double thr)
+{
+    const double a = sqrt(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
+    if (fabs(a) > thr) {
+        double m = a / thr - 1.0;
+        if (m > 1.0) m = 1.0;
+        return fabs(1.0 - m);
+    }
+    return 1.0;
+}
+
+static void plane_contact(oracle_rod* r)
+{
+    const softrod_config* c = &r->cfg;
+    const int n = r->n;
+    const double* nrm = c->plane_normal;
+    double fel[3][NMAX], vel[3][NMAX], resp_mag[NMAX], e_tot[3][NMAX];
+    int no_contact[NMAX];
+
+    /* ---- normal force ---- */
+    node_to_element_force(r, fel);
+    for (int k = 0; k < n; ++k) {
+        double fn = nrm[0] * fel[0][k] + nrm[1] * fel[1][k] + nrm[2] * fel[2][k];
+        double along[3] = { nrm[0] * fn, nrm[1] * fn, nrm[2] * fn };
+        if (fn > 0.0) along[0] = along[1] = along[2] = 0.0;
+        double resp[3] = { -along[0], -along[1], -along[2] };
+        double xe[3], dist = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            xe[i] = 0.5 * (r->x[i][k] + r->x[i][k + 1]);
+            dist += nrm[i] * (xe[i] - c->plane_origin[i]);
+        }
+        double pen = dist - r->radius[k];
+        if (pen > 0.0) pen = 0.0;
+        double vn = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            vel[i][k] = (r->mass[k + 1] * r->v[i][k + 1] + r->mass[k] * r->v[i][k]);
+            vel[i][k] /= (r->mass[k + 1] + r->mass[k]);
+            vn += nrm[i] * vel[i][k];
+        }
+        no_contact[k] = (dist - r->radius[k]) > c->surface_tol;
+        for (int i = 0; i < 3; ++i) {
+            const double elastic = -c->contact_k * (nrm[i] * pen);
+            const double damping = -c->contact_nu * (nrm[i] * vn);
+            double tot = resp[i] + elastic + damping;
+            if (no_contact[k]) { resp[i] = 0.0; tot = 0.0; }
+            e_tot[i][k] = tot;
+        }
+        resp_mag[k] = sqrt(resp[0] * resp[0] + resp[1] * resp[1] + resp[2] * resp[2]);
+    }
+    elements_to_nodes(r, e_tot);
+
+    /* ---- kinetic friction (axial, rolling) ---- */
+    double axial[3][NMAX], roll[3][NMAX], arm[3][NMAX], slip_ax[NMAX], slip_roll[NMAX];
+    for (int k = 0; k < n; ++k) {
+        double tn = 0.0, tp[3];
+        for (int i = 0; i < 3; ++i) tn += nrm[i] * r->tang[i][k];
+        for (int i = 0; i < 3; ++i) tp[i] = r->tang[i][k] - nrm[i] * tn;
+        const double tpm = sqrt(tp[0] * tp[0] + tp[1] * tp[1] + tp[2] * tp[2]);
+        for (int i = 0; i < 3; ++i) axial[i][k] = (1.0 / (tpm + 1e-14)) * tp[i];
+        double ve[3] = { vel[0][k], vel[1][k], vel[2][k] };
+        const double vax = ve[0] * axial[0][k] + ve[1] * axial[1][k] + ve[2] * axial[2][k];
+        double vax_vec[3] = { vax * axial[0][k], vax * axial[1][k], vax * axial[2][k] };
+        const double sgn = sign_of(vax);
+        const double kmu = 0.5 * (c->kinetic_mu[0] * (1 + sgn) + c->kinetic_mu[1] * (1 - sgn));
+        slip_ax[k] = slip_function(vax_vec, c->slip_velocity_tol);
+        /* rolling direction = axial x normal ; torque arm = -normal * radius */
+        roll[0][k] = axial[1][k] * nrm[2] - axial[2][k] * nrm[1];
+        roll[1][k] = axial[2][k] * nrm[0] - axial[0][k] * nrm[2];
+        roll[2][k] = axial[0][k] * nrm[1] - axial[1][k] * nrm[0];
+        for (int i = 0; i < 3; ++i) arm[i][k] = -nrm[i] * r->radius[k];
+        const double vroll = ve[0] * roll[0][k] + ve[1] * roll[1][k] + ve[2] * roll[2][k];
+        /* rotation velocity Q^T (omega x (Q arm)) */
+        double qa[3], wq[3], rot[3];
+        for (int i = 0; i < 3; ++i)
+            qa[i] = r->Q[i][0][k] * arm[0][k] + r->Q[i][1][k] * arm[1][k] + r->Q[i][2][k] * arm[2][k];
+        wq[0] = r->w[1][k] * qa[2] - r->w[2][k] * qa[1];
+        wq[1] = r->w[2][k] * qa[0] - r->w[0][k] * qa[2];
+        wq[2] = r->w[0][k] * qa[1] - r->w[1][k] * qa[0];
+        for (int i = 0; i < 3; ++i)
+            rot[i] = r->Q[0][i][k] * wq[0] + r->Q[1][i][k] * wq[1] + r->Q[2][i][k] * wq[2];
+        const double vrot = rot[0] * roll[0][k] + rot[1] * roll[1][k] + rot[2] * roll[2][k];
+        const double sroll = vroll + vrot;
+        double sroll_vec[3] = { sroll * roll[0][k], sroll * roll[1][k], sroll * roll[2][k] };
+        slip_roll[k] = slip_function(sroll_vec, c->slip_velocity_tol);
+        const double vm = sqrt(ve[0] * ve[0] + ve[1] * ve[1] + ve[2] * ve[2]) + 1e-14;
+        double u[3] = { ve[0] / vm, ve[1] / vm, ve[2] / vm };
+        const double uax = u[0] * axial[0][k] + u[1] * axial[1][k] + u[2] * axial[2][k];
+        const double uro = u[0] * roll[0][k] + u[1] * roll[1][k] + u[2] * roll[2][k];
+        double fk_ax[3], fk_ro[3];
+        for (int i = 0; i < 3; ++i) {
+            fk_ax[i] = -((1.0 - slip_ax[k]) * kmu * resp_mag[k] * uax * axial[i][k]);
+            fk_ro[i] = -((1.0 - slip_roll[k]) * c->kinetic_mu[2] * resp_mag[k] * uro * roll[i][k]);
+            if (no_contact[k]) { fk_ax[i] = 0.0; fk_ro[i] = 0.0; }
+            e_tot[i][k] = fk_ax[i];
+        }
+        /* torque = Q (arm x F_roll) */
+        double cr[3] = { arm[1][k] * fk_ro[2] - arm[2][k] * fk_ro[1],
+                         arm[2][k] * fk_ro[0] - arm[0][k] * fk_ro[2],
+                         arm[0][k] * fk_ro[1] - arm[1][k] * fk_ro[0] };
+        for (int i = 0; i < 3; ++i)
+            r->t_ext[i][k] += r->Q[i][0][k] * cr[0] + r->Q[i][1][k] * cr[1] + r->Q[i][2][k] * cr[2];
+        for (int i = 0; i < 3; ++i) vel[i][k] = fk_ro[i]; /* reuse as scratch for the scatter */
+    }
+    elements_to_nodes(r, e_tot);                 /* axial kinetic */
+    {
+        double tmp[3][NMAX];
+        for (int i = 0; i < 3; ++i) for (int k = 0; k < n; ++k) tmp[i][k] = vel[i][k];
+        elements_to_nodes(r, tmp);               /* rolling kinetic */
+    }
+
+    /* ---- static friction (axial, rolling) on the updated total forces ---- */
+    node_to_element_force(r, fel);
+    double fs_ro[3][NMAX];
+    for (int k = 0; k < n; ++k) {
+        const double fax = fel[0][k] * axial[0][k] + fel[1][k] * axial[1][k] + fel[2][k] * axial[2][k];
+        const double sg = sign_of(fax);
+        const double smu = 0.5 * (c->static_mu[0] * (1 + sg) + c->static_mu[1] * (1 - sg));
+        double maxf = slip_ax[k] * smu * resp_mag[k];
+        const double mag = fabs(fax) < maxf ? fabs(fax) : maxf;
+        for (int i = 0; i < 3; ++i) {
+            double f = -(mag * sg * axial[i][k]);
+            if (no_contact[k]) f = 0.0;
+            e_tot[i][k] = f;
+        }
+        /* rolling: total torques in the lab frame, Q^T (tau_int + tau_ext) */
+        double tt[3], tl[3];
+        for (int i = 0; i < 3; ++i) tl[i] = r->t_int[i][k] + r->t_ext[i][k];
+        for (int i = 0; i < 3; ++i)
+            tt[i] = r->Q[0][i][k] * tl[0] + r->Q[1][i][k] * tl[1] + r->Q[2][i][k] * tl[2];
+        const double tax = tt[0] * axial[0][k] + tt[1] * axial[1][k] + tt[2] * axial[2][k];
+        const double fro = fel[0][k] * roll[0][k] + fel[1][k] * roll[1][k] + fel[2][k] * roll[2][k];
+        const double noslip = -((r->radius[k] * fro - 2.0 * tax) / 3.0 / r->radius[k]);
+        maxf = slip_roll[k] * c->static_mu[2] * resp_mag[k];
+        const double sg2 = sign_of(noslip);
+        const double mag2 = fabs(noslip) < maxf ? fabs(noslip) : maxf;
+        for (int i = 0; i < 3; ++i) {
+            double f = mag2 * sg2 * roll[i][k];
+            if (no_contact[k]) f = 0.0;
+            fs_ro[i][k] = f;
+        }
+    }
+    elements_to_nodes(r, e_tot);                 /* axial static */
+    elements_to_nodes(r, fs_ro);                 /* rolling static */
+    for (int k = 0; k < n; ++k) {
+        double cr[3] = { arm[1][k] * fs_ro[2][k] - arm[2][k] * fs_ro[1][k],
+                         arm[2][k] * fs_ro[0][k] - arm[0][k] * fs_ro[2][k],
+                         arm[0][k] * fs_ro[1][k] - arm[1][k] * fs_ro[0][k] };
+        for (int i = 0; i < 3; ++i)
+            r->t_ext[i][k] += r->Q[i][0][k] * cr[0] + r->Q[i][1][k] * cr[1] + r->Q[i][2][k] * cr[2];
+    }
+}
+
 /* synchronize(): forcing in registration order — GravityForces (build.py:88-91)
  * then PendulumPointForces which ASSIGNS (build.py:100-101) */
 static void apply_forcing(oracle_rod* r)
@@ -462,7 +654,12 @@ static void position_verlet_step(oracle_rod* r)
     constrain_values(r);
     compute_internal_forces(r);
     compute_internal_torques(r);
+    /* synchronize(): operators in registration order — add_forcing_to(GravityForces)
+     * precedes detect_contact_between(...) in build_arm (octopus/build.py:236-283) */
+    const int has_contact = (r->cfg.features & SOFTROD_FEAT_PLANE_CONTACT_ANISO) != 0;
+    if (has_contact && r->cfg.contact_before_forcing) plane_contact(r);
     apply_forcing(r);
+    if (has_contact && !r->cfg.contact_before_forcing) plane_contact(r);
     dynamic_step(r, dt);
     /* _feature_group_constrain_rates: Damping registers before Constraints for
      * the mixin order of BaseSimulator (soft_pendulum.py:34-42); the two
@@ -667,6 +864,106 @@ void oracle_env_step3d(oracle_rod* r, const float action[2], float obs[9], doubl
     get_state3d(r, obs);
 }
 
+/* ---- OctoArmSingle-v0: octopus/arm_single_env.py ---- */
+static void center_of_mass(const oracle_rod* r, double com[3]) /* compute_position_center_of_mass */
+{
+    double msum = 0.0;
+    for (int k = 0; k <= r->n; ++k) msum += r->mass[k];
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+        for (int k = 0; k <= r->n; ++k) s += r->mass[k] * r->x[i][k];
+        com[i] = s / msum;
+    }
+}
+
+/* get_state, :186-219.  Mutates prev_kappa_state / prev_com_state like the reference.
+ * The 7x7 reshape of the reference (:193-194) is generalised to np.array_split-style
+ * bins so that n_elem - 1 need not be 49 (identical for 49). */
+static void get_state_arm(oracle_rod* r, float obs[25])
+{
+    const softrod_config* c = &r->cfg;
+    const int nv = r->n - 1;
+    double mk[7], mr[7];
+    int lo = 0;
+    for (int b = 0; b < 7; ++b) {
+        const int sz = nv / 7 + (b < nv % 7 ? 1 : 0);
+        double sk = 0.0, sr = 0.0;
+        for (int k = lo; k < lo + sz; ++k) {
+            sk += r->kappa[0][k];
+            sr += r->kappa[0][k] - r->prev_kappa[k];
+        }
+        mk[b] = sk / (double)sz;
+        mr[b] = sr / (double)sz;
+        lo += sz;
+    }
+    for (int k = 0; k < nv; ++k) r->prev_kappa[k] = r->kappa[0][k];
+    double com[3];
+    center_of_mass(r, com);
+    const double cr0 = com[0] - r->prev_com[0], cr1 = com[1] - r->prev_com[1];
+    r->prev_com[0] = com[0]; r->prev_com[1] = com[1];
+    for (int b = 0; b < 7; ++b) {
+        obs[b] = (float)((mk[b] - c->kappa_range[0]) / (c->kappa_range[1] - c->kappa_range[0]));
+        obs[7 + b] = (float)((mr[b] - c->kappa_rate_range[0]) /
+                             (c->kappa_rate_range[1] - c->kappa_rate_range[0]));
+    }
+    obs[14] = (float)cr0; obs[15] = (float)cr1;
+    for (int i = 0; i < 7; ++i) obs[16 + i] = r->prev_action7[i];
+    obs[23] = (float)c->target[0]; obs[24] = (float)c->target[1];
+}
+
+/* ArmSingleEnv.reset, :135-183 (build_arm: octopus/build.py:220-292) */
+void oracle_reset_arm(oracle_rod* r, float obs[25])
+{
+    const double start[3] = { 0.0, 0.0, 0.0 };
+    const double direction[3] = { 1.0, 0.0, 0.0 };
+    const double normal[3] = { 0.0, 0.0, 1.0 };
+    oracle_reset_straight(r, start, direction, normal);
+    for (int k = 0; k < r->n - 1; ++k) r->prev_kappa[k] = r->kappa[0][k];
+    double com[3];
+    center_of_mass(r, com);
+    r->prev_com[0] = com[0]; r->prev_com[1] = com[1];
+    get_state_arm(r, obs);
+}
+
+/* ArmSingleEnv.step, :237-316.  rest_kappa0: the interp1d output of set_action
+ * (:226-235), computed by the caller with scipy exactly as the reference does. */
+void oracle_env_step_arm(oracle_rod* r, const float action[7], const double* rest_kappa0,
+                         float obs[25], double* reward, uint8_t* terminated, uint8_t* truncated)
+{
+    const softrod_config* c = &r->cfg;
+    const int n = r->n;
+    for (int i = 0; i < 7; ++i) r->prev_action7[i] = action[i];
+    for (int k = 0; k < n - 1; ++k) r->rest_kappa[0][k] = rest_kappa0[k];
+    for (int s = 0; s < c->n_substeps; ++s) position_verlet_step(r);
+    /* control penalty: float32 arithmetic (np.square/mean on the float32 action, and
+     * python-float * np.float32 stays float32 under NumPy 2 promotion) */
+    float sq = 0.0f;
+    for (int i = 0; i < 7; ++i) sq += action[i] * action[i];
+    const float pen = (float)c->control_penalty_coeff * (sq / 7.0f);
+    int invalid = 0;
+    double wn = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k <= n; ++k)
+            if (isnan(r->x[i][k]) || isnan(r->v[i][k])) invalid = 1;
+        for (int k = 0; k < n; ++k) wn += r->w[i][k] * r->w[i][k];
+    }
+    if (sqrt(wn) > 250) invalid = 1;
+    double survive = 0.0, forward = 0.0;
+    *terminated = 0;
+    if (invalid) { *terminated = 1; survive = -1.0; }
+    else {
+        double com[3];
+        center_of_mass(r, com);
+        const double dx = com[0] - c->target[0], dy = com[1] - c->target[1];
+        const double dist = sqrt(dx * dx + dy * dy);
+        forward = exp(-dist / 0.35) - 0.096;
+        if (dist < 0.1) { survive = 5.0; *terminated = 1; }
+    }
+    *truncated = (r->time > c->final_time) ? 1 : 0;
+    *reward = forward - (double)pen + survive;
+    get_state_arm(r, obs);
+}
+
 /* batched driver for the cpu_baseline leg (OpenMP over rods when built with it) */
 void oracle_env_step_batch(oracle_rod** rods, int n_rods, const float* actions, float* obs,
                            double* reward, uint8_t* terminated, uint8_t* truncated)
@@ -677,6 +974,8 @@ void oracle_env_step_batch(oracle_rod** rods, int n_rods, const float* actions, 
                         truncated + e);
 }
 
+#define COPY3X(arr, cnt) do { for (int i = 0; i < 3; ++i) for (int k = 0; k < (cnt); ++k) \
+        out[i * (cnt) + k] = r->arr[i][k]; return 3 * (cnt); } while (0)
 /* field access for tests: name in {x,v,Q,w,tangents,kappa,sigma,mass,f_int,t_int,...} */
 int oracle_get(const oracle_rod* r, const char* name, double* out)
 {
@@ -708,6 +1007,10 @@ int oracle_get(const oracle_rod* r, const char* name, double* out)
     if (!strcmp(name, "dilatation")) { for (int k = 0; k < n; ++k) out[k] = r->dil[k]; return n; }
     if (!strcmp(name, "rest_lengths")) { for (int k = 0; k < n; ++k) out[k] = r->rest_len[k]; return n; }
     if (!strcmp(name, "damp_t")) { out[0] = r->damp_t; return 1; }
+    if (!strcmp(name, "rest_kappa")) COPY3X(rest_kappa, n - 1);
+    if (!strcmp(name, "radius")) { for (int k = 0; k < n; ++k) out[k] = r->radius[k]; return n; }
+    if (!strcmp(name, "f_ext")) COPY3X(f_ext, n + 1);
+    if (!strcmp(name, "t_ext")) COPY3X(t_ext, n);
     if (!strcmp(name, "control")) {
         out[0] = r->ctrl_pos[0]; out[1] = r->ctrl_pos[1];
         out[2] = r->ctrl_vel[0]; out[3] = r->ctrl_vel[1];

@@ -476,3 +476,58 @@ def test_softpendulum3d_determinism_and_masked_reset(torch_gpu, hip_lib):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][2]["x"], outs[1][2]["x"])
+
+
+# ---- OctoArmSingle-v0 (plane contact + anisotropic friction + rest-curvature actuation) -----
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+def test_arm_single_rollout_matches_oracle(torch_gpu, hip_lib, oracle_built, math_mode):
+    import gym_softrobot_amd as gsa
+
+    n, T = 6, 4
+    env = gsa.make_vec("OctoArmSingle-v0", n, device=0, math_mode=math_mode)
+    obs0, _ = env.reset()
+    obs0 = obs0.cpu().numpy().copy()
+    # gentle (|a| <= 6) and aggressive (|a| <= 22) curvature commands
+    rng = np.random.default_rng(11)
+    acts = rng.uniform(-1, 1, (T, n, 7)).astype(np.float32)
+    acts[:, : n // 2] *= 6.0
+    acts[:, n // 2 :] *= 22.0
+    rods = []
+    for i in range(n):
+        r = oracle_built.OracleRod(env.cfg)
+        o = r.reset_arm()
+        np.testing.assert_allclose(obs0[i], o, rtol=1e-6, atol=1e-7)
+        rods.append(r)
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(acts[t])
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for i, r in enumerate(rods):
+            o, rw, te, tr = r.env_step_arm(acts[t, i])
+            np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=2e-6)
+            np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-7)
+            assert bool(term[i]) == te and bool(trunc[i]) == tr
+    st = env.backend.state_numpy()
+    for i, r in enumerate(rods):
+        np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(st["Q"][i], r.get("Q"), rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(st["rest_kappa"][i][0], r.get("rest_kappa")[0], rtol=1e-12, atol=1e-12)
+        assert st["time"][i] == r.time
+    env.close()
+
+
+def test_arm_single_rest_and_api(torch_gpu, hip_lib):
+    import gym_softrobot_amd as gsa
+
+    env = gsa.make("OctoArmSingle-v0")
+    ob, info = env.reset(seed=0)
+    assert ob.shape == (25,) and ob.dtype == np.float32 and info == {}
+    # zero action: the arm rests on the plane, nothing moves (contact response cancels weight)
+    for _ in range(2):
+        o, r, te, tr, inf = env.step(np.zeros(7, np.float32))
+    assert isinstance(r, float) and not te and not tr
+    assert r == pytest.approx(np.exp(-0.825 / 0.35) - 0.096, rel=1e-9)
+    st = env._vec.backend.state_numpy()
+    assert np.abs(st["v"]).max() < 1e-10 and np.abs(st["x"][0, 2]).max() < 1e-12
+    np.testing.assert_allclose(o[14:16], 0.0, atol=1e-12)
+    assert inf["time"] == pytest.approx(2 * 714 * 7e-5, rel=1e-9)
+    env.close()
