@@ -80,6 +80,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--math-mode", choices=["fast", "libm"], default="fast")
+    ap.add_argument("--env", default="SoftPendulum-v0",
+                    choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0"],
+                    help="headline metric is SoftPendulum-v0; the others are the widened §8 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,15 +112,24 @@ def main() -> None:
     n_total = n_local * world
     K, W = args.steps, args.warmup
     math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
-    local = gsa.make_vec("SoftPendulum-v0", n_local, device=local_rank, math_mode=math_mode)
-    env = ShardedVecEnv(local, n_total)
-    env.reset(seed=0)  # global env i seeded i
-    lo, hi = env.lo, env.hi
-    # the truncation flag first fires on env.step #126; keep the window inside one episode
-    # by re-resetting (untimed) if a longer run was requested
+    local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode)
+    if args.env == "SoftPendulum-v0":
+        env = ShardedVecEnv(local, n_total)   # packed all-gather of the per-env outputs
+        env.reset(seed=0)  # global env i seeded i
+        lo, hi = env.lo, env.hi
+    else:
+        env = local                            # single-GPU measurement of the widened envs
+        lo, hi = 0, n_local
+        if world != 1:
+            raise SystemExit("--env other than SoftPendulum-v0 is a single-GPU measurement")
+        env.reset(seed=0)
+    adim = local.backend.action_dim
+    amax = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0}[args.env]
+    # the truncation flag of SoftPendulum first fires on env.step #126; the default window
+    # (55 steps) stays inside one episode
     T = W + K
-    acts = np.random.default_rng(1).uniform(-22, 22, (T, n_total, 1)).astype(np.float32)
-    acts_dev = torch.from_numpy(acts[:, lo:hi, 0].copy()).to(local.backend.device)
+    acts = np.random.default_rng(1).uniform(-amax, amax, (T, n_total, adim)).astype(np.float32)
+    acts_dev = torch.from_numpy(acts[:, lo:hi].copy()).to(local.backend.device)
 
     for t in range(W):
         env.step(acts_dev[t])
@@ -168,8 +180,9 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"SoftPendulum-v0, {n_local} envs x {int(cfg.n_elem)} elements per GPU "
-                            f"(BASELINE configs[1]; x{world} GPUs)",
+                "workload": f"{args.env}, {n_local} envs x {int(cfg.n_elem)} elements per GPU "
+                            + (f"(BASELINE configs[1]; x{world} GPUs)" if args.env == "SoftPendulum-v0"
+                               else "(widened row of SURVEY §8; not the headline metric)"),
                 "envs_total": n_total,
                 "substeps_per_env_step": nsub,
                 "math_mode": args.math_mode,
@@ -185,13 +198,18 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "kernel": "softrod_step_fast_kernel" if args.math_mode == "fast" else "softrod_step_libm_kernel",
+                "fp64_valu": {
+                    "note": "the binding unit: wave64 fp64 VALU ops issue in 4 cycles (78.6 TFLOP/s); "
+                            "SIMD-cycles per rod-substep below vs ~4 x fp64 instruction count (profiles/README.md)",
+                    "simd_cycles_per_rod_substep_at_2.4GHz": kernel_ms * 1e-3 * 2.4e9 * 1024 / (n_local * nsub),
+                },
                 "kernel_ms_avg": kernel_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "algorithmic bytes = rods x substeps x 2(18n+6) x 8 B (SURVEY 8d); the kernel keeps "
                         "the state in registers for all substeps, so real HBM traffic is ~1/400 of that",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.env == "SoftPendulum-v0":
             cores = len(os.sched_getaffinity(0))
             line["cpu_baseline"] = cpu_baseline(cfg, cores)
         else:

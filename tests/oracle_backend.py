@@ -18,6 +18,7 @@ class OracleBackend:
         self.n_envs = int(cfg.n_envs)
         self.device = torch.device("cpu")
         self.is3d = cfg.env_kind == _capi.ENV_SOFTPENDULUM3D
+        self.isarm = cfg.env_kind == _capi.ENV_ARM_SINGLE
         self.action_dim = _capi.action_dim(cfg.env_kind)
         self.obs_dim = _capi.obs_dim(cfg.env_kind)
         self.rods = [oracle_c.OracleRod(self.cfg, omp=omp) for _ in range(self.n_envs)]
@@ -36,7 +37,10 @@ class OracleBackend:
     def reset_straight(self, start, direction, normal, mask=None):
         for i, r in enumerate(self.rods):
             if mask is None or mask[i]:
-                r.reset_straight(start[i], direction[i], normal[i])
+                if self.isarm:
+                    r.reset_arm()   # also re-arms prev_kappa_state / prev_com_state
+                else:
+                    r.reset_straight(start[i], direction[i], normal[i])
 
     def observe(self, prev_action=None):
         pa = np.zeros((self.n_envs, self.action_dim), np.float32)
@@ -46,6 +50,15 @@ class OracleBackend:
             if self.is3d:
                 o = r.observe3d()
                 o[6:8] = pa[i]   # the env owns _prev_action; the rod only sees it at step time
+                self.obs[i] = torch.from_numpy(o)
+            elif self.isarm:
+                # get_state at reset: rates are zero, kappa is zero (straight arm)
+                o = np.zeros(25, np.float32)
+                c = self.cfg
+                o[0:7] = np.float32((0.0 - c.kappa_range[0]) / (c.kappa_range[1] - c.kappa_range[0]))
+                o[7:14] = np.float32((0.0 - c.kappa_rate_range[0]) / (c.kappa_rate_range[1] - c.kappa_rate_range[0]))
+                o[16:23] = pa[i]
+                o[23:25] = [c.target[0], c.target[1]]
                 self.obs[i] = torch.from_numpy(o)
             else:
                 r.set_prev_action(float(pa[i, 0]))
@@ -58,6 +71,8 @@ class OracleBackend:
             if self.is3d:
                 o, rw, te, tr, tilt = r.env_step3d(a[i])
                 self.aux[i, 0] = tilt
+            elif self.isarm:
+                o, rw, te, tr = r.env_step_arm(a[i])
             else:
                 o, rw, te, tr = r.env_step(a[i, 0])
             self.obs[i] = torch.from_numpy(o)

@@ -168,3 +168,37 @@ def test_softpendulum3d_base_limit_clips(oracle_built):
     assert xs[3][2] == 0.0 and xs[3][3] == 0.0          # clipped: no displacement, zero velocity
     assert xs[2][2] == pytest.approx((0.0025 - 2 * step) / (2 * 1e-4), rel=1e-9)
     vec.close()
+
+
+# ---- OctoArmSingle-v0 -------------------------------------------------------------------
+def test_arm_single_spaces_and_step(oracle_built):
+    cfg = _capi.arm_single_config(1)
+    assert cfg.n_substeps == 714 and cfg.final_time == 10.0       # arm_single_env.py:57-59,77
+    mu = 0.35 / (4.0 * 9.81 * 0.1)                                # octopus/build.py:247
+    assert list(cfg.kinetic_mu) == pytest.approx([mu, 1.5 * mu, 2 * mu])
+    assert list(cfg.static_mu) == pytest.approx([2 * mu, 3 * mu, 4 * mu])
+    env = gsa.ArmSingleEnv(backend=OracleBackend(cfg))
+    assert env.action_space.shape == (7,) and env.observation_space.shape == (25,)
+    ob, info = env.reset(seed=0)
+    assert ob.dtype == np.float32 and info == {} and env.observation_space.contains(ob)
+    assert ob[23] == 1.0 and ob[24] == 0.0
+    a = np.full(7, 2.0, np.float32)
+    o, r, te, tr, inf = env.step(a)
+    assert set(inf) == {"time", "TimeLimit.truncated"} and isinstance(r, float)
+    np.testing.assert_array_equal(o[16:23], a)
+    assert not te and not tr and r < 0          # exp(-d/0.35) - 0.096 - 0.001*mean(a^2)
+    # _prev_action survives reset (arm_single_env.py:97-99)
+    ob2, _ = env.reset()
+    np.testing.assert_array_equal(ob2[16:23], a)
+    env.close()
+
+
+def test_action_basis_reproduces_interp1d():
+    from scipy.interpolate import interp1d
+
+    W = _capi.action_basis(50, 7)
+    assert W.shape == (49, 7)
+    a = np.random.default_rng(0).uniform(-22, 22, 7).astype(np.float32)
+    ref = interp1d(np.linspace(0, 1, 7), a, kind="cubic", axis=-1)(np.linspace(0, 1, 49))
+    np.testing.assert_allclose(W @ a.astype(np.float64), ref, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(W.sum(axis=1), 1.0, atol=1e-13)     # reproduces constants

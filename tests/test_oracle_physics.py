@@ -174,3 +174,51 @@ def test_k7_point_force_assigns_not_adds(oracle_built):
     # after one substep from rest: v_x0 = dt * (F_int_x + action)/m0 * damp_t ; F_int ~ 0
     vx0 = rod.get("v")[0, 0]
     assert vx0 == pytest.approx(cfg.dt * 2.0 / m0 * rod.get("damp_t")[0], rel=1e-6)
+
+
+# ---- plane contact + anisotropic friction (OctoArmSingle-v0 feature set) ----------------------
+def _arm_cfg(**kw):
+    cfg = _capi.arm_single_config(1)
+    cfg.features = _capi.FEAT_GRAVITY | _capi.FEAT_PLANE_CONTACT_ANISO | _capi.FEAT_ANALYTICAL_DAMPER
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def test_k8_rod_dropped_on_plane_comes_to_rest_on_it(oracle_built):
+    # released 1 mm above the plane: falls, is caught by the penalty spring/damper and ends at
+    # rest with its surface within surface_tol of the plane, the response cancelling its weight
+    cfg = _arm_cfg()
+    rod = oracle_built.OracleRod(cfg)
+    r0 = cfg.base_radius
+    rod.reset_straight([0, 0, 1e-3], [1, 0, 0], [0, 0, 1])
+    rod.substeps(0.0, 100)
+    assert rod.get("v")[2].mean() == pytest.approx(-9.81 * 100 * cfg.dt, rel=1e-3)   # free fall
+    rod.substeps(0.0, 20000)
+    gap = rod.get("x")[2] - (cfg.plane_origin[2] + r0)
+    assert np.abs(rod.get("v")).max() < 1e-6
+    assert gap.max() <= cfg.surface_tol + 1e-9 and gap.min() > -1e-4
+    assert np.abs(rod.get("x")[1]).max() < 1e-12   # no sideways drift
+
+
+@pytest.mark.parametrize("direction,mu_index", [(+1.0, 0), (-1.0, 1)])
+def test_k9_axial_sliding_decelerates_with_kinetic_coulomb_friction(oracle_built, direction, mu_index):
+    # a rod sliding along its axis is slowed by mu_k g: mu_forward when moving towards its
+    # tip, mu_backward (1.5x) when moving towards its base (octopus/build.py:248-256)
+    cfg = _arm_cfg()
+    cfg.damping_constant = 0.0
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    v = np.zeros((3, cfg.n_elem + 1))
+    v0 = 0.2
+    v[0] = direction * v0
+    rod.set("v", v)
+    nsub = 1000
+    rod.substeps(0.0, nsub)
+    t = nsub * cfg.dt
+    vx = rod.get("v")[0]
+    mu = cfg.kinetic_mu[mu_index]
+    expect = direction * (v0 - mu * 9.81 * t)
+    assert np.allclose(vx, vx.mean(), rtol=0, atol=2e-4)        # rigid translation
+    assert vx.mean() == pytest.approx(expect, rel=2e-3)
+    assert np.abs(rod.get("x")[2]).max() < 1e-6                 # stays on the plane
