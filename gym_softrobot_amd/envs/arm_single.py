@@ -11,19 +11,22 @@ the curvature observation (:193-194) to np.array_split-style bins.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Union
+from typing import Optional
 
 import numpy as np
 
 from .. import _capi
 from ..spaces import Box
-from .soft_pendulum import _GymEnv, _time_table
+from .base import GymEnv as _GymEnv
+from .base import VecRodEnvBase
 
 
-class VecArmSingleEnv:
-    """N parallel OctoArmSingle-v0 envs resident on one GPU (see VecSoftPendulumEnv)."""
+class VecArmSingleEnv(VecRodEnvBase):
+    """N parallel OctoArmSingle-v0 envs resident on one GPU (see VecRodEnvBase)."""
 
     metadata = {"render_modes": ["rgb_array", "human"], "render_fps": 20}
+    action_low, action_high = -22.0, 22.0             # arm_single_env.py:84-90
+    clears_prev_action_on_reset = False               # _prev_action survives reset (:97-99)
 
     def __init__(
         self,
@@ -41,16 +44,18 @@ class VecArmSingleEnv:
         device: int = 0,
         math_mode: int = _capi.MATH_FAST,
         numpy_output: bool = False,
+        autoreset: bool = False,
         backend=None,
     ):
-        if render_mode not in {None, *self.metadata["render_modes"]}:
-            raise ValueError(f"Unsupported render mode: {render_mode}")
-        if config_generate_video:
-            raise NotImplementedError("diagnostic callbacks/video are outside the hot path (DESIGN.md)")
         if n_action != 7:
             raise NotImplementedError("the observation layout of the reference fixes n_action = 7")
-        self.render_mode = render_mode
-        self.num_envs = int(num_envs)
+        cfg = _capi.arm_single_config(
+            num_envs, final_time=final_time, time_step=time_step, recording_fps=recording_fps,
+            n_elems=n_elems, control_penalty_coeff=control_penalty_coeff, math_mode=math_mode,
+        )
+        super().__init__(num_envs, cfg, render_mode=render_mode,
+                         config_generate_video=config_generate_video, device=device,
+                         numpy_output=numpy_output, autoreset=autoreset, backend=backend)
         self.final_time = final_time
         self.time_step = time_step
         self.total_steps = int(self.final_time / self.time_step)
@@ -60,77 +65,14 @@ class VecArmSingleEnv:
         self.n_elems = n_elems
         self.n_seg = n_elems - 1
         self.policy_mode = policy_mode
-        self.n_action = n_action
-        self.numpy_output = numpy_output
-        self.single_action_space = Box(-22.0, 22.0, shape=(7,), dtype=np.float32)
-        self.single_observation_space = Box(-np.inf, np.inf, shape=(25,), dtype=np.float32)
-        self.action_space = Box(-22.0, 22.0, shape=(self.num_envs, 7), dtype=np.float32)
-        self.observation_space = Box(-np.inf, np.inf, shape=(self.num_envs, 25), dtype=np.float32)
 
-        self.cfg = _capi.arm_single_config(
-            self.num_envs, final_time=final_time, time_step=time_step, recording_fps=recording_fps,
-            n_elems=n_elems, control_penalty_coeff=control_penalty_coeff, math_mode=math_mode,
-        )
-        if backend is None:
-            from ..backend import HipRodBackend
-
-            backend = HipRodBackend(self.cfg, device=device)
-        self.backend = backend
-        import torch
-
-        # _prev_action survives reset (arm_single_env.py:97-99)
-        self._prev_action = torch.zeros((self.num_envs, 7), dtype=torch.float32, device=self.backend.device)
-        self._steps = np.zeros(self.num_envs, np.int64)
-        self._time_tab = _time_table(self.cfg, 8)
-
-    def _times(self) -> np.ndarray:
-        kmax = int(self._steps.max()) if self.num_envs else 0
-        if kmax >= len(self._time_tab):
-            self._time_tab = _time_table(self.cfg, max(2 * kmax, 16))
-        return self._time_tab[self._steps]
-
-    def _out(self, t):
-        return t.cpu().numpy() if self.numpy_output else t
-
-    def reset(
-        self,
-        *,
-        seed: Optional[Union[int, Sequence[Optional[int]]]] = None,
-        options: Optional[dict] = None,
-        mask: Optional[np.ndarray] = None,
-    ):
+    def _reset_backend(self, mask, use_mask):
         # build_arm draws nothing from the RNG: every reset starts from the same straight arm
         n = self.num_envs
-        m = np.ones(n, bool) if mask is None else np.asarray(mask, bool).reshape(n)
         start = np.zeros((n, 3))
         direction = np.tile(np.array([1.0, 0.0, 0.0]), (n, 1))   # octopus/build.py:236-238
         normal = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1))
-        self.backend.reset_straight(start, direction, normal, None if mask is None else m.astype(np.uint8))
-        self._steps[m] = 0
-        obs = self.backend.observe(self._prev_action)
-        return self._out(obs), {}
-
-    def step(self, actions):
-        import torch
-
-        a = torch.as_tensor(actions, dtype=torch.float32, device=self.backend.device)
-        a = a.reshape(self.num_envs, 7)
-        obs, reward, term, trunc = self.backend.step(a)
-        self._prev_action = a.detach().clone()
-        self._steps += 1
-        times = self._times()
-        infos = {"time": times, "TimeLimit.truncated": times > self.final_time}
-        return (
-            self._out(obs),
-            self._out(reward),
-            self._out(term.bool()),
-            self._out(trunc.bool()),
-            infos,
-        )
-
-    def close(self):
-        if self.backend is not None and hasattr(self.backend, "close"):
-            self.backend.close()
+        self.backend.reset_straight(start, direction, normal, mask.astype(np.uint8) if use_mask else None)
 
 
 class ArmSingleEnv(_GymEnv):

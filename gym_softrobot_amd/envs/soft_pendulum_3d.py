@@ -8,14 +8,14 @@ the kernel (SOFTROD_FEATURES_SOFTPENDULUM3D).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Union
+from typing import Optional
 
 import numpy as np
 
 from .. import _capi
-from ..seeding import np_random
 from ..spaces import Box
-from .soft_pendulum import _GymEnv, _time_table
+from .base import GymEnv as _GymEnv
+from .base import VecRodEnvBase
 
 
 def initial_tilt(rng: np.random.Generator) -> float:
@@ -23,10 +23,12 @@ def initial_tilt(rng: np.random.Generator) -> float:
     return float(np.deg2rad(rng.uniform(-1.0, 1.0)))
 
 
-class VecSoftPendulum3DEnv:
-    """N parallel SoftPendulum3D-v0 envs resident on one GPU (see VecSoftPendulumEnv)."""
+class VecSoftPendulum3DEnv(VecRodEnvBase):
+    """N parallel SoftPendulum3D-v0 envs resident on one GPU (see VecRodEnvBase)."""
 
     metadata = {"render_modes": ["rgb_array"], "render_fps": 25}
+    action_low, action_high = -1.0, 1.0               # soft_pendulum_3d.py:41-46
+    clears_prev_action_on_reset = True                # :68
 
     def __init__(
         self,
@@ -41,90 +43,37 @@ class VecSoftPendulum3DEnv:
         device: int = 0,
         math_mode: int = _capi.MATH_FAST,
         numpy_output: bool = False,
+        autoreset: bool = False,
         backend=None,
     ):
-        if render_mode not in {None, *self.metadata["render_modes"]}:
-            raise ValueError(f"Unsupported render mode: {render_mode}")
-        if config_generate_video:
-            raise NotImplementedError("diagnostic callbacks/video are outside the hot path (DESIGN.md)")
-        self.render_mode = render_mode
-        self.num_envs = int(num_envs)
+        cfg = _capi.softpendulum3d_config(
+            num_envs, final_time=final_time, time_step=time_step,
+            recording_fps=recording_fps, n_elems=n_elems, math_mode=math_mode,
+        )
+        super().__init__(num_envs, cfg, render_mode=render_mode,
+                         config_generate_video=config_generate_video, device=device,
+                         numpy_output=numpy_output, autoreset=autoreset, backend=backend)
         self.final_time = final_time
         self.time_step = time_step
         self.total_steps = int(self.final_time / self.time_step)
         self.recording_fps = recording_fps
         self.step_skip = int(1.0 / (recording_fps * time_step))
         self.n_elems = n_elems
-        self.numpy_output = numpy_output
-        self.n_action = 2
         self.base_step = 1e-3
         self.base_limit = 0.5
-        self.single_action_space = Box(-1.0, 1.0, shape=(2,), dtype=np.float32)
-        self.single_observation_space = Box(-np.inf, np.inf, shape=(9,), dtype=np.float32)
-        self.action_space = Box(-1.0, 1.0, shape=(self.num_envs, 2), dtype=np.float32)
-        self.observation_space = Box(-np.inf, np.inf, shape=(self.num_envs, 9), dtype=np.float32)
 
-        self.cfg = _capi.softpendulum3d_config(
-            self.num_envs, final_time=final_time, time_step=time_step,
-            recording_fps=recording_fps, n_elems=n_elems, math_mode=math_mode,
-        )
-        if backend is None:
-            from ..backend import HipRodBackend
-
-            backend = HipRodBackend(self.cfg, device=device)
-        self.backend = backend
-        self._rngs: List[Optional[np.random.Generator]] = [None] * self.num_envs
-        import torch
-
-        self._prev_action = torch.zeros((self.num_envs, 2), dtype=torch.float32, device=self.backend.device)
-        self._steps = np.zeros(self.num_envs, np.int64)
-        self._time_tab = _time_table(self.cfg, 8)
-
-    def _times(self) -> np.ndarray:
-        kmax = int(self._steps.max()) if self.num_envs else 0
-        if kmax >= len(self._time_tab):
-            self._time_tab = _time_table(self.cfg, max(2 * kmax, 16))
-        return self._time_tab[self._steps]
-
-    def _out(self, t):
-        return t.cpu().numpy() if self.numpy_output else t
-
-    def reset(
-        self,
-        *,
-        seed: Optional[Union[int, Sequence[Optional[int]]]] = None,
-        options: Optional[dict] = None,
-        mask: Optional[np.ndarray] = None,
-    ):
-        import torch
-
+    def _reset_backend(self, mask, use_mask):
         n = self.num_envs
-        if seed is None or isinstance(seed, (int, np.integer)):
-            seeds = [None if seed is None else int(seed) + i for i in range(n)]
-        else:
-            seeds = list(seed)
-            if len(seeds) != n:
-                raise ValueError("need one seed per env")
-        m = np.ones(n, bool) if mask is None else np.asarray(mask, bool).reshape(n)
         direction = np.zeros((n, 3))
         direction[:, 2] = 1.0
-        for i in range(n):
-            if not m[i]:
-                continue
-            if seeds[i] is not None or self._rngs[i] is None:
-                self._rngs[i], _ = np_random(seeds[i])
+        for i in np.nonzero(mask)[0]:
             tilt = initial_tilt(self._rngs[i])
             direction[i] = [np.sin(tilt), 0.0, np.cos(tilt)]  # soft_pendulum_3d/build.py:52
         start = np.zeros((n, 3))
         normal = np.tile(np.array([0.0, 1.0, 0.0]), (n, 1))   # :53
-        self.backend.reset_straight(start, direction, normal, None if mask is None else m.astype(np.uint8))
-        self._steps[m] = 0
-        # SoftPendulum3DEnv.reset clears _prev_action (soft_pendulum_3d.py:68)
-        self._prev_action[torch.from_numpy(m).to(self._prev_action.device)] = 0.0
-        obs = self.backend.observe(self._prev_action)
-        return self._out(obs), {}
+        self.backend.reset_straight(start, direction, normal, mask.astype(np.uint8) if use_mask else None)
 
-    def step(self, actions):
+    def _validate_actions(self, actions):
         import torch
 
         if isinstance(actions, np.ndarray) or not torch.is_tensor(actions):
@@ -132,24 +81,9 @@ class VecSoftPendulum3DEnv:
             if not (np.all(a_np >= -1.0) and np.all(a_np <= 1.0)):
                 # soft_pendulum_3d.py:116-117 (device tensors are the caller's responsibility)
                 raise ValueError(f"Action {actions!r} is outside {self.single_action_space}")
-        a = torch.as_tensor(actions, dtype=torch.float32, device=self.backend.device)
-        a = a.reshape(self.num_envs, 2)
-        obs, reward, term, trunc = self.backend.step(a)
-        self._prev_action = a.detach().clone()
-        self._steps += 1
-        times = self._times()
-        infos = {"time": times, "tilt": self._out(self.backend.aux[:, 0])}
-        return (
-            self._out(obs),
-            self._out(reward),
-            self._out(term.bool()),
-            self._out(trunc.bool()),
-            infos,
-        )
 
-    def close(self):
-        if self.backend is not None and hasattr(self.backend, "close"):
-            self.backend.close()
+    def _infos(self, times):
+        return {"time": times, "tilt": self._out(self.backend.aux[:, 0])}
 
 
 class SoftPendulum3DEnv(_GymEnv):

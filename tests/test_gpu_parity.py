@@ -531,3 +531,26 @@ def test_arm_single_rest_and_api(torch_gpu, hip_lib):
     np.testing.assert_allclose(o[14:16], 0.0, atol=1e-12)
     assert inf["time"] == pytest.approx(2 * 714 * 7e-5, rel=1e-9)
     env.close()
+
+
+def test_autoreset_on_gpu(torch_gpu, hip_lib):
+    # NEXT_STEP auto-reset through the HIP path: truncation after 3 short steps, reset on the 4th
+    import gym_softrobot_amd as gsa
+
+    kw = dict(final_time=5e-4, time_step=1e-4, recording_fps=5000, n_elems=20)
+    env = gsa.make_vec("SoftPendulum-v0", 5, device=0, autoreset=True, **kw)
+    obs0, _ = env.reset(seed=0)
+    obs0 = obs0.cpu().numpy().copy()
+    a = np.linspace(-5, 5, 5).astype(np.float32)
+    for k in range(1, 5):
+        obs, rew, term, trunc, _ = env.step(a)
+        if k == 3:
+            assert trunc.all().item()
+        if k == 4:
+            assert not trunc.any().item() and (rew == 0).all().item()
+            o = obs.cpu().numpy()
+            np.testing.assert_array_equal(o[:, :2], 0.0)
+            assert not np.allclose(o[:, 3], obs0[:, 3])   # a new initial angle was drawn
+            st = env.backend.state_numpy()
+            assert np.all(st["time"] == 0.0) and np.all(st["v"] == 0.0)
+    env.close()

@@ -202,3 +202,46 @@ def test_action_basis_reproduces_interp1d():
     ref = interp1d(np.linspace(0, 1, 7), a, kind="cubic", axis=-1)(np.linspace(0, 1, 49))
     np.testing.assert_allclose(W @ a.astype(np.float64), ref, rtol=0, atol=1e-13)
     np.testing.assert_allclose(W.sum(axis=1), 1.0, atol=1e-13)     # reproduces constants
+
+
+# ---- batched extras: auto-reset -------------------------------------------
+def test_autoreset_next_step_semantics(oracle_built):
+    kw = dict(final_time=5e-4, time_step=1e-4, recording_fps=5000, n_elems=6)   # 2 substeps/step
+    n = 3
+    cfg = _capi.softpendulum_config(n, **kw)
+    vec = gsa.VecSoftPendulumEnv(n, backend=OracleBackend(cfg), numpy_output=True, autoreset=True, **kw)
+    obs0, _ = vec.reset(seed=[1, 2, 3])
+    a = np.array([1.0, 2.0, 3.0], np.float32)
+    flags = []
+    for k in range(1, 6):
+        obs, rew, term, trunc, info = vec.step(a)
+        flags.append(trunc.copy())
+        if k == 3:
+            assert trunc.all()                      # time = 6e-4 > 5e-4 on the third step
+        if k == 4:
+            # NEXT_STEP: the call after the finished step resets instead of stepping
+            assert not trunc.any() and not term.any() and np.all(rew == 0.0)
+            np.testing.assert_array_equal(obs[:, :2], 0.0)       # fresh rod: x0 = vx0 = 0
+            np.testing.assert_array_equal(obs[:, 2], a)          # _prev_action survives reset
+            assert np.all(vec._steps == 0)
+            # the same RNG streams continue: second draw of each env's generator
+            for i, s in enumerate((1, 2, 3)):
+                rng, _ = np_random(s)
+                initial_angle(rng)
+                th = initial_angle(rng)
+                assert obs[i, 3] == pytest.approx(np.arctan(np.cos(th) / np.sin(th)), rel=1e-6)
+        if k == 5:
+            assert np.all(vec._steps == 1) and not trunc.any()
+    vec.close()
+
+
+def test_without_autoreset_envs_keep_running_past_truncation(oracle_built):
+    kw = dict(final_time=5e-4, time_step=1e-4, recording_fps=5000, n_elems=6)
+    cfg = _capi.softpendulum_config(2, **kw)
+    vec = gsa.VecSoftPendulumEnv(2, backend=OracleBackend(cfg), numpy_output=True, **kw)
+    vec.reset(seed=0)
+    for k in range(1, 6):
+        _, _, _, trunc, _ = vec.step(np.zeros(2, np.float32))
+        assert trunc.all() == (k >= 3)              # the reference has no auto-reset
+    assert np.all(vec._steps == 5)
+    vec.close()
