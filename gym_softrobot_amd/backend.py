@@ -164,7 +164,7 @@ class HipRodBackend:
         """Zero-copy torch views of the resident SoA state (softrod_state_view)."""
         v = SoftrodStateView()
         check(self._lib.softrod_state_view_get(self._h, C.byref(v)), self._h)
-        n, s = self.n_envs, LANE_STRIDE
+        n, s = self.n_envs, int(v.lane_stride)
 
         def view(ptr, comps):
             return torch.as_tensor(_DevArray(ptr, (comps, n, s), "<f8", self), device=self.device)

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -21,6 +22,8 @@ using namespace softrod;
 struct softrod_handle {
     softrod_config cfg;
     int device = 0;
+    int epl = 1;            // nodes/elements per lane: 1 (n_elem <= 63) or 2 (<= 126)
+    bool use_long = false;  // step/observe/reset through softrod_long.hpp
     RodParams P{};
     StatePtrs S{};
     double* d_init = nullptr;     // [N][18] staging for reset
@@ -137,7 +140,27 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
-    if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
+    if (h->use_long) {
+        const unsigned f = h->cfg.features;
+        const int e = h->cfg.env_kind;
+#define SR_LAUNCH_L(FEATS, ENV, EPL)                                                               \
+        hipLaunchKernelGGL((softrod_step_long_kernel<FEATS, ENV, EPL>), grid, block, 0, st, h->P, h->S, \
+                           actions, obs, reward, term, trunc, aux, n_sub, epilogue)
+        if (h->epl == 2) {
+            if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE)
+                SR_LAUNCH_L(SOFTROD_FEATURES_ARM_SINGLE, SOFTROD_ENV_ARM_SINGLE, 2);
+            else if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM)
+                SR_LAUNCH_L(SOFTROD_FEATURES_SOFTPENDULUM, SOFTROD_ENV_SOFTPENDULUM, 2);
+            else
+                SR_LAUNCH_L(kRuntimeFeatures, kRuntimeEnv, 2);
+        } else {
+            if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM)
+                SR_LAUNCH_L(SOFTROD_FEATURES_SOFTPENDULUM, SOFTROD_ENV_SOFTPENDULUM, 1);
+            else
+                SR_LAUNCH_L(kRuntimeFeatures, kRuntimeEnv, 1);
+        }
+#undef SR_LAUNCH_L
+    } else if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
         // instantiations specialised for the registered envs' feature sets; anything else
         // (known-answer tests, custom feature mixes) takes the run-time-mask instantiation
         const unsigned f = h->cfg.features;
@@ -171,7 +194,12 @@ int upload_and_reset(softrod_handle* h, hipStream_t st, bool use_mask) {
     if (use_mask)
         SR_HIP(h, hipMemcpyAsync(h->d_mask, h->h_mask, N, hipMemcpyHostToDevice, st));
     ResetArgs A{h->d_init, use_mask ? h->d_mask : nullptr};
-    hipLaunchKernelGGL(softrod_reset_kernel, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
+    if (h->use_long && h->epl == 2)
+        hipLaunchKernelGGL(softrod_reset_long_kernel<2>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
+    else if (h->use_long)
+        hipLaunchKernelGGL(softrod_reset_long_kernel<1>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
+    else
+        hipLaunchKernelGGL(softrod_reset_kernel, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
     SR_HIP(h, hipGetLastError());
     SR_HIP(h, hipEventRecord(h->ev_reset, st));
     return SOFTROD_OK;
@@ -308,8 +336,11 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     *out = nullptr;
     if (cfg->struct_size != sizeof(softrod_config))
         return fail(nullptr, SOFTROD_EINVAL, "softrod_config.struct_size mismatch");
-    if (cfg->n_envs < 1 || cfg->n_elem < 2 || cfg->n_elem > kLanes - 1)
-        return fail(nullptr, SOFTROD_EINVAL, "need n_envs >= 1 and 2 <= n_elem <= 63");
+    if (cfg->n_envs < 1 || cfg->n_elem < 2 || cfg->n_elem > 2 * kLanes - 2)
+        return fail(nullptr, SOFTROD_EINVAL, "need n_envs >= 1 and 2 <= n_elem <= 126");
+    if (cfg->n_elem > kLanes - 1 && cfg->math_mode != SOFTROD_MATH_FAST)
+        return fail(nullptr, SOFTROD_EINVAL,
+                    "rods longer than 63 elements (two per lane) exist for SOFTROD_MATH_FAST only");
     if (cfg->n_substeps < 0 || !(cfg->dt > 0.0))
         return fail(nullptr, SOFTROD_EINVAL, "need n_substeps >= 0 and dt > 0");
     if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
@@ -334,9 +365,14 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     if (!h) return fail(nullptr, SOFTROD_ENOMEM, "host allocation failed");
     h->cfg = *cfg;
     h->device = device;
+    h->epl = cfg->n_elem > kLanes - 1 ? 2 : 1;
+    {   // SOFTROD_FORCE_LONG=1 routes short rods through the slot-generic kernels too (tests)
+        const char* fl = std::getenv("SOFTROD_FORCE_LONG");
+        h->use_long = h->epl == 2 || (fl && fl[0] == '1' && cfg->math_mode == SOFTROD_MATH_FAST);
+    }
     fill_params(h->cfg, h->P);
     const size_t N = (size_t)cfg->n_envs;
-    const size_t rowb = N * kLanes * sizeof(double);
+    const size_t rowb = N * kLanes * h->epl * sizeof(double);
     int rc = SOFTROD_OK;
     auto alloc = [&](void** p, size_t bytes) {
         if (rc != SOFTROD_OK) return;
@@ -355,7 +391,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     alloc((void**)&h->S.kap, 3 * rowb);
     alloc((void**)&h->S.rkap, 3 * rowb);
     alloc((void**)&h->S.envmem, rowb);
-    alloc((void**)&h->d_basis, (size_t)kLanes * 7 * sizeof(double));
+    alloc((void**)&h->d_basis, (size_t)2 * kLanes * 7 * sizeof(double));
     h->S.basis = h->d_basis;
     alloc((void**)&h->d_init, N * 18 * sizeof(double));
     alloc((void**)&h->d_mask, N);
@@ -437,8 +473,16 @@ int softrod_observe(softrod_handle* h, const float* prev_action, float* obs, voi
     if (!h || !obs) return fail(h, SOFTROD_EINVAL, "null argument");
     if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no observation");
     SR_HIP(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(softrod_observe_kernel, dim3((unsigned)h->cfg.n_envs), dim3(kLanes), 0,
-                       (hipStream_t)stream, h->P, h->S, prev_action, obs);
+    const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
+    if (h->use_long && h->epl == 2)
+        hipLaunchKernelGGL(softrod_observe_long_kernel<2>, grid, block, 0, (hipStream_t)stream, h->P, h->S,
+                           prev_action, obs);
+    else if (h->use_long)
+        hipLaunchKernelGGL(softrod_observe_long_kernel<1>, grid, block, 0, (hipStream_t)stream, h->P, h->S,
+                           prev_action, obs);
+    else
+        hipLaunchKernelGGL(softrod_observe_kernel, grid, block, 0, (hipStream_t)stream, h->P, h->S,
+                           prev_action, obs);
     SR_HIP(h, hipGetLastError());
     return SOFTROD_OK;
 }
@@ -447,7 +491,7 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     if (!h || !out) return fail(h, SOFTROD_EINVAL, "null argument");
     out->n_envs = h->cfg.n_envs;
     out->n_elem = h->cfg.n_elem;
-    out->lane_stride = kLanes;
+    out->lane_stride = kLanes * h->epl;
     out->reserved = 0;
     out->position = h->S.pos;
     out->velocity = h->S.vel;

@@ -836,3 +836,4 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
 }  // namespace softrod
 
 #include "softrod_fast.hpp"
+#include "softrod_long.hpp"

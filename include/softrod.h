@@ -183,19 +183,20 @@ typedef struct softrod_handle softrod_handle;
 /*
  * Borrowed device pointers to the resident state (valid until destroy).
  * Layout (DESIGN.md "HBM layout"): structure-of-arrays, component-major, one
- * 64-entry row per rod so that lane k of the rod's wavefront owns node k,
- * element k and Voronoi vertex k:
- *     position[(c * n_envs + env) * 64 + node]        c = 0..2
- *     director[((r*3 + c) * n_envs + env) * 64 + elem]  row r of Q, lab comp. c
+ * row of `lane_stride` entries per rod (64 for n_elem <= 63: lane k of the rod's
+ * wavefront owns node k, element k and Voronoi vertex k; 128 for n_elem <= 126:
+ * lane k owns indices 2k and 2k+1):
+ *     position[(c * n_envs + env) * lane_stride + node]        c = 0..2
+ *     director[((r*3 + c) * n_envs + env) * lane_stride + elem]  row r of Q, lab comp. c
  * Mirrors rod.position_collection / velocity_collection / director_collection /
  * omega_collection / tangents of the reference (soft_pendulum.py:152-154).
  */
 typedef struct softrod_state_view {
     int32_t n_envs, n_elem, lane_stride, reserved;
-    double* position; /* [3][n_envs][64]    */
-    double* velocity; /* [3][n_envs][64]    */
-    double* director; /* [9][n_envs][64]    */
-    double* omega;    /* [3][n_envs][64]    */
+    double* position; /* [3][n_envs][lane_stride] */
+    double* velocity; /* [3][n_envs][lane_stride] */
+    double* director; /* [9][n_envs][lane_stride] */
+    double* omega;    /* [3][n_envs][lane_stride] */
     double* tangents; /* [3][n_envs][64]  as of the last force evaluation   */
     double* time;     /* [n_envs]  simulated time (soft_pendulum.py:141,184) */
     double* control;  /* [4][n_envs]  MovingBaseController position x,y and

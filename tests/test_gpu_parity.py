@@ -554,3 +554,64 @@ def test_autoreset_on_gpu(torch_gpu, hip_lib):
             st = env.backend.state_numpy()
             assert np.all(st["time"] == 0.0) and np.all(st["v"] == 0.0)
     env.close()
+
+
+# ---- rods longer than one node per lane (two per lane, softrod_long.hpp) ---------------------
+def test_long_rod_softpendulum_matches_oracle(torch_gpu, hip_lib, oracle_built):
+    import gym_softrobot_amd as gsa
+
+    for n_el in (64, 100, 126):
+        env = gsa.make_vec("SoftPendulum-v0", 3, device=0, n_elems=n_el)
+        env.reset(seed=4)
+        acts = np.random.default_rng(n_el).uniform(-22, 22, (3, 3)).astype(np.float32)
+        rods = []
+        for i in range(3):
+            r = oracle_built.OracleRod(env.cfg)
+            r.reset_pendulum(_theta(4 + i))
+            rods.append(r)
+        for t in range(3):
+            obs, rew, term, trunc, _ = env.step(acts[t])
+            obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+            for i, r in enumerate(rods):
+                o, rw, te, tr = r.env_step(acts[t, i])
+                np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=1e-7)
+                np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-9)
+                assert bool(term[i]) == te and bool(trunc[i]) == tr
+        st = env.backend.state_numpy()
+        for i, r in enumerate(rods):
+            np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-8)
+            np.testing.assert_allclose(st["Q"][i], r.get("Q"), rtol=RTOL, atol=1e-8)
+            np.testing.assert_allclose(st["w"][i], r.get("w"), rtol=RTOL, atol=1e-5)
+        env.close()
+
+
+def test_arm_single_100_elements_matches_oracle(torch_gpu, hip_lib, oracle_built):
+    # BASELINE config 3: OctoArmSingle-style, 100 elements (7 np.array_split bins of the 99
+    # curvatures instead of the reference's 7x7 reshape)
+    import gym_softrobot_amd as gsa
+
+    n, T = 4, 3
+    env = gsa.make_vec("OctoArmSingle-v0", n, device=0, n_elems=100)
+    obs0, _ = env.reset()
+    obs0 = obs0.cpu().numpy().copy()
+    rng = np.random.default_rng(5)
+    acts = (rng.uniform(-1, 1, (T, n, 7)) * np.array([4.0, 8.0, 14.0, 22.0])[None, :, None]).astype(np.float32)
+    rods = []
+    for i in range(n):
+        r = oracle_built.OracleRod(env.cfg)
+        o = r.reset_arm()
+        np.testing.assert_allclose(obs0[i], o, rtol=1e-6, atol=1e-7)
+        rods.append(r)
+    for t in range(T):
+        obs, rew, term, trunc, _ = env.step(acts[t])
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for i, r in enumerate(rods):
+            o, rw, te, tr = r.env_step_arm(acts[t, i])
+            np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=2e-6)
+            np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-7)
+            assert bool(term[i]) == te and bool(trunc[i]) == tr
+    st = env.backend.state_numpy()
+    for i, r in enumerate(rods):
+        np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(st["rest_kappa"][i][0], r.get("rest_kappa")[0], rtol=1e-12, atol=1e-12)
+    env.close()
