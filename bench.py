@@ -84,6 +84,7 @@ def main() -> None:
                     choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0"],
                     help="headline metric is SoftPendulum-v0; the others are the widened §8 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--n-elems", type=int, default=None, help="elements per rod (env default if omitted)")
     args = ap.parse_args()
 
     import numpy as np
@@ -112,7 +113,8 @@ def main() -> None:
     n_total = n_local * world
     K, W = args.steps, args.warmup
     math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
-    local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode)
+    extra = {} if args.n_elems is None else {"n_elems": args.n_elems}
+    local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode, **extra)
     if args.env == "SoftPendulum-v0":
         env = ShardedVecEnv(local, n_total)   # packed all-gather of the per-env outputs
         env.reset(seed=0)  # global env i seeded i

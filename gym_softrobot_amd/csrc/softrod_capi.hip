@@ -23,7 +23,6 @@ struct softrod_handle {
     softrod_config cfg;
     int device = 0;
     int epl = 1;            // nodes/elements per lane: 1 (n_elem <= 63) or 2 (<= 126)
-    bool use_long = false;  // step/observe/reset through softrod_long.hpp
     RodParams P{};
     StatePtrs S{};
     double* d_init = nullptr;     // [N][18] staging for reset
@@ -140,42 +139,28 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
-    if (h->use_long) {
+    if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
+        // instantiations specialised for the registered envs' feature sets (one or two
+        // slots per lane); anything else (known-answer tests, custom feature mixes) takes
+        // the run-time-mask instantiation
         const unsigned f = h->cfg.features;
         const int e = h->cfg.env_kind;
-#define SR_LAUNCH_L(FEATS, ENV, EPL)                                                               \
-        hipLaunchKernelGGL((softrod_step_long_kernel<FEATS, ENV, EPL>), grid, block, 0, st, h->P, h->S, \
+#define SR_LAUNCH(FEATS, ENV, EPL)                                                                  \
+        hipLaunchKernelGGL((softrod_step_fast_kernel<FEATS, ENV, EPL>), grid, block, 0, st, h->P, h->S, \
                            actions, obs, reward, term, trunc, aux, n_sub, epilogue)
-        if (h->epl == 2) {
-            if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE)
-                SR_LAUNCH_L(SOFTROD_FEATURES_ARM_SINGLE, SOFTROD_ENV_ARM_SINGLE, 2);
-            else if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM)
-                SR_LAUNCH_L(SOFTROD_FEATURES_SOFTPENDULUM, SOFTROD_ENV_SOFTPENDULUM, 2);
-            else
-                SR_LAUNCH_L(kRuntimeFeatures, kRuntimeEnv, 2);
-        } else {
-            if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM)
-                SR_LAUNCH_L(SOFTROD_FEATURES_SOFTPENDULUM, SOFTROD_ENV_SOFTPENDULUM, 1);
-            else
-                SR_LAUNCH_L(kRuntimeFeatures, kRuntimeEnv, 1);
-        }
-#undef SR_LAUNCH_L
-    } else if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
-        // instantiations specialised for the registered envs' feature sets; anything else
-        // (known-answer tests, custom feature mixes) takes the run-time-mask instantiation
-        const unsigned f = h->cfg.features;
-        const int e = h->cfg.env_kind;
-#define SR_LAUNCH(FEATS, ENV)                                                                   \
-        hipLaunchKernelGGL((softrod_step_fast_kernel<FEATS, ENV>), grid, block, 0, st, h->P, h->S, \
-                           actions, obs, reward, term, trunc, aux, n_sub, epilogue)
-        if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM)
-            SR_LAUNCH(SOFTROD_FEATURES_SOFTPENDULUM, SOFTROD_ENV_SOFTPENDULUM);
-        else if (f == SOFTROD_FEATURES_SOFTPENDULUM3D && e == SOFTROD_ENV_SOFTPENDULUM3D)
-            SR_LAUNCH(SOFTROD_FEATURES_SOFTPENDULUM3D, SOFTROD_ENV_SOFTPENDULUM3D);
-        else if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE)
-            SR_LAUNCH(SOFTROD_FEATURES_ARM_SINGLE, SOFTROD_ENV_ARM_SINGLE);
-        else
-            SR_LAUNCH(kRuntimeFeatures, kRuntimeEnv);
+#define SR_DISPATCH(EPL)                                                                            \
+        do {                                                                                        \
+            if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM)                \
+                SR_LAUNCH(SOFTROD_FEATURES_SOFTPENDULUM, SOFTROD_ENV_SOFTPENDULUM, EPL);            \
+            else if (f == SOFTROD_FEATURES_SOFTPENDULUM3D && e == SOFTROD_ENV_SOFTPENDULUM3D)       \
+                SR_LAUNCH(SOFTROD_FEATURES_SOFTPENDULUM3D, SOFTROD_ENV_SOFTPENDULUM3D, EPL);        \
+            else if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE)               \
+                SR_LAUNCH(SOFTROD_FEATURES_ARM_SINGLE, SOFTROD_ENV_ARM_SINGLE, EPL);                \
+            else                                                                                    \
+                SR_LAUNCH(kRuntimeFeatures, kRuntimeEnv, EPL);                                      \
+        } while (0)
+        if (h->epl == 2) SR_DISPATCH(2); else SR_DISPATCH(1);
+#undef SR_DISPATCH
 #undef SR_LAUNCH
     } else
         hipLaunchKernelGGL(softrod_step_libm_kernel, grid, block, 0, st, h->P, h->S,
@@ -194,12 +179,10 @@ int upload_and_reset(softrod_handle* h, hipStream_t st, bool use_mask) {
     if (use_mask)
         SR_HIP(h, hipMemcpyAsync(h->d_mask, h->h_mask, N, hipMemcpyHostToDevice, st));
     ResetArgs A{h->d_init, use_mask ? h->d_mask : nullptr};
-    if (h->use_long && h->epl == 2)
-        hipLaunchKernelGGL(softrod_reset_long_kernel<2>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
-    else if (h->use_long)
-        hipLaunchKernelGGL(softrod_reset_long_kernel<1>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
+    if (h->epl == 2)
+        hipLaunchKernelGGL(softrod_reset_kernel<2>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
     else
-        hipLaunchKernelGGL(softrod_reset_kernel, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
+        hipLaunchKernelGGL(softrod_reset_kernel<1>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
     SR_HIP(h, hipGetLastError());
     SR_HIP(h, hipEventRecord(h->ev_reset, st));
     return SOFTROD_OK;
@@ -366,10 +349,6 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     h->cfg = *cfg;
     h->device = device;
     h->epl = cfg->n_elem > kLanes - 1 ? 2 : 1;
-    {   // SOFTROD_FORCE_LONG=1 routes short rods through the slot-generic kernels too (tests)
-        const char* fl = std::getenv("SOFTROD_FORCE_LONG");
-        h->use_long = h->epl == 2 || (fl && fl[0] == '1' && cfg->math_mode == SOFTROD_MATH_FAST);
-    }
     fill_params(h->cfg, h->P);
     const size_t N = (size_t)cfg->n_envs;
     const size_t rowb = N * kLanes * h->epl * sizeof(double);
@@ -474,14 +453,11 @@ int softrod_observe(softrod_handle* h, const float* prev_action, float* obs, voi
     if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no observation");
     SR_HIP(h, hipSetDevice(h->device));
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
-    if (h->use_long && h->epl == 2)
-        hipLaunchKernelGGL(softrod_observe_long_kernel<2>, grid, block, 0, (hipStream_t)stream, h->P, h->S,
-                           prev_action, obs);
-    else if (h->use_long)
-        hipLaunchKernelGGL(softrod_observe_long_kernel<1>, grid, block, 0, (hipStream_t)stream, h->P, h->S,
+    if (h->epl == 2)
+        hipLaunchKernelGGL(softrod_observe_kernel<2>, grid, block, 0, (hipStream_t)stream, h->P, h->S,
                            prev_action, obs);
     else
-        hipLaunchKernelGGL(softrod_observe_kernel, grid, block, 0, (hipStream_t)stream, h->P, h->S,
+        hipLaunchKernelGGL(softrod_observe_kernel<1>, grid, block, 0, (hipStream_t)stream, h->P, h->S,
                            prev_action, obs);
     SR_HIP(h, hipGetLastError());
     return SOFTROD_OK;

@@ -10,8 +10,14 @@
 // (v_mov_b32_dpp wave_shl:1 / wave_shr:1, 2 per fp64 value) — no LDS round trip, no
 // barrier.
 //
-// Two step kernels share this file's state layout:
-//   softrod_step_libm_kernel  SOFTROD_MATH_LIBM: the substep exactly as PyElastica
+// Lane k owns nodes EPL*k .. EPL*k+EPL-1 (and the elements / Voronoi vertices of the same
+// indices): EPL = 1 for rods of up to 63 elements, EPL = 2 up to 126 (BASELINE config 3,
+// "100 elements").  Neighbours inside a lane are plain registers; only the last slot's
+// "next" and the first slot's "previous" cross lanes, so the DPP count per substep does not
+// grow with EPL.  Global rows are 64*EPL wide, index = node index.
+//
+// Two step kernels share this file's state layout and env prologue/epilogue:
+//   softrod_step_libm_kernel  SOFTROD_MATH_LIBM (EPL = 1): the substep exactly as PyElastica
 //                             writes it (sqrt / sincos / acos / pow / divisions, two
 //                             half kinematic steps, constrain_values after each) — the
 //                             on-device reference the fast kernel is tested against.
@@ -132,15 +138,85 @@ __device__ __forceinline__ int env_of(const RodParams& P) {
 }
 
 // ---------------------------------------------------------------------------------
-// per-lane register state
+// per-lane register state (EPL slots per lane)
 // ---------------------------------------------------------------------------------
-struct LaneState {
-    double x[3], v[3];  // node k
-    double Q[9], w[3];  // element k: Q row-major (rows d1,d2,d3 in lab frame), omega local
-    double t[3];        // tangent of element k at the last force evaluation
-    double kap[3];      // kappa of Voronoi vertex k at the last force evaluation
-    double rk[3];       // rest_kappa of Voronoi vertex k
+template <int EPL>
+struct LaneN {
+    double x[EPL][3], v[EPL][3];
+    double Q[EPL][9], w[EPL][3];
+    double t[EPL][3];
+    double kap[EPL][3], rk[EPL][3];
 };
+
+template <int EPL>
+struct ConstN {
+    double hx[EPL], hq[EPL];
+    double cf[EPL], ca[EPL][3];
+    double cw01[EPL], cw2[EPL];
+    double s01[EPL], s2[EPL];
+    double b01[EPL], bd[EPL];
+    double mass[EPL], mass_next[EPL];
+};
+
+// value of index+1 / index-1 for a per-slot array
+template <int EPL>
+__device__ __forceinline__ void shift_next(const double (&a)[EPL], double (&o)[EPL]) {
+#pragma unroll
+    for (int s = 0; s + 1 < EPL; ++s) o[s] = a[s + 1];
+    o[EPL - 1] = from_next(a[0]);
+}
+template <int EPL>
+__device__ __forceinline__ void shift_prev(const double (&a)[EPL], double (&o)[EPL]) {
+    o[0] = from_prev(a[EPL - 1]);
+#pragma unroll
+    for (int s = 1; s < EPL; ++s) o[s] = a[s - 1];
+}
+
+template <int EPL, unsigned F>
+__device__ __forceinline__ void load_lane(const StatePtrs& S, size_t N, int rod, int lane, LaneN<EPL>& L) {
+    constexpr size_t W = (size_t)kLanes * EPL;
+    const size_t base = (size_t)rod * W + (size_t)lane * EPL;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            L.x[s][c] = S.pos[c * N * W + base + s];
+            L.v[s][c] = S.vel[c * N * W + base + s];
+            L.w[s][c] = S.omg[c * N * W + base + s];
+            L.t[s][c] = S.tan[c * N * W + base + s];
+            if (F == kRuntimeFeatures || (F & SOFTROD_FEAT_REST_KAPPA_ACTION)) {
+                L.kap[s][c] = S.kap[c * N * W + base + s];
+                L.rk[s][c] = S.rkap[c * N * W + base + s];
+            } else {
+                L.kap[s][c] = 0.0;
+                L.rk[s][c] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) L.Q[s][c] = S.dir[c * N * W + base + s];
+    }
+}
+
+template <int EPL, unsigned F>
+__device__ __forceinline__ void store_lane(const StatePtrs& S, size_t N, int rod, int lane, const LaneN<EPL>& L) {
+    constexpr size_t W = (size_t)kLanes * EPL;
+    const size_t base = (size_t)rod * W + (size_t)lane * EPL;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            S.pos[c * N * W + base + s] = L.x[s][c];
+            S.vel[c * N * W + base + s] = L.v[s][c];
+            S.omg[c * N * W + base + s] = L.w[s][c];
+            S.tan[c * N * W + base + s] = L.t[s][c];
+            if (F == kRuntimeFeatures || (F & SOFTROD_FEAT_REST_KAPPA_ACTION))
+                S.kap[c * N * W + base + s] = L.kap[s][c];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) S.dir[c * N * W + base + s] = L.Q[s][c];
+    }
+}
+
 
 struct BcTargets {
     double pos[3];
@@ -154,74 +230,98 @@ struct EnvAction {
     double force;       // SoftPendulum: point_force[0] (float32 value held in float64)
 };
 
-// constrain_values.
-//   PENDULUM_BC   soft_pendulum/build.py:71-74: y,z of node 0 and director rows 0 and 2 of
-//                 element 0 are reset (row 1 is deliberately left alone);
-//   FIXED_BC      PyElastica OneEndFixedBC;
-//   MOVING_BASE   soft_pendulum_3d/build.py:31-34: node 0 = (controller x, y, fixed height),
-//                 element 0 director fixed.  (B.pos already holds the commanded position.)
-template <unsigned F>
-__device__ __forceinline__ void constrain_values(const RodParams& P, const BcTargets& B, int lane,
-                                                 LaneState& L) {
+__device__ __forceinline__ void load_bc(const StatePtrs& S, size_t N, int rod, BcTargets& B) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) B.pos[i] = S.bc[(size_t)i * N + rod];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) B.Q[i] = S.bc[(size_t)(3 + i) * N + rod];
+    B.vel[0] = B.vel[1] = B.vel[2] = 0.0;
+}
+
+// ---- boundary conditions act on node 0 / element 0 = lane 0, slot 0 -------------------------
+template <unsigned F, int EPL>
+__device__ __forceinline__ void constrain_values_n(const RodParams& P, const BcTargets& B, int lane,
+                                                   LaneN<EPL>& L) {
     const bool l0 = (lane == 0);
     if (has<F>(P, SOFTROD_FEAT_PENDULUM_BC)) {
-        L.x[1] = l0 ? B.pos[1] : L.x[1];
-        L.x[2] = l0 ? B.pos[2] : L.x[2];
+        L.x[0][1] = l0 ? B.pos[1] : L.x[0][1];
+        L.x[0][2] = l0 ? B.pos[2] : L.x[0][2];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            L.Q[j] = l0 ? B.Q[j] : L.Q[j];
-            L.Q[6 + j] = l0 ? B.Q[6 + j] : L.Q[6 + j];
+            L.Q[0][j] = l0 ? B.Q[j] : L.Q[0][j];
+            L.Q[0][6 + j] = l0 ? B.Q[6 + j] : L.Q[0][6 + j];
         }
     }
     if (has<F>(P, SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC)) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) L.x[j] = l0 ? B.pos[j] : L.x[j];
+        for (int j = 0; j < 3; ++j) L.x[0][j] = l0 ? B.pos[j] : L.x[0][j];
 #pragma unroll
-        for (int j = 0; j < 9; ++j) L.Q[j] = l0 ? B.Q[j] : L.Q[j];
+        for (int j = 0; j < 9; ++j) L.Q[0][j] = l0 ? B.Q[j] : L.Q[0][j];
     }
 }
 
-// constrain_rates (soft_pendulum/build.py:76-79, soft_pendulum_3d/build.py:36-39)
-template <unsigned F>
-__device__ __forceinline__ void constrain_rates(const RodParams& P, const BcTargets& B, int lane,
-                                                LaneState& L) {
+template <unsigned F, int EPL>
+__device__ __forceinline__ void constrain_rates_n(const RodParams& P, const BcTargets& B, int lane,
+                                                  LaneN<EPL>& L) {
     const bool l0 = (lane == 0);
     if (has<F>(P, SOFTROD_FEAT_PENDULUM_BC)) {
-        L.v[1] = l0 ? 0.0 : L.v[1];
-        L.v[2] = l0 ? 0.0 : L.v[2];
-        L.w[0] = l0 ? 0.0 : L.w[0];
-        L.w[2] = l0 ? 0.0 : L.w[2];
+        L.v[0][1] = l0 ? 0.0 : L.v[0][1];
+        L.v[0][2] = l0 ? 0.0 : L.v[0][2];
+        L.w[0][0] = l0 ? 0.0 : L.w[0][0];
+        L.w[0][2] = l0 ? 0.0 : L.w[0][2];
     }
     if (has<F>(P, SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            L.v[j] = l0 ? B.vel[j] : L.v[j];
-            L.w[j] = l0 ? 0.0 : L.w[j];
+            L.v[0][j] = l0 ? B.vel[j] : L.v[0][j];
+            L.w[0][j] = l0 ? 0.0 : L.w[0][j];
         }
     }
 }
 
-// LaplaceDissipationFilter.dampen_rates (elastica/dissipation.py nb_filter_rate):
-//   f <- rate ; repeat order times { f_interior <- (2 f_k - f_{k-1} - f_{k+1})/4 ; f_ends <- 0 } ;
-//   rate <- rate - f.      `q` is 0.25 on interior entries of the array and 0 elsewhere.
-__device__ __forceinline__ double laplace_filter(double rate, double q, int order) {
-    double f = rate;
-    for (int i = 0; i < order; ++i) f = ((-from_next(f) - from_prev(f)) + 2.0 * f) * q;
-    return rate - f;
+// ---- LaplaceDissipationFilter over the slot-interleaved arrays ---------------------------------
+template <int EPL>
+__device__ __forceinline__ void laplace_filter_n(double (&rate)[EPL], const double (&q)[EPL], int order) {
+    double f[EPL], nx[EPL], pv[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) f[s] = rate[s];
+    for (int i = 0; i < order; ++i) {
+        shift_next<EPL>(f, nx);
+        shift_prev<EPL>(f, pv);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) f[s] = ((-nx[s] - pv[s]) + 2.0 * f[s]) * q[s];
+    }
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) rate[s] = rate[s] - f[s];
 }
 
-__device__ __forceinline__ void laplace_filter_rates(const RodParams& P, int lane, LaneState& L) {
+template <int EPL>
+__device__ __forceinline__ void laplace_filter_rates_n(const RodParams& P, int lane, LaneN<EPL>& L) {
     const int n = P.n_elem;
-    const double qn = (lane >= 1 && lane <= n - 1) ? 0.25 : 0.0;   // nodes 1..n-1 of 0..n
-    const double qe = (lane >= 1 && lane <= n - 2) ? 0.25 : 0.0;   // elements 1..n-2 of 0..n-1
-    // the ends keep f = 0, i.e. are not filtered; entries beyond the rod hold rate 0
+    double qn[EPL], qe[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = lane * EPL + s;
+        qn[s] = (idx >= 1 && idx <= n - 1) ? 0.25 : 0.0;
+        qe[s] = (idx >= 1 && idx <= n - 2) ? 0.25 : 0.0;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double vq = (lane <= n) ? L.v[c] : 0.0, wq = (lane < n) ? L.w[c] : 0.0;
-        const double vf = laplace_filter(vq, qn, P.filter_order);
-        const double wf = laplace_filter(wq, qe, P.filter_order);
-        L.v[c] = (lane <= n) ? vf : L.v[c];
-        L.w[c] = (lane < n) ? wf : L.w[c];
+        double rv[EPL], rw[EPL];
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const int idx = lane * EPL + s;
+            rv[s] = (idx <= n) ? L.v[s][c] : 0.0;
+            rw[s] = (idx < n) ? L.w[s][c] : 0.0;
+        }
+        laplace_filter_n<EPL>(rv, qn, P.filter_order);
+        laplace_filter_n<EPL>(rw, qe, P.filter_order);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const int idx = lane * EPL + s;
+            L.v[s][c] = (idx <= n) ? rv[s] : L.v[s][c];
+            L.w[s][c] = (idx < n) ? rw[s] : L.w[s][c];
+        }
     }
 }
 
@@ -241,358 +341,69 @@ __device__ __forceinline__ ContactParams contact_params(const RodParams& P) {
     return C;
 }
 
-// =================================================================================
-// SOFTROD_MATH_LIBM: the substep as written by PyElastica
-// =================================================================================
-
-// overload_operator_kinematic_numba + _get_rotation_matrix:
-//   x += h v ;  Q <- R(h w) Q  with R the transposed Rodrigues matrix.
-__device__ __forceinline__ void libm_kinematic_step(const RodParams& P, double h, LaneState& L) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) L.x[i] += h * L.v[i];
-    double a0 = h * L.w[0], a1 = h * L.w[1], a2 = h * L.w[2];
-    const double th = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-    const double den = th + P.eps_rot_axis;
-    a0 /= den; a1 /= den; a2 /= den;
-    double up, cs;
-    sincos(th, &up, &cs);
-    const double usq = 1.0 - cs;
-    double R[9];
-    R[0] = 1.0 - usq * (a1 * a1 + a2 * a2);
-    R[4] = 1.0 - usq * (a0 * a0 + a2 * a2);
-    R[8] = 1.0 - usq * (a0 * a0 + a1 * a1);
-    R[1] = up * a2 + usq * a0 * a1;  R[3] = -up * a2 + usq * a0 * a1;
-    R[2] = -up * a1 + usq * a0 * a2; R[6] = up * a1 + usq * a0 * a2;
-    R[5] = up * a0 + usq * a1 * a2;  R[7] = -up * a0 + usq * a1 * a2;
-    double Qn[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            Qn[i * 3 + j] = R[i * 3 + 0] * L.Q[0 * 3 + j] + R[i * 3 + 1] * L.Q[1 * 3 + j] +
-                            R[i * 3 + 2] * L.Q[2 * 3 + j];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) L.Q[i] = Qn[i];
-}
-
-// Internal forces/torques + forcing + dynamic update + dampers + rate constraints:
-// steps (3)-(6) of the substep (DESIGN.md "substep order").
-__device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTargets& B, int lane,
-                                                  double action, double mass, LaneState& L) {
-    const int n = P.n_elem;
-    const bool node_valid = lane <= n;
-    const bool elem_valid = lane < n;
-    const bool vor_valid = lane < n - 1;
-
-    // ---- geometry: lengths, tangents, dilatation (_compute_all_dilatations) ----
-    const double xn0 = from_next(L.x[0]), xn1 = from_next(L.x[1]), xn2 = from_next(L.x[2]);
-    const double d0 = xn0 - L.x[0], d1 = xn1 - L.x[1], d2 = xn2 - L.x[2];
-    const double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2) + P.eps_length;
-    L.t[0] = d0 / len; L.t[1] = d1 / len; L.t[2] = d2 / len;
-    const double e = len / P.rest_len;
-
-    // ---- shear/stretch: sigma = e Q t - z ; n = S sigma ----
-    const double qt0 = L.Q[0] * L.t[0] + L.Q[1] * L.t[1] + L.Q[2] * L.t[2];
-    const double qt1 = L.Q[3] * L.t[0] + L.Q[4] * L.t[1] + L.Q[5] * L.t[2];
-    const double qt2 = L.Q[6] * L.t[0] + L.Q[7] * L.t[1] + L.Q[8] * L.t[2];
-    const double n0 = P.shear[0] * (e * qt0);
-    const double n1 = P.shear[1] * (e * qt1);
-    const double n2 = P.shear[2] * (e * qt2 - 1.0);
-
-    // ---- internal force: difference of Q^T n / e ----
-    double cs0 = (L.Q[0] * n0 + L.Q[3] * n1 + L.Q[6] * n2) / e;
-    double cs1 = (L.Q[1] * n0 + L.Q[4] * n1 + L.Q[7] * n2) / e;
-    double cs2 = (L.Q[2] * n0 + L.Q[5] * n1 + L.Q[8] * n2) / e;
-    cs0 = elem_valid ? cs0 : 0.0;
-    cs1 = elem_valid ? cs1 : 0.0;
-    cs2 = elem_valid ? cs2 : 0.0;
-    const double f0 = cs0 - from_prev(cs0);
-    const double f1 = cs1 - from_prev(cs1);
-    const double f2 = cs2 - from_prev(cs2);
-
-    // ---- bend/twist: kappa = -log(Q_{k+1} Q_k^T)/D  (_inv_rotate) ----
-    double Qn[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Qn[i] = from_next(L.Q[i]);
-    const double len_n = from_next(len);
-#define SR_ROWDOT(i, j) (Qn[3 * (i)] * L.Q[3 * (j)] + Qn[3 * (i) + 1] * L.Q[3 * (j) + 1] + \
-                         Qn[3 * (i) + 2] * L.Q[3 * (j) + 2])
-    const double vec0 = SR_ROWDOT(2, 1) - SR_ROWDOT(1, 2);
-    const double vec1 = SR_ROWDOT(0, 2) - SR_ROWDOT(2, 0);
-    const double vec2 = SR_ROWDOT(1, 0) - SR_ROWDOT(0, 1);
-    const double trace = (SR_ROWDOT(0, 0) + SR_ROWDOT(1, 1)) + SR_ROWDOT(2, 2);
-#undef SR_ROWDOT
-    const double theta = acos(0.5 * trace - 0.5 - P.acos_shift);
-    const double fk = (-0.5 * theta / sin(theta + P.eps_sin)) / P.rest_vor;
-    const double k0 = vec0 * fk, k1 = vec1 * fk, k2 = vec2 * fk;
-    L.kap[0] = k0; L.kap[1] = k1; L.kap[2] = k2;
-    const double m0 = P.bend[0] * (k0 - L.rk[0]), m1 = P.bend[1] * (k1 - L.rk[1]),
-                 m2 = P.bend[2] * (k2 - L.rk[2]);
-    const double vd = 0.5 * (len_n + len) / P.rest_vor;
-    const double e3 = 1.0 / (vd * vd * vd);
-    double c20 = m0 * e3, c21 = m1 * e3, c22 = m2 * e3;
-    const double dv3 = P.rest_vor * e3;
-    double c30 = (k1 * m2 - k2 * m1) * dv3;
-    double c31 = (k2 * m0 - k0 * m2) * dv3;
-    double c32 = (k0 * m1 - k1 * m0) * dv3;
-    c20 = vor_valid ? c20 : 0.0; c21 = vor_valid ? c21 : 0.0; c22 = vor_valid ? c22 : 0.0;
-    c30 = vor_valid ? c30 : 0.0; c31 = vor_valid ? c31 : 0.0; c32 = vor_valid ? c32 : 0.0;
-    // difference + trapezoid, Voronoi -> element (zeros beyond both ends do the end rules)
-    double tq0 = (c20 - from_prev(c20)) + 0.5 * (c30 + from_prev(c30));
-    double tq1 = (c21 - from_prev(c21)) + 0.5 * (c31 + from_prev(c31));
-    double tq2 = (c22 - from_prev(c22)) + 0.5 * (c32 + from_prev(c32));
-
-    // shear/stretch couple (Q t) x n * l_rest
-    tq0 += (qt1 * n2 - qt2 * n1) * P.rest_len;
-    tq1 += (qt2 * n0 - qt0 * n2) * P.rest_len;
-    tq2 += (qt0 * n1 - qt1 * n0) * P.rest_len;
-
-    // transport (J w / e) x w and unsteady dilatation (J w / e) (de/dt) / e
-    const double vn0 = from_next(L.v[0]), vn1 = from_next(L.v[1]), vn2 = from_next(L.v[2]);
-    const double rv = (L.x[0] * L.v[0] + L.x[1] * L.v[1]) + L.x[2] * L.v[2];
-    const double rvn = (xn0 * vn0 + xn1 * vn1) + xn2 * vn2;
-    const double rp1v = (xn0 * L.v[0] + xn1 * L.v[1]) + xn2 * L.v[2];
-    const double rvp1 = (L.x[0] * vn0 + L.x[1] * vn1) + L.x[2] * vn2;
-    const double dil_rate = (rv + rvn - rvp1 - rp1v) / len / P.rest_len;
-    const double jw0 = P.J[0] * L.w[0] / e, jw1 = P.J[1] * L.w[1] / e, jw2 = P.J[2] * L.w[2] / e;
-    tq0 += jw1 * L.w[2] - jw2 * L.w[1];
-    tq1 += jw2 * L.w[0] - jw0 * L.w[2];
-    tq2 += jw0 * L.w[1] - jw1 * L.w[0];
-    tq0 += jw0 * dil_rate / e; tq1 += jw1 * dil_rate / e; tq2 += jw2 * dil_rate / e;
-
-    // ---- synchronize(): operators in registration order.  Forcing: gravity, then the
-    // point force ASSIGNS F_ext[0,0]; contact (octopus/build.py:274-283) after it unless
-    // contact_before_forcing. ----
-    double fe0 = 0.0, fe1 = 0.0, fe2 = 0.0;
-    const bool has_contact = (P.features & SOFTROD_FEAT_PLANE_CONTACT_ANISO) != 0;
-    const double mass_next = (lane + 1 == n) ? 0.5 * P.mass_node : P.mass_node;
-    const double xn[3] = {xn0, xn1, xn2}, vn[3] = {vn0, vn1, vn2};
-    if (has_contact && P.contact_before_forcing) {
-        const double F[3] = {f0, f1, f2};
-        double tq[3] = {tq0, tq1, tq2}, fc[3];
-        plane_contact(contact_params(P), lane, n, mass, mass_next, L.x, xn, L.v, vn, L.t, L.Q, L.w,
-                      len, F, tq, fc);
-        fe0 = fc[0]; fe1 = fc[1]; fe2 = fc[2];
-        tq0 = tq[0]; tq1 = tq[1]; tq2 = tq[2];
-    }
-    if (P.features & SOFTROD_FEAT_GRAVITY) {
-        fe0 += P.gravity[0] * mass; fe1 += P.gravity[1] * mass; fe2 += P.gravity[2] * mass;
-    }
-    if (P.features & SOFTROD_FEAT_POINT_FORCE_NODE0_X) fe0 = (lane == 0) ? action : fe0;
-    if (P.features & SOFTROD_FEAT_TIP_FORCE) {
-        const bool tip = (lane == n);
-        fe0 += tip ? P.tip_force[0] : 0.0;
-        fe1 += tip ? P.tip_force[1] : 0.0;
-        fe2 += tip ? P.tip_force[2] : 0.0;
-    }
-    if (has_contact && !P.contact_before_forcing) {
-        const double F[3] = {f0 + (node_valid ? fe0 : 0.0), f1 + (node_valid ? fe1 : 0.0),
-                             f2 + (node_valid ? fe2 : 0.0)};
-        double tq[3] = {tq0, tq1, tq2}, fc[3];
-        plane_contact(contact_params(P), lane, n, mass, mass_next, L.x, xn, L.v, vn, L.t, L.Q, L.w,
-                      len, F, tq, fc);
-        fe0 += fc[0]; fe1 += fc[1]; fe2 += fc[2];
-        tq0 = tq[0]; tq1 = tq[1]; tq2 = tq[2];
-    }
-
-    // ---- accelerations and rate update (v += dt a ; w += dt alpha) ----
-    const double a0 = (f0 + fe0) / mass, a1 = (f1 + fe1) / mass, a2 = (f2 + fe2) / mass;
-    const double al0 = (P.invJ[0] * tq0) * e, al1 = (P.invJ[1] * tq1) * e, al2 = (P.invJ[2] * tq2) * e;
-    L.v[0] += node_valid ? P.dt * a0 : 0.0;
-    L.v[1] += node_valid ? P.dt * a1 : 0.0;
-    L.v[2] += node_valid ? P.dt * a2 : 0.0;
-    L.w[0] += elem_valid ? P.dt * al0 : 0.0;
-    L.w[1] += elem_valid ? P.dt * al1 : 0.0;
-    L.w[2] += elem_valid ? P.dt * al2 : 0.0;
-
-    // ---- dampers (registration order) and constrain_rates ----
-    if (!P.damp_before_constrain) constrain_rates<kRuntimeFeatures>(P, B, lane, L);
-    if (P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER) {
-        L.v[0] *= P.damp_t; L.v[1] *= P.damp_t; L.v[2] *= P.damp_t;
-        L.w[0] *= pow(P.damp_r[0], e);
-        L.w[1] *= pow(P.damp_r[1], e);
-        L.w[2] *= pow(P.damp_r[2], e);
-    }
-    if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates(P, lane, L);
-    if (P.damp_before_constrain) constrain_rates<kRuntimeFeatures>(P, B, lane, L);
-}
-
 // ---------------------------------------------------------------------------------
-// global <-> register state
+// env prologue (set_action) and epilogue (NaN check, reward, truncation, observation)
+//   SoftPendulum    soft_pendulum.py:163-166,196-251
+//   SoftPendulum3D  soft_pendulum_3d.py:99-113,130-174
+//   ArmSingle       octopus/arm_single_env.py:186-235,252-316
 // ---------------------------------------------------------------------------------
-// kappa / rest_kappa rows are only touched by feature sets that use them (intrinsic
-// curvature actuation) and by the run-time-mask instantiations.
-template <unsigned F = kRuntimeFeatures>
-__device__ __forceinline__ void load_state(const StatePtrs& S, size_t N, size_t row, LaneState& L) {
+template <int EPL>
+__device__ __forceinline__ void sum_tangents(const RodParams& P, int lane, const LaneN<EPL>& L, double tm[3]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        L.x[c] = S.pos[c * N * kLanes + row];
-        L.v[c] = S.vel[c * N * kLanes + row];
-        L.w[c] = S.omg[c * N * kLanes + row];
-        L.t[c] = S.tan[c * N * kLanes + row];
-    }
+        double p = 0.0;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) L.Q[c] = S.dir[c * N * kLanes + row];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (F == kRuntimeFeatures || (F & SOFTROD_FEAT_REST_KAPPA_ACTION)) {
-            L.kap[c] = S.kap[c * N * kLanes + row];
-            L.rk[c] = S.rkap[c * N * kLanes + row];
-        } else {
-            L.kap[c] = 0.0;
-            L.rk[c] = 0.0;
-        }
+        for (int s = 0; s < EPL; ++s) p += ((lane * EPL + s) < P.n_elem) ? L.t[s][c] : 0.0;
+        tm[c] = wave_sum(p) / (double)P.n_elem;
     }
 }
 
-template <unsigned F = kRuntimeFeatures>
-__device__ __forceinline__ void store_state(const StatePtrs& S, size_t N, size_t row, const LaneState& L) {
+template <int EPL>
+__device__ __forceinline__ void com_xy_n(const RodParams& P, const ConstN<EPL>& C, int lane,
+                                         const LaneN<EPL>& L, double com[2]) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        S.pos[c * N * kLanes + row] = L.x[c];
-        S.vel[c * N * kLanes + row] = L.v[c];
-        S.omg[c * N * kLanes + row] = L.w[c];
-        S.tan[c * N * kLanes + row] = L.t[c];
-    }
+    for (int c = 0; c < 2; ++c) {
+        double p = 0.0;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) S.dir[c * N * kLanes + row] = L.Q[c];
-    if (F == kRuntimeFeatures || (F & SOFTROD_FEAT_REST_KAPPA_ACTION)) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) S.kap[c * N * kLanes + row] = L.kap[c];
+        for (int s = 0; s < EPL; ++s) p += ((lane * EPL + s) <= P.n_elem) ? C.mass[s] * L.x[s][c] : 0.0;
+        com[c] = wave_sum(p) / P.mass_total;
     }
 }
 
-__device__ __forceinline__ void load_bc(const StatePtrs& S, size_t N, int rod, BcTargets& B) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) B.pos[i] = S.bc[(size_t)i * N + rod];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) B.Q[i] = S.bc[(size_t)(3 + i) * N + rod];
-    B.vel[0] = B.vel[1] = B.vel[2] = 0.0;
-}
-
-// ---------------------------------------------------------------------------------
-// env prologue: set_action
-// ---------------------------------------------------------------------------------
-//   SoftPendulum     point_force[:] = action                       soft_pendulum.py:163-166
-//   SoftPendulum3D   clipped base displacement -> controller        soft_pendulum_3d.py:99-113
-//   ArmSingle        rest_kappa[0,:] = interp1d(cubic)(action)      octopus/arm_single_env.py:226-235
-// All lanes compute the same wave-uniform values; lane 0 persists the controller.
-template <unsigned F, int E>
-__device__ __forceinline__ void env_set_action(const RodParams& P, const StatePtrs& S, size_t N,
-                                               int rod, int lane, const float* __restrict__ actions,
-                                               EnvAction& A, BcTargets& B, LaneState& L) {
-#pragma unroll
-    for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
-    A.force = 0.0;
-    const int env = env_of<E>(P);
-    if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
-        if (actions) { A.a[0] = actions[2 * rod]; A.a[1] = actions[2 * rod + 1]; }
-        if (has<F>(P, SOFTROD_FEAT_MOVING_BASE_BC)) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const double pos = S.ctrl[(size_t)i * N + rod];
-                double vel = S.ctrl[(size_t)(2 + i) * N + rod];
-                double next = pos;
-                if (actions) {
-                    const float disp = P.base_step * A.a[i];   // float32, as base_step * action
-                    next = fmin(fmax(pos + (double)disp, -P.base_limit), P.base_limit);  // np.clip
-                    vel = (next - pos) / P.step_time;
-                    if (lane == 0) {
-                        S.ctrl[(size_t)i * N + rod] = next;
-                        S.ctrl[(size_t)(2 + i) * N + rod] = vel;
-                    }
-                }
-                B.pos[i] = next;
-                B.vel[i] = vel;
-            }
-        }
-    } else if (env == SOFTROD_ENV_ARM_SINGLE) {
-        if (actions) {
-#pragma unroll
-            for (int i = 0; i < 7; ++i) A.a[i] = actions[7 * (size_t)rod + i];
-            if (has<F>(P, SOFTROD_FEAT_REST_KAPPA_ACTION)) {
-                double rk0 = 0.0;
-                if (lane < P.n_elem - 1) {
-                    const double* wrow = S.basis + (size_t)lane * 7;
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) rk0 += wrow[j] * (double)A.a[j];
-                }
-                L.rk[0] = rk0;
-                S.rkap[(size_t)rod * kLanes + lane] = rk0;   // rest_kappa[0, :] = action
-            }
-        }
-    } else {
-        if (actions) A.a[0] = actions[rod];
-        A.force = (double)A.a[0];  // float32 value held in float64
-    }
-}
-
-// theta = wrap(arctan(mean t_x / mean t_y)), soft_pendulum.py:154-156
-__device__ __forceinline__ double wrapped_theta(const RodParams& P, int lane, const LaneState& L) {
-    const bool elem_valid = lane < P.n_elem;
-    const double s0 = wave_sum(elem_valid ? L.t[0] : 0.0);
-    const double s1 = wave_sum(elem_valid ? L.t[1] : 0.0);
-    const double tm0 = s0 / (double)P.n_elem, tm1 = s1 / (double)P.n_elem;
-    const double th = atan(tm0 / tm1);
-    const double two_pi = 2.0 * M_PI;
-    double m = fmod(th + M_PI, two_pi);  // python float %: sign of the divisor
-    if (m != 0.0 && m < 0.0) m += two_pi;
-    return m - M_PI;
-}
-
-// _tilt_angle, soft_pendulum_3d.py:88-91
-__device__ __forceinline__ double tilt_angle(const RodParams& P, int lane, const LaneState& L) {
-    const bool elem_valid = lane < P.n_elem;
-    double tm[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) tm[c] = wave_sum(elem_valid ? L.t[c] : 0.0) / (double)P.n_elem;
-    const double nrm = sqrt(tm[0] * tm[0] + tm[1] * tm[1] + tm[2] * tm[2]);
-    const double tz = tm[2] / nrm;
-    return acos(fmin(fmax(tz, -1.0), 1.0));
-}
-
-__device__ __forceinline__ bool state_has_nan(const RodParams& P, int lane, const LaneState& L) {
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) bad = bad || isnan(L.x[c]) || isnan(L.v[c]);
-    return __any((lane <= P.n_elem) && bad);
-}
-
-// compute_position_center_of_mass()[:2]
-__device__ __forceinline__ void center_of_mass_xy(const RodParams& P, int lane, const LaneState& L,
-                                                  double com[2]) {
-    const int n = P.n_elem;
-    const double mass = (lane == 0 || lane == n) ? 0.5 * P.mass_node : P.mass_node;
-    const double m = (lane <= n) ? mass : 0.0;
-    com[0] = wave_sum(m * L.x[0]) / P.mass_total;
-    com[1] = wave_sum(m * L.x[1]) / P.mass_total;
-}
-
-// ArmSingleEnv.get_state (octopus/arm_single_env.py:186-219): 7-bin means of kappa[0] and of
-// its change since the previous call, change of the centre of mass, previous action, target.
-// Mutates prev_kappa_state / prev_com_state exactly like the reference.
-__device__ __forceinline__ void arm_get_state(const RodParams& P, const StatePtrs& S, size_t N,
-                                              int rod, int lane, const LaneState& L, const float* pa,
-                                              float* __restrict__ obs) {
+template <int EPL>
+__device__ __forceinline__ void arm_get_state_n(const RodParams& P, const StatePtrs& S, size_t N, int rod,
+                                                int lane, const ConstN<EPL>& C, const LaneN<EPL>& L,
+                                                const float* pa, float* __restrict__ obs) {
+    constexpr size_t W = (size_t)kLanes * EPL;
     const int nv = P.n_elem - 1;
-    const bool vor_valid = lane < nv;
-    const size_t mrow = (size_t)rod * kLanes + lane;
-    const double kap = L.kap[0];
-    const double prev = S.envmem[mrow];
-    const double rate = kap - prev;
-    if (vor_valid) S.envmem[mrow] = kap;
+    double kap[EPL], rate[EPL];
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = lane * EPL + s;
+        const size_t m = (size_t)rod * W + idx;
+        kap[s] = L.kap[s][0];
+        rate[s] = kap[s] - S.envmem[m];
+        if (idx < nv) S.envmem[m] = kap[s];
+    }
     double mk[7], mr[7];
     int lo = 0;
 #pragma unroll
     for (int b = 0; b < 7; ++b) {
-        const int sz = nv / 7 + (b < nv % 7 ? 1 : 0);   // np.array_split sizes (7 x 7 for nv = 49)
-        const bool in = vor_valid && lane >= lo && lane < lo + sz;
-        mk[b] = wave_sum(in ? kap : 0.0) / (double)sz;
-        mr[b] = wave_sum(in ? rate : 0.0) / (double)sz;
+        const int sz = nv / 7 + (b < nv % 7 ? 1 : 0);
+        double pk = 0.0, pr = 0.0;
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const int idx = lane * EPL + s;
+            const bool in = idx < nv && idx >= lo && idx < lo + sz;
+            pk += in ? kap[s] : 0.0;
+            pr += in ? rate[s] : 0.0;
+        }
+        mk[b] = wave_sum(pk) / (double)sz;
+        mr[b] = wave_sum(pr) / (double)sz;
         lo += sz;
     }
     double com[2];
-    center_of_mass_xy(P, lane, L, com);
+    com_xy_n<EPL>(P, C, lane, L, com);
     if (lane == 0) {
         const double pc0 = S.ctrl[(size_t)0 * N + rod], pc1 = S.ctrl[(size_t)1 * N + rod];
         S.ctrl[(size_t)0 * N + rod] = com[0];
@@ -613,83 +424,106 @@ __device__ __forceinline__ void arm_get_state(const RodParams& P, const StatePtr
     }
 }
 
-// observation only (get_state at reset)
-template <int E>
-__device__ __forceinline__ void env_observe(const RodParams& P, const StatePtrs& S, size_t N, int rod,
-                                            int lane, const LaneState& L, const float* pa,
-                                            float* __restrict__ obs) {
+template <int EPL>
+__device__ __forceinline__ double theta_n(const RodParams& P, int lane, const LaneN<EPL>& L) {
+    double tm[3];
+    sum_tangents<EPL>(P, lane, L, tm);
+    const double th = atan(tm[0] / tm[1]);
+    const double two_pi = 2.0 * M_PI;
+    double m = fmod(th + M_PI, two_pi);
+    if (m != 0.0 && m < 0.0) m += two_pi;
+    return m - M_PI;
+}
+
+template <int EPL>
+__device__ __forceinline__ double tilt_n(const RodParams& P, int lane, const LaneN<EPL>& L) {
+    double tm[3];
+    sum_tangents<EPL>(P, lane, L, tm);
+    const double nrm = sqrt(tm[0] * tm[0] + tm[1] * tm[1] + tm[2] * tm[2]);
+    return acos(fmin(fmax(tm[2] / nrm, -1.0), 1.0));
+}
+
+template <int E, int EPL>
+__device__ __forceinline__ void env_observe_n(const RodParams& P, const StatePtrs& S, size_t N, int rod,
+                                              int lane, const ConstN<EPL>& C, const LaneN<EPL>& L,
+                                              const float* pa, float* __restrict__ obs) {
     const int env = env_of<E>(P);
     if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
-        const double tilt = tilt_angle(P, lane, L);
+        const double tilt = tilt_n<EPL>(P, lane, L);
         if (lane == 0) {
             float* o = obs + 9 * (size_t)rod;
-            o[0] = (float)L.x[0]; o[1] = (float)L.x[1]; o[2] = (float)L.x[2];
-            o[3] = (float)L.v[0]; o[4] = (float)L.v[1]; o[5] = (float)L.v[2];
+            o[0] = (float)L.x[0][0]; o[1] = (float)L.x[0][1]; o[2] = (float)L.x[0][2];
+            o[3] = (float)L.v[0][0]; o[4] = (float)L.v[0][1]; o[5] = (float)L.v[0][2];
             o[6] = pa[0]; o[7] = pa[1];
             o[8] = (float)tilt;
         }
     } else if (env == SOFTROD_ENV_ARM_SINGLE) {
-        arm_get_state(P, S, N, rod, lane, L, pa, obs);
+        arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, pa, obs);
     } else {
-        const double th = wrapped_theta(P, lane, L);
+        const double th = theta_n<EPL>(P, lane, L);
         if (lane == 0) {
             float* o = obs + 4 * (size_t)rod;
-            o[0] = (float)L.x[0];
-            o[1] = (float)L.v[0];
+            o[0] = (float)L.x[0][0];
+            o[1] = (float)L.v[0][0];
             o[2] = pa[0];
             o[3] = (float)th;
         }
     }
 }
 
-// env epilogue: NaN check, reward, truncation, observation
-//   SoftPendulum    soft_pendulum.py:196-251       SoftPendulum3D  soft_pendulum_3d.py:130-174
-//   ArmSingle       octopus/arm_single_env.py:252-316
-template <int E>
-__device__ __forceinline__ void env_epilogue(const RodParams& P, const StatePtrs& S, size_t N, int rod,
-                                             int lane, const LaneState& L, double time,
-                                             const EnvAction& A, float* __restrict__ obs,
-                                             double* __restrict__ reward,
-                                             uint8_t* __restrict__ terminated,
-                                             uint8_t* __restrict__ truncated,
-                                             double* __restrict__ aux) {
-    const bool invalid = state_has_nan(P, lane, L);
+template <int E, int EPL>
+__device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePtrs& S, size_t N, int rod,
+                                               int lane, const ConstN<EPL>& C, const LaneN<EPL>& L,
+                                               double time, const EnvAction& A, float* __restrict__ obs,
+                                               double* __restrict__ reward,
+                                               uint8_t* __restrict__ terminated,
+                                               uint8_t* __restrict__ truncated,
+                                               double* __restrict__ aux) {
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        bool b = false;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b = b || isnan(L.x[s][c]) || isnan(L.v[s][c]);
+        bad = bad || (((lane * EPL + s) <= P.n_elem) && b);
+    }
+    const bool invalid = __any(bad);
     const int env = env_of<E>(P);
     if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
-        const double tilt = tilt_angle(P, lane, L);
+        const double tilt = tilt_n<EPL>(P, lane, L);
         if (lane == 0) {
             const double bx = S.ctrl[(size_t)0 * N + rod], by = S.ctrl[(size_t)1 * N + rod];
             const double base_distance = sqrt(bx * bx + by * by);
-            // 1e-3 * np.dot(action, action) stays float32 (NumPy 2 weak-scalar promotion)
             const float ctl = 1e-3f * (A.a[0] * A.a[0] + A.a[1] * A.a[1]);
             double r = -(tilt * tilt + 0.1 * (base_distance * base_distance) + (double)ctl);
             if (invalid) r = -50.0;
             reward[rod] = r;
             terminated[rod] = invalid ? 1 : 0;
-            truncated[rod] = (time >= P.final_time) ? 1 : 0;   // '>=' here, '>' in SoftPendulum
+            truncated[rod] = (time >= P.final_time) ? 1 : 0;
             if (aux) aux[rod] = tilt;
             float* o = obs + 9 * (size_t)rod;
-            o[0] = (float)L.x[0]; o[1] = (float)L.x[1]; o[2] = (float)L.x[2];
-            o[3] = (float)L.v[0]; o[4] = (float)L.v[1]; o[5] = (float)L.v[2];
+            o[0] = (float)L.x[0][0]; o[1] = (float)L.x[0][1]; o[2] = (float)L.x[0][2];
+            o[3] = (float)L.v[0][0]; o[4] = (float)L.v[0][1]; o[5] = (float)L.v[0][2];
             o[6] = A.a[0]; o[7] = A.a[1];
             o[8] = (float)tilt;
         }
     } else if (env == SOFTROD_ENV_ARM_SINGLE) {
-        // invalid also when ||omega||_F > 250 (:261-271)
-        const bool ev = lane < P.n_elem;
-        const double wn = wave_sum(ev ? L.w[0] * L.w[0] + L.w[1] * L.w[1] + L.w[2] * L.w[2] : 0.0);
-        const bool bad = invalid || (sqrt(wn) > 250.0);
+        double pw = 0.0;
+#pragma unroll
+        for (int s = 0; s < EPL; ++s)
+            pw += ((lane * EPL + s) < P.n_elem)
+                      ? L.w[s][0] * L.w[s][0] + L.w[s][1] * L.w[s][1] + L.w[s][2] * L.w[s][2] : 0.0;
+        const bool blown = invalid || (sqrt(wave_sum(pw)) > 250.0);
         double com[2];
-        center_of_mass_xy(P, lane, L, com);
+        com_xy_n<EPL>(P, C, lane, L, com);
         if (lane == 0) {
-            // control penalty in float32 (np.square/mean of the float32 action, weak scalar)
             float sq = 0.0f;
 #pragma unroll
             for (int i = 0; i < 7; ++i) sq += A.a[i] * A.a[i];
             const float pen = P.control_penalty_coeff * (sq / 7.0f);
             double forward = 0.0, survive = 0.0;
             bool term = false;
-            if (bad) { term = true; survive = -1.0; }
+            if (blown) { term = true; survive = -1.0; }
             else {
                 const double dx = com[0] - P.target[0], dy = com[1] - P.target[1];
                 const double dist = sqrt(dx * dx + dy * dy);
@@ -700,28 +534,300 @@ __device__ __forceinline__ void env_epilogue(const RodParams& P, const StatePtrs
             terminated[rod] = term ? 1 : 0;
             truncated[rod] = (time > P.final_time) ? 1 : 0;
         }
-        arm_get_state(P, S, N, rod, lane, L, A.a, obs);
+        arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, A.a, obs);
     } else {
-        const double th = wrapped_theta(P, lane, L);
+        const double th = theta_n<EPL>(P, lane, L);
         if (lane == 0) {
             double forward = 0.0, survive = 0.0;
             if (invalid) survive = -50.0;
-            else forward = fabs(L.x[0]) * 10.0 + th * th;
+            else forward = fabs(L.x[0][0]) * 10.0 + th * th;
             reward[rod] = forward - 0.0 + survive;
             terminated[rod] = invalid ? 1 : 0;
             truncated[rod] = (time > P.final_time) ? 1 : 0;
             float* o = obs + 4 * (size_t)rod;
-            o[0] = (float)L.x[0];
-            o[1] = (float)L.v[0];
+            o[0] = (float)L.x[0][0];
+            o[1] = (float)L.v[0][0];
             o[2] = A.a[0];
             o[3] = (float)th;
         }
     }
 }
 
+template <unsigned F, int EPL>
+__device__ __forceinline__ void build_const(const RodParams& P, int lane, const EnvAction& A,
+                                            ConstN<EPL>& C) {
+    const int n = P.n_elem;
+    const bool damp = has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER);
+    const double ct = damp ? P.damp_t : 1.0;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = lane * EPL + s;
+        const bool first = (idx == 0);
+        const bool held_q = first && has<F>(P, SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_FIXED_BC |
+                                               SOFTROD_FEAT_MOVING_BASE_BC);
+        const bool held_x = first && has<F>(P, SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC);
+        const bool node_valid = idx <= n, elem_valid = idx < n, vor_valid = idx < n - 1;
+        const double mass = (idx == 0 || idx == n) ? 0.5 * P.mass_node : P.mass_node;
+        C.mass[s] = mass;
+        C.mass_next[s] = (idx + 1 == n) ? 0.5 * P.mass_node : P.mass_node;
+        C.hx[s] = held_x ? 0.0 : 1.0;
+        C.hq[s] = held_q ? 0.0 : 1.0;
+        const double cdm = node_valid ? ct * P.dt / mass : 0.0;
+        C.cf[s] = cdm;
+        double fe0 = 0.0, fe1 = 0.0, fe2 = 0.0;
+        if (has<F>(P, SOFTROD_FEAT_GRAVITY)) {
+            fe0 = P.gravity[0] * mass; fe1 = P.gravity[1] * mass; fe2 = P.gravity[2] * mass;
+        }
+        if (has<F>(P, SOFTROD_FEAT_POINT_FORCE_NODE0_X)) fe0 = first ? A.force : fe0;
+        if (has<F>(P, SOFTROD_FEAT_TIP_FORCE) && idx == n) {
+            fe0 += P.tip_force[0]; fe1 += P.tip_force[1]; fe2 += P.tip_force[2];
+        }
+        C.ca[s][0] = cdm * fe0; C.ca[s][1] = cdm * fe1; C.ca[s][2] = cdm * fe2;
+        C.cw01[s] = elem_valid ? P.dt * P.invJ[0] : 0.0;
+        C.cw2[s] = elem_valid ? P.dt * P.invJ[2] : 0.0;
+        C.s01[s] = elem_valid ? P.shear[0] : 0.0;
+        C.s2[s] = elem_valid ? P.shear[2] : 0.0;
+        C.b01[s] = vor_valid ? P.bend[0] : 0.0;
+        C.bd[s] = vor_valid ? P.bend[2] - P.bend[0] : 0.0;
+    }
+}
+
+template <unsigned F, int E, int EPL>
+__device__ __forceinline__ void set_action_n(const RodParams& P, const StatePtrs& S, size_t N, int rod,
+                                             int lane, const float* __restrict__ actions, EnvAction& A,
+                                             BcTargets& B, LaneN<EPL>& L) {
+    constexpr size_t W = (size_t)kLanes * EPL;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
+    A.force = 0.0;
+    const int env = env_of<E>(P);
+    if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
+        if (actions) { A.a[0] = actions[2 * rod]; A.a[1] = actions[2 * rod + 1]; }
+        if (has<F>(P, SOFTROD_FEAT_MOVING_BASE_BC)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double pos = S.ctrl[(size_t)i * N + rod];
+                double vel = S.ctrl[(size_t)(2 + i) * N + rod];
+                double next = pos;
+                if (actions) {
+                    const float disp = P.base_step * A.a[i];
+                    next = fmin(fmax(pos + (double)disp, -P.base_limit), P.base_limit);
+                    vel = (next - pos) / P.step_time;
+                    if (lane == 0) {
+                        S.ctrl[(size_t)i * N + rod] = next;
+                        S.ctrl[(size_t)(2 + i) * N + rod] = vel;
+                    }
+                }
+                B.pos[i] = next;
+                B.vel[i] = vel;
+            }
+        }
+    } else if (env == SOFTROD_ENV_ARM_SINGLE) {
+        if (actions) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) A.a[i] = actions[7 * (size_t)rod + i];
+            if (has<F>(P, SOFTROD_FEAT_REST_KAPPA_ACTION)) {
+#pragma unroll
+                for (int s = 0; s < EPL; ++s) {
+                    const int idx = lane * EPL + s;
+                    double rk0 = 0.0;
+                    if (idx < P.n_elem - 1) {
+                        const double* wrow = S.basis + (size_t)idx * 7;
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) rk0 += wrow[j] * (double)A.a[j];
+                    }
+                    L.rk[s][0] = rk0;
+                    S.rkap[(size_t)rod * W + idx] = rk0;
+                }
+            }
+        }
+    } else {
+        if (actions) A.a[0] = actions[rod];
+        A.force = (double)A.a[0];
+    }
+}
+
+// =================================================================================
+// SOFTROD_MATH_LIBM: the substep as written by PyElastica
+// =================================================================================
+
+// overload_operator_kinematic_numba + _get_rotation_matrix:
+//   x += h v ;  Q <- R(h w) Q  with R the transposed Rodrigues matrix.
+__device__ __forceinline__ void libm_kinematic_step(const RodParams& P, double h, LaneN<1>& L) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) L.x[0][i] += h * L.v[0][i];
+    double a0 = h * L.w[0][0], a1 = h * L.w[0][1], a2 = h * L.w[0][2];
+    const double th = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+    const double den = th + P.eps_rot_axis;
+    a0 /= den; a1 /= den; a2 /= den;
+    double up, cs;
+    sincos(th, &up, &cs);
+    const double usq = 1.0 - cs;
+    double R[9];
+    R[0] = 1.0 - usq * (a1 * a1 + a2 * a2);
+    R[4] = 1.0 - usq * (a0 * a0 + a2 * a2);
+    R[8] = 1.0 - usq * (a0 * a0 + a1 * a1);
+    R[1] = up * a2 + usq * a0 * a1;  R[3] = -up * a2 + usq * a0 * a1;
+    R[2] = -up * a1 + usq * a0 * a2; R[6] = up * a1 + usq * a0 * a2;
+    R[5] = up * a0 + usq * a1 * a2;  R[7] = -up * a0 + usq * a1 * a2;
+    double Qn[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Qn[i * 3 + j] = R[i * 3 + 0] * L.Q[0][0 * 3 + j] + R[i * 3 + 1] * L.Q[0][1 * 3 + j] +
+                            R[i * 3 + 2] * L.Q[0][2 * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) L.Q[0][i] = Qn[i];
+}
+
+// Internal forces/torques + forcing + dynamic update + dampers + rate constraints:
+// steps (3)-(6) of the substep (DESIGN.md "substep order").
+__device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTargets& B, int lane,
+                                                  double action, double mass, LaneN<1>& L) {
+    const int n = P.n_elem;
+    const bool node_valid = lane <= n;
+    const bool elem_valid = lane < n;
+    const bool vor_valid = lane < n - 1;
+
+    // ---- geometry: lengths, tangents, dilatation (_compute_all_dilatations) ----
+    const double xn0 = from_next(L.x[0][0]), xn1 = from_next(L.x[0][1]), xn2 = from_next(L.x[0][2]);
+    const double d0 = xn0 - L.x[0][0], d1 = xn1 - L.x[0][1], d2 = xn2 - L.x[0][2];
+    const double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2) + P.eps_length;
+    L.t[0][0] = d0 / len; L.t[0][1] = d1 / len; L.t[0][2] = d2 / len;
+    const double e = len / P.rest_len;
+
+    // ---- shear/stretch: sigma = e Q t - z ; n = S sigma ----
+    const double qt0 = L.Q[0][0] * L.t[0][0] + L.Q[0][1] * L.t[0][1] + L.Q[0][2] * L.t[0][2];
+    const double qt1 = L.Q[0][3] * L.t[0][0] + L.Q[0][4] * L.t[0][1] + L.Q[0][5] * L.t[0][2];
+    const double qt2 = L.Q[0][6] * L.t[0][0] + L.Q[0][7] * L.t[0][1] + L.Q[0][8] * L.t[0][2];
+    const double n0 = P.shear[0] * (e * qt0);
+    const double n1 = P.shear[1] * (e * qt1);
+    const double n2 = P.shear[2] * (e * qt2 - 1.0);
+
+    // ---- internal force: difference of Q^T n / e ----
+    double cs0 = (L.Q[0][0] * n0 + L.Q[0][3] * n1 + L.Q[0][6] * n2) / e;
+    double cs1 = (L.Q[0][1] * n0 + L.Q[0][4] * n1 + L.Q[0][7] * n2) / e;
+    double cs2 = (L.Q[0][2] * n0 + L.Q[0][5] * n1 + L.Q[0][8] * n2) / e;
+    cs0 = elem_valid ? cs0 : 0.0;
+    cs1 = elem_valid ? cs1 : 0.0;
+    cs2 = elem_valid ? cs2 : 0.0;
+    const double f0 = cs0 - from_prev(cs0);
+    const double f1 = cs1 - from_prev(cs1);
+    const double f2 = cs2 - from_prev(cs2);
+
+    // ---- bend/twist: kappa = -log(Q_{k+1} Q_k^T)/D  (_inv_rotate) ----
+    double Qn[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Qn[i] = from_next(L.Q[0][i]);
+    const double len_n = from_next(len);
+#define SR_ROWDOT(i, j) (Qn[3 * (i)] * L.Q[0][3 * (j)] + Qn[3 * (i) + 1] * L.Q[0][3 * (j) + 1] + \
+                         Qn[3 * (i) + 2] * L.Q[0][3 * (j) + 2])
+    const double vec0 = SR_ROWDOT(2, 1) - SR_ROWDOT(1, 2);
+    const double vec1 = SR_ROWDOT(0, 2) - SR_ROWDOT(2, 0);
+    const double vec2 = SR_ROWDOT(1, 0) - SR_ROWDOT(0, 1);
+    const double trace = (SR_ROWDOT(0, 0) + SR_ROWDOT(1, 1)) + SR_ROWDOT(2, 2);
+#undef SR_ROWDOT
+    const double theta = acos(0.5 * trace - 0.5 - P.acos_shift);
+    const double fk = (-0.5 * theta / sin(theta + P.eps_sin)) / P.rest_vor;
+    const double k0 = vec0 * fk, k1 = vec1 * fk, k2 = vec2 * fk;
+    L.kap[0][0] = k0; L.kap[0][1] = k1; L.kap[0][2] = k2;
+    const double m0 = P.bend[0] * (k0 - L.rk[0][0]), m1 = P.bend[1] * (k1 - L.rk[0][1]),
+                 m2 = P.bend[2] * (k2 - L.rk[0][2]);
+    const double vd = 0.5 * (len_n + len) / P.rest_vor;
+    const double e3 = 1.0 / (vd * vd * vd);
+    double c20 = m0 * e3, c21 = m1 * e3, c22 = m2 * e3;
+    const double dv3 = P.rest_vor * e3;
+    double c30 = (k1 * m2 - k2 * m1) * dv3;
+    double c31 = (k2 * m0 - k0 * m2) * dv3;
+    double c32 = (k0 * m1 - k1 * m0) * dv3;
+    c20 = vor_valid ? c20 : 0.0; c21 = vor_valid ? c21 : 0.0; c22 = vor_valid ? c22 : 0.0;
+    c30 = vor_valid ? c30 : 0.0; c31 = vor_valid ? c31 : 0.0; c32 = vor_valid ? c32 : 0.0;
+    // difference + trapezoid, Voronoi -> element (zeros beyond both ends do the end rules)
+    double tq0 = (c20 - from_prev(c20)) + 0.5 * (c30 + from_prev(c30));
+    double tq1 = (c21 - from_prev(c21)) + 0.5 * (c31 + from_prev(c31));
+    double tq2 = (c22 - from_prev(c22)) + 0.5 * (c32 + from_prev(c32));
+
+    // shear/stretch couple (Q t) x n * l_rest
+    tq0 += (qt1 * n2 - qt2 * n1) * P.rest_len;
+    tq1 += (qt2 * n0 - qt0 * n2) * P.rest_len;
+    tq2 += (qt0 * n1 - qt1 * n0) * P.rest_len;
+
+    // transport (J w / e) x w and unsteady dilatation (J w / e) (de/dt) / e
+    const double vn0 = from_next(L.v[0][0]), vn1 = from_next(L.v[0][1]), vn2 = from_next(L.v[0][2]);
+    const double rv = (L.x[0][0] * L.v[0][0] + L.x[0][1] * L.v[0][1]) + L.x[0][2] * L.v[0][2];
+    const double rvn = (xn0 * vn0 + xn1 * vn1) + xn2 * vn2;
+    const double rp1v = (xn0 * L.v[0][0] + xn1 * L.v[0][1]) + xn2 * L.v[0][2];
+    const double rvp1 = (L.x[0][0] * vn0 + L.x[0][1] * vn1) + L.x[0][2] * vn2;
+    const double dil_rate = (rv + rvn - rvp1 - rp1v) / len / P.rest_len;
+    const double jw0 = P.J[0] * L.w[0][0] / e, jw1 = P.J[1] * L.w[0][1] / e, jw2 = P.J[2] * L.w[0][2] / e;
+    tq0 += jw1 * L.w[0][2] - jw2 * L.w[0][1];
+    tq1 += jw2 * L.w[0][0] - jw0 * L.w[0][2];
+    tq2 += jw0 * L.w[0][1] - jw1 * L.w[0][0];
+    tq0 += jw0 * dil_rate / e; tq1 += jw1 * dil_rate / e; tq2 += jw2 * dil_rate / e;
+
+    // ---- synchronize(): operators in registration order.  Forcing: gravity, then the
+    // point force ASSIGNS F_ext[0,0]; contact (octopus/build.py:274-283) after it unless
+    // contact_before_forcing. ----
+    double fe0 = 0.0, fe1 = 0.0, fe2 = 0.0;
+    const bool has_contact = (P.features & SOFTROD_FEAT_PLANE_CONTACT_ANISO) != 0;
+    const double mass_next = (lane + 1 == n) ? 0.5 * P.mass_node : P.mass_node;
+    const double xn[1][3] = {{xn0, xn1, xn2}}, vn[1][3] = {{vn0, vn1, vn2}};
+    ConstN<1> CK;
+    CK.mass[0] = mass;
+    CK.mass_next[0] = mass_next;
+    const double len1[1] = {len};
+    if (has_contact && P.contact_before_forcing) {
+        const double F[1][3] = {{f0, f1, f2}};
+        double tq[1][3] = {{tq0, tq1, tq2}}, fc[1][3];
+        plane_contact_n<1>(contact_params(P), P, lane, CK, L, xn, vn, len1, F, tq, fc);
+        fe0 = fc[0][0]; fe1 = fc[0][1]; fe2 = fc[0][2];
+        tq0 = tq[0][0]; tq1 = tq[0][1]; tq2 = tq[0][2];
+    }
+    if (P.features & SOFTROD_FEAT_GRAVITY) {
+        fe0 += P.gravity[0] * mass; fe1 += P.gravity[1] * mass; fe2 += P.gravity[2] * mass;
+    }
+    if (P.features & SOFTROD_FEAT_POINT_FORCE_NODE0_X) fe0 = (lane == 0) ? action : fe0;
+    if (P.features & SOFTROD_FEAT_TIP_FORCE) {
+        const bool tip = (lane == n);
+        fe0 += tip ? P.tip_force[0] : 0.0;
+        fe1 += tip ? P.tip_force[1] : 0.0;
+        fe2 += tip ? P.tip_force[2] : 0.0;
+    }
+    if (has_contact && !P.contact_before_forcing) {
+        const double F[1][3] = {{f0 + (node_valid ? fe0 : 0.0), f1 + (node_valid ? fe1 : 0.0),
+                                 f2 + (node_valid ? fe2 : 0.0)}};
+        double tq[1][3] = {{tq0, tq1, tq2}}, fc[1][3];
+        plane_contact_n<1>(contact_params(P), P, lane, CK, L, xn, vn, len1, F, tq, fc);
+        fe0 += fc[0][0]; fe1 += fc[0][1]; fe2 += fc[0][2];
+        tq0 = tq[0][0]; tq1 = tq[0][1]; tq2 = tq[0][2];
+    }
+
+    // ---- accelerations and rate update (v += dt a ; w += dt alpha) ----
+    const double a0 = (f0 + fe0) / mass, a1 = (f1 + fe1) / mass, a2 = (f2 + fe2) / mass;
+    const double al0 = (P.invJ[0] * tq0) * e, al1 = (P.invJ[1] * tq1) * e, al2 = (P.invJ[2] * tq2) * e;
+    L.v[0][0] += node_valid ? P.dt * a0 : 0.0;
+    L.v[0][1] += node_valid ? P.dt * a1 : 0.0;
+    L.v[0][2] += node_valid ? P.dt * a2 : 0.0;
+    L.w[0][0] += elem_valid ? P.dt * al0 : 0.0;
+    L.w[0][1] += elem_valid ? P.dt * al1 : 0.0;
+    L.w[0][2] += elem_valid ? P.dt * al2 : 0.0;
+
+    // ---- dampers (registration order) and constrain_rates ----
+    if (!P.damp_before_constrain) constrain_rates_n<kRuntimeFeatures, 1>(P, B, lane, L);
+    if (P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER) {
+        L.v[0][0] *= P.damp_t; L.v[0][1] *= P.damp_t; L.v[0][2] *= P.damp_t;
+        L.w[0][0] *= pow(P.damp_r[0], e);
+        L.w[0][1] *= pow(P.damp_r[1], e);
+        L.w[0][2] *= pow(P.damp_r[2], e);
+    }
+    if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates_n<1>(P, lane, L);
+    if (P.damp_before_constrain) constrain_rates_n<kRuntimeFeatures, 1>(P, B, lane, L);
+}
+
 // ---------------------------------------------------------------------------------
 // LIBM kernel: one env.step (or `n_sub` bare substeps) for every rod of the shard.
-// grid = n_envs blocks of one wavefront.
+// grid = n_envs blocks of one wavefront; one node per lane (n_elem <= 63).
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kLanes)
 softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
@@ -731,50 +837,33 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
     const int rod = blockIdx.x;
     const int lane = threadIdx.x;
     const size_t N = (size_t)P.n_envs;
-    const size_t row = (size_t)rod * kLanes + lane;
 
-    LaneState L;
-    load_state(S, N, row, L);
+    LaneN<1> L;
+    load_lane<1, kRuntimeFeatures>(S, N, rod, lane, L);
     BcTargets B;
     load_bc(S, N, rod, B);
     EnvAction A;
-    env_set_action<kRuntimeFeatures, kRuntimeEnv>(P, S, N, rod, lane, actions, A, B, L);
+    set_action_n<kRuntimeFeatures, kRuntimeEnv, 1>(P, S, N, rod, lane, actions, A, B, L);
+    ConstN<1> C;
+    build_const<kRuntimeFeatures, 1>(P, lane, A, C);
 
     double time = S.time[rod];
-    const int n = P.n_elem;
-    const double mass = (lane == 0 || lane == n) ? 0.5 * P.mass_node : P.mass_node;
+    const double mass = C.mass[0];
 
     for (int s = 0; s < n_sub; ++s) {
         libm_kinematic_step(P, P.half_dt, L);
         if (P.time_two_half_adds) time += P.half_dt;
-        constrain_values<kRuntimeFeatures>(P, B, lane, L);
+        constrain_values_n<kRuntimeFeatures, 1>(P, B, lane, L);
         libm_dynamic_step(P, B, lane, A.force, mass, L);
         libm_kinematic_step(P, P.half_dt, L);
         time += P.time_two_half_adds ? P.half_dt : P.dt;
-        constrain_values<kRuntimeFeatures>(P, B, lane, L);
+        constrain_values_n<kRuntimeFeatures, 1>(P, B, lane, L);
     }
 
-    store_state(S, N, row, L);
+    store_lane<1, kRuntimeFeatures>(S, N, rod, lane, L);
     if (lane == 0) S.time[rod] = time;
     if (epilogue)
-        env_epilogue<kRuntimeEnv>(P, S, N, rod, lane, L, time, A, obs, reward, terminated, truncated, aux);
-}
-
-// get_state() outside a step (reset observation), soft_pendulum.py:145-161
-__global__ void __launch_bounds__(kLanes)
-softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ prev_action,
-                       float* __restrict__ obs) {
-    const int rod = blockIdx.x;
-    const int lane = threadIdx.x;
-    const size_t N = (size_t)P.n_envs;
-    LaneState L;
-    load_state(S, N, (size_t)rod * kLanes + lane, L);
-    const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2
-                   : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : 1;
-    float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (prev_action)
-        for (int i = 0; i < adim; ++i) pa[i] = prev_action[adim * (size_t)rod + i];
-    env_observe<kRuntimeEnv>(P, S, N, rod, lane, L, pa, obs);
+        env_epilogue_n<kRuntimeEnv, 1>(P, S, N, rod, lane, C, L, time, A, obs, reward, terminated, truncated, aux);
 }
 
 // Reset: expand the host-computed straight-rod description of each masked rod
@@ -785,55 +874,99 @@ struct ResetArgs {
     const uint8_t* mask;  // [N] or nullptr
 };
 
+template <int EPL>
+__global__ void __launch_bounds__(kLanes)
+softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ prev_action,
+                            float* __restrict__ obs) {
+    const int rod = blockIdx.x;
+    const int lane = threadIdx.x;
+    const size_t N = (size_t)P.n_envs;
+    LaneN<EPL> L;
+    load_lane<EPL, kRuntimeFeatures>(S, N, rod, lane, L);
+    EnvAction A;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
+    A.force = 0.0;
+    ConstN<EPL> C;
+    build_const<kRuntimeFeatures, EPL>(P, lane, A, C);
+    const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2
+                   : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : 1;
+    float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (prev_action)
+        for (int i = 0; i < adim; ++i) pa[i] = prev_action[adim * (size_t)rod + i];
+    env_observe_n<kRuntimeEnv, EPL>(P, S, N, rod, lane, C, L, pa, obs);
+}
+
+template <int EPL>
 __global__ void __launch_bounds__(kLanes)
 softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
+    constexpr size_t W = (size_t)kLanes * EPL;
     const int rod = blockIdx.x;
     const int lane = threadIdx.x;
     if (A.mask && !A.mask[rod]) return;
     const size_t N = (size_t)P.n_envs;
-    const size_t row = (size_t)rod * kLanes + lane;
     const double* in = A.init + (size_t)rod * 18;
     const int n = P.n_elem;
-    LaneState L;
+    LaneN<EPL> L;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        // np.linspace(start, end, n+1): start + k*step, last point = end.  Lanes beyond the
-        // rod keep marching so that |dx| stays finite and non-zero there.
-        double xv = in[c] + (double)lane * in[3 + c];
-        if (lane == n) xv = in[6 + c];
-        L.x[c] = xv;
-        L.v[c] = 0.0;
-        L.w[c] = 0.0;
-        L.kap[c] = 0.0;   // a straight rod: kappa = 0 at allocation
-        L.rk[c] = 0.0;
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = lane * EPL + s;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double xv = in[c] + (double)idx * in[3 + c];
+            if (idx == n) xv = in[6 + c];
+            L.x[s][c] = xv;
+            L.v[s][c] = 0.0; L.w[s][c] = 0.0; L.kap[s][c] = 0.0; L.rk[s][c] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) L.Q[s][c] = in[9 + c];
     }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) L.Q[c] = in[9 + c];
-    // CosseratRod.__init__ evaluates the strains once, so rod.tangents is valid at reset
-    const double xn0 = from_next(L.x[0]), xn1 = from_next(L.x[1]), xn2 = from_next(L.x[2]);
-    const double d0 = xn0 - L.x[0], d1 = xn1 - L.x[1], d2 = xn2 - L.x[2];
-    const double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2) + P.eps_length;
-    L.t[0] = d0 / len; L.t[1] = d1 / len; L.t[2] = d2 / len;
-    store_state(S, N, row, L);
+    for (int c = 0; c < 3; ++c) {
+        double a[EPL], o[EPL];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) S.rkap[c * N * kLanes + row] = 0.0;
-    S.envmem[row] = 0.0;   // prev_kappa_state = kappa[0] at reset (arm_single_env.py:172)
+        for (int s = 0; s < EPL; ++s) a[s] = L.x[s][c];
+        shift_next<EPL>(a, o);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) L.t[s][c] = o[s] - L.x[s][c];
+    }
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const double len = sqrt(L.t[s][0] * L.t[s][0] + L.t[s][1] * L.t[s][1] + L.t[s][2] * L.t[s][2]) +
+                           P.eps_length;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) L.t[s][c] /= len;
+    }
+    store_lane<EPL, kRuntimeFeatures>(S, N, rod, lane, L);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const size_t m = (size_t)rod * W + (size_t)lane * EPL + s;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) S.rkap[c * N * W + m] = 0.0;
+        S.envmem[m] = 0.0;
+    }
     double com[2] = {0.0, 0.0};
-    if (P.env_kind == SOFTROD_ENV_ARM_SINGLE) center_of_mass_xy(P, lane, L, com);
+    if (P.env_kind == SOFTROD_ENV_ARM_SINGLE) {
+        EnvAction A0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) A0.a[i] = 0.0f;
+        A0.force = 0.0;
+        ConstN<EPL> C;
+        build_const<kRuntimeFeatures, EPL>(P, lane, A0, C);
+        com_xy_n<EPL>(P, C, lane, L, com);
+    }
     if (lane == 0) {
         S.time[rod] = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) S.bc[(size_t)i * N + rod] = in[i];
 #pragma unroll
         for (int i = 0; i < 9; ++i) S.bc[(size_t)(3 + i) * N + rod] = in[9 + i];
-        // MovingBaseController() is rebuilt by reset (soft_pendulum_3d.py:66);
-        // ArmSingle: prev_com_state = centre of mass at reset (arm_single_env.py:173)
 #pragma unroll
         for (int i = 0; i < 4; ++i) S.ctrl[(size_t)i * N + rod] = (i < 2) ? com[i] : 0.0;
     }
 }
 
+
 }  // namespace softrod
 
 #include "softrod_fast.hpp"
-#include "softrod_long.hpp"

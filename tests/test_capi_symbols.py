@@ -42,8 +42,12 @@ def test_create_rejects_bad_config_and_never_falls_back(hip_lib):
     cfg.struct_size = 8
     assert hip_lib.softrod_create(C.byref(cfg), 0, C.byref(h)) == -1
     cfg = _capi.softpendulum_config(4)
-    cfg.n_elem = 64  # one rod per 64-lane wavefront: at most 63 elements
+    cfg.n_elem = 127  # one rod per 64-lane wavefront, two nodes per lane: at most 126 elements
     assert hip_lib.softrod_create(C.byref(cfg), 0, C.byref(h)) == -1
+    cfg.n_elem = 64   # two nodes per lane exist for the fast kernel only
+    cfg.math_mode = _capi.MATH_LIBM
+    assert hip_lib.softrod_create(C.byref(cfg), 0, C.byref(h)) == -1
+    assert b"SOFTROD_MATH_FAST" in hip_lib.softrod_last_error(None)
     assert not h.value
 
 
