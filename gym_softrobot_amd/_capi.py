@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -132,6 +132,7 @@ class SoftrodStateView(C.Structure):
         ("kappa", C.c_void_p),
         ("rest_kappa", C.c_void_p),
         ("env_memory", C.c_void_p),
+        ("prev_action", C.c_void_p),
     ]
 
 

@@ -180,6 +180,7 @@ class HipRodBackend:
             "kappa": view(v.kappa, 3),
             "rest_kappa": view(v.rest_kappa, 3),
             "env_memory": torch.as_tensor(_DevArray(v.env_memory, (n, s), "<f8", self), device=self.device),
+            "prev_action": torch.as_tensor(_DevArray(v.prev_action, (n, 7), "<f4", self), device=self.device),
         }
 
     def state_numpy(self) -> Dict[str, np.ndarray]:

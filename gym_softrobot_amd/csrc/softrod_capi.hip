@@ -370,6 +370,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     alloc((void**)&h->S.kap, 3 * rowb);
     alloc((void**)&h->S.rkap, 3 * rowb);
     alloc((void**)&h->S.envmem, rowb);
+    alloc((void**)&h->S.prev_action, N * 7 * sizeof(float));
     alloc((void**)&h->d_basis, (size_t)2 * kLanes * 7 * sizeof(double));
     h->S.basis = h->d_basis;
     alloc((void**)&h->d_init, N * 18 * sizeof(double));
@@ -479,6 +480,7 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->kappa = h->S.kap;
     out->rest_kappa = h->S.rkap;
     out->env_memory = h->S.envmem;
+    out->prev_action = h->S.prev_action;
     return SOFTROD_OK;
 }
 
@@ -530,7 +532,7 @@ int softrod_destroy(softrod_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->d_basis, h->d_init, h->d_mask};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->d_basis, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

@@ -87,6 +87,7 @@ struct StatePtrs {
                    //             (ArmSingle: [0..1] = prev_com_state)
     double* kap;   // [3][N][64]  kappa as of the last force evaluation
     double* rkap;  // [3][N][64]  rest_kappa
+    float* prev_action;   // [N][7]   the env's _prev_action (soft_pendulum.py:97-99,165)
     double* envmem;       // [N][64]  ArmSingle prev_kappa_state
     const double* basis;  // [(n_elem-1)][n_action]  rest_kappa[0,:] = basis @ action
 };
@@ -489,6 +490,10 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
     }
     const bool invalid = __any(bad);
     const int env = env_of<E>(P);
+    if (lane == 0) {   // set_action: self._prev_action[:] = action
+#pragma unroll
+        for (int i = 0; i < 7; ++i) S.prev_action[7 * (size_t)rod + i] = A.a[i];
+    }
     if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
         const double tilt = tilt_n<EPL>(P, lane, L);
         if (lane == 0) {
@@ -892,8 +897,8 @@ softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __rest
     const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2
                    : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : 1;
     float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (prev_action)
-        for (int i = 0; i < adim; ++i) pa[i] = prev_action[adim * (size_t)rod + i];
+    for (int i = 0; i < adim; ++i)
+        pa[i] = prev_action ? prev_action[adim * (size_t)rod + i] : S.prev_action[7 * (size_t)rod + i];
     env_observe_n<kRuntimeEnv, EPL>(P, S, N, rod, lane, C, L, pa, obs);
 }
 
@@ -957,6 +962,10 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
     }
     if (lane == 0) {
         S.time[rod] = 0.0;
+        if (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) {   // _prev_action.fill(0), soft_pendulum_3d.py:68
+#pragma unroll
+            for (int i = 0; i < 7; ++i) S.prev_action[7 * (size_t)rod + i] = 0.0f;
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) S.bc[(size_t)i * N + rod] = in[i];
 #pragma unroll

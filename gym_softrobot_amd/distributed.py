@@ -88,7 +88,7 @@ class ShardedVecEnv:
         seeds = None if seed is None else [int(seed) + i for i in range(self.lo, self.hi)]
         m = None if mask is None else np.asarray(mask)[self.lo : self.hi]
         obs, info = self.local.reset(seed=seeds, mask=m)
-        if not self.gather:
+        if not self.gather or self.world == 1:
             return obs, info
         n = obs.shape[0]
         zeros64 = torch.zeros(n, dtype=torch.float64, device=obs.device)
@@ -102,7 +102,7 @@ class ShardedVecEnv:
         if a.numel() == self.total_envs:
             a = a[self.lo : self.hi]
         obs, rew, term, trunc, info = self.local.step(a)
-        if not self.gather:
+        if not self.gather or self.world == 1:
             return obs, rew, term, trunc, info
         g = self._all_gather(pack_outputs(obs, rew, term, trunc, self._packed))
         o, r, te, tr = unpack_outputs(g)

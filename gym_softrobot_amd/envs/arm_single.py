@@ -26,7 +26,6 @@ class VecArmSingleEnv(VecRodEnvBase):
 
     metadata = {"render_modes": ["rgb_array", "human"], "render_fps": 20}
     action_low, action_high = -22.0, 22.0             # arm_single_env.py:84-90
-    clears_prev_action_on_reset = False               # _prev_action survives reset (:97-99)
 
     def __init__(
         self,

@@ -78,7 +78,6 @@ class VecRodEnvBase:
     metadata: Dict[str, Any] = {"render_modes": ["rgb_array"], "render_fps": 25}
     action_low: float = -1.0
     action_high: float = 1.0
-    clears_prev_action_on_reset: bool = False
 
     def __init__(self, num_envs: int, cfg: _capi.SoftrodConfig, *, render_mode, config_generate_video,
                  device: int, numpy_output: bool, autoreset: bool, backend):
@@ -86,8 +85,6 @@ class VecRodEnvBase:
             raise ValueError(f"Unsupported render mode: {render_mode}")  # soft_pendulum.py:69-70
         if config_generate_video:
             raise NotImplementedError("diagnostic callbacks/video are outside the hot path (DESIGN.md)")
-        import torch
-
         self.render_mode = render_mode
         self.num_envs = int(num_envs)
         self.cfg = cfg
@@ -107,9 +104,6 @@ class VecRodEnvBase:
             backend = HipRodBackend(cfg, device=device)
         self.backend = backend
         self._rngs: List[Optional[np.random.Generator]] = [None] * self.num_envs
-        self._prev_action = torch.zeros(
-            (self.num_envs, self.action_dim), dtype=torch.float32, device=self.backend.device
-        )
         self._steps = np.zeros(self.num_envs, np.int64)  # env.steps since each env's reset
         self._time_tab = time_table(cfg, 8)
         self._needs_reset = np.zeros(self.num_envs, bool)
@@ -156,17 +150,15 @@ class VecRodEnvBase:
         options: Optional[dict] = None,
         mask: Optional[np.ndarray] = None,
     ):
-        import torch
-
         n = self.num_envs
         m = np.ones(n, bool) if mask is None else np.asarray(mask, bool).reshape(n)
         self._seed_rngs(seed, m)
         self._reset_backend(m, mask is not None)
         self._steps[m] = 0
         self._needs_reset[m] = False
-        if self.clears_prev_action_on_reset:
-            self._prev_action[torch.from_numpy(m).to(self._prev_action.device)] = 0.0
-        obs = self.backend.observe(self._prev_action)
+        # _prev_action lives with the resident state (softrod_state_view.prev_action): it
+        # survives reset except where the reference clears it (soft_pendulum_3d.py:68)
+        obs = self.backend.observe(None)
         return self._out(obs), {}
 
     def step(self, actions):
@@ -176,8 +168,7 @@ class VecRodEnvBase:
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.backend.device)
         a = a.reshape(self.num_envs, self.action_dim)
         pending = self._needs_reset.copy() if self.autoreset else None
-        obs, reward, term, trunc = self.backend.step(a)
-        self._prev_action = a.detach().clone()  # set_action: _prev_action[:] = action
+        obs, reward, term, trunc = self.backend.step(a)   # also records _prev_action[:] = action
         self._steps += 1
         if pending is not None and pending.any():
             # NEXT_STEP auto-reset: these envs finished on the previous call; their step above
@@ -186,23 +177,21 @@ class VecRodEnvBase:
             self._seed_rngs(None, pending)
             self._reset_backend(pending, True)
             self._steps[pending] = 0
-            if self.clears_prev_action_on_reset:
-                self._prev_action[torch.from_numpy(pending).to(self._prev_action.device)] = 0.0
-            robs = self.backend.observe(self._prev_action)
+            robs = self.backend.observe(None)
             pm = torch.from_numpy(pending).to(robs.device)
             obs = torch.where(pm[:, None], robs, keep)
             reward = torch.where(pm, torch.zeros_like(reward), reward)
             term = torch.where(pm, torch.zeros_like(term), term)
             trunc = torch.where(pm, torch.zeros_like(trunc), trunc)
         if self.autoreset:
-            self._needs_reset = (term.bool() | trunc.bool()).cpu().numpy()
+            self._needs_reset = (term | trunc).cpu().numpy().astype(bool)
         times = self._times()
         infos = self._infos(times)
         return (
             self._out(obs),
             self._out(reward),
-            self._out(term.bool()),
-            self._out(trunc.bool()),
+            self._out(term.view(torch.bool)),     # uint8 0/1 -> bool, zero-copy
+            self._out(trunc.view(torch.bool)),
             infos,
         )
 

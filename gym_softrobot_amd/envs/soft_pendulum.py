@@ -33,7 +33,6 @@ class VecSoftPendulumEnv(VecRodEnvBase):
 
     metadata = {"render_modes": ["rgb_array"], "render_fps": 25}
     action_low, action_high = -22.0, 22.0            # soft_pendulum.py:84-90
-    clears_prev_action_on_reset = False              # _prev_action survives reset (:97-99)
 
     def __init__(
         self,

@@ -28,7 +28,6 @@ class VecSoftPendulum3DEnv(VecRodEnvBase):
 
     metadata = {"render_modes": ["rgb_array"], "render_fps": 25}
     action_low, action_high = -1.0, 1.0               # soft_pendulum_3d.py:41-46
-    clears_prev_action_on_reset = True                # :68
 
     def __init__(
         self,

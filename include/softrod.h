@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 3
+#define SOFTROD_ABI_VERSION 4
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -207,6 +207,9 @@ typedef struct softrod_state_view {
     double* env_memory; /* [n_envs][64]  env-side memory between steps:
                          prev_kappa_state[0..n-2], prev_com_state at 60,61
                          (arm_single_env.py:172-173,190-198)                 */
+    float* prev_action; /* [n_envs][7]  the env's _prev_action, written by
+                         softrod_step (soft_pendulum.py:165), cleared by reset
+                         only where the reference does (soft_pendulum_3d.py:68) */
 } softrod_state_view;
 
 /* Fill `cfg` with SoftPendulumEnv.__init__ defaults (soft_pendulum.py:59-78)
@@ -264,7 +267,7 @@ int softrod_step(softrod_handle* h, const float* actions, float* obs,
 
 /* Replaces: get_state() at reset (soft_pendulum.py:145-161,
  * soft_pendulum_3d.py:93-98).  prev_action is device [n_envs][action_dim]
- * float32 or NULL (= zeros).                                                */
+ * float32, or NULL = the resident copy of the last stepped action.          */
 int softrod_observe(softrod_handle* h, const float* prev_action, float* obs,
                     void* stream);
 

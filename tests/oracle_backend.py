@@ -37,13 +37,15 @@ class OracleBackend:
     def reset_straight(self, start, direction, normal, mask=None):
         for i, r in enumerate(self.rods):
             if mask is None or mask[i]:
+                if self.is3d:
+                    self._prev[i] = 0.0   # SoftPendulum3DEnv.reset clears _prev_action
                 if self.isarm:
                     r.reset_arm()   # also re-arms prev_kappa_state / prev_com_state
                 else:
                     r.reset_straight(start[i], direction[i], normal[i])
 
     def observe(self, prev_action=None):
-        pa = np.zeros((self.n_envs, self.action_dim), np.float32)
+        pa = self._prev     # resident _prev_action, like softrod_state_view.prev_action
         if prev_action is not None:
             pa = torch.as_tensor(prev_action).reshape(self.n_envs, self.action_dim).numpy()
         for i, r in enumerate(self.rods):
@@ -67,6 +69,7 @@ class OracleBackend:
 
     def step(self, actions):
         a = torch.as_tensor(actions, dtype=torch.float32).reshape(self.n_envs, self.action_dim).numpy()
+        self._prev = a.copy()
         for i, r in enumerate(self.rods):
             if self.is3d:
                 o, rw, te, tr, tilt = r.env_step3d(a[i])
