@@ -115,16 +115,9 @@ def main() -> None:
     math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
     extra = {} if args.n_elems is None else {"n_elems": args.n_elems}
     local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode, **extra)
-    if args.env == "SoftPendulum-v0":
-        env = ShardedVecEnv(local, n_total)   # packed all-gather of the per-env outputs
-        env.reset(seed=0)  # global env i seeded i
-        lo, hi = env.lo, env.hi
-    else:
-        env = local                            # single-GPU measurement of the widened envs
-        lo, hi = 0, n_local
-        if world != 1:
-            raise SystemExit("--env other than SoftPendulum-v0 is a single-GPU measurement")
-        env.reset(seed=0)
+    env = ShardedVecEnv(local, n_total)   # world > 1: kernel-packed rows + one all-gather per step
+    env.reset(seed=0)                      # global env i seeded i
+    lo, hi = env.lo, env.hi
     adim = local.backend.action_dim
     amax = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0}[args.env]
     # the truncation flag of SoftPendulum first fires on env.step #126; the default window

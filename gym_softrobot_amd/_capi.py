@@ -286,6 +286,7 @@ _EXPORTS = {
     "softrod_reset": (C.c_int, [_VP, _VP, _VP, _VP]),
     "softrod_reset_straight": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "softrod_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "softrod_step_packed": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "softrod_observe": (C.c_int, [_VP, _VP, _VP, _VP]),
     "softrod_substeps": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "softrod_state_view_get": (C.c_int, [_VP, C.POINTER(SoftrodStateView)]),

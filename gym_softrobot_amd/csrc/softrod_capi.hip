@@ -134,7 +134,7 @@ void fill_params(const softrod_config& c, RodParams& P) {
 }
 
 int launch_step(softrod_handle* h, const float* actions, float* obs, double* reward,
-                uint8_t* term, uint8_t* trunc, double* aux, int n_sub, int epilogue,
+                uint8_t* term, uint8_t* trunc, double* aux, int n_sub, int epilogue, int pack,
                 hipStream_t st) {
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
     const bool timing = h->timed < (int)h->ev_start.size();
@@ -147,7 +147,7 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
         const int e = h->cfg.env_kind;
 #define SR_LAUNCH(FEATS, ENV, EPL)                                                                  \
         hipLaunchKernelGGL((softrod_step_fast_kernel<FEATS, ENV, EPL>), grid, block, 0, st, h->P, h->S, \
-                           actions, obs, reward, term, trunc, aux, n_sub, epilogue)
+                           actions, obs, reward, term, trunc, aux, n_sub, epilogue, pack)
 #define SR_DISPATCH(EPL)                                                                            \
         do {                                                                                        \
             if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM)                \
@@ -164,7 +164,7 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
 #undef SR_LAUNCH
     } else
         hipLaunchKernelGGL(softrod_step_libm_kernel, grid, block, 0, st, h->P, h->S,
-                           actions, obs, reward, term, trunc, aux, n_sub, epilogue);
+                           actions, obs, reward, term, trunc, aux, n_sub, epilogue, pack);
     SR_HIP(h, hipGetLastError());
     if (timing) {
         SR_HIP(h, hipEventRecord(h->ev_stop[h->timed], st));
@@ -437,7 +437,18 @@ int softrod_step(softrod_handle* h, const float* actions, float* obs, double* re
     if (h->cfg.env_kind == SOFTROD_ENV_NONE)
         return fail(h, SOFTROD_EINVAL, "env_kind NONE has no step epilogue; use softrod_substeps");
     SR_HIP(h, hipSetDevice(h->device));
-    return launch_step(h, actions, obs, reward, terminated, truncated, aux, h->cfg.n_substeps, 1,
+    return launch_step(h, actions, obs, reward, terminated, truncated, aux, h->cfg.n_substeps, 1, 0,
+                       (hipStream_t)stream);
+}
+
+int softrod_step_packed(softrod_handle* h, const float* actions, float* packed, double* aux, void* stream) {
+    if (!h || !actions || !packed) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (h->cfg.env_kind == SOFTROD_ENV_NONE)
+        return fail(h, SOFTROD_EINVAL, "env_kind NONE has no step epilogue; use softrod_substeps");
+    if ((h->cfg.features & SOFTROD_FEAT_REST_KAPPA_ACTION) && !h->basis_set)
+        return fail(h, SOFTROD_EINVAL, "softrod_set_action_basis must be called before softrod_step");
+    SR_HIP(h, hipSetDevice(h->device));
+    return launch_step(h, actions, packed, nullptr, nullptr, nullptr, aux, h->cfg.n_substeps, 1, 1,
                        (hipStream_t)stream);
 }
 
@@ -446,7 +457,7 @@ int softrod_substeps(softrod_handle* h, const float* actions, int n, void* strea
     if (actions && h->cfg.env_kind != SOFTROD_ENV_SOFTPENDULUM && h->cfg.env_kind != SOFTROD_ENV_NONE)
         return fail(h, SOFTROD_EINVAL, "softrod_substeps takes no actions for this env_kind");
     SR_HIP(h, hipSetDevice(h->device));
-    return launch_step(h, actions, nullptr, nullptr, nullptr, nullptr, nullptr, n, 0, (hipStream_t)stream);
+    return launch_step(h, actions, nullptr, nullptr, nullptr, nullptr, nullptr, n, 0, 0, (hipStream_t)stream);
 }
 
 int softrod_observe(softrod_handle* h, const float* prev_action, float* obs, void* stream) {

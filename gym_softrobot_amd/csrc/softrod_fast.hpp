@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures
 softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                         double* __restrict__ aux, const int n_sub, const int epilogue) {
+                         double* __restrict__ aux, const int n_sub, const int epilogue, const int pack) {
     const int rod = blockIdx.x;
     const int lane = threadIdx.x;
     const size_t N = (size_t)P.n_envs;
@@ -373,7 +373,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     store_lane<EPL, F>(S, N, rod, lane, L);
     if (lane == 0) S.time[rod] = time;
     if (epilogue)
-        env_epilogue_n<E, EPL>(P, S, N, rod, lane, C, L, time, A, obs, reward, terminated, truncated, aux);
+        env_epilogue_n<E, EPL>(P, S, N, rod, lane, C, L, time, A, obs, reward, terminated, truncated, aux, pack);
 }
 
 

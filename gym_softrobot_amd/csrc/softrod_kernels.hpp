@@ -371,10 +371,36 @@ __device__ __forceinline__ void com_xy_n(const RodParams& P, const ConstN<EPL>& 
     }
 }
 
+// Per-env outputs.  pack = 0: separate arrays obs[N][od], reward[N], terminated[N],
+// truncated[N].  pack = 1 (multi-GPU path): `obs` points at rows of ro + 4 32-bit words,
+// ro = od rounded up to even (so the float64 reward is 8-byte aligned in every row):
+//   [obs (od floats) | pad | reward (float64, 2 words) | terminated, truncated (bytes 0, 1) | 0]
+// so that ONE all-gather moves everything and the receiver unpacks with views only.
+__device__ __forceinline__ float* out_row(float* obs, int rod, int od, int pack) {
+    return obs + (size_t)rod * (size_t)(pack ? od + (od & 1) + 4 : od);
+}
+__device__ __forceinline__ void emit_scalars(float* row, int od, int pack, int rod, double r, bool te,
+                                             bool tr, double* __restrict__ reward,
+                                             uint8_t* __restrict__ terminated,
+                                             uint8_t* __restrict__ truncated) {
+    if (pack) {
+        const int ro = od + (od & 1);
+        if (od & 1) row[od] = 0.0f;
+        row[ro] = __int_as_float(__double2loint(r));
+        row[ro + 1] = __int_as_float(__double2hiint(r));
+        row[ro + 2] = __int_as_float((te ? 1 : 0) | ((tr ? 1 : 0) << 8));
+        row[ro + 3] = 0.0f;
+    } else {
+        reward[rod] = r;
+        terminated[rod] = te ? 1 : 0;
+        truncated[rod] = tr ? 1 : 0;
+    }
+}
+
 template <int EPL>
 __device__ __forceinline__ void arm_get_state_n(const RodParams& P, const StatePtrs& S, size_t N, int rod,
                                                 int lane, const ConstN<EPL>& C, const LaneN<EPL>& L,
-                                                const float* pa, float* __restrict__ obs) {
+                                                const float* pa, float* __restrict__ o) {
     constexpr size_t W = (size_t)kLanes * EPL;
     const int nv = P.n_elem - 1;
     double kap[EPL], rate[EPL];
@@ -409,7 +435,6 @@ __device__ __forceinline__ void arm_get_state_n(const RodParams& P, const StateP
         const double pc0 = S.ctrl[(size_t)0 * N + rod], pc1 = S.ctrl[(size_t)1 * N + rod];
         S.ctrl[(size_t)0 * N + rod] = com[0];
         S.ctrl[(size_t)1 * N + rod] = com[1];
-        float* o = obs + 25 * (size_t)rod;
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
             o[b] = (float)((mk[b] - P.kappa_range[0]) / (P.kappa_range[1] - P.kappa_range[0]));
@@ -459,7 +484,7 @@ __device__ __forceinline__ void env_observe_n(const RodParams& P, const StatePtr
             o[8] = (float)tilt;
         }
     } else if (env == SOFTROD_ENV_ARM_SINGLE) {
-        arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, pa, obs);
+        arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, pa, obs + 25 * (size_t)rod);
     } else {
         const double th = theta_n<EPL>(P, lane, L);
         if (lane == 0) {
@@ -479,7 +504,7 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
                                                double* __restrict__ reward,
                                                uint8_t* __restrict__ terminated,
                                                uint8_t* __restrict__ truncated,
-                                               double* __restrict__ aux) {
+                                               double* __restrict__ aux, const int pack) {
     bool bad = false;
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
@@ -502,11 +527,10 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
             const float ctl = 1e-3f * (A.a[0] * A.a[0] + A.a[1] * A.a[1]);
             double r = -(tilt * tilt + 0.1 * (base_distance * base_distance) + (double)ctl);
             if (invalid) r = -50.0;
-            reward[rod] = r;
-            terminated[rod] = invalid ? 1 : 0;
-            truncated[rod] = (time >= P.final_time) ? 1 : 0;
+            float* o = out_row(obs, rod, 9, pack);
+            // '>=' here, '>' in SoftPendulum
+            emit_scalars(o, 9, pack, rod, r, invalid, time >= P.final_time, reward, terminated, truncated);
             if (aux) aux[rod] = tilt;
-            float* o = obs + 9 * (size_t)rod;
             o[0] = (float)L.x[0][0]; o[1] = (float)L.x[0][1]; o[2] = (float)L.x[0][2];
             o[3] = (float)L.v[0][0]; o[4] = (float)L.v[0][1]; o[5] = (float)L.v[0][2];
             o[6] = A.a[0]; o[7] = A.a[1];
@@ -535,21 +559,19 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
                 forward = exp(-dist / 0.35) - 0.096;
                 if (dist < 0.1) { survive = 5.0; term = true; }
             }
-            reward[rod] = forward - (double)pen + survive;
-            terminated[rod] = term ? 1 : 0;
-            truncated[rod] = (time > P.final_time) ? 1 : 0;
+            emit_scalars(out_row(obs, rod, 25, pack), 25, pack, rod, forward - (double)pen + survive, term,
+                         time > P.final_time, reward, terminated, truncated);
         }
-        arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, A.a, obs);
+        arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, A.a, out_row(obs, rod, 25, pack));
     } else {
         const double th = theta_n<EPL>(P, lane, L);
         if (lane == 0) {
             double forward = 0.0, survive = 0.0;
             if (invalid) survive = -50.0;
             else forward = fabs(L.x[0][0]) * 10.0 + th * th;
-            reward[rod] = forward - 0.0 + survive;
-            terminated[rod] = invalid ? 1 : 0;
-            truncated[rod] = (time > P.final_time) ? 1 : 0;
-            float* o = obs + 4 * (size_t)rod;
+            float* o = out_row(obs, rod, 4, pack);
+            emit_scalars(o, 4, pack, rod, forward - 0.0 + survive, invalid, time > P.final_time, reward,
+                         terminated, truncated);
             o[0] = (float)L.x[0][0];
             o[1] = (float)L.v[0][0];
             o[2] = A.a[0];
@@ -838,7 +860,7 @@ __global__ void __launch_bounds__(kLanes)
 softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
-                         double* __restrict__ aux, const int n_sub, const int epilogue) {
+                         double* __restrict__ aux, const int n_sub, const int epilogue, const int pack) {
     const int rod = blockIdx.x;
     const int lane = threadIdx.x;
     const size_t N = (size_t)P.n_envs;
@@ -868,7 +890,8 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
     store_lane<1, kRuntimeFeatures>(S, N, rod, lane, L);
     if (lane == 0) S.time[rod] = time;
     if (epilogue)
-        env_epilogue_n<kRuntimeEnv, 1>(P, S, N, rod, lane, C, L, time, A, obs, reward, terminated, truncated, aux);
+        env_epilogue_n<kRuntimeEnv, 1>(P, S, N, rod, lane, C, L, time, A, obs, reward, terminated, truncated,
+                                       aux, pack);
 }
 
 // Reset: expand the host-computed straight-rod description of each masked rod

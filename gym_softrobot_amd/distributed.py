@@ -6,10 +6,12 @@ The reference has no counterpart (single env, single process); envs never intera
 trivially: env i lives on rank i // (N / world).  After each step every rank holds the
 outputs of all N envs (what a centralised policy needs).  The collective is
 latency-bound (32 B/env), so it is a single `all_gather_into_tensor` on one packed
-buffer rather than one collective per output:
+buffer rather than one collective per output.  The step kernel writes the packed rows
+itself (`softrod_step_packed`), and the receiver unpacks with views only, so a step of
+the sharded env is exactly two device operations per rank: the kernel and the all-gather.
 
-    packed[e] = [obs0, obs1, obs2, obs3, reward_lo, reward_hi, terminated, truncated]
-                 (8 x 32-bit words; the float64 reward travels bit-exactly as two words)
+    row = [obs (obs_dim float32) | pad to even | reward (float64 as 2 words, 8-byte aligned)
+           | terminated, truncated (bytes 0, 1 of one word) | 0]
 
 Backend `nccl` is RCCL over xGMI on the MI355X node; `gloo` drives the same code in
 the CPU tests (tests/test_distributed_gloo.py).  `gather=False` leaves outputs sharded
@@ -23,7 +25,10 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-PACK_WORDS = 8
+
+def packed_width(obs_dim: int) -> int:
+    """32-bit words per env in the packed row (include/softrod.h, softrod_step_packed)."""
+    return obs_dim + (obs_dim & 1) + 4
 
 
 def shard_bounds(total_envs: int, world: int, rank: int) -> Tuple[int, int]:
@@ -35,31 +40,37 @@ def shard_bounds(total_envs: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def pack_outputs(obs, reward, terminated, truncated, out=None) -> torch.Tensor:
-    """(n,4) f32, (n,) f64, (n,) u8/bool, (n,) u8/bool -> (n, 8) f32 (bit-exact)."""
-    n = obs.shape[0]
+    """Host-side twin of the kernel's packed epilogue (reset observations, test doubles):
+    (n,od) f32, (n,) f64, (n,) u8/bool, (n,) u8/bool -> (n, packed_width(od)) f32, bit-exact."""
+    n, od = obs.shape
+    ro = od + (od & 1)
     if out is None:
-        out = torch.empty((n, PACK_WORDS), dtype=torch.float32, device=obs.device)
-    out[:, 0:4] = obs
-    out[:, 4:6] = reward.contiguous().view(torch.float32).view(n, 2)
-    out[:, 6] = terminated.to(torch.float32)
-    out[:, 7] = truncated.to(torch.float32)
+        out = torch.zeros((n, ro + 4), dtype=torch.float32, device=obs.device)
+    else:
+        out.zero_()
+    out[:, 0:od] = obs
+    out[:, ro : ro + 2] = reward.contiguous().view(torch.float32).view(n, 2)
+    flags = out.view(torch.uint8)
+    flags[:, 4 * (ro + 2)] = terminated.to(torch.uint8)
+    flags[:, 4 * (ro + 2) + 1] = truncated.to(torch.uint8)
     return out
 
 
-def unpack_outputs(packed: torch.Tensor):
-    n = packed.shape[0]
-    obs = packed[:, 0:4]
-    reward = packed[:, 4:6].contiguous().view(torch.float64).view(n)
-    terminated = packed[:, 6] != 0
-    truncated = packed[:, 7] != 0
+def unpack_outputs(packed: torch.Tensor, obs_dim: int):
+    """Views only: no device work."""
+    ro = obs_dim + (obs_dim & 1)
+    obs = packed[:, 0:obs_dim]
+    reward = packed[:, ro : ro + 2].view(torch.float64)[:, 0]
+    flags = packed.view(torch.uint8)
+    terminated = flags[:, 4 * (ro + 2)].view(torch.bool)
+    truncated = flags[:, 4 * (ro + 2) + 1].view(torch.bool)
     return obs, reward, terminated, truncated
 
 
 class ShardedVecEnv:
     """Wraps this rank's local vec env (N/world envs) and presents the global batch.
 
-    local_env: object with reset(seed=[...], mask=...) / step(actions) returning torch
-    tensors (VecSoftPendulumEnv); it must have been built with num_envs = N / world.
+    local_env: a VecRodEnvBase built with num_envs = N / world.
     """
 
     def __init__(self, local_env, total_envs: int, group: Optional[dist.ProcessGroup] = None,
@@ -73,13 +84,12 @@ class ShardedVecEnv:
         if local_env.num_envs != self.hi - self.lo:
             raise ValueError("local env size does not match this rank's shard")
         self.gather = gather
+        self.obs_dim = local_env.obs_dim
         dev = local_env.backend.device
-        self._packed = torch.empty((self.hi - self.lo, PACK_WORDS), dtype=torch.float32, device=dev)
-        self._global = torch.empty((self.total_envs, PACK_WORDS), dtype=torch.float32, device=dev)
+        w = packed_width(self.obs_dim)
+        self._global = torch.empty((self.total_envs, w), dtype=torch.float32, device=dev)
 
     def _all_gather(self, packed: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
-            return packed
         dist.all_gather_into_tensor(self._global, packed, group=self.group)
         return self._global
 
@@ -93,19 +103,19 @@ class ShardedVecEnv:
         n = obs.shape[0]
         zeros64 = torch.zeros(n, dtype=torch.float64, device=obs.device)
         zeros8 = torch.zeros(n, dtype=torch.uint8, device=obs.device)
-        g = self._all_gather(pack_outputs(obs, zeros64, zeros8, zeros8, self._packed))
-        return unpack_outputs(g)[0], info
+        g = self._all_gather(pack_outputs(obs, zeros64, zeros8, zeros8))
+        return unpack_outputs(g, self.obs_dim)[0], info
 
     def step(self, actions):
-        """actions: global (N,) / (N,1) tensor or array, or this rank's shard."""
-        a = torch.as_tensor(actions, dtype=torch.float32).reshape(-1)
-        if a.numel() == self.total_envs:
+        """actions: global (N, action_dim) tensor or array, or this rank's shard."""
+        adim = self.local.action_dim
+        a = torch.as_tensor(actions, dtype=torch.float32).reshape(-1, adim)
+        if a.shape[0] == self.total_envs and self.world > 1:
             a = a[self.lo : self.hi]
-        obs, rew, term, trunc, info = self.local.step(a)
         if not self.gather or self.world == 1:
-            return obs, rew, term, trunc, info
-        g = self._all_gather(pack_outputs(obs, rew, term, trunc, self._packed))
-        o, r, te, tr = unpack_outputs(g)
+            return self.local.step(a)
+        packed, info = self.local.step_packed(a)
+        o, r, te, tr = unpack_outputs(self._all_gather(packed), self.obs_dim)
         return o, r, te, tr, info
 
     def close(self):

@@ -195,6 +195,19 @@ class VecRodEnvBase:
             infos,
         )
 
+    def step_packed(self, actions):
+        """step() with every per-env output in one (N, packed_width) float32 buffer written
+        by the kernel itself (distributed.unpack_outputs gives views); no auto-reset."""
+        import torch
+
+        if self.autoreset:
+            raise NotImplementedError("step_packed does not auto-reset; use step()")
+        self._validate_actions(actions)
+        a = torch.as_tensor(actions, dtype=torch.float32, device=self.backend.device)
+        packed = self.backend.step_packed(a.reshape(self.num_envs, self.action_dim))
+        self._steps += 1
+        return packed, self._infos(self._times())
+
     def close(self):
         if self.backend is not None and hasattr(self.backend, "close"):
             self.backend.close()

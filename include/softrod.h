@@ -265,6 +265,14 @@ int softrod_step(softrod_handle* h, const float* actions, float* obs,
                  double* reward, uint8_t* terminated, uint8_t* truncated,
                  double* aux, void* stream);
 
+/* softrod_step with all per-env outputs in ONE buffer, for the multi-GPU path (one
+ * all-gather per env.step, unpacked with views only): packed is device
+ * [n_envs][ro + 4] 32-bit words per env, ro = obs_dim rounded up to even:
+ *   [ obs (obs_dim x float32) | pad to ro | reward (float64, 2 words, 8-byte
+ *     aligned) | terminated, truncated (bytes 0 and 1 of one word) | 0 ]       */
+int softrod_step_packed(softrod_handle* h, const float* actions, float* packed,
+                        double* aux, void* stream);
+
 /* Replaces: get_state() at reset (soft_pendulum.py:145-161,
  * soft_pendulum_3d.py:93-98).  prev_action is device [n_envs][action_dim]
  * float32, or NULL = the resident copy of the last stepped action.          */

@@ -84,5 +84,11 @@ class OracleBackend:
             self.truncated[i] = int(tr)
         return self.obs, self.reward, self.terminated, self.truncated
 
+    def step_packed(self, actions):
+        from gym_softrobot_amd.distributed import pack_outputs
+
+        o, r, te, tr = self.step(actions)
+        return pack_outputs(o, r, te, tr)
+
     def close(self):
         self.rods = []

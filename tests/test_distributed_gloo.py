@@ -76,9 +76,16 @@ def test_pack_unpack_roundtrip_is_bit_exact():
     rew[3] = -50.0
     term = (torch.arange(n) % 3 == 0).to(torch.uint8)
     trunc = (torch.arange(n) % 2 == 0)
-    o, r, te, tr = unpack_outputs(pack_outputs(obs, rew, term, trunc))
+    o, r, te, tr = unpack_outputs(pack_outputs(obs, rew, term, trunc), 4)
     assert torch.equal(o, obs) and torch.equal(r, rew)
     assert torch.equal(te, term.bool()) and torch.equal(tr, trunc)
+    # odd observation widths are padded so that the float64 reward stays 8-byte aligned
+    for od in (9, 25):
+        obs = torch.randn((n, od), generator=g)
+        p = pack_outputs(obs, rew, term, trunc)
+        assert p.shape == (n, od + 1 + 4)
+        o, r, te, tr = unpack_outputs(p, od)
+        assert torch.equal(o, obs) and torch.equal(r, rew) and torch.equal(te, term.bool()) and torch.equal(tr, trunc)
 
 
 def test_shard_bounds():

@@ -615,3 +615,26 @@ def test_arm_single_100_elements_matches_oracle(torch_gpu, hip_lib, oracle_built
         np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-7)
         np.testing.assert_allclose(st["rest_kappa"][i][0], r.get("rest_kappa")[0], rtol=1e-12, atol=1e-12)
     env.close()
+
+
+@pytest.mark.parametrize("env_id,amax", [("SoftPendulum-v0", 22.0), ("SoftPendulum3D-v0", 1.0), ("OctoArmSingle-v0", 8.0)])
+def test_packed_step_equals_separate_outputs(torch_gpu, hip_lib, env_id, amax):
+    # the multi-GPU path lets the kernel write one packed row per env; unpacking is views only
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd.distributed import packed_width, unpack_outputs
+
+    n = 5
+    a_env, b_env = gsa.make_vec(env_id, n, device=0), gsa.make_vec(env_id, n, device=0)
+    a_env.reset(seed=3)
+    b_env.reset(seed=3)
+    acts = np.random.default_rng(8).uniform(-amax, amax, (2, n, a_env.action_dim)).astype(np.float32)
+    for t in range(2):
+        o, r, te, tr, _ = a_env.step(acts[t])
+        packed, _ = b_env.step_packed(acts[t])
+        assert packed.shape == (n, packed_width(a_env.obs_dim))
+        po, pr, pte, ptr = unpack_outputs(packed, a_env.obs_dim)
+        assert torch_gpu.equal(po, o) and torch_gpu.equal(pr, r)
+        assert torch_gpu.equal(pte, te) and torch_gpu.equal(ptr, tr)
+        assert pr.dtype == torch_gpu.float64 and pte.dtype == torch_gpu.bool
+    a_env.close()
+    b_env.close()
