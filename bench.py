@@ -104,10 +104,16 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the hot path has no CPU fallback")
+    if os.environ.get("SOFTROD_BENCH_ALL_RANKS_ON_DEVICE0") == "1":
+        local_rank = 0   # smoke-testing the N>1 code path on a 1-GPU box (not a measurement)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SOFTROD_BENCH_DIST_BACKEND", "nccl")   # "gloo": 1-GPU smoke test only
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n_local = args.envs_per_gpu
     n_total = n_local * world
