@@ -73,6 +73,15 @@ _SHAPES = {
 }
 
 
+def filter_rate(rate, order: int) -> np.ndarray:
+    """LaplaceDissipationFilter's nb_filter_rate on one 1-D array (test access)."""
+    lib = _load(False)
+    a = np.ascontiguousarray(rate, dtype=np.float64).copy()
+    lib.oracle_filter_rate.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.oracle_filter_rate(a.ctypes.data, int(a.size), int(order))
+    return a
+
+
 class OracleRod:
     """One rod stepped by the C oracle."""
 

@@ -635,6 +635,9 @@ static void filter_rate(double* rate, int m, int order)
     for (int k = 0; k < m; ++k) rate[k] = rate[k] - f[k];
 }
 
+/* exported for tests: the bare filter on one array */
+void oracle_filter_rate(double* rate, int m, int order) { filter_rate(rate, m, order); }
+
 static void laplace_filter(oracle_rod* r)
 {
     if (!(r->cfg.features & SOFTROD_FEAT_LAPLACE_FILTER)) return;

@@ -222,3 +222,28 @@ def test_k9_axial_sliding_decelerates_with_kinetic_coulomb_friction(oracle_built
     assert np.allclose(vx, vx.mean(), rtol=0, atol=2e-4)        # rigid translation
     assert vx.mean() == pytest.approx(expect, rel=2e-3)
     assert np.abs(rod.get("x")[2]).max() < 1e-6                 # stays on the plane
+
+
+# ---- LaplaceDissipationFilter (SoftPendulum3D-v0) -------------------------------------------
+def test_k10_laplace_filter_is_a_high_frequency_low_pass(oracle_built):
+    # f_k <- (2 f_k - f_{k-1} - f_{k+1})/4 has the interior eigenfunctions sin(k theta) with
+    # eigenvalue sin^2(theta/2): `order` passes remove sin^(2 order)(theta/2) of a mode, i.e.
+    # nothing of a smooth field and everything of the sawtooth; boundary entries are never
+    # filtered.  (A mode with nodes at both ends, theta = j pi/(m-1), is exact for all passes.)
+    m, order = 41, 7
+    k = np.arange(m)
+    for j in (1, 5, 20, 39):
+        theta = j * np.pi / (m - 1)
+        f = np.sin(k * theta)
+        out = oracle_built.filter_rate(f, order)
+        keep = 1.0 - np.sin(theta / 2) ** (2 * order)
+        np.testing.assert_allclose(out[1:-1], keep * f[1:-1], rtol=0, atol=1e-13)
+    saw = (-1.0) ** k
+    out = oracle_built.filter_rate(saw, order)
+    assert out[0] == saw[0] and out[-1] == saw[-1]            # ends untouched
+    assert np.abs(out[order + 1 : -(order + 1)]).max() < 1e-12   # annihilated away from the ends
+    const = np.full(m, 2.5)
+    out = oracle_built.filter_rate(const, order)
+    # a constant has zero second difference in the interior; only the cells next to the
+    # ends (whose neighbour is pinned to 0 after the first pass) lose a little
+    np.testing.assert_allclose(out[order + 1 : -(order + 1)], 2.5, rtol=0, atol=1e-13)
