@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -23,6 +23,7 @@ FEAT_MOVING_BASE_BC = 1 << 6
 FEAT_LAPLACE_FILTER = 1 << 7
 FEAT_PLANE_CONTACT_ANISO = 1 << 8
 FEAT_REST_KAPPA_ACTION = 1 << 9
+FEAT_OCTO_HEAD = 1 << 10
 FEATURES_SOFTPENDULUM = (
     FEAT_GRAVITY | FEAT_POINT_FORCE_NODE0_X | FEAT_PENDULUM_BC | FEAT_ANALYTICAL_DAMPER
 )
@@ -38,15 +39,18 @@ ENV_NONE = 0
 ENV_SOFTPENDULUM = 1
 ENV_SOFTPENDULUM3D = 2
 ENV_ARM_SINGLE = 3
+ENV_OCTO_FLAT = 4
+FEATURES_OCTO_FLAT = FEATURES_ARM_SINGLE | FEAT_OCTO_HEAD
 
 MATH_LIBM = 0
 MATH_FAST = 1
 
 LANE_STRIDE = 64  # one wavefront row per rod (softrod_state_view.lane_stride)
 
-_ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2, ENV_ARM_SINGLE: 7}
-_OBS_DIM = {ENV_NONE: 4, ENV_SOFTPENDULUM: 4, ENV_SOFTPENDULUM3D: 9, ENV_ARM_SINGLE: 25}
-_AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1, ENV_ARM_SINGLE: 0}
+_ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2, ENV_ARM_SINGLE: 7, ENV_OCTO_FLAT: 24}
+_OBS_DIM = {ENV_NONE: 4, ENV_SOFTPENDULUM: 4, ENV_SOFTPENDULUM3D: 9, ENV_ARM_SINGLE: 25,
+            ENV_OCTO_FLAT: 8 * 56 + 13}
+_AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1, ENV_ARM_SINGLE: 0, ENV_OCTO_FLAT: 0}
 
 
 def action_dim(env_kind: int) -> int:
@@ -106,6 +110,13 @@ class SoftrodConfig(C.Structure):
         ("target", C.c_double * 2),
         ("kappa_range", C.c_double * 2),
         ("kappa_rate_range", C.c_double * 2),
+        ("n_arm", C.c_int32),
+        ("n_knots", C.c_int32),
+        ("head_radius", C.c_double),
+        ("head_density", C.c_double),
+        ("joint_k", C.c_double),
+        ("joint_nu", C.c_double),
+        ("joint_kt", C.c_double),
     ]
 
     def copy(self) -> "SoftrodConfig":
@@ -252,6 +263,34 @@ def arm_single_config(
     cfg.target[0], cfg.target[1] = 1.0, 0.0         # arm_single_env.py:165
     cfg.kappa_range[0], cfg.kappa_range[1] = -49.33508476187419, 49.33545827754751
     cfg.kappa_rate_range[0], cfg.kappa_rate_range[1] = -21.063520620377012, 24.664591289161944
+    return cfg
+
+
+def octo_flat_config(
+    n_envs: int = 1,
+    *,
+    final_time: float = 5.0,
+    time_step: float = 7.0e-5,
+    recording_fps: int = 5,
+    n_elems: int = 10,
+    n_arm: int = 8,
+    n_action: int = 3,
+    math_mode: int = MATH_FAST,
+) -> SoftrodConfig:
+    """FlatEnv.__init__ (octopus/flat_env.py:55-110) and build_octopus
+    (octopus/build.py:30-217): per-arm rod constants as arm_single_config, plus the rigid
+    head, the joints and the head boundary condition."""
+    cfg = arm_single_config(n_envs, final_time=final_time, time_step=time_step,
+                            recording_fps=recording_fps, n_elems=n_elems, math_mode=math_mode)
+    cfg.features = FEATURES_OCTO_FLAT
+    cfg.env_kind = ENV_OCTO_FLAT
+    cfg.n_arm = int(n_arm)
+    cfg.n_knots = int(n_action)
+    cfg.head_radius = 0.04
+    cfg.head_density = 700.0
+    cfg.joint_k = 1e6
+    cfg.joint_nu = 1e-3
+    cfg.joint_kt = 1e0
     return cfg
 
 

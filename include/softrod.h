@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 4
+#define SOFTROD_ABI_VERSION 5
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -87,6 +87,11 @@ enum softrod_feature {
     /* set_action: rest_kappa[0, :] = cubic interp1d of the action
      *                                             octopus/arm_single_env.py:226-235 */
     SOFTROD_FEAT_REST_KAPPA_ACTION = 1u << 9,
+    /* OctoFlat: n_arm rods per env joined to a rigid Cylinder head by
+     * FixedJoint2Rigid, head held by BodyBoundaryCondition
+     *   octopus/build.py:52-132, utils/custom_elastica/joint.py:20-225,
+     *   utils/custom_elastica/constraint.py:8-85                               */
+    SOFTROD_FEAT_OCTO_HEAD = 1u << 10,
 };
 
 #define SOFTROD_FEATURES_SOFTPENDULUM                                             \
@@ -98,6 +103,8 @@ enum softrod_feature {
 #define SOFTROD_FEATURES_ARM_SINGLE                                               \
     (SOFTROD_FEAT_GRAVITY | SOFTROD_FEAT_PLANE_CONTACT_ANISO |                   \
      SOFTROD_FEAT_ANALYTICAL_DAMPER | SOFTROD_FEAT_REST_KAPPA_ACTION)
+#define SOFTROD_FEATURES_OCTO_FLAT                                                \
+    (SOFTROD_FEATURES_ARM_SINGLE | SOFTROD_FEAT_OCTO_HEAD)
 
 /* env_kind: which env's set_action / NaN check / reward / observation the step
  * kernel's prologue and epilogue implement.                                     */
@@ -105,6 +112,7 @@ enum softrod_feature {
 #define SOFTROD_ENV_SOFTPENDULUM 1   /* soft_pendulum/soft_pendulum.py:149-251     */
 #define SOFTROD_ENV_SOFTPENDULUM3D 2 /* soft_pendulum_3d/soft_pendulum_3d.py:93-174 */
 #define SOFTROD_ENV_ARM_SINGLE 3     /* octopus/arm_single_env.py:186-316           */
+#define SOFTROD_ENV_OCTO_FLAT 4      /* octopus/flat_env.py:231-408                 */
 
 /* math_mode (HIP library only; the oracle always uses libm). */
 #define SOFTROD_MATH_LIBM 0 /* sqrt/sin/cos/acos/pow evaluated as written   */
@@ -171,11 +179,19 @@ typedef struct softrod_config {
     double target[2];         /* (1, 0)                 arm_single_env.py:165   */
     double kappa_range[2];    /* arm_single_env.py:111                          */
     double kappa_rate_range[2]; /* :113                                         */
+    /* ---- OctoFlat-v0 (octopus/build.py:30-132, flat_env.py:55-110) ---- */
+    int32_t n_arm;            /* 8 rods per env (n_elem is per arm: 10)         */
+    int32_t n_knots;          /* n_action per arm: 3 (flat_env.py:62)           */
+    double head_radius;       /* 0.04                   octopus/build.py:38     */
+    double head_density;      /* 700                    :39                     */
+    double joint_k;           /* body_arm_k  1e6        :36                     */
+    double joint_nu;          /* 1e-3                   :128                    */
+    double joint_kt;          /* body_arm_kt 1e0        :37                     */
 } softrod_config;
 
 /* Per-env I/O widths implied by env_kind. */
-int softrod_action_dim(int env_kind); /* 1, 2, 7                            */
-int softrod_obs_dim(int env_kind);    /* 4, 9, 25                           */
+int softrod_action_dim(int env_kind); /* 1, 2, 7, 24                        */
+int softrod_obs_dim(int env_kind);    /* 4, 9, 25, 8*56 + 13 = 461          */
 int softrod_aux_dim(int env_kind);    /* 0, 1 (info["tilt"], float64), 0    */
 
 typedef struct softrod_handle softrod_handle;

@@ -51,6 +51,19 @@ def _load(omp: bool) -> C.CDLL:
     lib.oracle_env_step3d.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.oracle_reset_arm.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_env_step_arm.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.oracle_octo_create.restype = C.c_void_p
+    lib.oracle_octo_create.argtypes = [C.POINTER(SoftrodConfig)]
+    lib.oracle_octo_destroy.argtypes = [C.c_void_p]
+    lib.oracle_octo_reset.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    lib.oracle_octo_env_step.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    lib.oracle_octo_substeps.argtypes = [C.c_void_p, C.c_int]
+    lib.oracle_octo_time.restype = C.c_double
+    lib.oracle_octo_time.argtypes = [C.c_void_p]
+    lib.oracle_octo_arm.restype = C.c_void_p
+    lib.oracle_octo_arm.argtypes = [C.c_void_p, C.c_int]
+    lib.oracle_octo_crossings.restype = C.c_int
+    lib.oracle_octo_crossings.argtypes = [C.c_void_p]
+    lib.oracle_octo_head.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_get.restype = C.c_int
     lib.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.oracle_set.restype = C.c_int
@@ -193,6 +206,93 @@ class OracleRod:
         assert arr.shape == _SHAPES[name](self.n), (arr.shape, name)
         if self._lib.oracle_set(self._h, name.encode(), arr.ctypes.data) != 0:
             raise KeyError(name)
+
+
+class _ArmView:
+    """Read access to one arm of an OracleOcto through the per-rod accessors."""
+
+    def __init__(self, lib, handle, n):
+        self._lib, self._h, self.n = lib, handle, n
+
+    get = OracleRod.get
+    set = OracleRod.set
+
+
+class OracleOcto:
+    """OctoFlat-v0 (8 arms + rigid head) stepped by the C oracle (octoflat_oracle.inc.c)."""
+
+    def __init__(self, cfg: SoftrodConfig):
+        self._lib = _load(False)
+        self.cfg = cfg.copy()
+        self.n_arm = int(cfg.n_arm)
+        self.n = int(cfg.n_elem)
+        self._h = self._lib.oracle_octo_create(C.byref(self.cfg))
+        if not self._h:
+            raise ValueError("oracle_octo_create rejected the configuration")
+        self.width = (self.n - 1) + (self.n + 1) * 4 + int(cfg.n_knots)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.oracle_octo_destroy(self._h)
+            self._h = None
+
+    def _obs(self):
+        return np.empty((self.n_arm, self.width), np.float32), np.empty(13, np.float32)
+
+    def reset(self, target):
+        """build_octopus geometry with scipy, exactly as octopus/build.py:73-80."""
+        from scipy.spatial.transform import Rotation as Rot
+
+        rotation_angle = 360 / self.n_arm
+        pos, dirs = [], []
+        for arm_i in range(self.n_arm):
+            rot = Rot.from_euler("z", rotation_angle * arm_i, degrees=True)
+            pos.append(rot.apply([self.cfg.head_radius, 0.0, 0.0]))
+            dirs.append(rot.apply([1.0, 0.0, 0.0]))
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64)
+        tgt = np.ascontiguousarray(target, dtype=np.float64)
+        ind, sh = self._obs()
+        self._lib.oracle_octo_reset(self._h, pos.ctypes.data, dirs.ctypes.data, tgt.ctypes.data,
+                                    ind.ctypes.data, sh.ctypes.data)
+        return {"individual": ind, "shared": sh}
+
+    def env_step(self, action):
+        """set_action's zero-padded cubic interp1d (flat_env.py:288-311) with scipy."""
+        from scipy.interpolate import interp1d
+
+        nk = int(self.cfg.n_knots)
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(self.n_arm * nk)
+        k = a.reshape((self.n_arm, nk))
+        k = np.concatenate([np.zeros((self.n_arm, 1)), k, np.zeros((self.n_arm, 1))], axis=-1)
+        rk = interp1d(np.linspace(0, 1, nk + 2), k, kind="cubic", axis=-1)(np.linspace(0, 1, self.n - 1))
+        rk = np.ascontiguousarray(rk, dtype=np.float64)
+        ind, sh = self._obs()
+        rew = np.empty(1, np.float64)
+        term = np.empty(1, np.uint8)
+        trunc = np.empty(1, np.uint8)
+        self._lib.oracle_octo_env_step(self._h, a.ctypes.data, rk.ctypes.data, ind.ctypes.data,
+                                       sh.ctypes.data, rew.ctypes.data, term.ctypes.data, trunc.ctypes.data)
+        return {"individual": ind, "shared": sh}, float(rew[0]), bool(term[0]), bool(trunc[0])
+
+    def substeps(self, n: int) -> None:
+        self._lib.oracle_octo_substeps(self._h, int(n))
+
+    @property
+    def time(self) -> float:
+        return self._lib.oracle_octo_time(self._h)
+
+    def arm(self, a: int) -> _ArmView:
+        return _ArmView(self._lib, self._lib.oracle_octo_arm(self._h, int(a)), self.n)
+
+    def crossings(self) -> int:
+        return int(self._lib.oracle_octo_crossings(self._h))
+
+    def head(self):
+        out = np.empty(22, np.float64)
+        self._lib.oracle_octo_head(self._h, out.ctypes.data)
+        return {"x": out[0:3], "v": out[3:6], "Q": out[6:15].reshape(3, 3), "w": out[15:18],
+                "mass": out[18], "J": out[19:22]}
 
 
 class OracleBatch:

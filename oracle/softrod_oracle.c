@@ -1042,3 +1042,5 @@ int oracle_set(oracle_rod* r, const char* name, const double* in)
 }
 
 size_t oracle_config_size(void) { return sizeof(softrod_config); }
+
+#include "octoflat_oracle.inc.c"

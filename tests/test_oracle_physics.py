@@ -247,3 +247,67 @@ def test_k10_laplace_filter_is_a_high_frequency_low_pass(oracle_built):
     # a constant has zero second difference in the interior; only the cells next to the
     # ends (whose neighbour is pinned to 0 after the first pass) lose a little
     np.testing.assert_allclose(out[order + 1 : -(order + 1)], 2.5, rtol=0, atol=1e-13)
+
+
+# ---- OctoFlat-v0: 8 arms + rigid head + joints (BASELINE config 5) ---------------------------------
+def test_k11_octopus_rest_joints_and_head_constraint(oracle_built):
+    cfg = _capi.octo_flat_config(1)
+    o = oracle_built.OracleOcto(cfg)
+    st = o.reset([1.0, 1.5])
+    assert st["individual"].shape == (8, 56) and st["shared"].shape == (13,)
+    # Cylinder(start=(0,0,-r0), length 2 r0, radius 0.04, density 700): mass and the
+    # rod-style inertia PyElastica gives a Cylinder
+    h = o.head()
+    r0, R = 0.007, 0.04
+    assert h["mass"] == pytest.approx(np.pi * R * R * 2 * r0 * 700.0, rel=1e-12)
+    assert h["J"][2] == pytest.approx(2 * (np.pi * R * R) ** 2 / (4 * np.pi) * 700.0 * 2 * r0, rel=1e-12)
+    np.testing.assert_allclose(h["x"], 0.0, atol=1e-18)
+    # zero action: everything stays put (joint springs relaxed, plane carries the weight)
+    o.substeps(1500)
+    assert np.abs(o.head()["v"]).max() < 1e-9
+    assert max(np.abs(o.arm(a).get("v")).max() for a in range(8)) < 1e-9
+    # the same curl on all arms: by the 8-fold symmetry the head neither translates nor turns,
+    # the arm bases stay on the rim (k = 1e6 spring), the head stays upright and planar
+    act = np.tile(np.array([6.0, 10.0, 4.0], np.float32), 8)
+    for _ in range(2):
+        obs, rew, term, trunc = o.env_step(act)
+    h = o.head()
+    assert not term and not trunc
+    assert np.abs(h["x"][:2]).max() < 1e-7 and h["x"][2] == 0.0
+    np.testing.assert_array_equal(h["Q"][2], [0.0, 0.0, 1.0])
+    assert h["w"][0] == 0.0 and h["w"][1] == 0.0 and h["v"][2] == 0.0
+    np.testing.assert_allclose(h["Q"] @ h["Q"].T, np.eye(3), atol=1e-12)
+    for a in range(8):
+        ang = np.deg2rad(45.0 * a)
+        rim = h["x"][:2] + 0.04 * (np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]) @ (-h["Q"][1][:2]))
+        base = o.arm(a).get("x")[:2, 0]
+        assert np.linalg.norm(base - rim) < 5e-6
+    # the arms really curled (rest curvature reached through friction)
+    assert np.abs(o.arm(0).get("kappa")[0]).max() > 3.0
+    assert o.crossings() == 0
+
+
+def test_k12_arm_crossing_count(oracle_built):
+    # utils/intersection.py on known polylines: flat_env.py:347-357 counts pairs (i-1, i) for
+    # i = 0..n_arm-2, so (last, 0), (0, 1), ... (n_arm-3, n_arm-2); pair (n_arm-2, n_arm-1) never
+    cfg = _capi.octo_flat_config(1)
+    o = oracle_built.OracleOcto(cfg)
+    o.reset([1.0, 1.0])
+    assert o.crossings() == 0
+    n = cfg.n_elem
+    s = np.linspace(0.0, 1.0, n + 1)
+    zig = np.zeros((3, n + 1))
+    zig[0] = 2.0 + s
+    zig[1] = 0.05 * (-1.0) ** np.arange(n + 1)          # zig-zag around y = 0: crosses a line 10 times
+    line = np.zeros((3, n + 1))
+    line[0] = 2.0 + s
+    line[1] = 0.013
+    o.arm(2).set("x", zig)
+    o.arm(3).set("x", line + np.array([[0.0], [0.0], [0.0]]))
+    assert o.crossings() == n                            # pair (2, 3): every zig segment crosses once
+    o.arm(6).set("x", zig)
+    o.arm(7).set("x", line)
+    assert o.crossings() == n                            # pair (6, 7) is never tested (reference quirk)
+    o.arm(0).set("x", zig + np.array([[5.0], [0.0], [0.0]]))
+    o.arm(7).set("x", line + np.array([[5.0], [0.0], [0.0]]))
+    assert o.crossings() == 2 * n                        # pair (7, 0) is tested (index -1 wraps)
