@@ -3,9 +3,11 @@ Gymnasium surface of gym-softrobot's SoftPendulum-v0 / SoftPendulum3D-v0 (DESIGN
 from . import _capi
 from .envs import (
     ArmSingleEnv,
+    FlatEnv,
     SoftPendulum3DEnv,
     SoftPendulumEnv,
     VecArmSingleEnv,
+    VecOctoFlatEnv,
     VecSoftPendulum3DEnv,
     VecSoftPendulumEnv,
 )
@@ -17,11 +19,15 @@ __version__ = "0.2.0"
 register(id="SoftPendulum-v0", entry_point=SoftPendulumEnv)
 register(id="SoftPendulum3D-v0", entry_point=SoftPendulum3DEnv)
 register(id="OctoArmSingle-v0", entry_point=ArmSingleEnv)
+# gym_softrobot/__init__.py:6-15
+register(id="OctoFlat-v0", entry_point=FlatEnv)
+register(id="OctoFlatLite-v0", entry_point=FlatEnv, kwargs=dict(n_arm=1, n_action=8))
 
 _VEC = {
     "SoftPendulum-v0": VecSoftPendulumEnv,
     "SoftPendulum3D-v0": VecSoftPendulum3DEnv,
     "OctoArmSingle-v0": VecArmSingleEnv,
+    "OctoFlat-v0": VecOctoFlatEnv,
 }
 
 
@@ -34,5 +40,5 @@ def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
 
 __all__ = [
     "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
-    "ArmSingleEnv", "VecArmSingleEnv", "make", "make_vec", "register", "registered", "_capi",
+    "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv", "make", "make_vec", "register", "registered", "_capi",
 ]

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -132,7 +132,7 @@ class SoftrodStateView(C.Structure):
         ("n_envs", C.c_int32),
         ("n_elem", C.c_int32),
         ("lane_stride", C.c_int32),
-        ("reserved", C.c_int32),
+        ("arm_stride", C.c_int32),
         ("position", C.c_void_p),
         ("velocity", C.c_void_p),
         ("director", C.c_void_p),
@@ -144,6 +144,7 @@ class SoftrodStateView(C.Structure):
         ("rest_kappa", C.c_void_p),
         ("env_memory", C.c_void_p),
         ("prev_action", C.c_void_p),
+        ("head", C.c_void_p),
     ]
 
 
@@ -306,6 +307,46 @@ def action_basis(n_elems: int, n_action: int = 7):
     return np.ascontiguousarray(np.stack(cols, axis=1), dtype=np.float64)
 
 
+def octo_action_basis(n_elems: int, n_knots: int = 3):
+    """W with rest_kappa[0,:] = W @ knots for FlatEnv.set_action (octopus/flat_env.py:288-311):
+    cubic `interp1d` through the knots padded with one zero at each end."""
+    import numpy as np
+    from scipy.interpolate import interp1d
+
+    x = np.linspace(0, 1, n_knots + 2)
+    xs = np.linspace(0, 1, n_elems - 1)
+    eye = np.concatenate([np.zeros((n_knots, 1)), np.eye(n_knots), np.zeros((n_knots, 1))], axis=-1)
+    w = interp1d(x, eye, kind="cubic", axis=-1)(xs)          # (n_knots, n_elems-1)
+    return np.ascontiguousarray(w.T, dtype=np.float64)
+
+
+def octo_arm_frames(n_arm: int, head_radius: float):
+    """Arm start points and directions of build_octopus (octopus/build.py:73-80)."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation as Rot
+
+    rotation_angle = 360 / n_arm
+    pos, dirs = [], []
+    for arm_i in range(n_arm):
+        rot = Rot.from_euler("z", rotation_angle * arm_i, degrees=True)
+        pos.append(rot.apply([head_radius, 0.0, 0.0]))
+        dirs.append(rot.apply([1.0, 0.0, 0.0]))
+    return np.ascontiguousarray(pos, np.float64), np.ascontiguousarray(dirs, np.float64)
+
+
+def config_action_dim(cfg: "SoftrodConfig") -> int:
+    if int(cfg.env_kind) == ENV_OCTO_FLAT:
+        return int(cfg.n_arm) * int(cfg.n_knots)
+    return action_dim(cfg.env_kind)
+
+
+def config_obs_dim(cfg: "SoftrodConfig") -> int:
+    if int(cfg.env_kind) == ENV_OCTO_FLAT:
+        n = int(cfg.n_elem)
+        return int(cfg.n_arm) * ((n - 1) + 4 * (n + 1) + int(cfg.n_knots)) + 13
+    return obs_dim(cfg.env_kind)
+
+
 class SoftrodError(RuntimeError):
     pass
 
@@ -320,6 +361,10 @@ _EXPORTS = {
     "softrod_config_softpendulum": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_softpendulum3d": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_arm_single": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_config_octo_flat": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_config_action_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),
+    "softrod_config_obs_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),
+    "softrod_reset_octo": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "softrod_set_action_basis": (C.c_int, [_VP, _VP]),
     "softrod_create": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "softrod_reset": (C.c_int, [_VP, _VP, _VP, _VP]),

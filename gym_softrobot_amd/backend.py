@@ -39,15 +39,19 @@ class HipRodBackend:
         self._lib = load_library()
         self.cfg = cfg.copy()
         self.n_envs = int(cfg.n_envs)
-        self.action_dim = _capi.action_dim(cfg.env_kind)
-        self.obs_dim = _capi.obs_dim(cfg.env_kind)
+        self.action_dim = _capi.config_action_dim(cfg)
+        self.obs_dim = _capi.config_obs_dim(cfg)
+        self.is_octo = bool(cfg.features & _capi.FEAT_OCTO_HEAD)
         self.aux_dim = _capi.aux_dim(cfg.env_kind)
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
         self._h = C.c_void_p()
         check(self._lib.softrod_create(C.byref(self.cfg), self.device_index, C.byref(self._h)))
         if self.cfg.features & _capi.FEAT_REST_KAPPA_ACTION:
-            basis = _capi.action_basis(int(cfg.n_elem), self.action_dim)
+            if self.is_octo:
+                basis = _capi.octo_action_basis(int(cfg.n_elem), int(cfg.n_knots))
+            else:
+                basis = _capi.action_basis(int(cfg.n_elem), self.action_dim)
             check(self._lib.softrod_set_action_basis(self._h, basis.ctypes.data), self._h)
         n = self.n_envs
         with torch.cuda.device(self.device):
@@ -105,6 +109,24 @@ class HipRodBackend:
         check(
             self._lib.softrod_reset_straight(
                 self._h, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                m.ctypes.data if m is not None else None, self._stream(),
+            ),
+            self._h,
+        )
+
+    def reset_octo(self, targets, mask: Optional[np.ndarray] = None) -> None:
+        """FlatEnv.reset: targets (n_envs, 2); the arm frames are build_octopus's."""
+        na = int(self.cfg.n_arm)
+        pos, dirs = _capi.octo_arm_frames(na, float(self.cfg.head_radius))
+        pos = np.ascontiguousarray(np.broadcast_to(pos, (self.n_envs, na, 3)))
+        dirs = np.ascontiguousarray(np.broadcast_to(dirs, (self.n_envs, na, 3)))
+        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, 2)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.n_envs)
+        check(
+            self._lib.softrod_reset_octo(
+                self._h, pos.ctypes.data, dirs.ctypes.data, tg.ctypes.data,
                 m.ctypes.data if m is not None else None, self._stream(),
             ),
             self._h,
@@ -197,7 +219,35 @@ class HipRodBackend:
             "kappa": view(v.kappa, 3),
             "rest_kappa": view(v.rest_kappa, 3),
             "env_memory": torch.as_tensor(_DevArray(v.env_memory, (n, s), "<f8", self), device=self.device),
-            "prev_action": torch.as_tensor(_DevArray(v.prev_action, (n, 7), "<f4", self), device=self.device),
+            "prev_action": torch.as_tensor(_DevArray(v.prev_action, (n, max(7, self.action_dim)), "<f4", self),
+                                           device=self.device),
+            "head": torch.as_tensor(_DevArray(v.head, (20, n), "<f8", self), device=self.device),
+            "arm_stride": int(v.arm_stride),
+        }
+
+    def octo_state_numpy(self) -> Dict[str, np.ndarray]:
+        """Host copy of an OctoFlat batch: arms as x,v (N,A,3,n+1), Q (N,A,3,3,n), w (N,A,3,n),
+        kappa/rest_kappa (N,A,3,n-1); head as x,v,w (N,3), Q (N,3,3); target (N,2); time (N,)."""
+        st = self.state()
+        ne, na, seg = int(self.cfg.n_elem), int(self.cfg.n_arm), int(st["arm_stride"])
+        torch.cuda.synchronize(self.device)
+
+        def arms(t, comps, width):
+            a = t[:, :, : na * seg].reshape(comps, self.n_envs, na, seg)[..., :width]
+            return a.permute(1, 2, 0, 3).cpu().numpy()
+
+        hd = st["head"].cpu().numpy()
+        return {
+            "x": arms(st["position"], 3, ne + 1),
+            "v": arms(st["velocity"], 3, ne + 1),
+            "w": arms(st["omega"], 3, ne),
+            "Q": arms(st["director"], 9, ne).reshape(self.n_envs, na, 3, 3, ne),
+            "kappa": arms(st["kappa"], 3, ne - 1),
+            "rest_kappa": arms(st["rest_kappa"], 3, ne - 1),
+            "head_x": hd[0:3].T.copy(), "head_v": hd[3:6].T.copy(),
+            "head_Q": hd[6:15].T.reshape(self.n_envs, 3, 3).copy(), "head_w": hd[15:18].T.copy(),
+            "target": hd[18:20].T.copy(),
+            "time": st["time"].cpu().numpy(),
         }
 
     def state_numpy(self) -> Dict[str, np.ndarray]:

@@ -23,6 +23,8 @@ struct softrod_handle {
     softrod_config cfg;
     int device = 0;
     int epl = 1;            // nodes/elements per lane: 1 (n_elem <= 63) or 2 (<= 126)
+    int nw = 1;             // wavefronts per env: 1, or ceil(n_arm*seg/64) for OctoFlat
+    size_t init_stride = 18;  // doubles of reset staging per env
     RodParams P{};
     StatePtrs S{};
     double* d_init = nullptr;     // [N][18] staging for reset
@@ -131,15 +133,45 @@ void fill_params(const softrod_config& c, RodParams& P) {
     P.slip_tol = c.slip_velocity_tol;
     P.surface_tol = c.surface_tol;
     P.r0_sqrt_rest_len = r * std::sqrt(rest_len);   // radius = sqrt(V/(pi l)) = r0 sqrt(l_rest/l)
+    if (c.features & SOFTROD_FEAT_OCTO_HEAD) {
+        // arms `seg` slots apart; Cylinder(length = 2 r0, radius = head_radius, density)
+        // (octopus/build.py:95-105; elastica/rigidbody/cylinder.py)
+        P.seg_shift = n <= 15 ? 4 : (n <= 31 ? 5 : 6);
+        P.seg = 1 << P.seg_shift;
+        P.n_arm = c.n_arm;
+        P.n_action = c.n_knots;
+        const double hl = 2.0 * c.base_radius, hr = c.head_radius;
+        const double harea = M_PI * hr * hr;
+        P.head_mass = (M_PI * hr * hr * hl) * c.head_density;
+        const double s1 = harea * harea / (4.0 * M_PI);
+        const double smoa[3] = {s1, s1, 2.0 * s1};
+        for (int i = 0; i < 3; ++i) {
+            P.head_J[i] = smoa[i] * c.head_density * hl;
+            P.head_invJ[i] = 1.0 / P.head_J[i];
+        }
+        P.head_radius = hr;
+        P.joint_k = c.joint_k;
+        P.joint_nu = c.joint_nu;
+        P.joint_kt = c.joint_kt;
+    }
 }
+
+bool is_octo(const softrod_handle* h) { return (h->cfg.features & SOFTROD_FEAT_OCTO_HEAD) != 0; }
 
 int launch_step(softrod_handle* h, const float* actions, float* obs, double* reward,
                 uint8_t* term, uint8_t* trunc, double* aux, int n_sub, int epilogue, int pack,
                 hipStream_t st) {
-    const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
+    const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes * h->nw);
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
-    if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
+    if (is_octo(h)) {
+        if (h->nw <= 2)
+            hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_OCTO_FLAT, 2>), grid, block, 0, st,
+                               h->P, h->S, actions, obs, reward, term, trunc, n_sub, epilogue, pack);
+        else
+            hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_OCTO_FLAT, 8>), grid, block, 0, st,
+                               h->P, h->S, actions, obs, reward, term, trunc, n_sub, epilogue, pack);
+    } else if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
         // instantiations specialised for the registered envs' feature sets (one or two
         // slots per lane); anything else (known-answer tests, custom feature mixes) takes
         // the run-time-mask instantiation
@@ -175,11 +207,14 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
 
 int upload_and_reset(softrod_handle* h, hipStream_t st, bool use_mask) {
     const size_t N = (size_t)h->cfg.n_envs;
-    SR_HIP(h, hipMemcpyAsync(h->d_init, h->h_init, N * 18 * sizeof(double), hipMemcpyHostToDevice, st));
+    SR_HIP(h, hipMemcpyAsync(h->d_init, h->h_init, N * h->init_stride * sizeof(double), hipMemcpyHostToDevice, st));
     if (use_mask)
         SR_HIP(h, hipMemcpyAsync(h->d_mask, h->h_mask, N, hipMemcpyHostToDevice, st));
     ResetArgs A{h->d_init, use_mask ? h->d_mask : nullptr};
-    if (h->epl == 2)
+    if (is_octo(h)) {
+        OctoResetArgs OA{h->d_init, h->d_init + N * (size_t)h->cfg.n_arm * 18, use_mask ? h->d_mask : nullptr};
+        hipLaunchKernelGGL(softrod_octo_reset_kernel, dim3((unsigned)N), dim3(kLanes * h->nw), 0, st, h->P, h->S, OA);
+    } else if (h->epl == 2)
         hipLaunchKernelGGL(softrod_reset_kernel<2>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
     else
         hipLaunchKernelGGL(softrod_reset_kernel<1>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
@@ -237,10 +272,21 @@ extern "C" {
 int softrod_abi_version(void) { return SOFTROD_ABI_VERSION; }
 
 int softrod_action_dim(int env_kind) {
-    return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 2 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 7 : 1;
+    return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 2 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 7
+         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 24 : 1;
 }
 int softrod_obs_dim(int env_kind) {
-    return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 9 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 25 : 4;
+    return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 9 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 25
+         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 8 * 56 + 13 : 4;
+}
+int softrod_config_action_dim(const softrod_config* cfg) {
+    if (!cfg) return 0;
+    return cfg->env_kind == SOFTROD_ENV_OCTO_FLAT ? cfg->n_arm * cfg->n_knots : softrod_action_dim(cfg->env_kind);
+}
+int softrod_config_obs_dim(const softrod_config* cfg) {
+    if (!cfg) return 0;
+    if (cfg->env_kind != SOFTROD_ENV_OCTO_FLAT) return softrod_obs_dim(cfg->env_kind);
+    return cfg->n_arm * ((cfg->n_elem - 1) + 4 * (cfg->n_elem + 1) + cfg->n_knots) + 13;
 }
 int softrod_aux_dim(int env_kind) { return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 1 : 0; }
 
@@ -314,6 +360,24 @@ int softrod_config_arm_single(softrod_config* cfg, int n_envs) {
     return SOFTROD_OK;
 }
 
+int softrod_config_octo_flat(softrod_config* cfg, int n_envs) {
+    const int rc = softrod_config_arm_single(cfg, n_envs);   // per-arm constants: build.py:30-49,134-200
+    if (rc != SOFTROD_OK) return rc;
+    cfg->features = SOFTROD_FEATURES_OCTO_FLAT;
+    cfg->env_kind = SOFTROD_ENV_OCTO_FLAT;
+    cfg->n_elem = 10;                                    // octopus/flat_env.py:62
+    cfg->final_time = 5.0;                               // :58
+    cfg->n_substeps = (int)(1.0 / (5 * cfg->dt));        // recording_fps = 5 (:60) -> 2857
+    cfg->n_arm = 8;                                      // :61
+    cfg->n_knots = 3;                                    // n_action (:63)
+    cfg->head_radius = 0.04;                             // octopus/build.py:95-105
+    cfg->head_density = 700.0;
+    cfg->joint_k = 1e6;                                  // :117-132
+    cfg->joint_nu = 1e-3;
+    cfg->joint_kt = 1e0;
+    return SOFTROD_OK;
+}
+
 int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) {
     if (!cfg || !out) return fail(nullptr, SOFTROD_EINVAL, "null argument");
     *out = nullptr;
@@ -328,8 +392,24 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "need n_substeps >= 0 and dt > 0");
     if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
-    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_ARM_SINGLE)
+    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_OCTO_FLAT)
         return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
+    const bool octo = (cfg->features & SOFTROD_FEAT_OCTO_HEAD) != 0;
+    if (octo != (cfg->env_kind == SOFTROD_ENV_OCTO_FLAT))
+        return fail(nullptr, SOFTROD_EINVAL, "SOFTROD_FEAT_OCTO_HEAD and SOFTROD_ENV_OCTO_FLAT go together");
+    if (octo) {
+        if (cfg->features != SOFTROD_FEATURES_OCTO_FLAT || cfg->math_mode != SOFTROD_MATH_FAST)
+            return fail(nullptr, SOFTROD_EINVAL,
+                        "OctoFlat exists for SOFTROD_FEATURES_OCTO_FLAT and SOFTROD_MATH_FAST only");
+        if (cfg->n_elem > kLanes - 1 || cfg->n_arm < 1 || cfg->n_knots < 1 || cfg->n_knots > cfg->n_elem ||
+            (cfg->n_elem - 1) * cfg->n_knots > 2 * kLanes * 7)
+            return fail(nullptr, SOFTROD_EINVAL, "OctoFlat needs n_elem <= 63, n_arm >= 1, 1 <= n_knots <= n_elem");
+        const int seg = cfg->n_elem <= 15 ? 16 : (cfg->n_elem <= 31 ? 32 : 64);
+        if (cfg->n_arm * seg > 8 * kLanes)
+            return fail(nullptr, SOFTROD_EINVAL, "OctoFlat: n_arm * slots-per-arm must not exceed 512");
+        if (!(cfg->head_radius > 0.0) || !(cfg->head_density > 0.0))
+            return fail(nullptr, SOFTROD_EINVAL, "OctoFlat needs head_radius > 0 and head_density > 0");
+    }
     if ((cfg->features & SOFTROD_FEAT_LAPLACE_FILTER) && (cfg->filter_order < 1 || cfg->n_elem < 3))
         return fail(nullptr, SOFTROD_EINVAL, "LaplaceDissipationFilter needs filter_order >= 1");
     {
@@ -351,7 +431,12 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     h->epl = cfg->n_elem > kLanes - 1 ? 2 : 1;
     fill_params(h->cfg, h->P);
     const size_t N = (size_t)cfg->n_envs;
-    const size_t rowb = N * kLanes * h->epl * sizeof(double);
+    if (octo) {
+        h->nw = (cfg->n_arm * h->P.seg + kLanes - 1) / kLanes;
+        h->init_stride = (size_t)cfg->n_arm * 18 + 2;
+    }
+    const size_t adim = (size_t)softrod_config_action_dim(cfg);
+    const size_t rowb = N * kLanes * h->epl * h->nw * sizeof(double);
     int rc = SOFTROD_OK;
     auto alloc = [&](void** p, size_t bytes) {
         if (rc != SOFTROD_OK) return;
@@ -370,12 +455,13 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     alloc((void**)&h->S.kap, 3 * rowb);
     alloc((void**)&h->S.rkap, 3 * rowb);
     alloc((void**)&h->S.envmem, rowb);
-    alloc((void**)&h->S.prev_action, N * 7 * sizeof(float));
+    alloc((void**)&h->S.prev_action, N * (adim > 7 ? adim : 7) * sizeof(float));
+    alloc((void**)&h->S.head, 20 * N * sizeof(double));
     alloc((void**)&h->d_basis, (size_t)2 * kLanes * 7 * sizeof(double));
     h->S.basis = h->d_basis;
-    alloc((void**)&h->d_init, N * 18 * sizeof(double));
+    alloc((void**)&h->d_init, N * h->init_stride * sizeof(double));
     alloc((void**)&h->d_mask, N);
-    if (rc == SOFTROD_OK && hipHostMalloc((void**)&h->h_init, N * 18 * sizeof(double)) != hipSuccess) rc = SOFTROD_ENOMEM;
+    if (rc == SOFTROD_OK && hipHostMalloc((void**)&h->h_init, N * h->init_stride * sizeof(double)) != hipSuccess) rc = SOFTROD_ENOMEM;
     if (rc == SOFTROD_OK && hipHostMalloc((void**)&h->h_mask, N) != hipSuccess) rc = SOFTROD_ENOMEM;
     if (rc == SOFTROD_OK && hipEventCreateWithFlags(&h->ev_reset, hipEventDisableTiming) != hipSuccess)
         rc = SOFTROD_EHIP;
@@ -387,8 +473,31 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     return SOFTROD_OK;
 }
 
+int softrod_reset_octo(softrod_handle* h, const double* arm_start, const double* arm_direction,
+                       const double* target, const uint8_t* mask, void* stream) {
+    if (!h || !arm_start || !arm_direction || !target) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (!is_octo(h)) return fail(h, SOFTROD_EINVAL, "softrod_reset_octo is for SOFTROD_ENV_OCTO_FLAT");
+    SR_HIP(h, hipSetDevice(h->device));
+    SR_HIP(h, hipEventSynchronize(h->ev_reset));
+    const int N = h->cfg.n_envs, na = h->cfg.n_arm;
+    const double normal[3] = {0.0, 0.0, 1.0};             // octopus/build.py:82
+    double* tgt = h->h_init + (size_t)N * na * 18;
+    for (int e = 0; e < N; ++e) {
+        if (mask) h->h_mask[e] = mask[e];
+        if (mask && !mask[e]) continue;
+        for (int a = 0; a < na; ++a) {
+            const size_t k = (size_t)e * na + a;
+            straight_init(h->cfg, arm_start + 3 * k, arm_direction + 3 * k, normal, h->h_init + k * 18);
+        }
+        tgt[2 * (size_t)e] = target[2 * (size_t)e];
+        tgt[2 * (size_t)e + 1] = target[2 * (size_t)e + 1];
+    }
+    return upload_and_reset(h, (hipStream_t)stream, mask != nullptr);
+}
+
 int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask, void* stream) {
     if (!h || !theta0) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat resets through softrod_reset_octo");
     SR_HIP(h, hipSetDevice(h->device));
     SR_HIP(h, hipEventSynchronize(h->ev_reset));  // previous upload out of the pinned buffers
     const int N = h->cfg.n_envs;
@@ -408,6 +517,7 @@ int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask, 
 int softrod_reset_straight(softrod_handle* h, const double* start, const double* direction,
                            const double* normal, const uint8_t* mask, void* stream) {
     if (!h || !start || !direction || !normal) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat resets through softrod_reset_octo");
     SR_HIP(h, hipSetDevice(h->device));
     SR_HIP(h, hipEventSynchronize(h->ev_reset));
     const int N = h->cfg.n_envs;
@@ -422,7 +532,7 @@ int softrod_reset_straight(softrod_handle* h, const double* start, const double*
 int softrod_set_action_basis(softrod_handle* h, const double* basis) {
     if (!h || !basis) return fail(h, SOFTROD_EINVAL, "null argument");
     SR_HIP(h, hipSetDevice(h->device));
-    const size_t bytes = (size_t)(h->cfg.n_elem - 1) * 7 * sizeof(double);
+    const size_t bytes = (size_t)(h->cfg.n_elem - 1) * (is_octo(h) ? h->cfg.n_knots : 7) * sizeof(double);
     SR_HIP(h, hipMemcpy(h->d_basis, basis, bytes, hipMemcpyHostToDevice));
     h->basis_set = true;
     return SOFTROD_OK;
@@ -465,7 +575,10 @@ int softrod_observe(softrod_handle* h, const float* prev_action, float* obs, voi
     if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no observation");
     SR_HIP(h, hipSetDevice(h->device));
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
-    if (h->epl == 2)
+    if (is_octo(h))
+        hipLaunchKernelGGL(softrod_octo_observe_kernel, grid, dim3(kLanes * h->nw), 0, (hipStream_t)stream,
+                           h->P, h->S, prev_action, obs);
+    else if (h->epl == 2)
         hipLaunchKernelGGL(softrod_observe_kernel<2>, grid, block, 0, (hipStream_t)stream, h->P, h->S,
                            prev_action, obs);
     else
@@ -479,8 +592,8 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     if (!h || !out) return fail(h, SOFTROD_EINVAL, "null argument");
     out->n_envs = h->cfg.n_envs;
     out->n_elem = h->cfg.n_elem;
-    out->lane_stride = kLanes * h->epl;
-    out->reserved = 0;
+    out->lane_stride = kLanes * h->epl * h->nw;
+    out->arm_stride = is_octo(h) ? h->P.seg : 0;
     out->position = h->S.pos;
     out->velocity = h->S.vel;
     out->director = h->S.dir;
@@ -492,6 +605,7 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->rest_kappa = h->S.rkap;
     out->env_memory = h->S.envmem;
     out->prev_action = h->S.prev_action;
+    out->head = h->S.head;
     return SOFTROD_OK;
 }
 
@@ -543,7 +657,7 @@ int softrod_destroy(softrod_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->d_basis, h->d_init, h->d_mask};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_basis, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

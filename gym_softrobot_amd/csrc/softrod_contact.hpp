@@ -56,7 +56,7 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
     }
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const int idx = lane * EPL + s;
+        const int idx = slot_local(P, lane * EPL + s);
         const bool first = (idx == 0), last = (idx == n - 1);
         radius[s] = C.r0_sqrt_rest_len / sqrt(len[s]);
         double fel[3];
@@ -158,7 +158,7 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
     // static friction
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const int idx = lane * EPL + s;
+        const int idx = slot_local(P, lane * EPL + s);
         const bool first = (idx == 0), last = (idx == n - 1);
         double fel[3];
 #pragma unroll

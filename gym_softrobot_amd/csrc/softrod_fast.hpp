@@ -136,10 +136,18 @@ __device__ __forceinline__ void kinematic_n(double h, const ConstN<EPL>& C, Lane
     }
 }
 
+// Connections (joints) plug in between the internal loads and the contact operator, in
+// the registration order of build_octopus (octopus/build.py:117-200).
+struct NoConnections {
+    template <int EPL>
+    __device__ __forceinline__ void operator()(double (&)[EPL][3], double (&)[EPL][3], const LaneN<EPL>&,
+                                               const double (&)[EPL][3]) const {}
+};
+
 // ---- forces, torques, rate update, dampers, constrain_rates -------------------------------------
-template <unsigned F, int EPL>
+template <unsigned F, int EPL, class Connections = NoConnections>
 __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>& C, const BcTargets& B,
-                                          int lane, LaneN<EPL>& L) {
+                                          int lane, LaneN<EPL>& L, Connections&& connect = Connections()) {
     const int n = P.n_elem;
     double xn[EPL][3], vn[EPL][3], d[EPL][3];
     double len[EPL], il[EPL], e[EPL], ie[EPL];
@@ -159,7 +167,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
     // geometry, shear/stretch stress in the lab frame
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const bool elem_valid = (lane * EPL + s) < n;
+        const bool elem_valid = slot_local<F>(P, lane * EPL + s) < n;
 #pragma unroll
         for (int c = 0; c < 3; ++c) d[s][c] = xn[s][c] - L.x[s][c];
         double dd = fma(d[s][2], d[s][2], fma(d[s][1], d[s][1], d[s][0] * d[s][0]));
@@ -208,7 +216,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
     double up[EPL][3], um[EPL][3];
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const bool vor_valid = (lane * EPL + s) < n - 1;
+        const bool vor_valid = slot_local<F>(P, lane * EPL + s) < n - 1;
         const double* Q = L.Q[s];
         const double* N_ = Qn[s];
 #define SR_RD(i, j) fma(N_[3 * (i) + 2], Q[3 * (j) + 2], fma(N_[3 * (i) + 1], Q[3 * (j) + 1], \
@@ -276,12 +284,13 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         tq[s][1] = fma(js01, w[1], tq[s][1]);
         tq[s][2] = fma(js2, w[2], tq[s][2]);
     }
+    connect(f, tq, L, xn);
     // plane contact
     if (has<F>(P, SOFTROD_FEAT_PLANE_CONTACT_ANISO)) {
         double Fg[EPL][3], fc[EPL][3];
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
-            const bool node_valid = (lane * EPL + s) <= n;
+            const bool node_valid = slot_local<F>(P, lane * EPL + s) <= n;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 Fg[s][c] = f[s][c];
@@ -298,7 +307,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
     // rate update fused with the analytical damper
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const bool elem_valid = (lane * EPL + s) < n;
+        const bool elem_valid = slot_local<F>(P, lane * EPL + s) < n;
 #pragma unroll
         for (int c = 0; c < 3; ++c) L.v[s][c] = fma(P.damp_t, L.v[s][c], fma(C.cf[s], f[s][c], C.ca[s][c]));
         const double ce01 = C.cw01[s] * e[s], ce2 = C.cw2[s] * e[s];

@@ -73,6 +73,10 @@ struct RodParams {
     double contact_k, contact_nu, slip_tol, surface_tol;
     double kin_mu[3], stat_mu[3];
     double r0_sqrt_rest_len;         // radius_k = r0 sqrt(l_rest / l_k)  (volume preserving)
+    // OctoFlat-v0: n_arm rods per wave, `seg` slots apart (0 = one rod per wave), + rigid head
+    int seg, n_arm, seg_shift, pad1;
+    double head_mass, head_J[3], head_invJ[3], head_radius;
+    double joint_k, joint_nu, joint_kt;
 };
 
 struct StatePtrs {
@@ -90,6 +94,7 @@ struct StatePtrs {
     float* prev_action;   // [N][7]   the env's _prev_action (soft_pendulum.py:97-99,165)
     double* envmem;       // [N][64]  ArmSingle prev_kappa_state
     const double* basis;  // [(n_elem-1)][n_action]  rest_kappa[0,:] = basis @ action
+    double* head;  // [20][N]  OctoFlat rigid head: x[3], v[3], Q[9], w[3], target[2]
 };
 
 // ---------------------------------------------------------------------------------
@@ -136,6 +141,21 @@ template <int E>
 __device__ __forceinline__ int env_of(const RodParams& P) {
     if constexpr (E == kRuntimeEnv) return P.env_kind;
     else return E;
+}
+// Index of a slot inside its rod.  One rod per wave: the slot index itself.  OctoFlat packs
+// n_arm rods `seg` slots apart (seg a power of two; the slots between an arm's last node and
+// the next arm's first are ghosts with zero stiffness — PyElastica's own memory-block idea;
+// slots past the last arm get an index beyond every rod so that all validity tests fail).
+// For OctoFlat `raw` is the slot index within the env's block of waves (threadIdx.x).
+template <unsigned F = kRuntimeFeatures>
+__device__ __forceinline__ int slot_local(const RodParams& P, int raw) {
+    if constexpr (F != kRuntimeFeatures) {
+        if constexpr ((F & SOFTROD_FEAT_OCTO_HEAD) != 0)
+            return (raw & (P.seg - 1)) | (raw >= P.n_arm * P.seg ? (1 << 20) : 0);
+        else return raw;
+    } else {
+        return P.seg ? ((raw & (P.seg - 1)) | (raw >= P.n_arm * P.seg ? (1 << 20) : 0)) : raw;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -302,7 +322,7 @@ __device__ __forceinline__ void laplace_filter_rates_n(const RodParams& P, int l
     double qn[EPL], qe[EPL];
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const int idx = lane * EPL + s;
+        const int idx = slot_local(P, lane * EPL + s);
         qn[s] = (idx >= 1 && idx <= n - 1) ? 0.25 : 0.0;
         qe[s] = (idx >= 1 && idx <= n - 2) ? 0.25 : 0.0;
     }
@@ -311,7 +331,7 @@ __device__ __forceinline__ void laplace_filter_rates_n(const RodParams& P, int l
         double rv[EPL], rw[EPL];
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
-            const int idx = lane * EPL + s;
+            const int idx = slot_local(P, lane * EPL + s);
             rv[s] = (idx <= n) ? L.v[s][c] : 0.0;
             rw[s] = (idx < n) ? L.w[s][c] : 0.0;
         }
@@ -319,7 +339,7 @@ __device__ __forceinline__ void laplace_filter_rates_n(const RodParams& P, int l
         laplace_filter_n<EPL>(rw, qe, P.filter_order);
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
-            const int idx = lane * EPL + s;
+            const int idx = slot_local(P, lane * EPL + s);
             L.v[s][c] = (idx <= n) ? rv[s] : L.v[s][c];
             L.w[s][c] = (idx < n) ? rw[s] : L.w[s][c];
         }
@@ -354,7 +374,7 @@ __device__ __forceinline__ void sum_tangents(const RodParams& P, int lane, const
     for (int c = 0; c < 3; ++c) {
         double p = 0.0;
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) p += ((lane * EPL + s) < P.n_elem) ? L.t[s][c] : 0.0;
+        for (int s = 0; s < EPL; ++s) p += (slot_local(P, lane * EPL + s) < P.n_elem) ? L.t[s][c] : 0.0;
         tm[c] = wave_sum(p) / (double)P.n_elem;
     }
 }
@@ -366,7 +386,8 @@ __device__ __forceinline__ void com_xy_n(const RodParams& P, const ConstN<EPL>& 
     for (int c = 0; c < 2; ++c) {
         double p = 0.0;
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) p += ((lane * EPL + s) <= P.n_elem) ? C.mass[s] * L.x[s][c] : 0.0;
+        for (int s = 0; s < EPL; ++s)
+            p += (slot_local(P, lane * EPL + s) <= P.n_elem) ? C.mass[s] * L.x[s][c] : 0.0;
         com[c] = wave_sum(p) / P.mass_total;
     }
 }
@@ -511,7 +532,7 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
         bool b = false;
 #pragma unroll
         for (int c = 0; c < 3; ++c) b = b || isnan(L.x[s][c]) || isnan(L.v[s][c]);
-        bad = bad || (((lane * EPL + s) <= P.n_elem) && b);
+        bad = bad || ((slot_local(P, lane * EPL + s) <= P.n_elem) && b);
     }
     const bool invalid = __any(bad);
     const int env = env_of<E>(P);
@@ -540,7 +561,7 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
         double pw = 0.0;
 #pragma unroll
         for (int s = 0; s < EPL; ++s)
-            pw += ((lane * EPL + s) < P.n_elem)
+            pw += (slot_local(P, lane * EPL + s) < P.n_elem)
                       ? L.w[s][0] * L.w[s][0] + L.w[s][1] * L.w[s][1] + L.w[s][2] * L.w[s][2] : 0.0;
         const bool blown = invalid || (sqrt(wave_sum(pw)) > 250.0);
         double com[2];
@@ -588,7 +609,7 @@ __device__ __forceinline__ void build_const(const RodParams& P, int lane, const 
     const double ct = damp ? P.damp_t : 1.0;
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const int idx = lane * EPL + s;
+        const int idx = slot_local<F>(P, lane * EPL + s);
         const bool first = (idx == 0);
         const bool held_q = first && has<F>(P, SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_FIXED_BC |
                                                SOFTROD_FEAT_MOVING_BASE_BC);
@@ -1002,3 +1023,4 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
 }  // namespace softrod
 
 #include "softrod_fast.hpp"
+#include "softrod_octo.hpp"

@@ -1,0 +1,449 @@
+// softrod_octo.hpp — OctoFlat-v0: n_arm Cosserat rods joined to one rigid head, one env per
+// workgroup (BASELINE.json configs[4]).
+//
+// What it restates, and from where (each mirrored by oracle/octoflat_oracle.inc.c):
+//   build_octopus                      gym_softrobot/envs/octopus/build.py:52-217
+//   FixedJoint2Rigid                   gym_softrobot/utils/custom_elastica/joint.py:20-225
+//   BodyBoundaryCondition              gym_softrobot/utils/custom_elastica/constraint.py:8-85
+//   intersection (arm crossing)        gym_softrobot/utils/intersection.py:12-77
+//   FlatEnv get_state/set_action/step  gym_softrobot/envs/octopus/flat_env.py:231-408
+//   Cylinder / RigidBodyBase           pyelastica==1.0.0 (recalled, not on disk)
+//
+// Mapping.  The arms of one env sit `seg` slots apart (seg = 16 for the reference's 10
+// elements per arm) in a block of nw = ceil(n_arm*seg/64) wavefronts, ONE NODE PER LANE, so
+// the whole rod machinery of softrod_fast.hpp (DPP stencils, fused damper, contact) runs
+// unchanged: an arm never straddles a wavefront and the ghost slots between arms carry no
+// stiffness, no mass coefficient and no contact.  The rigid head (x, v, Q, w: 18 doubles)
+// is replicated in registers of every lane.  Per substep the only cross-arm traffic is the
+// head's net joint force/torque: two xor-shuffles inside each wave, 6 doubles per wave
+// through LDS (double-buffered, ONE s_barrier per substep), then every lane integrates the
+// same head with the same operands, so the replicas stay bit-identical.
+//
+// State rows: the env's slots are rows [env*nw + wave][64] of the SoA arrays (the generic
+// one-rod-per-wave layout with N*nw rows); arm a = slots a*seg .. a*seg+n_elem.
+#pragma once
+
+namespace softrod {
+
+struct HeadState {
+    double x[3], v[3], Q[9], w[3];
+};
+
+__device__ __forceinline__ void load_head(const StatePtrs& S, size_t N, int env, HeadState& H, double tgt[2]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        H.x[i] = S.head[(size_t)i * N + env];
+        H.v[i] = S.head[(size_t)(3 + i) * N + env];
+        H.w[i] = S.head[(size_t)(15 + i) * N + env];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H.Q[i] = S.head[(size_t)(6 + i) * N + env];
+    tgt[0] = S.head[(size_t)18 * N + env];
+    tgt[1] = S.head[(size_t)19 * N + env];
+}
+
+__device__ __forceinline__ void store_head(const StatePtrs& S, size_t N, int env, const HeadState& H) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        S.head[(size_t)i * N + env] = H.x[i];
+        S.head[(size_t)(3 + i) * N + env] = H.v[i];
+        S.head[(size_t)(15 + i) * N + env] = H.w[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) S.head[(size_t)(6 + i) * N + env] = H.Q[i];
+}
+
+// Kinematic half/full step of the rigid body followed by
+// BodyBoundaryCondition.compute_contrain_values (constraint.py:41-58): z held, d3 = e_z,
+// d1 and d2 renormalised in the plane.  Position z never moves because constrain_rates
+// keeps v_z = 0, so it is not rewritten.
+__device__ __forceinline__ void head_kinematic(double h, HeadState& H) {
+    LaneN<1> T;
+    ConstN<1> C1;
+    C1.hx[0] = 1.0; C1.hq[0] = 1.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { T.x[0][i] = H.x[i]; T.v[0][i] = H.v[i]; T.w[0][i] = H.w[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T.Q[0][i] = H.Q[i];
+    kinematic_n<1>(h, C1, T);
+    H.x[0] = T.x[0][0]; H.x[1] = T.x[0][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double a = T.Q[0][3 * i], b = T.Q[0][3 * i + 1];
+        const double inv = fast_rsqrt(fma(a, a, b * b));
+        H.Q[3 * i] = a * inv; H.Q[3 * i + 1] = b * inv; H.Q[3 * i + 2] = 0.0;
+    }
+    H.Q[6] = 0.0; H.Q[7] = 0.0; H.Q[8] = 1.0;
+}
+
+// np.linalg.solve on the 4x4 system of utils/intersection.py:60-66 — LU with partial
+// pivoting, fully unrolled so that every index is a compile-time constant (registers, no
+// scratch).  Returns false for a singular matrix (numpy raises LinAlgError; the reference
+// would crash there, the oracle skips the pair).
+__device__ __forceinline__ bool solve4_t01(double (&A)[4][4], double (&b)[4], double& t0, double& t1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int m = k;
+        double best = fabs(A[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) {
+            const double v = fabs(A[i][k]);
+            if (v > best) { best = v; m = i; }
+        }
+        if (best == 0.0) return false;
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) {
+            if (m == i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const double t = A[k][j]; A[k][j] = A[i][j]; A[i][j] = t; }
+                const double t = b[k]; b[k] = b[i]; b[i] = t;
+            }
+        }
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) {
+            const double f = A[i][k] / A[k][k];
+#pragma unroll
+            for (int j = k; j < 4; ++j) A[i][j] -= f * A[k][j];
+            b[i] -= f * b[k];
+        }
+    }
+    double x[4];
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        double s = b[i];
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) s -= A[i][j] * x[j];
+        x[i] = s / A[i][i];
+    }
+    t0 = x[0]; t1 = x[1];
+    return true;
+}
+
+// FlatEnv.get_state (centralized), flat_env.py:231-286.
+//   individual[arm] = [kappa0 (n-1) | x - cx (n+1) | y - cy (n+1) | vx (n+1) | vy (n+1) | prev_action (nk)]
+//   shared          = [target - head_xy | head v_xy | head directors (9)]
+__device__ __forceinline__ void octo_write_obs(const RodParams& P, int tid, const LaneN<1>& L,
+                                               const HeadState& H, const double tgt[2],
+                                               const float* __restrict__ prev_action,
+                                               float* __restrict__ o) {
+    const int n = P.n_elem, nk = P.n_action;
+    const int width = (n - 1) + 4 * (n + 1) + nk;
+    const int r = tid & (P.seg - 1), arm = tid >> P.seg_shift;
+    if (arm < P.n_arm) {
+        float* row = o + (size_t)arm * width;
+        if (r < n - 1) row[r] = (float)L.kap[0][0];
+        if (r <= n) {
+            row[(n - 1) + r] = (float)(L.x[0][0] - H.x[0]);
+            row[(n - 1) + (n + 1) + r] = (float)(L.x[0][1] - H.x[1]);
+            row[(n - 1) + 2 * (n + 1) + r] = (float)L.v[0][0];
+            row[(n - 1) + 3 * (n + 1) + r] = (float)L.v[0][1];
+        }
+        if (r < nk) row[(n - 1) + 4 * (n + 1) + r] = prev_action[arm * nk + r];
+    }
+    if (tid == 0) {
+        float* sh = o + (size_t)P.n_arm * width;
+        sh[0] = (float)(tgt[0] - H.x[0]);
+        sh[1] = (float)(tgt[1] - H.x[1]);
+        sh[2] = (float)H.v[0];
+        sh[3] = (float)H.v[1];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sh[4 + i] = (float)H.Q[i];
+    }
+}
+
+__device__ __forceinline__ int octo_obs_dim(const RodParams& P) {
+    return P.n_arm * ((P.n_elem - 1) + 4 * (P.n_elem + 1) + P.n_action) + 13;
+}
+
+// ---------------------------------------------------------------------------------
+// One env.step (or n_sub bare substeps) of every env of the shard.
+// grid = n_envs, block = 64*nw threads.  MAXW bounds nw for the register allocator.
+// ---------------------------------------------------------------------------------
+template <unsigned F, int MAXW>
+__global__ void __launch_bounds__(kLanes * MAXW, 2)
+softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
+                         float* __restrict__ obs, double* __restrict__ reward,
+                         uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
+                         const int n_sub, const int epilogue, const int pack) {
+    __shared__ double xch[2][MAXW][6];
+    __shared__ double sxy[kLanes * MAXW][2];
+    __shared__ int scount;
+
+    const int env = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    const size_t N = (size_t)P.n_envs, NR = N * (size_t)nw;
+    const int row = env * nw + wave;
+    const int n = P.n_elem, nk = P.n_action;
+    const int r = tid & (P.seg - 1), arm = tid >> P.seg_shift;
+    const bool arm_ok = arm < P.n_arm;
+
+    LaneN<1> L;
+    load_lane<1, F>(S, NR, row, lane, L);
+    HeadState H;
+    double tgt[2];
+    load_head(S, N, env, H, tgt);
+    const double before[2] = {H.x[0], H.x[1]};
+
+    // set_action (flat_env.py:288-311): rest_kappa[0,:] = zero-padded cubic interp1d of the
+    // arm's knots = basis @ knots
+    if (actions) {
+        double rk0 = 0.0;
+        if (arm_ok && r < n - 1) {
+            const float* a = actions + (size_t)env * (P.n_arm * nk) + arm * nk;
+            for (int j = 0; j < nk; ++j) rk0 += S.basis[r * nk + j] * (double)a[j];
+        }
+        L.rk[0][0] = rk0;
+        S.rkap[(size_t)row * kLanes + lane] = rk0;
+    }
+
+    // joint frame of this arm: z_rotation(head d2, 360/n_arm * arm degrees), joint.py:66-71
+    const bool base = arm_ok && r == 0;
+    const double ang = (360.0 / (double)P.n_arm * (double)arm) / 180.0 * M_PI;
+    const double ct = cos(ang), st = sin(ang);
+
+    EnvAction A;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
+    A.force = 0.0;
+    ConstN<1> C;
+    build_const<F, 1>(P, tid, A, C);
+    BcTargets B;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { B.pos[i] = 0.0; B.vel[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) B.Q[i] = 0.0;
+    RodParams Pk = P;
+    if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
+    const double head_inv_mass = 1.0 / P.head_mass;
+
+    double time = S.time[env];
+    int parity = 0;
+
+    auto connect = [&](double (&f)[1][3], double (&tq)[1][3], const LaneN<1>& Lc, const double (&xn)[1][3]) {
+        // FixedJoint2Rigid.apply_forces (joint.py:48-123): spring + normal damping between the
+        // arm's node 0 and the point head_radius along the arm's direction from the head axis
+        const double b0 = H.Q[3], b1 = H.Q[4], b2 = H.Q[5];
+        const double dir[3] = {-(ct * b0 - st * b1), -(st * b0 + ct * b1), -b2};
+        const double pos[3] = {fma(dir[0], P.head_radius, H.x[0]), fma(dir[1], P.head_radius, H.x[1]),
+                               dir[2] * P.head_radius};
+        double dv[3], d2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { dv[i] = Lc.x[0][i] - pos[i]; d2 = fma(dv[i], dv[i], d2); }
+        const bool apart = d2 > (2.220446049250313e-12 * 2.220446049250313e-12);
+        const double idist = apart ? fast_rsqrt(d2) : 0.0;
+        double nv[3], rel = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { nv[i] = dv[i] * idist; rel = fma(Lc.v[0][i] - H.v[i], nv[i], rel); }
+        double fj[3], link[3], force[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            fj[i] = fma(P.joint_k, dv[i], -P.joint_nu * (rel * nv[i]));
+            link[i] = xn[0][i] - Lc.x[0][i];
+            // apply_torques (joint.py:125-219): node 1 pulled towards its rest place on the ray
+            force[i] = -P.joint_kt * (xn[0][i] - fma(P.rest_len, dir[i], pos[i]));
+        }
+        const double tj[3] = {link[1] * force[2] - link[2] * force[1], link[2] * force[0] - link[0] * force[2],
+                              link[0] * force[1] - link[1] * force[0]};
+        double red[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            red[i] = base ? fj[i] : 0.0;
+            red[3 + i] = base ? tj[i] : 0.0;
+            f[0][i] -= red[i];
+            const double* Q = Lc.Q[0];
+            tq[0][i] += base ? fma(Q[3 * i + 2], tj[2], fma(Q[3 * i + 1], tj[1], Q[3 * i] * tj[0])) : 0.0;
+        }
+        // net load on the head: arms of this wave, then the waves of the env through LDS
+        for (int off = 32; off >= P.seg; off >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) red[i] += __shfl_xor(red[i], off);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xch[parity][wave][i] = red[i];
+        }
+        __syncthreads();
+        double tot[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int w = 0; w < nw; ++w) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tot[i] += xch[parity][w][i];
+        }
+        parity ^= 1;
+        // RigidBodyBase.update_accelerations + the rate update, then
+        // BodyBoundaryCondition.compute_constrain_rates (constraint.py:60-85)
+        const double* Qh = H.Q;
+        double th[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            th[i] = -fma(Qh[3 * i + 2], tot[5], fma(Qh[3 * i + 1], tot[4], Qh[3 * i] * tot[3]));
+        const double jw[3] = {P.head_J[0] * H.w[0], P.head_J[1] * H.w[1], P.head_J[2] * H.w[2]};
+        const double lt[3] = {jw[1] * H.w[2] - jw[2] * H.w[1], jw[2] * H.w[0] - jw[0] * H.w[2],
+                              jw[0] * H.w[1] - jw[1] * H.w[0]};
+        H.v[0] = fma(P.dt, tot[0] * head_inv_mass, H.v[0]);
+        H.v[1] = fma(P.dt, tot[1] * head_inv_mass, H.v[1]);
+        H.v[2] = 0.0;
+        H.w[0] = 0.0;
+        H.w[1] = 0.0;
+        H.w[2] = fma(P.dt, P.head_invJ[2] * (lt[2] + th[2]), H.w[2]);
+    };
+
+    if (n_sub > 0) {
+        kinematic_n<1>(P.half_dt, C, L);
+        head_kinematic(P.half_dt, H);
+        if (P.time_two_half_adds) time += P.half_dt;
+        for (int s = 0; s < n_sub; ++s) {
+            dynamic_n<F, 1>(Pk, C, B, tid, L, connect);
+            const bool last = (s == n_sub - 1);
+            const double h = last ? P.half_dt : P.dt;
+            kinematic_n<1>(h, C, L);
+            head_kinematic(h, H);
+            time += P.time_two_half_adds ? P.half_dt : P.dt;
+            if (!last && P.time_two_half_adds) time += P.half_dt;
+        }
+    }
+    store_lane<1, F>(S, NR, row, lane, L);
+    if (tid == 0) {
+        S.time[env] = time;
+        store_head(S, N, env, H);
+    }
+    if (!epilogue) return;
+
+    // ---- FlatEnv.step epilogue, flat_env.py:330-408 ----
+    const int adim = P.n_arm * nk;
+    if (tid < adim) S.prev_action[(size_t)env * adim + tid] = actions[(size_t)env * adim + tid];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bad = bad || isnan(L.x[0][c]) || isnan(L.v[0][c]);
+    bad = bad && arm_ok && r <= n;
+    sxy[tid][0] = L.x[0][0];
+    sxy[tid][1] = L.x[0][1];
+    if (tid == 0) scount = 0;
+    const int invalid = __syncthreads_or(bad ? 1 : 0);
+    // arm crossings: pairs (i-1, i) for i = 0..n_arm-2, index -1 wrapping to the last arm
+    int cnt = 0;
+    const int per = n * n, total = (P.n_arm - 1) * per;
+    for (int q = tid; q < total; q += blockDim.x) {
+        const int i = q / per, rem = q - i * per;
+        const int ii = rem / n, jj = rem - ii * n;
+        const int a1 = (i - 1 + P.n_arm) % P.n_arm, a2 = i;
+        const int s1 = a1 * P.seg + ii, s2 = a2 * P.seg + jj;
+        const double x1a = sxy[s1][0], x1b = sxy[s1 + 1][0], y1a = sxy[s1][1], y1b = sxy[s1 + 1][1];
+        const double x2a = sxy[s2][0], x2b = sxy[s2 + 1][0], y2a = sxy[s2][1], y2b = sxy[s2 + 1][1];
+        const bool c1 = fmin(x1a, x1b) <= fmax(x2a, x2b);
+        const bool c2 = fmax(x1a, x1b) >= fmin(x2a, x2b);
+        const bool c3 = fmin(y1a, y1b) <= fmax(y2a, y2b);
+        const bool c4 = fmax(y1a, y1b) >= fmin(y2a, y2b);
+        if (!(c1 && c2 && c3 && c4)) continue;
+        double M[4][4] = {{x1b - x1a, 0.0, -1.0, 0.0}, {0.0, x2b - x2a, -1.0, 0.0},
+                          {y1b - y1a, 0.0, 0.0, -1.0}, {0.0, y2b - y2a, 0.0, -1.0}};
+        double bv[4] = {-x1a, -x2a, -y1a, -y2a};
+        double t0, t1;
+        if (!solve4_t01(M, bv, t0, t1)) continue;
+        if (t0 >= 0.0 && t1 >= 0.0 && t0 <= 1.0 && t1 <= 1.0) ++cnt;
+    }
+    if (cnt) atomicAdd(&scount, cnt);
+    __syncthreads();
+    const int od = octo_obs_dim(P);
+    float* o = out_row(obs, env, od, pack);
+    if (tid == 0) {
+        const double tx = tgt[0] - H.x[0], ty = tgt[1] - H.x[1];
+        const double dist = sqrt(tx * tx + ty * ty);
+        double survive = 0.0, forward = 0.0;
+        bool term = false;
+        if (invalid) { term = true; survive = -50.0; }
+        else {
+            survive = -0.02 * (double)scount;
+            const double bx = tgt[0] - before[0], by = tgt[1] - before[1];
+            forward = (dist - sqrt(bx * bx + by * by)) / P.step_time;
+            if (dist < 0.1) { survive = 100.0; term = true; }
+        }
+        double rew = forward - 0.0 + survive - 0.0;
+        if (term) rew -= dist - 0.1;
+        emit_scalars(o, od, pack, env, rew, term, time > P.final_time, reward, terminated, truncated);
+    }
+    octo_write_obs(P, tid, L, H, tgt, actions + (size_t)env * adim, o);
+}
+
+// get_state after reset (or at any time): prev_action = the resident copy unless given.
+__global__ void __launch_bounds__(1024)
+softrod_octo_observe_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ prev_action,
+                            float* __restrict__ obs) {
+    const int env = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    const size_t N = (size_t)P.n_envs, NR = N * (size_t)nw;
+    LaneN<1> L;
+    load_lane<1, kRuntimeFeatures>(S, NR, env * nw + wave, lane, L);
+    HeadState H;
+    double tgt[2];
+    load_head(S, N, env, H, tgt);
+    const int adim = P.n_arm * P.n_action;
+    const float* pa = (prev_action ? prev_action : S.prev_action) + (size_t)env * adim;
+    octo_write_obs(P, tid, L, H, tgt, pa, obs + (size_t)env * octo_obs_dim(P));
+}
+
+// FlatEnv.reset -> build_octopus (octopus/build.py:52-217).
+//   init[env][arm][18]  straight_rod description of each arm (start, step, end, Q rows)
+//   target[env][2]      (2 - 0.5) * np_random.random(2) + 0.5, flat_env.py:221
+// The head is Cylinder(start=(0,0,-r0), direction=e_z, normal=e_y, length 2 r0) (:103-105):
+// centre (0,0,0), directors rows e_y, e_z x e_y = -e_x, e_z; finalize() applies the head
+// constraint once, which leaves these exact values unchanged.
+struct OctoResetArgs {
+    const double* init;
+    const double* target;
+    const uint8_t* mask;
+};
+
+__global__ void __launch_bounds__(1024)
+softrod_octo_reset_kernel(const RodParams P, const StatePtrs S, const OctoResetArgs A) {
+    const int env = blockIdx.x;
+    if (A.mask && !A.mask[env]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nw = blockDim.x >> 6;
+    const size_t N = (size_t)P.n_envs, NR = N * (size_t)nw;
+    const int row = env * nw + wave;
+    const int n = P.n_elem;
+    const int r = tid & (P.seg - 1);
+    int arm = tid >> P.seg_shift;
+    if (arm >= P.n_arm) arm = P.n_arm - 1;   // slots past the last arm: finite filler
+    const double* in = A.init + ((size_t)env * P.n_arm + arm) * 18;
+    LaneN<1> L;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double xv = in[c] + (double)r * in[3 + c];
+        if (r == n) xv = in[6 + c];
+        L.x[0][c] = xv;
+        L.v[0][c] = 0.0; L.w[0][c] = 0.0; L.kap[0][c] = 0.0; L.rk[0][c] = 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) L.Q[0][c] = in[9 + c];
+    double len2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        L.t[0][c] = from_next(L.x[0][c]) - L.x[0][c];
+        len2 += L.t[0][c] * L.t[0][c];
+    }
+    const double len = sqrt(len2) + P.eps_length;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L.t[0][c] /= len;
+    store_lane<1, kRuntimeFeatures>(S, NR, row, lane, L);
+    const size_t m = (size_t)row * kLanes + lane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) S.rkap[c * NR * kLanes + m] = 0.0;
+    S.envmem[m] = 0.0;
+    if (tid == 0) {
+        S.time[env] = 0.0;
+        HeadState H;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { H.x[i] = 0.0; H.v[i] = 0.0; H.w[i] = 0.0; }
+        const double Q0[9] = {0.0, 1.0, 0.0, -1.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H.Q[i] = Q0[i];
+        store_head(S, N, env, H);
+        S.head[(size_t)18 * N + env] = A.target[2 * (size_t)env];
+        S.head[(size_t)19 * N + env] = A.target[2 * (size_t)env + 1];
+    }
+}
+
+}  // namespace softrod

@@ -90,8 +90,8 @@ class VecRodEnvBase:
         self.cfg = cfg
         self.numpy_output = numpy_output
         self.autoreset = bool(autoreset)
-        self.action_dim = _capi.action_dim(cfg.env_kind)
-        self.obs_dim = _capi.obs_dim(cfg.env_kind)
+        self.action_dim = _capi.config_action_dim(cfg)
+        self.obs_dim = _capi.config_obs_dim(cfg)
         self.n_action = self.action_dim
         lo, hi = self.action_low, self.action_high
         self.single_action_space = Box(lo, hi, shape=(self.action_dim,), dtype=np.float32)

@@ -6,10 +6,35 @@ from __future__ import annotations
 import numpy as np
 
 try:  # pragma: no cover - gymnasium is not installed in the build image
-    from gymnasium.spaces import Box  # type: ignore
+    from gymnasium.spaces import Box, Dict  # type: ignore
     HAVE_GYMNASIUM = True
 except Exception:  # noqa: BLE001
     HAVE_GYMNASIUM = False
+
+    class Dict:  # type: ignore[no-redef]
+        """Subset of gymnasium.spaces.Dict used by FlatEnv (octopus/flat_env.py:100-109)."""
+
+        def __init__(self, spaces):
+            self.spaces = dict(spaces)
+
+        def __getitem__(self, key):
+            return self.spaces[key]
+
+        def keys(self):
+            return self.spaces.keys()
+
+        def sample(self):
+            return {k: s.sample() for k, s in self.spaces.items()}
+
+        def contains(self, x) -> bool:
+            return isinstance(x, dict) and x.keys() == self.spaces.keys() and all(
+                self.spaces[k].contains(x[k]) for k in self.spaces)
+
+        def __contains__(self, x):
+            return self.contains(x)
+
+        def __repr__(self):
+            return "Dict(" + ", ".join(f"{k!r}: {s!r}" for k, s in self.spaces.items()) + ")"
 
     class Box:  # type: ignore[no-redef]
         def __init__(self, low, high, shape=None, dtype=np.float32, seed=None):

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 5
+#define SOFTROD_ABI_VERSION 6
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -189,10 +189,16 @@ typedef struct softrod_config {
     double joint_kt;          /* body_arm_kt 1e0        :37                     */
 } softrod_config;
 
-/* Per-env I/O widths implied by env_kind. */
+/* Per-env I/O widths implied by env_kind (OctoFlat: at the reference's n_arm = 8,
+ * n_elem = 10, n_knots = 3). */
 int softrod_action_dim(int env_kind); /* 1, 2, 7, 24                        */
 int softrod_obs_dim(int env_kind);    /* 4, 9, 25, 8*56 + 13 = 461          */
 int softrod_aux_dim(int env_kind);    /* 0, 1 (info["tilt"], float64), 0    */
+/* The same for a given configuration: OctoFlat widths follow n_arm, n_elem and n_knots
+ * (flat_env.py:112-141): action n_arm*n_knots; obs n_arm*((n-1) + 4(n+1) + n_knots) + 13,
+ * the "individual" rows followed by "shared" (flat_env.py:231-286). */
+int softrod_config_action_dim(const softrod_config* cfg);
+int softrod_config_obs_dim(const softrod_config* cfg);
 
 typedef struct softrod_handle softrod_handle;
 
@@ -208,7 +214,9 @@ typedef struct softrod_handle softrod_handle;
  * omega_collection / tangents of the reference (soft_pendulum.py:152-154).
  */
 typedef struct softrod_state_view {
-    int32_t n_envs, n_elem, lane_stride, reserved;
+    int32_t n_envs, n_elem, lane_stride;
+    int32_t arm_stride; /* OctoFlat: arm a of an env is slots a*arm_stride ..
+                           a*arm_stride + n_elem of the env's row; else 0        */
     double* position; /* [3][n_envs][lane_stride] */
     double* velocity; /* [3][n_envs][lane_stride] */
     double* director; /* [9][n_envs][lane_stride] */
@@ -225,7 +233,11 @@ typedef struct softrod_state_view {
                          (arm_single_env.py:172-173,190-198)                 */
     float* prev_action; /* [n_envs][7]  the env's _prev_action, written by
                          softrod_step (soft_pendulum.py:165), cleared by reset
-                         only where the reference does (soft_pendulum_3d.py:68) */
+                         only where the reference does (soft_pendulum_3d.py:68);
+                         OctoFlat: [n_envs][n_arm*n_knots]                     */
+    double* head;     /* [20][n_envs]  OctoFlat rigid head (octopus/build.py:103-105):
+                         position[3], velocity[3], directors[9] (row-major),
+                         omega[3], target[2] (flat_env.py:221); else unused    */
 } softrod_state_view;
 
 /* Fill `cfg` with SoftPendulumEnv.__init__ defaults (soft_pendulum.py:59-78)
@@ -237,6 +249,9 @@ int softrod_config_softpendulum3d(softrod_config* cfg, int n_envs);
 /* Same for ArmSingleEnv (octopus/arm_single_env.py:55-113) and build_arm
  * (octopus/build.py:220-292).                                               */
 int softrod_config_arm_single(softrod_config* cfg, int n_envs);
+/* Same for FlatEnv (octopus/flat_env.py:55-110) and build_octopus
+ * (octopus/build.py:30-217): 8 arms of 10 elements, rigid head, joints.     */
+int softrod_config_octo_flat(softrod_config* cfg, int n_envs);
 
 /* Replaces the constant part of set_action's
  *   interp1d(linspace(0,1,n_action), action, kind="cubic")(linspace(0,1,n_seg))
@@ -267,6 +282,18 @@ int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask,
 int softrod_reset_straight(softrod_handle* h, const double* start,
                            const double* direction, const double* normal,
                            const uint8_t* mask, void* stream);
+
+/* Replaces: the state part of FlatEnv.reset (octopus/flat_env.py:171-229) ->
+ * build_octopus (octopus/build.py:52-217): n_arm straight rods (normal e_z), the
+ * Cylinder head at the origin, finalize()'s first constraint pass, time = 0.
+ *   arm_start, arm_direction  host [n_envs][n_arm][3]: the
+ *       Rotation.from_euler("z", 360/n_arm * i, degrees=True).apply(...) results of
+ *       build.py:76-80, computed by the caller as the reference does
+ *   target                    host [n_envs][2]: (2 - 0.5) * np_random.random(2) + 0.5
+ *   mask                      as softrod_reset                                 */
+int softrod_reset_octo(softrod_handle* h, const double* arm_start,
+                       const double* arm_direction, const double* target,
+                       const uint8_t* mask, void* stream);
 
 /* Replaces: Env.step for every rod (soft_pendulum.py:176-251,
  * soft_pendulum_3d.py:115-174): set_action -> n_substeps x PositionVerlet.step

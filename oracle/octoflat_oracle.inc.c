@@ -275,7 +275,8 @@ static void octo_get_state(const oracle_octo* o, float* individual, float* share
 oracle_octo* oracle_octo_create(const softrod_config* cfg)
 {
     if (!cfg || cfg->struct_size != sizeof(softrod_config)) return NULL;
-    if (cfg->n_arm < 1 || cfg->n_arm > OCTO_MAX_ARM || cfg->n_knots != 3) return NULL;
+    if (cfg->n_arm < 1 || cfg->n_arm > OCTO_MAX_ARM || cfg->n_knots < 1 ||
+        cfg->n_arm * cfg->n_knots > 3 * OCTO_MAX_ARM) return NULL;
     oracle_octo* o = (oracle_octo*)calloc(1, sizeof(oracle_octo));
     if (!o) return NULL;
     o->cfg = *cfg;
@@ -370,6 +371,13 @@ int oracle_octo_crossings(oracle_octo* o)
         c += count_intersections(o->arm[(i - 1 + o->n_arm) % o->n_arm], o->arm[i]);
     return c;
 }
+/* state injection for the windowed parity tests: x[3], v[3], Q[9], w[3] ; time */
+void oracle_octo_set_head(oracle_octo* o, const double* in)
+{
+    for (int i = 0; i < 3; ++i) { o->head.x[i] = in[i]; o->head.v[i] = in[3 + i]; o->head.w[i] = in[15 + i]; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o->head.Q[i][j] = in[6 + 3 * i + j];
+}
+void oracle_octo_set_time(oracle_octo* o, double t) { o->time = t; }
 /* head state: x[3], v[3], Q[9], w[3], mass, J[3] -> 22 doubles */
 void oracle_octo_head(const oracle_octo* o, double* out)
 {

@@ -64,6 +64,8 @@ def _load(omp: bool) -> C.CDLL:
     lib.oracle_octo_crossings.restype = C.c_int
     lib.oracle_octo_crossings.argtypes = [C.c_void_p]
     lib.oracle_octo_head.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_octo_set_head.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_octo_set_time.argtypes = [C.c_void_p, C.c_double]
     lib.oracle_get.restype = C.c_int
     lib.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.oracle_set.restype = C.c_int
@@ -287,6 +289,21 @@ class OracleOcto:
 
     def crossings(self) -> int:
         return int(self._lib.oracle_octo_crossings(self._h))
+
+    def set_head(self, x, v, Q, w) -> None:
+        buf = np.ascontiguousarray(np.concatenate([np.ravel(x), np.ravel(v), np.ravel(Q), np.ravel(w)]),
+                                   dtype=np.float64)
+        self._lib.oracle_octo_set_head(self._h, buf.ctypes.data)
+
+    def copy_state_from(self, other: "OracleOcto") -> None:
+        """Overwrite the dynamic state (arms, head, time) with `other`'s."""
+        for a in range(self.n_arm):
+            src, dst = other.arm(a), self.arm(a)
+            for name in ("x", "v", "Q", "w", "rest_kappa"):
+                dst.set(name, src.get(name))
+        h = other.head()
+        self.set_head(h["x"], h["v"], h["Q"], h["w"])
+        self._lib.oracle_octo_set_time(self._h, other.time)
 
     def head(self):
         out = np.empty(22, np.float64)

@@ -19,8 +19,9 @@ def _env(**kw):
 
 def test_registry_lists_softpendulum():
     assert "SoftPendulum-v0" in gsa.registered()
+    assert {"OctoFlat-v0", "OctoFlatLite-v0", "OctoArmSingle-v0"} <= set(gsa.registered())
     with pytest.raises(KeyError):
-        gsa.make("OctoFlat-v0")
+        gsa.make("OctoCrawl-v0")   # not on the accelerated path
 
 
 def test_seeding_matches_gymnasium_convention():
