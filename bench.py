@@ -78,10 +78,11 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=None,
+                    help=f"default {ENVS_PER_GPU}; OctoFlat-v0: 1024 (BASELINE configs[4]: 8192 envs on 8 GPUs)")
     ap.add_argument("--math-mode", choices=["fast", "libm"], default="fast")
     ap.add_argument("--env", default="SoftPendulum-v0",
-                    choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0"],
+                    choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0", "OctoFlat-v0"],
                     help="headline metric is SoftPendulum-v0; the others are the widened §8 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n-elems", type=int, default=None, help="elements per rod (env default if omitted)")
@@ -115,7 +116,7 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
-    n_local = args.envs_per_gpu
+    n_local = args.envs_per_gpu or (1024 if args.env == "OctoFlat-v0" else ENVS_PER_GPU)
     n_total = n_local * world
     K, W = args.steps, args.warmup
     math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
@@ -125,7 +126,8 @@ def main() -> None:
     env.reset(seed=0)                      # global env i seeded i
     lo, hi = env.lo, env.hi
     adim = local.backend.action_dim
-    amax = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0}[args.env]
+    amax = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
+            "OctoFlat-v0": 22.0}[args.env]
     # the truncation flag of SoftPendulum first fires on env.step #126; the default window
     # (55 steps) stays inside one episode
     T = W + K
@@ -157,7 +159,11 @@ def main() -> None:
     if rank == 0:
         cfg = local.cfg
         nsub = int(cfg.n_substeps)
-        bytes_per_launch = n_local * nsub * algorithmic_bytes_per_rod_substep(int(cfg.n_elem))
+        octo = args.env == "OctoFlat-v0"
+        rods_per_env = int(cfg.n_arm) if octo else 1
+        # OctoFlat: n_arm rods + the rigid head (x, v, Q, w = 18 doubles read and written)
+        bytes_per_launch = n_local * nsub * (rods_per_env * algorithmic_bytes_per_rod_substep(int(cfg.n_elem))
+                                             + (2 * 18 * 8 if octo else 0))
         kernel_ms = float(np.mean(kt))
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
@@ -181,14 +187,15 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.env}, {n_local} envs x {int(cfg.n_elem)} elements per GPU "
+                "workload": f"{args.env}, {n_local} envs x "
+                            + (f"{rods_per_env} arms x " if octo else "") + f"{int(cfg.n_elem)} elements per GPU "
                             + (f"(BASELINE configs[1]; x{world} GPUs)" if args.env == "SoftPendulum-v0"
                                else "(widened row of SURVEY §8; not the headline metric)"),
                 "envs_total": n_total,
                 "substeps_per_env_step": nsub,
                 "math_mode": args.math_mode,
                 "sharding": "contiguous env blocks per rank; one packed all_gather per step" if world > 1 else "single GPU",
-                "rod_substeps_per_sec": n_total * K * nsub / elapsed,
+                "rod_substeps_per_sec": n_total * rods_per_env * K * nsub / elapsed,
                 "non_finite_envs_at_end": n_bad,
             },
             "roofline": {
@@ -198,11 +205,13 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "softrod_step_fast_kernel" if args.math_mode == "fast" else "softrod_step_libm_kernel",
+                "kernel": "softrod_octo_step_kernel" if octo else
+                          ("softrod_step_fast_kernel" if args.math_mode == "fast" else "softrod_step_libm_kernel"),
                 "fp64_valu": {
                     "note": "the binding unit: wave64 fp64 VALU ops issue in 4 cycles (78.6 TFLOP/s); "
                             "SIMD-cycles per rod-substep below vs ~4 x fp64 instruction count (profiles/README.md)",
-                    "simd_cycles_per_rod_substep_at_2.4GHz": kernel_ms * 1e-3 * 2.4e9 * 1024 / (n_local * nsub),
+                    "simd_cycles_per_rod_substep_at_2.4GHz":
+                        kernel_ms * 1e-3 * 2.4e9 * 1024 / (n_local * rods_per_env * nsub),
                 },
                 "kernel_ms_avg": kernel_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,

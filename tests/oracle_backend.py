@@ -19,9 +19,14 @@ class OracleBackend:
         self.device = torch.device("cpu")
         self.is3d = cfg.env_kind == _capi.ENV_SOFTPENDULUM3D
         self.isarm = cfg.env_kind == _capi.ENV_ARM_SINGLE
-        self.action_dim = _capi.action_dim(cfg.env_kind)
-        self.obs_dim = _capi.obs_dim(cfg.env_kind)
-        self.rods = [oracle_c.OracleRod(self.cfg, omp=omp) for _ in range(self.n_envs)]
+        self.isocto = cfg.env_kind == _capi.ENV_OCTO_FLAT
+        self.action_dim = _capi.config_action_dim(cfg)
+        self.obs_dim = _capi.config_obs_dim(cfg)
+        if self.isocto:
+            self.rods = [oracle_c.OracleOcto(self.cfg) for _ in range(self.n_envs)]
+            self._octo_obs = [None] * self.n_envs
+        else:
+            self.rods = [oracle_c.OracleRod(self.cfg, omp=omp) for _ in range(self.n_envs)]
         self.obs = torch.zeros((self.n_envs, self.obs_dim), dtype=torch.float32)
         self.reward = torch.zeros(self.n_envs, dtype=torch.float64)
         self.terminated = torch.zeros(self.n_envs, dtype=torch.uint8)
@@ -44,7 +49,17 @@ class OracleBackend:
                 else:
                     r.reset_straight(start[i], direction[i], normal[i])
 
+    def reset_octo(self, targets, mask=None):
+        for i, r in enumerate(self.rods):
+            if mask is None or mask[i]:
+                ob = r.reset(targets[i])
+                self._octo_obs[i] = np.concatenate([ob["individual"].ravel(), ob["shared"]])
+
     def observe(self, prev_action=None):
+        if self.isocto:     # the oracle keeps _prev_action itself (it survives reset)
+            for i in range(self.n_envs):
+                self.obs[i] = torch.from_numpy(self._octo_obs[i])
+            return self.obs
         pa = self._prev     # resident _prev_action, like softrod_state_view.prev_action
         if prev_action is not None:
             pa = torch.as_tensor(prev_action).reshape(self.n_envs, self.action_dim).numpy()
@@ -71,7 +86,11 @@ class OracleBackend:
         a = torch.as_tensor(actions, dtype=torch.float32).reshape(self.n_envs, self.action_dim).numpy()
         self._prev = a.copy()
         for i, r in enumerate(self.rods):
-            if self.is3d:
+            if self.isocto:
+                ob, rw, te, tr = r.env_step(a[i])
+                o = np.concatenate([ob["individual"].ravel(), ob["shared"]])
+                self._octo_obs[i] = o
+            elif self.is3d:
                 o, rw, te, tr, tilt = r.env_step3d(a[i])
                 self.aux[i, 0] = tilt
             elif self.isarm:

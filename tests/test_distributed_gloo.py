@@ -21,6 +21,33 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _octo_worker(rank, world, port, total, q):
+    """OctoFlat-v0 through the sharded env: odd obs_dim (461) -> padded packed rows."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.distributed import ShardedVecEnv, shard_bounds
+    from tests.oracle_backend import OracleBackend
+
+    lo, hi = shard_bounds(total, world, rank)
+    cfg = _capi.octo_flat_config(hi - lo)
+    cfg.n_substeps = 12
+    local = gsa.VecOctoFlatEnv(hi - lo, backend=OracleBackend(cfg))
+    local.cfg.n_substeps = 12
+    env = ShardedVecEnv(local, total)
+    obs0, _ = env.reset(seed=3)
+    obs0 = obs0.clone().numpy()      # the gathered buffer is reused by the next call
+    acts = np.random.default_rng(8).uniform(-22, 22, (total, 24)).astype(np.float32)
+    o, r, te, tr, _ = env.step(acts)
+    if rank == 0:
+        q.put((obs0, o.clone().numpy(), r.clone().numpy(), te.clone().numpy(), tr.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, total, T, q):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -113,3 +140,31 @@ def test_world2_gloo_matches_single_process(oracle_built):
     for g, r in zip(got[1:], ref[1:]):
         for a, b in zip(g, r):
             np.testing.assert_array_equal(a, b)
+
+
+def test_world2_gloo_octoflat_matches_single_process(oracle_built):
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from tests.oracle_backend import OracleBackend
+
+    total, world = 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_octo_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = _capi.octo_flat_config(total)
+    cfg.n_substeps = 12
+    env = gsa.VecOctoFlatEnv(total, backend=OracleBackend(cfg), numpy_output=True)
+    env.cfg.n_substeps = 12
+    obs0, _ = env.reset(seed=3)
+    acts = np.random.default_rng(8).uniform(-22, 22, (total, 24)).astype(np.float32)
+    ref = (obs0.copy(),) + tuple(np.asarray(x).copy() for x in env.step(acts)[:4])
+    assert got[0].shape == (total, 461)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)

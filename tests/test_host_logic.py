@@ -246,3 +246,76 @@ def test_without_autoreset_envs_keep_running_past_truncation(oracle_built):
         assert trunc.all() == (k >= 3)              # the reference has no auto-reset
     assert np.all(vec._steps == 5)
     vec.close()
+
+
+# ---- OctoFlat-v0 / OctoFlatLite-v0 ---------------------------------------------------------
+def test_octo_flat_config_and_spaces(oracle_built):
+    cfg = _capi.octo_flat_config(1)
+    assert cfg.n_substeps == 2857 and cfg.final_time == 5.0 and cfg.n_elem == 10   # flat_env.py:58-62,78
+    assert (cfg.n_arm, cfg.n_knots) == (8, 3)
+    assert _capi.config_action_dim(cfg) == 24 and _capi.config_obs_dim(cfg) == 8 * 56 + 13
+    cfg.n_substeps = 20        # keep the CPU suite quick; host logic does not depend on it
+    env = gsa.FlatEnv(backend=OracleBackend(cfg))
+    assert env.action_space.shape == (24,) and float(env.action_space.high[0]) == 22.0
+    assert env.observation_space["individual"].shape == (8, 56)
+    assert env.observation_space["shared"].shape == (13,)
+    ob, info = env.reset(seed=0)
+    assert info == {} and env.observation_space.contains(ob)
+    rng, _ = np_random(0)
+    tgt = (2 - 0.5) * rng.random(2) + 0.5                           # flat_env.py:221
+    np.testing.assert_array_equal(env._target, tgt)
+    # shared = [target - head_xy, head v_xy, head directors]; the head starts at the origin
+    np.testing.assert_allclose(ob["shared"][:2], tgt.astype(np.float32))
+    np.testing.assert_array_equal(ob["shared"][2:4], 0.0)
+    np.testing.assert_array_equal(ob["shared"][4:].reshape(3, 3), [[0, 1, 0], [-1, 0, 0], [0, 0, 1]])
+    # individual row: kappa (9) | x - cx (11) | y - cy (11) | vx (11) | vy (11) | prev action (3)
+    row = ob["individual"][2]                                       # arm 2 points along +y
+    np.testing.assert_allclose(row[9:20], 0.0, atol=1e-7)
+    np.testing.assert_allclose(row[20:31], 0.04 + 0.35 * np.arange(11) / 10, rtol=1e-6)
+    a = env.action_space.sample()
+    ob2, r, te, tr, inf = env.step(a)
+    assert env.observation_space.contains(ob2) and isinstance(r, float)
+    assert isinstance(te, bool) and isinstance(tr, bool) and set(inf) == {"time", "TimeLimit.truncated"}
+    np.testing.assert_array_equal(ob2["individual"][:, -3:], a.reshape(8, 3))
+    # _prev_action survives reset (flat_env.py:142-151 sets it in __init__ only)
+    ob3, _ = env.reset()
+    np.testing.assert_array_equal(ob3["individual"][:, -3:], a.reshape(8, 3))
+    assert not np.array_equal(env._target, tgt)                     # next draw of the same stream
+    with pytest.raises(NotImplementedError):
+        gsa.FlatEnv(policy_mode="decentralized", backend=OracleBackend(cfg))
+    env.close()
+
+
+def test_octo_flat_lite_and_vec(oracle_built):
+    env = gsa.make("OctoFlatLite-v0", backend=OracleBackend(_capi.octo_flat_config(1, n_arm=1, n_action=8)))
+    assert env.action_space.shape == (8,) and env.observation_space["individual"].shape == (1, 61)
+    env.close()
+    n = 2
+    cfg = _capi.octo_flat_config(n)
+    cfg.n_substeps = 10
+    vec = gsa.VecOctoFlatEnv(n, backend=OracleBackend(cfg), numpy_output=True)
+    vec.cfg.n_substeps = 10
+    obs, _ = vec.reset(seed=4)
+    assert obs.shape == (n, 461)
+    d = vec.split_obs(obs)
+    assert d["individual"].shape == (n, 8, 56) and d["shared"].shape == (n, 13)
+    for i in range(n):
+        rng, _ = np_random(4 + i)
+        np.testing.assert_array_equal(vec.targets[i], (2 - 0.5) * rng.random(2) + 0.5)
+    o, r, te, tr, info = vec.step(np.zeros((n, 24), np.float32))
+    assert o.shape == (n, 461) and r.shape == (n,) and te.dtype == bool
+    vec.reset(mask=np.array([False, True]))
+    assert vec._steps.tolist() == [1, 0]
+    vec.close()
+
+
+def test_octo_action_basis_reproduces_padded_interp1d():
+    from scipy.interpolate import interp1d
+
+    W = _capi.octo_action_basis(10, 3)
+    assert W.shape == (9, 3)
+    a = np.random.default_rng(0).uniform(-22, 22, 3).astype(np.float32)
+    k = np.concatenate([[0.0], a, [0.0]])
+    ref = interp1d(np.linspace(0, 1, 5), k, kind="cubic", axis=-1)(np.linspace(0, 1, 9))   # flat_env.py:296-308
+    np.testing.assert_allclose(W @ a.astype(np.float64), ref, rtol=0, atol=1e-13)
+    assert np.all(W[0] == 0.0) and np.all(W[-1] == 0.0)              # clamped to zero at both ends
