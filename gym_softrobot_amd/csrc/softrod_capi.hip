@@ -133,6 +133,9 @@ void fill_params(const softrod_config& c, RodParams& P) {
     P.slip_tol = c.slip_velocity_tol;
     P.surface_tol = c.surface_tol;
     P.r0_sqrt_rest_len = r * std::sqrt(rest_len);   // radius = sqrt(V/(pi l)) = r0 sqrt(l_rest/l)
+    if ((c.features & SOFTROD_FEAT_PLANE_CONTACT_ANISO) && c.plane_normal[0] == 0.0 &&
+        c.plane_normal[1] == 0.0 && c.plane_normal[2] == 1.0)
+        P.features |= kFeatPlaneZup;   // what both reference builds use (octopus/build.py:233)
     if (c.features & SOFTROD_FEAT_OCTO_HEAD) {
         // arms `seg` slots apart; Cylinder(length = 2 r0, radius = head_radius, density)
         // (octopus/build.py:95-105; elastica/rigidbody/cylinder.py)
@@ -164,13 +167,16 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes * h->nw);
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
+    const bool zup = (h->P.features & kFeatPlaneZup) != 0;
     if (is_octo(h)) {
-        if (h->nw <= 2)
-            hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_OCTO_FLAT, 2>), grid, block, 0, st,
-                               h->P, h->S, actions, obs, reward, term, trunc, n_sub, epilogue, pack);
-        else
-            hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_OCTO_FLAT, 8>), grid, block, 0, st,
-                               h->P, h->S, actions, obs, reward, term, trunc, n_sub, epilogue, pack);
+#define SR_OCTO(FEATS, MAXW)                                                                        \
+        hipLaunchKernelGGL((softrod_octo_step_kernel<FEATS, MAXW>), grid, block, 0, st, h->P, h->S,     \
+                           actions, obs, reward, term, trunc, n_sub, epilogue, pack)
+        if (zup) { if (h->nw <= 2) SR_OCTO(SOFTROD_FEATURES_OCTO_FLAT | kFeatPlaneZup, 2);
+                   else SR_OCTO(SOFTROD_FEATURES_OCTO_FLAT | kFeatPlaneZup, 8); }
+        else     { if (h->nw <= 2) SR_OCTO(SOFTROD_FEATURES_OCTO_FLAT, 2);
+                   else SR_OCTO(SOFTROD_FEATURES_OCTO_FLAT, 8); }
+#undef SR_OCTO
     } else if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
         // instantiations specialised for the registered envs' feature sets (one or two
         // slots per lane); anything else (known-answer tests, custom feature mixes) takes
@@ -186,8 +192,8 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
                 SR_LAUNCH(SOFTROD_FEATURES_SOFTPENDULUM, SOFTROD_ENV_SOFTPENDULUM, EPL);            \
             else if (f == SOFTROD_FEATURES_SOFTPENDULUM3D && e == SOFTROD_ENV_SOFTPENDULUM3D)       \
                 SR_LAUNCH(SOFTROD_FEATURES_SOFTPENDULUM3D, SOFTROD_ENV_SOFTPENDULUM3D, EPL);        \
-            else if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE)               \
-                SR_LAUNCH(SOFTROD_FEATURES_ARM_SINGLE, SOFTROD_ENV_ARM_SINGLE, EPL);                \
+            else if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE && zup)        \
+                SR_LAUNCH(SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup, SOFTROD_ENV_ARM_SINGLE, EPL); \
             else                                                                                    \
                 SR_LAUNCH(kRuntimeFeatures, kRuntimeEnv, EPL);                                      \
         } while (0)

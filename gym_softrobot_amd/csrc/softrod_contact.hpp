@@ -10,6 +10,14 @@
 // wave_shl DPP shift, element->node scatters pull element k-1 with one wave_shr shift;
 // the two rounds (normal + kinetic friction, then static friction on the updated
 // totals) cost 12 fp64 values across lanes per substep.
+//
+// Two compile-time switches keep the fp64 instruction count down (the kernel is bound by
+// it, profiles/README.md):
+//   ZUP  the plane normal is exactly e_z — what both reference builds use
+//        (octopus/build.py:233) — so every product with the normal's zero components,
+//        and the z component of the axial / rolling directions, drops out;
+//   FM   SOFTROD_MATH_FAST: each division is one Newton-refined v_rcp_f64 / v_rsq_f64
+//        (<= 1 ulp) instead of the IEEE division / sqrt sequence.
 #pragma once
 
 namespace softrod {
@@ -23,16 +31,29 @@ struct ContactParams {
 
 __device__ __forceinline__ double sign_of(double x) { return (double)((x > 0.0) - (x < 0.0)); }
 
-// find_slipping_elements on a vector of magnitude |a|
-__device__ __forceinline__ double slip_function(double a, double thr) {
-    const double m = fmin(a / thr - 1.0, 1.0);
+template <bool FM>
+__device__ __forceinline__ double inv_of(double x) {
+    if constexpr (FM) return fast_rcp(x);
+    else return 1.0 / x;
+}
+template <bool FM>
+__device__ __forceinline__ double sqrt_of(double x) {   // x >= 0
+    if constexpr (FM) return x > 0.0 ? x * fast_rsqrt(x) : 0.0;
+    else return sqrt(x);
+}
+
+// find_slipping_elements on a vector of magnitude |a|; inv_thr = 1 / slip_velocity_tol
+template <bool FM>
+__device__ __forceinline__ double slip_function(double a, double thr, double inv_thr) {
+    const double q = FM ? a * inv_thr : a / thr;
+    const double m = fmin(q - 1.0, 1.0);
     return (fabs(a) > thr) ? fabs(1.0 - m) : 1.0;
 }
 
 // In:  F[s][3]   nodal internal + external force of node EPL*lane+s (so far)
 //      tq[s][3]  element internal + external torque (local frame) (so far)
 // Out: fc[s][3]  contact force added to that node;  tq += contact torques.
-template <int EPL>
+template <int EPL, bool ZUP, bool FM>
 __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const RodParams& P, int lane,
                                                 const ConstN<EPL>& K, const LaneN<EPL>& L,
                                                 const double (&xn)[EPL][3], const double (&vn)[EPL][3],
@@ -40,10 +61,12 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
                                                 double (&tq)[EPL][3], double (&fc)[EPL][3]) {
     const int n = P.n_elem;
     const double* nr = C.normal;
-    double E[EPL][3], ax[EPL][3], ro[EPL][3], arm[EPL][3], radius[EPL], nmag[EPL];
+    constexpr int D = ZUP ? 2 : 3;          // non-zero components of the in-plane directions
+    double E[EPL][3], ax[EPL][3], ro[EPL][3], radius[EPL], nmag[EPL];
     double slip_ax[EPL], slip_ro[EPL];
     bool contact[EPL];
     double Fn[EPL][3];
+    const double inv_slip = inv_of<FM>(C.slip_tol);
     // node -> element average of the total force
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -58,7 +81,7 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
     for (int s = 0; s < EPL; ++s) {
         const int idx = slot_local(P, lane * EPL + s);
         const bool first = (idx == 0), last = (idx == n - 1);
-        radius[s] = C.r0_sqrt_rest_len / sqrt(len[s]);
+        radius[s] = FM ? C.r0_sqrt_rest_len * fast_rsqrt(len[s]) : C.r0_sqrt_rest_len / sqrt(len[s]);
         double fel[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -66,71 +89,122 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
             fel[i] += first ? 0.5 * F[s][i] : 0.0;
             fel[i] += last ? 0.5 * Fn[s][i] : 0.0;
         }
-        const double fn = nr[0] * fel[0] + nr[1] * fel[1] + nr[2] * fel[2];
-        double dist = 0.0, vel[3], vnrm = 0.0;
+        const double inv_m = inv_of<FM>(K.mass_next[s] + K.mass[s]);
+        double vel[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const double xe = 0.5 * (L.x[s][i] + xn[s][i]);
-            dist += nr[i] * (xe - C.origin[i]);
-            vel[i] = (K.mass_next[s] * vn[s][i] + K.mass[s] * L.v[s][i]) / (K.mass_next[s] + K.mass[s]);
-            vnrm += nr[i] * vel[i];
+            const double num = K.mass_next[s] * vn[s][i] + K.mass[s] * L.v[s][i];
+            vel[i] = FM ? num * inv_m : num / (K.mass_next[s] + K.mass[s]);
+        }
+        double fn, dist, vnrm;
+        if constexpr (ZUP) {
+            fn = fel[2];
+            dist = 0.5 * (L.x[s][2] + xn[s][2]) - C.origin[2];
+            vnrm = vel[2];
+        } else {
+            fn = nr[0] * fel[0] + nr[1] * fel[1] + nr[2] * fel[2];
+            dist = 0.0; vnrm = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double xe = 0.5 * (L.x[s][i] + xn[s][i]);
+                dist += nr[i] * (xe - C.origin[i]);
+                vnrm += nr[i] * vel[i];
+            }
         }
         const double pen = fmin(dist - radius[s], 0.0);
         contact[s] = (idx < n) && !((dist - radius[s]) > C.surface_tol);
         const double resp = (fn > 0.0) ? 0.0 : -fn;
         nmag[s] = contact[s] ? fabs(resp) : 0.0;
-        const double ntot = resp + (-C.k * pen) + (-C.nu * vnrm);
+        const double ntot = contact[s] ? resp + (-C.k * pen) + (-C.nu * vnrm) : 0.0;
+        // kinetic friction: axial direction = tangent projected on the plane, rolling = ax x n
+        if constexpr (ZUP) {
+            ax[s][0] = L.t[s][0]; ax[s][1] = L.t[s][1]; ax[s][2] = 0.0;
+        } else {
+            const double tn = nr[0] * L.t[s][0] + nr[1] * L.t[s][1] + nr[2] * L.t[s][2];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) E[s][i] = contact[s] ? nr[i] * ntot : 0.0;
-        // kinetic friction
-        const double tn = nr[0] * L.t[s][0] + nr[1] * L.t[s][1] + nr[2] * L.t[s][2];
+            for (int i = 0; i < 3; ++i) ax[s][i] = L.t[s][i] - nr[i] * tn;
+        }
+        double a2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ax[s][i] = L.t[s][i] - nr[i] * tn;
-        const double tpm = sqrt(ax[s][0] * ax[s][0] + ax[s][1] * ax[s][1] + ax[s][2] * ax[s][2]);
-        const double itp = 1.0 / (tpm + 1e-14);
+        for (int i = 0; i < D; ++i) a2 += ax[s][i] * ax[s][i];
+        const double itp = inv_of<FM>(sqrt_of<FM>(a2) + 1e-14);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ax[s][i] *= itp;
-        ro[s][0] = ax[s][1] * nr[2] - ax[s][2] * nr[1];
-        ro[s][1] = ax[s][2] * nr[0] - ax[s][0] * nr[2];
-        ro[s][2] = ax[s][0] * nr[1] - ax[s][1] * nr[0];
+        for (int i = 0; i < D; ++i) ax[s][i] *= itp;
+        if constexpr (ZUP) {
+            ro[s][0] = ax[s][1]; ro[s][1] = -ax[s][0]; ro[s][2] = 0.0;
+        } else {
+            ro[s][0] = ax[s][1] * nr[2] - ax[s][2] * nr[1];
+            ro[s][1] = ax[s][2] * nr[0] - ax[s][0] * nr[2];
+            ro[s][2] = ax[s][0] * nr[1] - ax[s][1] * nr[0];
+        }
+        double vax = 0.0, vroll = 0.0, axn2 = 0.0, ron2 = 0.0, v2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) arm[s][i] = -nr[i] * radius[s];
-        const double vax = vel[0] * ax[s][0] + vel[1] * ax[s][1] + vel[2] * ax[s][2];
-        const double axn = sqrt(ax[s][0] * ax[s][0] + ax[s][1] * ax[s][1] + ax[s][2] * ax[s][2]);
+        for (int i = 0; i < D; ++i) {
+            vax += vel[i] * ax[s][i];
+            vroll += vel[i] * ro[s][i];
+            axn2 += ax[s][i] * ax[s][i];
+            ron2 += ro[s][i] * ro[s][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v2 += vel[i] * vel[i];
+        const double axn = sqrt_of<FM>(axn2);
+        const double ron = ZUP ? axn : sqrt_of<FM>(ron2);   // |ax x e_z| = |ax| term by term
         const double sgn = sign_of(vax);
         const double kmu = 0.5 * (C.kin_mu[0] * (1 + sgn) + C.kin_mu[1] * (1 - sgn));
-        slip_ax[s] = slip_function(fabs(vax) * axn, C.slip_tol);
-        const double vroll = vel[0] * ro[s][0] + vel[1] * ro[s][1] + vel[2] * ro[s][2];
+        slip_ax[s] = slip_function<FM>(fabs(vax) * axn, C.slip_tol, inv_slip);
+        // velocity of the contact point from the element's spin: Q^T (w x Q arm), arm = -n radius
         const double* Q = L.Q[s];
         const double* w = L.w[s];
         double qa[3], rot[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            qa[i] = Q[3 * i] * arm[s][0] + Q[3 * i + 1] * arm[s][1] + Q[3 * i + 2] * arm[s][2];
+        for (int i = 0; i < 3; ++i) {
+            if constexpr (ZUP) qa[i] = -radius[s] * Q[3 * i + 2];
+            else qa[i] = -radius[s] * (Q[3 * i] * nr[0] + Q[3 * i + 1] * nr[1] + Q[3 * i + 2] * nr[2]);
+        }
         const double wq[3] = {w[1] * qa[2] - w[2] * qa[1], w[2] * qa[0] - w[0] * qa[2],
                               w[0] * qa[1] - w[1] * qa[0]};
+        double vrot = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) rot[i] = Q[i] * wq[0] + Q[3 + i] * wq[1] + Q[6 + i] * wq[2];
-        const double vrot = rot[0] * ro[s][0] + rot[1] * ro[s][1] + rot[2] * ro[s][2];
+        for (int i = 0; i < D; ++i) {
+            rot[i] = Q[i] * wq[0] + Q[3 + i] * wq[1] + Q[6 + i] * wq[2];
+            vrot += rot[i] * ro[s][i];
+        }
         const double sroll = vroll + vrot;
-        const double ron = sqrt(ro[s][0] * ro[s][0] + ro[s][1] * ro[s][1] + ro[s][2] * ro[s][2]);
-        slip_ro[s] = slip_function(fabs(sroll) * ron, C.slip_tol);
-        const double vm = sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]) + 1e-14;
-        const double uax = (vel[0] / vm) * ax[s][0] + (vel[1] / vm) * ax[s][1] + (vel[2] / vm) * ax[s][2];
-        const double uro = (vel[0] / vm) * ro[s][0] + (vel[1] / vm) * ro[s][1] + (vel[2] / vm) * ro[s][2];
+        slip_ro[s] = slip_function<FM>(fabs(sroll) * ron, C.slip_tol, inv_slip);
+        const double ivm = inv_of<FM>(sqrt_of<FM>(v2) + 1e-14);
+        double uax = 0.0, uro = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const double u = FM ? vel[i] * ivm : vel[i] / (sqrt(v2) + 1e-14);
+            uax += u * ax[s][i];
+            uro += u * ro[s][i];
+        }
         const double ka = contact[s] ? -((1.0 - slip_ax[s]) * kmu * nmag[s] * uax) : 0.0;
         const double kr = contact[s] ? -((1.0 - slip_ro[s]) * C.kin_mu[2] * nmag[s] * uro) : 0.0;
-        double fr[3];
+        double fr[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            fr[i] = kr * ro[s][i];
-            E[s][i] += ka * ax[s][i] + fr[i];
+        for (int i = 0; i < D; ++i) fr[i] = kr * ro[s][i];
+        if constexpr (ZUP) {
+            E[s][0] = ka * ax[s][0] + fr[0];
+            E[s][1] = ka * ax[s][1] + fr[1];
+            E[s][2] = ntot;
+            // arm x fr with arm = (0, 0, -radius)
+            const double cr0 = radius[s] * fr[1], cr1 = -radius[s] * fr[0];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tq[s][i] += Q[3 * i] * cr0 + Q[3 * i + 1] * cr1;
+        } else {
+            double arm[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                arm[i] = -nr[i] * radius[s];
+                E[s][i] = nr[i] * ntot + ka * ax[s][i] + fr[i];
+            }
+            const double cr[3] = {arm[1] * fr[2] - arm[2] * fr[1], arm[2] * fr[0] - arm[0] * fr[2],
+                                  arm[0] * fr[1] - arm[1] * fr[0]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                tq[s][i] += Q[3 * i] * cr[0] + Q[3 * i + 1] * cr[1] + Q[3 * i + 2] * cr[2];
         }
-        const double cr[3] = {arm[s][1] * fr[2] - arm[s][2] * fr[1], arm[s][2] * fr[0] - arm[s][0] * fr[2],
-                              arm[s][0] * fr[1] - arm[s][1] * fr[0]};
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            tq[s][i] += Q[3 * i] * cr[0] + Q[3 * i + 1] * cr[1] + Q[3 * i + 2] * cr[2];
     }
     // scatter round 1 and the updated nodal totals
     double F2[EPL][3];
@@ -146,8 +220,9 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
             F2[s][i] = F[s][i] + fc[s][i];
         }
     }
+    // static friction acts in the plane: with ZUP only x, y of the totals are needed
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < D; ++i) {
         double a[EPL], o[EPL];
 #pragma unroll
         for (int s = 0; s < EPL; ++s) a[s] = F2[s][i];
@@ -155,45 +230,57 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
 #pragma unroll
         for (int s = 0; s < EPL; ++s) Fn[s][i] = o[s];
     }
-    // static friction
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         const int idx = slot_local(P, lane * EPL + s);
         const bool first = (idx == 0), last = (idx == n - 1);
-        double fel[3];
+        double fel[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < D; ++i) {
             fel[i] = 0.5 * (F2[s][i] + Fn[s][i]);
             fel[i] += first ? 0.5 * F2[s][i] : 0.0;
             fel[i] += last ? 0.5 * Fn[s][i] : 0.0;
         }
-        const double fax = fel[0] * ax[s][0] + fel[1] * ax[s][1] + fel[2] * ax[s][2];
+        double fax = 0.0, fro = 0.0, tax = 0.0;
+        const double* Q = L.Q[s];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            fax += fel[i] * ax[s][i];
+            fro += fel[i] * ro[s][i];
+            const double tt = Q[i] * tq[s][0] + Q[3 + i] * tq[s][1] + Q[6 + i] * tq[s][2];
+            tax += tt * ax[s][i];
+        }
         const double sg = sign_of(fax);
         const double smu = 0.5 * (C.stat_mu[0] * (1 + sg) + C.stat_mu[1] * (1 - sg));
         const double sa = contact[s] ? -(fmin(fabs(fax), slip_ax[s] * smu * nmag[s]) * sg) : 0.0;
-        const double* Q = L.Q[s];
-        double tt[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) tt[i] = Q[i] * tq[s][0] + Q[3 + i] * tq[s][1] + Q[6 + i] * tq[s][2];
-        const double tax = tt[0] * ax[s][0] + tt[1] * ax[s][1] + tt[2] * ax[s][2];
-        const double fro = fel[0] * ro[s][0] + fel[1] * ro[s][1] + fel[2] * ro[s][2];
-        const double noslip = -((radius[s] * fro - 2.0 * tax) / 3.0 / radius[s]);
+        const double noslip = FM ? -((radius[s] * fro - 2.0 * tax) * (1.0 / 3.0) * inv_of<true>(radius[s]))
+                                 : -((radius[s] * fro - 2.0 * tax) / 3.0 / radius[s]);
         const double sr = contact[s]
             ? fmin(fabs(noslip), slip_ro[s] * C.stat_mu[2] * nmag[s]) * sign_of(noslip) : 0.0;
-        double fr[3];
+        double fr[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < D; ++i) {
             fr[i] = sr * ro[s][i];
             E[s][i] = sa * ax[s][i] + fr[i];
         }
-        const double cr[3] = {arm[s][1] * fr[2] - arm[s][2] * fr[1], arm[s][2] * fr[0] - arm[s][0] * fr[2],
-                              arm[s][0] * fr[1] - arm[s][1] * fr[0]};
+        if constexpr (ZUP) {
+            E[s][2] = 0.0;
+            const double cr0 = radius[s] * fr[1], cr1 = -radius[s] * fr[0];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            tq[s][i] += Q[3 * i] * cr[0] + Q[3 * i + 1] * cr[1] + Q[3 * i + 2] * cr[2];
+            for (int i = 0; i < 3; ++i) tq[s][i] += Q[3 * i] * cr0 + Q[3 * i + 1] * cr1;
+        } else {
+            double arm[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) arm[i] = -nr[i] * radius[s];
+            const double cr[3] = {arm[1] * fr[2] - arm[2] * fr[1], arm[2] * fr[0] - arm[0] * fr[2],
+                                  arm[0] * fr[1] - arm[1] * fr[0]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                tq[s][i] += Q[3 * i] * cr[0] + Q[3 * i + 1] * cr[1] + Q[3 * i + 2] * cr[2];
+        }
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < D; ++i) {
         double a[EPL], o[EPL];
 #pragma unroll
         for (int s = 0; s < EPL; ++s) a[s] = E[s][i];

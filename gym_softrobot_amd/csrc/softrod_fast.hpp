@@ -29,26 +29,6 @@
 
 namespace softrod {
 
-// 1/x: v_rcp_f64 seed (~2^-25) + two Newton steps -> <= 1 ulp for normal x.
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    return r;
-}
-// 1/sqrt(x): v_rsq_f64 seed + two Newton steps.
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    double r = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    double e = fma(-hx * r, r, 0.5);
-    r = fma(r, e, r);
-    e = fma(-hx * r, r, 0.5);
-    r = fma(r, e, r);
-    return r;
-}
-
 // sin(th)/th and (1-cos(th))/th^2 from t = th^2.  t < 1e-3: degree-3 Taylor in t
 // (remainders t^4/9! < 3e-18, t^4/10! < 3e-19).  Otherwise (|omega| dt > 0.03 rad: only
 // when a simulation is blowing up) the angle is halved k times and rebuilt with
@@ -298,7 +278,10 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
                     Fg[s][c] += node_valid ? P.gravity[c] * C.mass[s] : 0.0;
             }
         }
-        plane_contact_n<EPL>(contact_params(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);
+        if (has<F>(P, kFeatPlaneZup))
+            plane_contact_n<EPL, true, true>(contact_params(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);
+        else
+            plane_contact_n<EPL, false, true>(contact_params(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);
 #pragma unroll
         for (int s = 0; s < EPL; ++s)
 #pragma unroll

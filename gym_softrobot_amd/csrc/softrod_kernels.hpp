@@ -43,6 +43,9 @@ constexpr int kLanes = 64;
 // the registered envs (so that unused features cost neither instructions nor registers)
 // plus one instantiation that reads the mask at run time (known-answer tests).
 constexpr unsigned kRuntimeFeatures = 0xFFFFFFFFu;
+// Internal pseudo-feature (never in softrod_config.features): the contact plane's normal is
+// exactly e_z, set by the host in RodParams.features and in the template mask.
+constexpr unsigned kFeatPlaneZup = 1u << 30;
 constexpr int kRuntimeEnv = -1;
 
 // Wave-uniform parameters: passed by value, so they land in SGPRs (kernarg segment).
@@ -344,6 +347,27 @@ __device__ __forceinline__ void laplace_filter_rates_n(const RodParams& P, int l
             L.w[s][c] = (idx < n) ? rw[s] : L.w[s][c];
         }
     }
+}
+
+// ---- SOFTROD_MATH_FAST primitives (softrod_fast.hpp explains where they are used) ----
+// 1/x: v_rcp_f64 seed (~2^-25) + two Newton steps -> <= 1 ulp for normal x.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+// 1/sqrt(x): v_rsq_f64 seed + two Newton steps.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    double e = fma(-hx * r, r, 0.5);
+    r = fma(r, e, r);
+    e = fma(-hx * r, r, 0.5);
+    r = fma(r, e, r);
+    return r;
 }
 
 }  // namespace softrod
@@ -828,7 +852,7 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     if (has_contact && P.contact_before_forcing) {
         const double F[1][3] = {{f0, f1, f2}};
         double tq[1][3] = {{tq0, tq1, tq2}}, fc[1][3];
-        plane_contact_n<1>(contact_params(P), P, lane, CK, L, xn, vn, len1, F, tq, fc);
+        plane_contact_n<1, false, false>(contact_params(P), P, lane, CK, L, xn, vn, len1, F, tq, fc);
         fe0 = fc[0][0]; fe1 = fc[0][1]; fe2 = fc[0][2];
         tq0 = tq[0][0]; tq1 = tq[0][1]; tq2 = tq[0][2];
     }
@@ -846,7 +870,7 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
         const double F[1][3] = {{f0 + (node_valid ? fe0 : 0.0), f1 + (node_valid ? fe1 : 0.0),
                                  f2 + (node_valid ? fe2 : 0.0)}};
         double tq[1][3] = {{tq0, tq1, tq2}}, fc[1][3];
-        plane_contact_n<1>(contact_params(P), P, lane, CK, L, xn, vn, len1, F, tq, fc);
+        plane_contact_n<1, false, false>(contact_params(P), P, lane, CK, L, xn, vn, len1, F, tq, fc);
         fe0 += fc[0][0]; fe1 += fc[0][1]; fe2 += fc[0][2];
         tq0 = tq[0][0]; tq1 = tq[0][1]; tq2 = tq[0][2];
     }

@@ -15,7 +15,11 @@ import os
 import sys
 from collections import defaultdict
 
-KERNEL = "softrod_step_"
+KERNELS = ("softrod_step_", "softrod_octo_step_")
+
+
+def is_step_kernel(name):
+    return any(k in name for k in KERNELS)
 
 
 def read_csv(path):
@@ -46,7 +50,7 @@ def counters(root, sub):
     regs = {}
     for p in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in read_csv(p):
-            if KERNEL not in r.get("Kernel_Name", ""):
+            if not is_step_kernel(r.get("Kernel_Name", "")):
                 continue
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
             regs = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
@@ -58,7 +62,7 @@ def main(root):
     doc = {"dir": os.path.basename(root.rstrip("/"))}
     ks = kernel_stats(root)
     doc["kernel_stats"] = ks[:8]
-    step = [k for k in ks if KERNEL in k["name"]]
+    step = [k for k in ks if is_step_kernel(k["name"])]
     if step:
         doc["step_kernel_avg_ms"] = step[0]["avg_ns"] / 1e6
         doc["step_kernel_calls"] = step[0]["calls"]
