@@ -319,10 +319,13 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
 #ifndef SOFTROD_FAST_WAVES
 #define SOFTROD_FAST_WAVES 3
 #endif
+#ifndef SOFTROD_CONTACT_WAVES
+#define SOFTROD_CONTACT_WAVES 2
+#endif
 // Two slots per lane need the whole 512-entry register file (1 wave per SIMD); the contact
 // instantiation trades a wave of occupancy for not spilling.
 template <unsigned F, int E, int EPL>
-__global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & SOFTROD_FEAT_PLANE_CONTACT_ANISO)) ? 2 : SOFTROD_FAST_WAVES)))
+__global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & SOFTROD_FEAT_PLANE_CONTACT_ANISO)) ? SOFTROD_CONTACT_WAVES : SOFTROD_FAST_WAVES)))
 softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,

@@ -15,9 +15,10 @@
 // unchanged: an arm never straddles a wavefront and the ghost slots between arms carry no
 // stiffness, no mass coefficient and no contact.  The rigid head (x, v, Q, w: 18 doubles)
 // is replicated in registers of every lane.  Per substep the only cross-arm traffic is the
-// head's net joint force/torque: two xor-shuffles inside each wave, 6 doubles per wave
-// through LDS (double-buffered, ONE s_barrier per substep), then every lane integrates the
-// same head with the same operands, so the replicas stay bit-identical.
+// head's net joint load: three doubles per arm through LDS (double-buffered, ONE s_barrier
+// per substep, consumed after the arms' contact and rate update so that the round trip is
+// hidden), then every lane integrates the same head with the same operands in the same
+// order, so the replicas stay bit-identical.
 //
 // State rows: the env's slots are rows [env*nw + wave][64] of the SoA arrays (the generic
 // one-rod-per-wave layout with N*nw rows); arm a = slots a*seg .. a*seg+n_elem.
@@ -55,24 +56,23 @@ __device__ __forceinline__ void store_head(const StatePtrs& S, size_t N, int env
 
 // Kinematic half/full step of the rigid body followed by
 // BodyBoundaryCondition.compute_contrain_values (constraint.py:41-58): z held, d3 = e_z,
-// d1 and d2 renormalised in the plane.  Position z never moves because constrain_rates
-// keeps v_z = 0, so it is not rewritten.
+// d1 and d2 renormalised in the plane.  compute_constrain_rates (constraint.py:60-85) keeps
+// v_z = 0 and omega = (0, 0, w_z) — established at kernel entry and after every rate update —
+// so the step is a planar one: x, y advance, z stays, and the transposed Rodrigues matrix
+// R(h w) reduces to a rotation about e_z acting on the x, y components of d1 and d2.
 __device__ __forceinline__ void head_kinematic(double h, HeadState& H) {
-    LaneN<1> T;
-    ConstN<1> C1;
-    C1.hx[0] = 1.0; C1.hq[0] = 1.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { T.x[0][i] = H.x[i]; T.v[0][i] = H.v[i]; T.w[0][i] = H.w[i]; }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) T.Q[0][i] = H.Q[i];
-    kinematic_n<1>(h, C1, T);
-    H.x[0] = T.x[0][0]; H.x[1] = T.x[0][1];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double a = T.Q[0][3 * i], b = T.Q[0][3 * i + 1];
-        const double inv = fast_rsqrt(fma(a, a, b * b));
-        H.Q[3 * i] = a * inv; H.Q[3 * i + 1] = b * inv; H.Q[3 * i + 2] = 0.0;
-    }
+    H.x[0] = fma(h, H.v[0], H.x[0]);
+    H.x[1] = fma(h, H.v[1], H.x[1]);
+    const double a = h * H.w[2];
+    const double t = a * a;
+    double sc, cc;
+    sinc_cosc(t, sc, cc);
+    const double sn = sc * a, cs = fma(-cc, t, 1.0);
+    const double q00 = fma(sn, H.Q[3], cs * H.Q[0]), q01 = fma(sn, H.Q[4], cs * H.Q[1]);
+    const double q10 = fma(-sn, H.Q[0], cs * H.Q[3]), q11 = fma(-sn, H.Q[1], cs * H.Q[4]);
+    const double i0 = fast_rsqrt(fma(q00, q00, q01 * q01)), i1 = fast_rsqrt(fma(q10, q10, q11 * q11));
+    H.Q[0] = q00 * i0; H.Q[1] = q01 * i0; H.Q[2] = 0.0;
+    H.Q[3] = q10 * i1; H.Q[4] = q11 * i1; H.Q[5] = 0.0;
     H.Q[6] = 0.0; H.Q[7] = 0.0; H.Q[8] = 1.0;
 }
 
@@ -159,13 +159,16 @@ __device__ __forceinline__ int octo_obs_dim(const RodParams& P) {
 // One env.step (or n_sub bare substeps) of every env of the shard.
 // grid = n_envs, block = 64*nw threads.  MAXW bounds nw for the register allocator.
 // ---------------------------------------------------------------------------------
+#ifndef SOFTROD_OCTO_WAVES
+#define SOFTROD_OCTO_WAVES 2
+#endif
 template <unsigned F, int MAXW>
-__global__ void __launch_bounds__(kLanes * MAXW, 2)
+__global__ void __launch_bounds__(kLanes * MAXW, SOFTROD_OCTO_WAVES)
 softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                          const int n_sub, const int epilogue, const int pack) {
-    __shared__ double xch[2][MAXW][6];
+    __shared__ double xch[2][MAXW * 4][3];   // [buffer][arm][Fx, Fy, Tz]
     __shared__ double sxy[kLanes * MAXW][2];
     __shared__ int scount;
 
@@ -183,6 +186,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     HeadState H;
     double tgt[2];
     load_head(S, N, env, H, tgt);
+    H.v[2] = 0.0; H.w[0] = 0.0; H.w[1] = 0.0;   // compute_constrain_rates holds these at zero
     const double before[2] = {H.x[0], H.x[1]};
 
     // set_action (flat_env.py:288-311): rest_kappa[0,:] = zero-padded cubic interp1d of the
@@ -222,11 +226,11 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
 
     auto connect = [&](double (&f)[1][3], double (&tq)[1][3], const LaneN<1>& Lc, const double (&xn)[1][3]) {
         // FixedJoint2Rigid.apply_forces (joint.py:48-123): spring + normal damping between the
-        // arm's node 0 and the point head_radius along the arm's direction from the head axis
-        const double b0 = H.Q[3], b1 = H.Q[4], b2 = H.Q[5];
-        const double dir[3] = {-(ct * b0 - st * b1), -(st * b0 + ct * b1), -b2};
-        const double pos[3] = {fma(dir[0], P.head_radius, H.x[0]), fma(dir[1], P.head_radius, H.x[1]),
-                               dir[2] * P.head_radius};
+        // arm's node 0 and the point head_radius along the arm's direction from the head axis.
+        // The head's d2 lies in the plane (constrain_values), so the direction has no z part.
+        const double b0 = H.Q[3], b1 = H.Q[4];
+        const double dir[2] = {-(ct * b0 - st * b1), -(st * b0 + ct * b1)};
+        const double pos[3] = {fma(dir[0], P.head_radius, H.x[0]), fma(dir[1], P.head_radius, H.x[1]), 0.0};
         double dv[3], d2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { dv[i] = Lc.x[0][i] - pos[i]; d2 = fma(dv[i], dv[i], d2); }
@@ -235,57 +239,52 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         double nv[3], rel = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { nv[i] = dv[i] * idist; rel = fma(Lc.v[0][i] - H.v[i], nv[i], rel); }
+        const double damp = P.joint_nu * rel;
         double fj[3], link[3], force[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            fj[i] = fma(P.joint_k, dv[i], -P.joint_nu * (rel * nv[i]));
+            fj[i] = fma(P.joint_k, dv[i], -damp * nv[i]);
             link[i] = xn[0][i] - Lc.x[0][i];
-            // apply_torques (joint.py:125-219): node 1 pulled towards its rest place on the ray
-            force[i] = -P.joint_kt * (xn[0][i] - fma(P.rest_len, dir[i], pos[i]));
         }
+        // apply_torques (joint.py:125-219): node 1 pulled towards its rest place on the ray
+        force[0] = -P.joint_kt * (xn[0][0] - fma(P.rest_len, dir[0], pos[0]));
+        force[1] = -P.joint_kt * (xn[0][1] - fma(P.rest_len, dir[1], pos[1]));
+        force[2] = -P.joint_kt * xn[0][2];
         const double tj[3] = {link[1] * force[2] - link[2] * force[1], link[2] * force[0] - link[0] * force[2],
                               link[0] * force[1] - link[1] * force[0]};
-        double red[6];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            red[i] = base ? fj[i] : 0.0;
-            red[3 + i] = base ? tj[i] : 0.0;
-            f[0][i] -= red[i];
+            f[0][i] -= base ? fj[i] : 0.0;
             const double* Q = Lc.Q[0];
             tq[0][i] += base ? fma(Q[3 * i + 2], tj[2], fma(Q[3 * i + 1], tj[1], Q[3 * i] * tj[0])) : 0.0;
         }
-        // net load on the head: arms of this wave, then the waves of the env through LDS
-        for (int off = 32; off >= P.seg; off >>= 1) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) red[i] += __shfl_xor(red[i], off);
+        // Net load on the head.  Its rates are held to (vx, vy, 0), (0, 0, wz) and its d3 to e_z,
+        // so only Fx, Fy and the lab-frame torque about z (= torque along d3) reach it.  Every
+        // arm posts its three numbers in LDS; they are consumed after the arms' contact and
+        // rate update (head_update below), which hides the LDS round trip and lets the waves
+        // of the env reach the barrier together.
+        if (base) {
+            xch[parity][arm][0] = fj[0];
+            xch[parity][arm][1] = fj[1];
+            xch[parity][arm][2] = tj[2];
         }
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) xch[parity][wave][i] = red[i];
-        }
+    };
+    // RigidBodyBase.update_accelerations + the rate update under
+    // BodyBoundaryCondition.compute_constrain_rates (constraint.py:60-85): with
+    // w = (0, 0, wz) the gyroscopic term J w x w vanishes identically.  Every lane sums the
+    // arms in the same order (arm 0 first, as the reference's loop over connections), so the
+    // head replicas stay bit-identical.  LDS is double-buffered: ONE barrier per substep.
+    auto head_update = [&]() {
         __syncthreads();
-        double tot[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int w = 0; w < nw; ++w) {
+        double tot[3] = {0.0, 0.0, 0.0};
+        for (int a = 0; a < P.n_arm; ++a) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) tot[i] += xch[parity][w][i];
+            for (int i = 0; i < 3; ++i) tot[i] += xch[parity][a][i];
         }
         parity ^= 1;
-        // RigidBodyBase.update_accelerations + the rate update, then
-        // BodyBoundaryCondition.compute_constrain_rates (constraint.py:60-85)
-        const double* Qh = H.Q;
-        double th[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            th[i] = -fma(Qh[3 * i + 2], tot[5], fma(Qh[3 * i + 1], tot[4], Qh[3 * i] * tot[3]));
-        const double jw[3] = {P.head_J[0] * H.w[0], P.head_J[1] * H.w[1], P.head_J[2] * H.w[2]};
-        const double lt[3] = {jw[1] * H.w[2] - jw[2] * H.w[1], jw[2] * H.w[0] - jw[0] * H.w[2],
-                              jw[0] * H.w[1] - jw[1] * H.w[0]};
         H.v[0] = fma(P.dt, tot[0] * head_inv_mass, H.v[0]);
         H.v[1] = fma(P.dt, tot[1] * head_inv_mass, H.v[1]);
-        H.v[2] = 0.0;
-        H.w[0] = 0.0;
-        H.w[1] = 0.0;
-        H.w[2] = fma(P.dt, P.head_invJ[2] * (lt[2] + th[2]), H.w[2]);
+        H.w[2] = fma(P.dt, P.head_invJ[2] * (-tot[2]), H.w[2]);
     };
 
     if (n_sub > 0) {
@@ -297,6 +296,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             const bool last = (s == n_sub - 1);
             const double h = last ? P.half_dt : P.dt;
             kinematic_n<1>(h, C, L);
+            head_update();
             head_kinematic(h, H);
             time += P.time_two_half_adds ? P.half_dt : P.dt;
             if (!last && P.time_two_half_adds) time += P.half_dt;
