@@ -47,28 +47,43 @@ __device__ __forceinline__ void sinc_cosc(double t, double& sc, double& cc) {
 }
 
 // theta/sin(theta) as a function of y = sin^2(theta/2) = (1 - cos theta)/2:
-//   asin(sqrt y)/(sqrt y sqrt(1-y)) = sum_k (2k)!!/(2k+1)!! y^k.
-// y < 2.5e-3 (neighbouring elements < 0.1 rad apart): 6 terms, remainder 0.34 y^6 < 1e-16.
-// Otherwise the half-angle recursion y' = y / (2 (1 + sqrt(1-y))) is applied until it
-// fits and theta/sin(theta) = 2^k (phi/sin phi) sin(phi)/sin(theta).
+//   asin(sqrt y)/(sqrt y sqrt(1-y)) = sum_k c_k y^k,  c_k = (2k)!!/(2k+1)!! = c_{k-1} 2k/(2k+1).
+// The series is truncated where its remainder c_K y^K/(1-y) drops below 1e-17, in three
+// wave-uniform tiers (the trip from one tier to the next costs one s_cbranch):
+//   y < 2.5e-3 (neighbouring elements < 0.1 rad apart, a 50-element rod at rest):  6 terms
+//   y < 0.04   (< 0.40 rad: the falling / whipping pendulum):                      12 terms
+//   y < 0.15   (< 0.79 rad: 10-element octopus arms at full curl):                 20 terms
+// Beyond that the half-angle recursion y' = y / (2 (1 + sqrt(1-y))) is applied until the last
+// tier fits and theta/sin(theta) = 2^k (phi/sin phi) sin(phi)/sin(theta).
+template <int K>
+__device__ __forceinline__ double theta_over_sin_series(double y) {
+    // c_k by the recurrence, folded at compile time
+    double c[K];
+    c[0] = 1.0;
+#pragma unroll
+    for (int k = 1; k < K; ++k) c[k] = c[k - 1] * (double)(2 * k) / (double)(2 * k + 1);
+    double g = c[K - 1];
+#pragma unroll
+    for (int k = K - 2; k >= 0; --k) g = fma(g, y, c[k]);
+    return g;
+}
+
 __device__ __forceinline__ double theta_over_sin(double y, bool valid) {
+    if (!__any(valid && !(y < 2.5e-3))) return theta_over_sin_series<6>(y);
+    if (!__any(valid && !(y < 0.04))) return theta_over_sin_series<12>(y);
     const double y0 = y;
     int k = 0;
-    while (__any(valid && !(y < 2.5e-3)) && k < 12) {
+    while (__any(valid && !(y < 0.15)) && k < 12) {
         const double om = fmax(1.0 - y, 1.0e-300);
-        y = 0.5 * y / (1.0 + om * fast_rsqrt(om));
+        y = 0.5 * y * fast_rcp(1.0 + om * fast_rsqrt(om));
         ++k;
     }
-    double g = 256.0 / 693.0;            // k = 5
-    g = fma(g, y, 128.0 / 315.0);        // k = 4
-    g = fma(g, y, 16.0 / 35.0);          // k = 3
-    g = fma(g, y, 8.0 / 15.0);           // k = 2
-    g = fma(g, y, 2.0 / 3.0);            // k = 1
-    g = fma(g, y, 1.0);
+    double g = theta_over_sin_series<20>(y);
     if (k > 0) {
         // sin(phi) = 2 sqrt(y(1-y)) at both levels
-        const double a = y * (1.0 - y), b = fmax(y0 * (1.0 - y0), 1.0e-300);
+        const double a = fmax(y * (1.0 - y), 1.0e-300), b = fmax(y0 * (1.0 - y0), 1.0e-300);
         g *= (double)(1 << k) * (a * fast_rsqrt(a)) * fast_rsqrt(b);
+        g = (y0 < 1.0e-30) ? 1.0 : g;     // a straight joint in a wave that had to halve
     }
     return g;
 }
@@ -84,6 +99,10 @@ __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid, doubl
     e2 = fma(x2, fma(x2, fma(x2, fma(x2, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
     for (; k > 0; --k) { e0 *= e0; e2 *= e2; }
 }
+
+}  // namespace softrod
+#include "softrod_planar.hpp"
+namespace softrod {
 
 // ---- kinematic step, per slot ------------------------------------------------------------------
 template <int EPL>
@@ -319,6 +338,9 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
 #ifndef SOFTROD_FAST_WAVES
 #define SOFTROD_FAST_WAVES 3
 #endif
+#ifndef SOFTROD_PLANAR_EPL_OK
+#define SOFTROD_PLANAR_EPL_OK(epl) true
+#endif
 #ifndef SOFTROD_CONTACT_WAVES
 #define SOFTROD_CONTACT_WAVES 2
 #endif
@@ -354,7 +376,26 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     RodParams Pk = P;
     if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
 
-    if (n_sub > 0) {
+    bool stepped = false;
+    if constexpr (F == SOFTROD_FEATURES_SOFTPENDULUM && SOFTROD_PLANAR_EPL_OK(EPL)) {
+        // SoftPendulum-v0 lives in the x-y plane: same substep without the identically
+        // zero out-of-plane terms (softrod_planar.hpp); any other state takes the 3-D loop
+        PlanarN<EPL> Z;
+        if (n_sub > 0 && planar_from_lane<EPL>(P, B, lane, L, Z)) {
+            planar_kinematic_n<EPL>(P.half_dt, C, Z);
+            if (P.time_two_half_adds) time += P.half_dt;
+            for (int s = 0; s < n_sub; ++s) {
+                planar_dynamic_n<EPL>(Pk, C, lane, Z);
+                const bool last = (s == n_sub - 1);
+                planar_kinematic_n<EPL>(last ? P.half_dt : P.dt, C, Z);
+                time += P.time_two_half_adds ? P.half_dt : P.dt;
+                if (!last && P.time_two_half_adds) time += P.half_dt;
+            }
+            planar_to_lane<EPL>(Z, L);
+            stepped = true;
+        }
+    }
+    if (n_sub > 0 && !stepped) {
         kinematic_n<EPL>(P.half_dt, C, L);
         if (P.time_two_half_adds) time += P.half_dt;
         for (int s = 0; s < n_sub; ++s) {

@@ -1,0 +1,202 @@
+// softrod_planar.hpp — the SoftPendulum-v0 substep when the rod lies in the x-y plane.
+//
+// build_soft_pendulum (gym_softrobot/envs/soft_pendulum/build.py:46-113) starts the rod in
+// the plane z = 0 (direction (cos t, sin t, 0), normal (sin t, -cos t, 0)), and everything
+// that acts on it is in-plane: gravity along -y (:88-91), the point force along x (:94-105),
+// the pendulum constraint (:65-85).  The 3-D Cosserat update then keeps, IN IEEE
+// ARITHMETIC AND EXACTLY, every out-of-plane quantity at zero: x_z = v_z = 0, d1_z = d3_z =
+// 0, d2 = (0, 0, +-1), omega = (0, w, 0) in the local frame, kappa = (0, k, 0); products
+// with exact zeros are exact zeros and sums of them stay zero.  So for such a state the
+// general kernel spends two thirds of its fp64 instructions computing zeros.
+//
+// This file is that same substep with the zeros removed: positions and velocities have two
+// components, the frame is the unit vector d3 = (c, s) (d1 = d2 x d3 = (-s2 s, s2 c) with
+// s2 = d2_z), the angular velocity and the curvature are scalars.  Every formula below is
+// the corresponding line of dynamic_n / kinematic_n (softrod_fast.hpp) with the identically
+// zero terms dropped; the comment on each block says which.  The only non-identical step is
+// that d1 is rebuilt from d3 instead of being rotated separately (they differ by the
+// rounding of one rotation, ~1e-16).
+//
+// The step kernel takes this path only if the loaded state IS planar (planar_from_lane:
+// exact zeros where the argument above needs them, d1 consistent with d3 to 1e-12); any
+// other state — e.g. one written through softrod_state_view — runs the general 3-D loop.
+#pragma once
+
+namespace softrod {
+
+template <int EPL>
+struct PlanarN {
+    double x[EPL][2], v[EPL][2];
+    double c[EPL], s[EPL];     // d3 = (c, s, 0)
+    double s2[EPL];            // d2 = (0, 0, s2), s2 = +-1
+    double w[EPL];             // omega = (0, w, 0) in the local frame
+    double t[EPL][2];          // tangents as of the last force evaluation
+};
+
+// exp(x) for the damper (see exp_pair)
+__device__ __forceinline__ double exp_one(double x, bool valid) {
+    int k = 0;
+    while (__any(valid && !(fabs(x) < 1.0e-3)) && k < 60) { x *= 0.5; ++k; }
+    double e = fma(x, fma(x, fma(x, fma(x, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
+    for (; k > 0; --k) e *= e;
+    return e;
+}
+
+// Wave-uniform: true if the whole rod (and its forcing) is planar in the sense above.
+template <int EPL>
+__device__ __forceinline__ bool planar_from_lane(const RodParams& P, const BcTargets& B, int lane,
+                                                 const LaneN<EPL>& L, PlanarN<EPL>& Z) {
+    const int n = P.n_elem;
+    bool ok = (P.gravity[2] == 0.0) && (B.pos[2] == 0.0) && (B.Q[2] == 0.0) && (B.Q[8] == 0.0);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = lane * EPL + s;
+        const double* Q = L.Q[s];
+        // d2_z = -(cos^2 + sin^2) as straight_rod's cross product rounds it: +-1 to an ulp;
+        // the planar update leaves row 1 of Q untouched, exactly like the 3-D one (R4 = 1)
+        const double s2 = (Q[5] < 0.0) ? -1.0 : 1.0, c = Q[6], sn = Q[7];
+        const bool node_ok = (L.x[s][2] == 0.0) && (L.v[s][2] == 0.0);
+        const bool elem_ok = (Q[2] == 0.0) && (Q[3] == 0.0) && (Q[4] == 0.0) && (Q[8] == 0.0) &&
+                             (fabs(fabs(Q[5]) - 1.0) <= 1.0e-12) && (L.w[s][0] == 0.0) && (L.w[s][2] == 0.0) &&
+                             (fabs(fma(s2, sn, Q[0])) <= 1.0e-12) && (fabs(fma(-s2, c, Q[1])) <= 1.0e-12) &&
+                             (fabs(fma(c, c, fma(sn, sn, -1.0))) <= 1.0e-12);
+        ok = ok && (idx > n || node_ok) && (idx >= n || elem_ok);
+        Z.x[s][0] = L.x[s][0]; Z.x[s][1] = L.x[s][1];
+        Z.v[s][0] = L.v[s][0]; Z.v[s][1] = L.v[s][1];
+        Z.c[s] = c; Z.s[s] = sn; Z.s2[s] = (idx < n) ? s2 : 1.0;
+        Z.w[s] = L.w[s][1];
+        Z.t[s][0] = L.t[s][0]; Z.t[s][1] = L.t[s][1];
+    }
+    return !__any(!ok);
+}
+
+template <int EPL>
+__device__ __forceinline__ void planar_to_lane(const PlanarN<EPL>& Z, LaneN<EPL>& L) {
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        L.x[s][0] = Z.x[s][0]; L.x[s][1] = Z.x[s][1];
+        L.v[s][0] = Z.v[s][0]; L.v[s][1] = Z.v[s][1];
+        L.Q[s][0] = -Z.s2[s] * Z.s[s]; L.Q[s][1] = Z.s2[s] * Z.c[s];
+        L.Q[s][6] = Z.c[s]; L.Q[s][7] = Z.s[s];
+        L.w[s][1] = Z.w[s];
+        L.t[s][0] = Z.t[s][0]; L.t[s][1] = Z.t[s][1]; L.t[s][2] = 0.0;
+    }
+}
+
+// kinematic_n with a = (0, h w, 0): R0 = R8 = cos, R6 = -R2 = sin, R4 = 1, the rest 0, so
+// the new d3 = sin * d1 + cos * d3.
+template <int EPL>
+__device__ __forceinline__ void planar_kinematic_n(double h, const ConstN<EPL>& C, PlanarN<EPL>& Z) {
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const double hp = h * C.hx[s];
+        Z.x[s][0] = fma(hp, Z.v[s][0], Z.x[s][0]);
+        Z.x[s][1] = fma(hp, Z.v[s][1], Z.x[s][1]);
+        const double a = (h * C.hq[s]) * Z.w[s];
+        const double t = a * a;
+        double sc, cc;
+        sinc_cosc(t, sc, cc);
+        const double sn = (sc * a) * Z.s2[s], cs = fma(-cc, t, 1.0);
+        const double c = Z.c[s], sv = Z.s[s];
+        Z.c[s] = fma(-sn, sv, cs * c);
+        Z.s[s] = fma(sn, c, cs * sv);
+    }
+}
+
+// dynamic_n for SOFTROD_FEATURES_SOFTPENDULUM (gravity and the point force live in C.ca,
+// the analytical damper is fused, the pendulum constraint pins v_y of node 0).
+template <int EPL>
+__device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const ConstN<EPL>& C, int lane,
+                                                 PlanarN<EPL>& Z) {
+    const int n = P.n_elem;
+    double xn[EPL][2], vn[EPL][2], d[EPL][2];
+    double len[EPL], il[EPL], e[EPL], ie[EPL];
+    double qt0[EPL], qt2[EPL], np0[EPL], np2[EPL], cs[EPL][2], f[EPL][2], tq[EPL];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        double a[EPL], o[EPL], av[EPL], ov[EPL];
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) { a[s] = Z.x[s][c]; av[s] = Z.v[s][c]; }
+        shift_next<EPL>(a, o);
+        shift_next<EPL>(av, ov);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) { xn[s][c] = o[s]; vn[s][c] = ov[s]; }
+    }
+    // geometry and shear/stretch: qt = Q t has no d2 component, so n = S (Q t - z/e) has none
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const bool elem_valid = (lane * EPL + s) < n;
+        d[s][0] = xn[s][0] - Z.x[s][0];
+        d[s][1] = xn[s][1] - Z.x[s][1];
+        double dd = fma(d[s][1], d[s][1], d[s][0] * d[s][0]);
+        dd = elem_valid ? dd : 1.0;
+        const double r = fast_rsqrt(dd);
+        len[s] = fma(dd, r, P.eps_length);
+        il[s] = fma(-P.eps_length * r, r, r);
+        Z.t[s][0] = d[s][0] * il[s];
+        Z.t[s][1] = d[s][1] * il[s];
+        e[s] = len[s] * P.inv_rest_len;
+        ie[s] = P.rest_len * il[s];
+        const double d1x = -Z.s2[s] * Z.s[s], d1y = Z.s2[s] * Z.c[s];
+        qt0[s] = fma(d1y, Z.t[s][1], d1x * Z.t[s][0]);
+        qt2[s] = fma(Z.s[s], Z.t[s][1], Z.c[s] * Z.t[s][0]);
+        np0[s] = C.s01[s] * qt0[s];
+        np2[s] = C.s2[s] * (qt2[s] - ie[s]);
+        cs[s][0] = fma(Z.c[s], np2[s], d1x * np0[s]);
+        cs[s][1] = fma(Z.s[s], np2[s], d1y * np0[s]);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        double a[EPL], o[EPL];
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) a[s] = cs[s][c];
+        shift_prev<EPL>(a, o);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) f[s][c] = cs[s][c] - o[s];
+    }
+    // bend: Q+ Q^T is a rotation about d2 by D = angle(d3+) - angle(d3); of _inv_rotate's
+    // vector only component 1 = RD(0,2) - RD(2,0) = -2 s2 sin D survives, trace = 1 + 2 cos D
+    double cnx[EPL], snx[EPL], len_n[EPL], up[EPL];
+    shift_next<EPL>(Z.c, cnx);
+    shift_next<EPL>(Z.s, snx);
+    shift_next<EPL>(len, len_n);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const bool vor_valid = (lane * EPL + s) < n - 1;
+        const double sinD = fma(snx[s], Z.c[s], -cnx[s] * Z.s[s]);
+        const double cosD = fma(cnx[s], Z.c[s], snx[s] * Z.s[s]);
+        const double y = fma(-0.5, cosD, 0.5 + 0.5 * P.acos_shift);
+        const double gk = theta_over_sin(y, vor_valid) * (-0.5 * P.inv_rest_vor);
+        const double k1 = (-2.0 * Z.s2[s] * sinD) * gk;
+        const double vd = (len_n[s] + len[s]) * (0.5 * P.inv_rest_vor);
+        const double rvd = fast_rcp(vd);
+        up[s] = C.b01[s] * k1 * (rvd * rvd * rvd);       // B kappa / vd^3; kappa x B kappa = 0
+    }
+    {
+        double o[EPL];
+        shift_prev<EPL>(up, o);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) tq[s] = up[s] - o[s];
+    }
+    // shear couple (component 1 of (Q t) x n), unsteady dilatation; the transport term
+    // (J w) x w vanishes for w = (0, w, 0)
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        tq[s] = fma(len[s], fma(qt2[s], np0[s], -qt0[s] * np2[s]), tq[s]);
+        const double num = fma(d[s][1], vn[s][1] - Z.v[s][1], d[s][0] * (vn[s][0] - Z.v[s][0]));
+        const double sdil = num * il[s] * il[s];
+        tq[s] = fma((P.J[0] * ie[s]) * sdil, Z.w[s], tq[s]);
+    }
+    // rate update fused with the analytical damper, then constrain_rates (v_y of node 0)
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const bool elem_valid = (lane * EPL + s) < n;
+        Z.v[s][0] = fma(P.damp_t, Z.v[s][0], fma(C.cf[s], f[s][0], C.ca[s][0]));
+        Z.v[s][1] = fma(P.damp_t, Z.v[s][1], fma(C.cf[s], f[s][1], C.ca[s][1]));
+        const double w = fma(C.cw01[s] * e[s], tq[s], Z.w[s]);
+        Z.w[s] = w * exp_one(e[s] * P.damp_logr[0], elem_valid);
+    }
+    Z.v[0][1] = (lane == 0) ? 0.0 : Z.v[0][1];
+}
+
+}  // namespace softrod

@@ -284,8 +284,11 @@ def _inject(be, name, arr):
     st[name][:, :, : arr.shape[1]] = t[:, None, :]
 
 
-def test_fast_kernel_large_bending_angles(torch_gpu, hip_lib, oracle_built):
-    # neighbouring elements > 0.1 rad apart -> half-angle recursion in theta_over_sin
+@pytest.mark.parametrize("E,F,lo,hi", [(1e6, 20.0, 0.1, 0.4), (3e5, 20.0, 0.4, 0.79), (1e5, 40.0, 0.79, 2.0)],
+                         ids=["12-term", "20-term", "halving"])
+def test_fast_kernel_large_bending_angles(torch_gpu, hip_lib, oracle_built, E, F, lo, hi):
+    # neighbouring elements > 0.1 / 0.4 / 0.79 rad apart -> the longer series of theta_over_sin
+    # and, beyond them, its half-angle recursion
     from gym_softrobot_amd import _capi
 
     n_el = 10
@@ -293,7 +296,9 @@ def test_fast_kernel_large_bending_angles(torch_gpu, hip_lib, oracle_built):
     cfg.features = _capi.FEAT_FIXED_BC | _capi.FEAT_TIP_FORCE | _capi.FEAT_ANALYTICAL_DAMPER
     cfg.damping_constant = 0.8
     cfg.dt = 2e-4
-    cfg.tip_force[1] = 20.0
+    cfg.tip_force[1] = F
+    cfg.youngs_modulus = E
+    cfg.shear_modulus = E / 3.0
     be = _backend(cfg)
     be.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
     rod = oracle_built.OracleRod(cfg)
@@ -303,10 +308,60 @@ def test_fast_kernel_large_bending_angles(torch_gpu, hip_lib, oracle_built):
     st = be.state_numpy()
     rod.refresh_strains()
     ang = np.abs(rod.get("kappa")).max() * (1.0 / n_el)
-    assert ang > 0.15, ang                      # the slow branch really ran
+    assert lo < ang < hi, ang                   # the intended branch really ran
     np.testing.assert_allclose(st["x"][0], rod.get("x"), rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(st["Q"][1], rod.get("Q"), rtol=1e-7, atol=1e-9)
     be.close()
+
+
+def test_planar_and_general_paths_of_softpendulum(torch_gpu, hip_lib, oracle_built):
+    """SoftPendulum-v0 states are planar and take the 2-D substep (softrod_planar.hpp); a
+    state that is not — here: an out-of-plane velocity written through the state view —
+    must take the general 3-D loop.  Both against the oracle, and against each other when
+    the perturbation is far below the tolerance."""
+    import gym_softrobot_amd as gsa
+
+    n = 3
+    env = gsa.make_vec("SoftPendulum-v0", n, device=0)
+    env.reset(seed=0)
+    rods = []
+    for i in range(n):
+        r = oracle_built.OracleRod(env.cfg)
+        r.reset_pendulum(_theta(i))
+        rods.append(r)
+    st = env.backend.state()
+    # env 0: planar.  env 1: v_z = 0.3 m/s on nodes 10..29.  env 2: v_z = 1e-200 (3-D loop,
+    # numerically the planar trajectory)
+    for i, amp in ((1, 0.3), (2, 1e-200)):
+        v = rods[i].get("v")
+        v[2, 10:30] = amp
+        rods[i].set("v", v)
+        st["velocity"][2, i, 10:30] = amp
+    acts = np.random.default_rng(4).uniform(-22, 22, (3, n)).astype(np.float32)
+    for t in range(3):
+        obs, rew, term, trunc, _ = env.step(acts[t])
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for i, r in enumerate(rods):
+            o, rw, te, tr = r.env_step(acts[t, i])
+            np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=1e-7)
+            np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-9)
+    sn = env.backend.state_numpy()
+    for i, r in enumerate(rods):
+        np.testing.assert_allclose(sn["x"][i], r.get("x"), rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(sn["Q"][i], r.get("Q"), rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(sn["w"][i], r.get("w"), rtol=RTOL, atol=1e-5)
+    assert np.all(sn["x"][0][2] == 0.0) and np.all(sn["v"][0][2] == 0.0)      # stayed exactly planar
+    assert np.abs(sn["x"][1][2]).max() > 1e-3                                    # really left the plane
+    # env 2 ran the 3-D loop on (numerically) the planar problem of a clone of itself
+    env2 = gsa.make_vec("SoftPendulum-v0", n, device=0)
+    env2.reset(seed=0)
+    for t in range(3):
+        env2.step(acts[t])
+    sp = env2.backend.state_numpy()
+    np.testing.assert_allclose(sn["x"][2][:2], sp["x"][2][:2], rtol=1e-9, atol=1e-11)
+    np.testing.assert_array_equal(sn["x"][0], sp["x"][0])
+    env.close()
+    env2.close()
 
 
 def test_fast_kernel_large_rotation_rates(torch_gpu, hip_lib, oracle_built):
