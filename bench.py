@@ -169,8 +169,9 @@ def main() -> None:
         traffic = None
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists():  # measured with rocprofv3 --pmc (separate passes), see profiles/README.md
-            try:
-                traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+            try:   # keyed by workload: only a measurement of THIS env / size / batch is reported
+                key = f"{args.env}|n_elem={int(cfg.n_elem)}|envs={n_local}"
+                traffic = json.loads(tf.read_text()).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
