@@ -85,6 +85,9 @@ def main() -> None:
                     choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0", "OctoFlat-v0"],
                     help="headline metric is SoftPendulum-v0; the others are the widened §8 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--autoreset", choices=["off", "host", "device"], default="off",
+                    help="NEXT_STEP auto-reset of finished envs (default off: the headline window "
+                         "stays inside one episode); 'device' = staged reset records, no host read")
     ap.add_argument("--n-elems", type=int, default=None, help="elements per rod (env default if omitted)")
     args = ap.parse_args()
 
@@ -121,6 +124,8 @@ def main() -> None:
     K, W = args.steps, args.warmup
     math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
     extra = {} if args.n_elems is None else {"n_elems": args.n_elems}
+    if args.autoreset != "off":
+        extra["autoreset"] = True if args.autoreset == "host" else "device"
     local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode, **extra)
     env = ShardedVecEnv(local, n_total)   # world > 1: kernel-packed rows + one all-gather per step
     env.reset(seed=0)                      # global env i seeded i
@@ -153,7 +158,7 @@ def main() -> None:
         elapsed = float(el.item())
 
     kt = local.backend.kernel_times_ms()
-    assert len(kt) == K
+    assert len(kt) == K or args.autoreset != "off"
     n_bad = int((~torch.isfinite(obs).all(dim=1)).sum().item())
 
     if rank == 0:
@@ -195,6 +200,7 @@ def main() -> None:
                 "envs_total": n_total,
                 "substeps_per_env_step": nsub,
                 "math_mode": args.math_mode,
+                "autoreset": args.autoreset,
                 "sharding": "contiguous env blocks per rank; one packed all_gather per step" if world > 1 else "single GPU",
                 "rod_substeps_per_sec": n_total * rods_per_env * K * nsub / elapsed,
                 "non_finite_envs_at_end": n_bad,

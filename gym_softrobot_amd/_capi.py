@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -365,6 +365,12 @@ _EXPORTS = {
     "softrod_config_action_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),
     "softrod_config_obs_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),
     "softrod_reset_octo": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "softrod_autoreset_enable": (C.c_int, [_VP, C.c_int]),
+    "softrod_queue_push": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
+    "softrod_queue_push_straight": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
+    "softrod_queue_push_octo": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
+    "softrod_queue_status": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "softrod_queue_advance": (C.c_int, [_VP, _VP, _VP]),
     "softrod_set_action_basis": (C.c_int, [_VP, _VP]),
     "softrod_create": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "softrod_reset": (C.c_int, [_VP, _VP, _VP, _VP]),

@@ -132,6 +132,53 @@ class HipRodBackend:
             self._h,
         )
 
+    # -- device-side auto-reset (softrod_autoreset_enable / softrod_queue_*) ---------------------
+    def autoreset_enable(self, depth: int) -> None:
+        check(self._lib.softrod_autoreset_enable(self._h, int(depth)), self._h)
+        self.queue_depth = int(depth)
+
+    @staticmethod
+    def _counts(counts, n):
+        return np.ascontiguousarray(counts, dtype=np.int32).reshape(n)
+
+    def queue_push(self, theta0, counts) -> None:
+        th = np.ascontiguousarray(theta0, dtype=np.float64).reshape(self.n_envs, -1)
+        c = self._counts(counts, self.n_envs)
+        check(self._lib.softrod_queue_push(self._h, th.ctypes.data, c.ctypes.data, th.shape[1], self._stream()),
+              self._h)
+
+    def queue_push_straight(self, start, direction, normal, counts) -> None:
+        arrs = [np.ascontiguousarray(v, dtype=np.float64).reshape(self.n_envs, -1, 3)
+                for v in (start, direction, normal)]
+        c = self._counts(counts, self.n_envs)
+        check(self._lib.softrod_queue_push_straight(
+            self._h, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, c.ctypes.data,
+            arrs[0].shape[1], self._stream()), self._h)
+
+    def queue_push_octo(self, targets, counts) -> None:
+        na = int(self.cfg.n_arm)
+        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, -1, 2)
+        m = tg.shape[1]
+        pos, dirs = _capi.octo_arm_frames(na, float(self.cfg.head_radius))
+        pos = np.ascontiguousarray(np.broadcast_to(pos, (self.n_envs, m, na, 3)))
+        dirs = np.ascontiguousarray(np.broadcast_to(dirs, (self.n_envs, m, na, 3)))
+        c = self._counts(counts, self.n_envs)
+        check(self._lib.softrod_queue_push_octo(
+            self._h, pos.ctypes.data, dirs.ctypes.data, tg.ctypes.data, c.ctypes.data, m, self._stream()),
+            self._h)
+
+    def queue_status(self):
+        """(consumed[n_envs], underflow) — synchronises the stream."""
+        cons = np.zeros(self.n_envs, np.int32)
+        uf = C.c_int32(0)
+        check(self._lib.softrod_queue_status(self._h, cons.ctypes.data, C.byref(uf), self._stream()), self._h)
+        return cons, int(uf.value)
+
+    def queue_advance(self, by) -> None:
+        """Mark by[e] staged records of env e as used (by[e] < 0: all of them)."""
+        b = np.ascontiguousarray(by, dtype=np.int32).reshape(self.n_envs)
+        check(self._lib.softrod_queue_advance(self._h, b.ctypes.data, self._stream()), self._h)
+
     def observe(self, prev_action: Optional[torch.Tensor] = None) -> torch.Tensor:
         pa = None
         if prev_action is not None:
@@ -198,6 +245,14 @@ class HipRodBackend:
         ms = C.c_float()
         check(self._lib.softrod_last_kernel_ms(self._h, C.byref(ms)), self._h)
         return float(ms.value)
+
+    def prev_action_rows(self) -> torch.Tensor:
+        """Writable (n_envs, action_dim) view of the resident `_prev_action`."""
+        if getattr(self, "_prev_rows", None) is None:
+            self._prev_rows = self.state()["prev_action"]
+            if not self.is_octo:
+                self._prev_rows = self._prev_rows[:, : self.action_dim]
+        return self._prev_rows
 
     def state(self) -> Dict[str, torch.Tensor]:
         """Zero-copy torch views of the resident SoA state (softrod_state_view)."""

@@ -36,6 +36,17 @@ struct softrod_handle {
     std::vector<hipEvent_t> ev_start, ev_stop;  // timing ring (softrod_set_timing)
     int timed = 0;                  // launches recorded since set_timing
     hipEvent_t ev_reset = nullptr;  // guards reuse of the pinned staging buffers
+    // device-side auto-reset (softrod_autoreset_enable)
+    int q_depth = 0;
+    double* d_queue = nullptr;      // [depth][N][init_stride]
+    double* h_queue = nullptr;      // pinned mirror
+    int* d_consumed = nullptr;      // [N]
+    int* d_produced = nullptr;      // [N]
+    int* d_underflow = nullptr;     // [1]
+    uint8_t* d_flags = nullptr;     // [2][N]: needs_reset, skip
+    int* h_produced = nullptr;      // pinned [N]
+    std::vector<int> seen_consumed; // as of the last softrod_queue_status
+    hipEvent_t ev_queue = nullptr;  // guards reuse of h_queue / h_produced
     std::string err;
 };
 
@@ -165,6 +176,18 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
                 uint8_t* term, uint8_t* trunc, double* aux, int n_sub, int epilogue, int pack,
                 hipStream_t st) {
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes * h->nw);
+    if (h->q_depth > 0 && epilogue) {   // NEXT_STEP auto-reset pass: finished envs restart instead of stepping
+        if (is_octo(h))
+            hipLaunchKernelGGL(softrod_octo_autoreset_kernel, grid, block, 0, st, h->P, h->S, obs, reward, term,
+                               trunc, pack);
+        else if (h->epl == 2)
+            hipLaunchKernelGGL(softrod_autoreset_kernel<2>, grid, block, 0, st, h->P, h->S, obs, reward, term,
+                               trunc, aux, pack);
+        else
+            hipLaunchKernelGGL(softrod_autoreset_kernel<1>, grid, block, 0, st, h->P, h->S, obs, reward, term,
+                               trunc, aux, pack);
+        SR_HIP(h, hipGetLastError());
+    }
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
     const bool zup = (h->P.features & kFeatPlaneZup) != 0;
@@ -501,6 +524,159 @@ int softrod_reset_octo(softrod_handle* h, const double* arm_start, const double*
     return upload_and_reset(h, (hipStream_t)stream, mask != nullptr);
 }
 
+// ---- device-side auto-reset ------------------------------------------------------------------
+int softrod_autoreset_enable(softrod_handle* h, int depth) {
+    if (!h || depth < 1 || depth > 4096) return fail(h, SOFTROD_EINVAL, "need 1 <= depth <= 4096");
+    if (h->q_depth) return fail(h, SOFTROD_EINVAL, "auto-reset is already enabled");
+    if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no episodes");
+    SR_HIP(h, hipSetDevice(h->device));
+    const size_t N = (size_t)h->cfg.n_envs;
+    const size_t qb = (size_t)depth * N * h->init_stride * sizeof(double);
+    SR_HIP(h, hipMalloc((void**)&h->d_queue, qb));
+    SR_HIP(h, hipMemset(h->d_queue, 0, qb));
+    SR_HIP(h, hipHostMalloc((void**)&h->h_queue, qb));
+    SR_HIP(h, hipMalloc((void**)&h->d_consumed, N * sizeof(int)));
+    SR_HIP(h, hipMalloc((void**)&h->d_produced, N * sizeof(int)));
+    SR_HIP(h, hipMalloc((void**)&h->d_underflow, sizeof(int)));
+    SR_HIP(h, hipMalloc((void**)&h->d_flags, 2 * N));
+    SR_HIP(h, hipMemset(h->d_consumed, 0, N * sizeof(int)));
+    SR_HIP(h, hipMemset(h->d_produced, 0, N * sizeof(int)));
+    SR_HIP(h, hipMemset(h->d_underflow, 0, sizeof(int)));
+    SR_HIP(h, hipMemset(h->d_flags, 0, 2 * N));
+    SR_HIP(h, hipHostMalloc((void**)&h->h_produced, N * sizeof(int)));
+    std::memset(h->h_produced, 0, N * sizeof(int));
+    SR_HIP(h, hipEventCreateWithFlags(&h->ev_queue, hipEventDisableTiming));
+    h->seen_consumed.assign(N, 0);
+    h->q_depth = depth;
+    h->S.needs_reset = h->d_flags;
+    h->S.skip = h->d_flags + N;
+    h->S.queue = h->d_queue;
+    h->S.q_consumed = h->d_consumed;
+    h->S.q_produced = h->d_produced;
+    h->S.q_underflow = h->d_underflow;
+    h->S.q_depth = depth;
+    h->S.q_record = (int)h->init_stride;
+    return SOFTROD_OK;
+}
+
+namespace {
+// Next free record of env e, or nullptr if staging `count` more would overwrite records the
+// device may not have consumed yet (as far as the last softrod_queue_status knows).
+int queue_begin(softrod_handle* h, const int32_t* counts, int max_count) {
+    if (!h->q_depth) return fail(h, SOFTROD_EINVAL, "call softrod_autoreset_enable first");
+    if (!counts || max_count < 0) return fail(h, SOFTROD_EINVAL, "bad argument");
+    const int N = h->cfg.n_envs;
+    for (int e = 0; e < N; ++e) {
+        if (counts[e] < 0 || counts[e] > max_count) return fail(h, SOFTROD_EINVAL, "counts[e] out of range");
+        if (h->h_produced[e] + counts[e] - h->seen_consumed[e] > h->q_depth)
+            return fail(h, SOFTROD_EINVAL, "reset queue overflow: staged + new records exceed depth");
+    }
+    SR_HIP(h, hipSetDevice(h->device));
+    SR_HIP(h, hipEventSynchronize(h->ev_queue));   // previous upload out of the pinned mirror
+    return SOFTROD_OK;
+}
+double* queue_slot(softrod_handle* h, int e, int k) {
+    return h->h_queue + ((size_t)(k % h->q_depth) * (size_t)h->cfg.n_envs + (size_t)e) * h->init_stride;
+}
+int queue_commit(softrod_handle* h, hipStream_t st) {
+    const size_t N = (size_t)h->cfg.n_envs;
+    SR_HIP(h, hipMemcpyAsync(h->d_queue, h->h_queue, (size_t)h->q_depth * N * h->init_stride * sizeof(double),
+                             hipMemcpyHostToDevice, st));
+    SR_HIP(h, hipMemcpyAsync(h->d_produced, h->h_produced, N * sizeof(int), hipMemcpyHostToDevice, st));
+    SR_HIP(h, hipEventRecord(h->ev_queue, st));
+    return SOFTROD_OK;
+}
+}  // namespace
+
+int softrod_queue_push(softrod_handle* h, const double* theta0, const int32_t* counts, int max_count,
+                       void* stream) {
+    if (!h || !theta0) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat stages resets through softrod_queue_push_octo");
+    const int rc = queue_begin(h, counts, max_count);
+    if (rc != SOFTROD_OK) return rc;
+    for (int e = 0; e < h->cfg.n_envs; ++e)
+        for (int j = 0; j < counts[e]; ++j) {
+            const double th = theta0[(size_t)e * max_count + j];
+            const double start[3] = {0.0, 0.0, 0.0};
+            const double direction[3] = {1.0 * std::cos(th), 1.0 * std::sin(th), 0.0};
+            const double normal[3] = {1.0 * std::sin(th), -1.0 * std::cos(th), 0.0};
+            straight_init(h->cfg, start, direction, normal, queue_slot(h, e, h->h_produced[e]++));
+        }
+    return queue_commit(h, (hipStream_t)stream);
+}
+
+int softrod_queue_push_straight(softrod_handle* h, const double* start, const double* direction,
+                                const double* normal, const int32_t* counts, int max_count, void* stream) {
+    if (!h || !start || !direction || !normal) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat stages resets through softrod_queue_push_octo");
+    const int rc = queue_begin(h, counts, max_count);
+    if (rc != SOFTROD_OK) return rc;
+    for (int e = 0; e < h->cfg.n_envs; ++e)
+        for (int j = 0; j < counts[e]; ++j) {
+            const size_t k = ((size_t)e * max_count + j) * 3;
+            straight_init(h->cfg, start + k, direction + k, normal + k, queue_slot(h, e, h->h_produced[e]++));
+        }
+    return queue_commit(h, (hipStream_t)stream);
+}
+
+int softrod_queue_push_octo(softrod_handle* h, const double* arm_start, const double* arm_direction,
+                            const double* target, const int32_t* counts, int max_count, void* stream) {
+    if (!h || !arm_start || !arm_direction || !target) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (!is_octo(h)) return fail(h, SOFTROD_EINVAL, "softrod_queue_push_octo is for SOFTROD_ENV_OCTO_FLAT");
+    const int rc = queue_begin(h, counts, max_count);
+    if (rc != SOFTROD_OK) return rc;
+    const int na = h->cfg.n_arm;
+    const double normal[3] = {0.0, 0.0, 1.0};
+    for (int e = 0; e < h->cfg.n_envs; ++e)
+        for (int j = 0; j < counts[e]; ++j) {
+            double* rec = queue_slot(h, e, h->h_produced[e]++);
+            const size_t k = (size_t)e * max_count + j;
+            for (int a = 0; a < na; ++a)
+                straight_init(h->cfg, arm_start + (k * na + a) * 3, arm_direction + (k * na + a) * 3, normal,
+                              rec + (size_t)a * 18);
+            rec[(size_t)na * 18] = target[2 * k];
+            rec[(size_t)na * 18 + 1] = target[2 * k + 1];
+        }
+    return queue_commit(h, (hipStream_t)stream);
+}
+
+int softrod_queue_status(softrod_handle* h, int32_t* consumed, int32_t* underflow, void* stream) {
+    if (!h || !consumed) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (!h->q_depth) return fail(h, SOFTROD_EINVAL, "call softrod_autoreset_enable first");
+    SR_HIP(h, hipSetDevice(h->device));
+    const size_t N = (size_t)h->cfg.n_envs;
+    int uf = 0;
+    SR_HIP(h, hipMemcpyAsync(consumed, h->d_consumed, N * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    SR_HIP(h, hipMemcpyAsync(&uf, h->d_underflow, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    SR_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    for (size_t e = 0; e < N; ++e) h->seen_consumed[e] = consumed[e];
+    if (underflow) *underflow = uf;
+    return SOFTROD_OK;
+}
+
+int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream) {
+    if (!h || !by) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (!h->q_depth) return fail(h, SOFTROD_EINVAL, "call softrod_autoreset_enable first");
+    SR_HIP(h, hipSetDevice(h->device));
+    const int N = h->cfg.n_envs;
+    // consumed += by (by < 0: := produced).  The device counters are only ever written by the
+    // auto-reset pass, which is stream-ordered with these copies.
+    std::vector<int> cons((size_t)N);
+    SR_HIP(h, hipMemcpyAsync(cons.data(), h->d_consumed, (size_t)N * sizeof(int), hipMemcpyDeviceToHost,
+                             (hipStream_t)stream));
+    SR_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    for (int e = 0; e < N; ++e) {
+        int c = by[e] < 0 ? h->h_produced[e] : cons[(size_t)e] + by[e];
+        if (c > h->h_produced[e]) c = h->h_produced[e];
+        cons[(size_t)e] = c;
+        h->seen_consumed[(size_t)e] = c;
+    }
+    SR_HIP(h, hipMemcpyAsync(h->d_consumed, cons.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice,
+                             (hipStream_t)stream));
+    SR_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    return SOFTROD_OK;
+}
+
 int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask, void* stream) {
     if (!h || !theta0) return fail(h, SOFTROD_EINVAL, "null argument");
     if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat resets through softrod_reset_octo");
@@ -662,6 +838,11 @@ int softrod_destroy(softrod_handle* h) {
     if (!h) return SOFTROD_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    void* qbufs[] = {h->d_queue, h->d_consumed, h->d_produced, h->d_underflow, h->d_flags};
+    for (void* p : qbufs) (void)hipFree(p);
+    if (h->h_queue) (void)hipHostFree(h->h_queue);
+    if (h->h_produced) (void)hipHostFree(h->h_produced);
+    if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
                     h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_basis, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);

@@ -355,6 +355,10 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     const int rod = blockIdx.x;
     const int lane = threadIdx.x;
     const size_t N = (size_t)P.n_envs;
+    if (epilogue && S.skip && S.skip[rod]) {   // reset by the auto-reset pass of this env.step
+        if (lane == 0) S.skip[rod] = 0;
+        return;
+    }
 
     LaneN<EPL> L;
     load_lane<EPL, F>(S, N, rod, lane, L);

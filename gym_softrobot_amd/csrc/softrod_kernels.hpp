@@ -98,6 +98,14 @@ struct StatePtrs {
     double* envmem;       // [N][64]  ArmSingle prev_kappa_state
     const double* basis;  // [(n_elem-1)][n_action]  rest_kappa[0,:] = basis @ action
     double* head;  // [20][N]  OctoFlat rigid head: x[3], v[3], Q[9], w[3], target[2]
+    // device-side auto-reset (softrod_autoreset_enable), all nullptr when off
+    uint8_t* needs_reset;   // [N] set by the step epilogue: terminated | truncated
+    uint8_t* skip;          // [N] set by the auto-reset pass: this env was reset instead of stepped
+    const double* queue;    // [depth][N][record]  pre-drawn reset records
+    int* q_consumed;        // [N] records used so far
+    const int* q_produced;  // [N] records staged so far
+    int* q_underflow;       // [1] envs that needed a record when none was staged
+    int q_depth, q_record;
 };
 
 // ---------------------------------------------------------------------------------
@@ -427,7 +435,9 @@ __device__ __forceinline__ float* out_row(float* obs, int rod, int od, int pack)
 __device__ __forceinline__ void emit_scalars(float* row, int od, int pack, int rod, double r, bool te,
                                              bool tr, double* __restrict__ reward,
                                              uint8_t* __restrict__ terminated,
-                                             uint8_t* __restrict__ truncated) {
+                                             uint8_t* __restrict__ truncated,
+                                             uint8_t* needs_reset = nullptr) {
+    if (needs_reset) needs_reset[rod] = (te || tr) ? 1 : 0;
     if (pack) {
         const int ro = od + (od & 1);
         if (od & 1) row[od] = 0.0f;
@@ -517,23 +527,22 @@ __device__ __forceinline__ double tilt_n(const RodParams& P, int lane, const Lan
 template <int E, int EPL>
 __device__ __forceinline__ void env_observe_n(const RodParams& P, const StatePtrs& S, size_t N, int rod,
                                               int lane, const ConstN<EPL>& C, const LaneN<EPL>& L,
-                                              const float* pa, float* __restrict__ obs) {
+                                              const float* pa, float* __restrict__ o) {
+    // o: this rod's observation row
     const int env = env_of<E>(P);
     if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
         const double tilt = tilt_n<EPL>(P, lane, L);
         if (lane == 0) {
-            float* o = obs + 9 * (size_t)rod;
             o[0] = (float)L.x[0][0]; o[1] = (float)L.x[0][1]; o[2] = (float)L.x[0][2];
             o[3] = (float)L.v[0][0]; o[4] = (float)L.v[0][1]; o[5] = (float)L.v[0][2];
             o[6] = pa[0]; o[7] = pa[1];
             o[8] = (float)tilt;
         }
     } else if (env == SOFTROD_ENV_ARM_SINGLE) {
-        arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, pa, obs + 25 * (size_t)rod);
+        arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, pa, o);
     } else {
         const double th = theta_n<EPL>(P, lane, L);
         if (lane == 0) {
-            float* o = obs + 4 * (size_t)rod;
             o[0] = (float)L.x[0][0];
             o[1] = (float)L.v[0][0];
             o[2] = pa[0];
@@ -574,7 +583,8 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
             if (invalid) r = -50.0;
             float* o = out_row(obs, rod, 9, pack);
             // '>=' here, '>' in SoftPendulum
-            emit_scalars(o, 9, pack, rod, r, invalid, time >= P.final_time, reward, terminated, truncated);
+            emit_scalars(o, 9, pack, rod, r, invalid, time >= P.final_time, reward, terminated, truncated,
+                         S.needs_reset);
             if (aux) aux[rod] = tilt;
             o[0] = (float)L.x[0][0]; o[1] = (float)L.x[0][1]; o[2] = (float)L.x[0][2];
             o[3] = (float)L.v[0][0]; o[4] = (float)L.v[0][1]; o[5] = (float)L.v[0][2];
@@ -605,7 +615,7 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
                 if (dist < 0.1) { survive = 5.0; term = true; }
             }
             emit_scalars(out_row(obs, rod, 25, pack), 25, pack, rod, forward - (double)pen + survive, term,
-                         time > P.final_time, reward, terminated, truncated);
+                         time > P.final_time, reward, terminated, truncated, S.needs_reset);
         }
         arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, A.a, out_row(obs, rod, 25, pack));
     } else {
@@ -616,7 +626,7 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
             else forward = fabs(L.x[0][0]) * 10.0 + th * th;
             float* o = out_row(obs, rod, 4, pack);
             emit_scalars(o, 4, pack, rod, forward - 0.0 + survive, invalid, time > P.final_time, reward,
-                         terminated, truncated);
+                         terminated, truncated, S.needs_reset);
             o[0] = (float)L.x[0][0];
             o[1] = (float)L.v[0][0];
             o[2] = A.a[0];
@@ -909,6 +919,10 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
     const int rod = blockIdx.x;
     const int lane = threadIdx.x;
     const size_t N = (size_t)P.n_envs;
+    if (epilogue && S.skip && S.skip[rod]) {   // reset by the auto-reset pass of this env.step
+        if (lane == 0) S.skip[rod] = 0;
+        return;
+    }
 
     LaneN<1> L;
     load_lane<1, kRuntimeFeatures>(S, N, rod, lane, L);
@@ -967,20 +981,16 @@ softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __rest
     float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = 0; i < adim; ++i)
         pa[i] = prev_action ? prev_action[adim * (size_t)rod + i] : S.prev_action[7 * (size_t)rod + i];
-    env_observe_n<kRuntimeEnv, EPL>(P, S, N, rod, lane, C, L, pa, obs);
+    const int od = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 9 : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 25 : 4;
+    env_observe_n<kRuntimeEnv, EPL>(P, S, N, rod, lane, C, L, pa, obs + (size_t)od * rod);
 }
 
+// One rod's reset from its 18-double record; leaves the fresh state in L as well.
 template <int EPL>
-__global__ void __launch_bounds__(kLanes)
-softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
+__device__ __forceinline__ void reset_rod(const RodParams& P, const StatePtrs& S, size_t N, int rod, int lane,
+                                          const double* __restrict__ in, LaneN<EPL>& L) {
     constexpr size_t W = (size_t)kLanes * EPL;
-    const int rod = blockIdx.x;
-    const int lane = threadIdx.x;
-    if (A.mask && !A.mask[rod]) return;
-    const size_t N = (size_t)P.n_envs;
-    const double* in = A.init + (size_t)rod * 18;
     const int n = P.n_elem;
-    LaneN<EPL> L;
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         const int idx = lane * EPL + s;
@@ -1030,6 +1040,7 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
     }
     if (lane == 0) {
         S.time[rod] = 0.0;
+        if (S.needs_reset) S.needs_reset[rod] = 0;
         if (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) {   // _prev_action.fill(0), soft_pendulum_3d.py:68
 #pragma unroll
             for (int i = 0; i < 7; ++i) S.prev_action[7 * (size_t)rod + i] = 0.0f;
@@ -1043,6 +1054,59 @@ softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
     }
 }
 
+
+
+template <int EPL>
+__global__ void __launch_bounds__(kLanes)
+softrod_reset_kernel(const RodParams P, const StatePtrs S, const ResetArgs A) {
+    const int rod = blockIdx.x;
+    if (A.mask && !A.mask[rod]) return;
+    LaneN<EPL> L;
+    reset_rod<EPL>(P, S, (size_t)P.n_envs, rod, threadIdx.x, A.init + (size_t)rod * 18, L);
+}
+
+// Device-side auto-reset pass, launched before the step kernel when softrod_autoreset_enable
+// is on (Gymnasium-1.0 VectorEnv NEXT_STEP semantics): an env whose
+// previous step ended its episode consumes its next pre-drawn reset record instead of
+// stepping; this call reports its reset observation, reward 0 and both flags clear, and the
+// step kernel skips it.  No host round trip: the records were drawn from the env's own
+// NumPy stream ahead of time (softrod_queue_push*).
+template <int EPL>
+__global__ void __launch_bounds__(kLanes)
+softrod_autoreset_kernel(const RodParams P, const StatePtrs S, float* __restrict__ obs,
+                         double* __restrict__ reward, uint8_t* __restrict__ terminated,
+                         uint8_t* __restrict__ truncated, double* __restrict__ aux, const int pack) {
+    const int rod = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!S.needs_reset[rod]) return;
+    const size_t N = (size_t)P.n_envs;
+    const int k = S.q_consumed[rod];
+    if (k >= S.q_produced[rod]) {          // nothing staged: the env stays finished, the host is told
+        if (lane == 0) atomicAdd(S.q_underflow, 1);
+        return;
+    }
+    const double* in = S.queue + ((size_t)(k % S.q_depth) * N + rod) * (size_t)S.q_record;
+    LaneN<EPL> L;
+    reset_rod<EPL>(P, S, N, rod, lane, in, L);
+    EnvAction A;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
+    A.force = 0.0;
+    ConstN<EPL> C;
+    build_const<kRuntimeFeatures, EPL>(P, lane, A, C);
+    float pa[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pa[i] = S.prev_action[7 * (size_t)rod + i];
+    const int od = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 9 : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 25 : 4;
+    float* o = out_row(obs, rod, od, pack);
+    env_observe_n<kRuntimeEnv, EPL>(P, S, N, rod, lane, C, L, pa, o);
+    if (lane == 0) {
+        emit_scalars(o, od, pack, rod, 0.0, false, false, reward, terminated, truncated, S.needs_reset);
+        if (aux && P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) aux[rod] = (double)o[8];
+        S.skip[rod] = 1;
+        S.q_consumed[rod] = k + 1;
+    }
+}
 
 }  // namespace softrod
 

@@ -180,6 +180,11 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     const int n = P.n_elem, nk = P.n_action;
     const int r = tid & (P.seg - 1), arm = tid >> P.seg_shift;
     const bool arm_ok = arm < P.n_arm;
+    if (epilogue && S.skip && S.skip[env]) {   // reset by the auto-reset pass of this env.step
+        __syncthreads();                       // every thread has read the flag
+        if (tid == 0) S.skip[env] = 0;
+        return;
+    }
 
     LaneN<1> L;
     load_lane<1, F>(S, NR, row, lane, L);
@@ -360,7 +365,8 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         }
         double rew = forward - 0.0 + survive - 0.0;
         if (term) rew -= dist - 0.1;
-        emit_scalars(o, od, pack, env, rew, term, time > P.final_time, reward, terminated, truncated);
+        emit_scalars(o, od, pack, env, rew, term, time > P.final_time, reward, terminated, truncated,
+                     S.needs_reset);
     }
     octo_write_obs(P, tid, L, H, tgt, actions + (size_t)env * adim, o);
 }
@@ -395,10 +401,11 @@ struct OctoResetArgs {
     const uint8_t* mask;
 };
 
-__global__ void __launch_bounds__(1024)
-softrod_octo_reset_kernel(const RodParams P, const StatePtrs S, const OctoResetArgs A) {
-    const int env = blockIdx.x;
-    if (A.mask && !A.mask[env]) return;
+// One env's reset from its n_arm straight-rod records and its target; the fresh per-lane
+// state is left in L, the head in H.
+__device__ __forceinline__ void octo_reset_env(const RodParams& P, const StatePtrs& S, int env,
+                                               const double* __restrict__ arms, const double* __restrict__ target,
+                                               LaneN<1>& L, HeadState& H) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nw = blockDim.x >> 6;
     const size_t N = (size_t)P.n_envs, NR = N * (size_t)nw;
@@ -407,8 +414,7 @@ softrod_octo_reset_kernel(const RodParams P, const StatePtrs S, const OctoResetA
     const int r = tid & (P.seg - 1);
     int arm = tid >> P.seg_shift;
     if (arm >= P.n_arm) arm = P.n_arm - 1;   // slots past the last arm: finite filler
-    const double* in = A.init + ((size_t)env * P.n_arm + arm) * 18;
-    LaneN<1> L;
+    const double* in = arms + (size_t)arm * 18;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         double xv = in[c] + (double)r * in[3 + c];
@@ -432,17 +438,57 @@ softrod_octo_reset_kernel(const RodParams P, const StatePtrs S, const OctoResetA
 #pragma unroll
     for (int c = 0; c < 3; ++c) S.rkap[c * NR * kLanes + m] = 0.0;
     S.envmem[m] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { H.x[i] = 0.0; H.v[i] = 0.0; H.w[i] = 0.0; }
+    const double Q0[9] = {0.0, 1.0, 0.0, -1.0, 0.0, 0.0, 0.0, 0.0, 1.0};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H.Q[i] = Q0[i];
     if (tid == 0) {
         S.time[env] = 0.0;
-        HeadState H;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { H.x[i] = 0.0; H.v[i] = 0.0; H.w[i] = 0.0; }
-        const double Q0[9] = {0.0, 1.0, 0.0, -1.0, 0.0, 0.0, 0.0, 0.0, 1.0};
-#pragma unroll
-        for (int i = 0; i < 9; ++i) H.Q[i] = Q0[i];
+        if (S.needs_reset) S.needs_reset[env] = 0;
         store_head(S, N, env, H);
-        S.head[(size_t)18 * N + env] = A.target[2 * (size_t)env];
-        S.head[(size_t)19 * N + env] = A.target[2 * (size_t)env + 1];
+        S.head[(size_t)18 * N + env] = target[0];
+        S.head[(size_t)19 * N + env] = target[1];
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+softrod_octo_reset_kernel(const RodParams P, const StatePtrs S, const OctoResetArgs A) {
+    const int env = blockIdx.x;
+    if (A.mask && !A.mask[env]) return;
+    LaneN<1> L;
+    HeadState H;
+    octo_reset_env(P, S, env, A.init + (size_t)env * P.n_arm * 18, A.target + 2 * (size_t)env, L, H);
+}
+
+// Device-side auto-reset pass for OctoFlat (see softrod_autoreset_kernel): the queue record
+// is [n_arm][18] arm frames followed by the target (2).
+__global__ void __launch_bounds__(1024)
+softrod_octo_autoreset_kernel(const RodParams P, const StatePtrs S, float* __restrict__ obs,
+                              double* __restrict__ reward, uint8_t* __restrict__ terminated,
+                              uint8_t* __restrict__ truncated, const int pack) {
+    const int env = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (!S.needs_reset[env]) return;
+    const size_t N = (size_t)P.n_envs;
+    const int k = S.q_consumed[env];
+    if (k >= S.q_produced[env]) {
+        if (tid == 0) atomicAdd(S.q_underflow, 1);
+        return;
+    }
+    const double* in = S.queue + ((size_t)(k % S.q_depth) * N + env) * (size_t)S.q_record;
+    const double tgt[2] = {in[P.n_arm * 18], in[P.n_arm * 18 + 1]};
+    LaneN<1> L;
+    HeadState H;
+    octo_reset_env(P, S, env, in, tgt, L, H);
+    const int od = octo_obs_dim(P);
+    float* o = out_row(obs, env, od, pack);
+    octo_write_obs(P, tid, L, H, tgt, S.prev_action + (size_t)env * (P.n_arm * P.n_action), o);
+    __syncthreads();                           // every thread has read needs_reset / q_consumed
+    if (tid == 0) {
+        emit_scalars(o, od, pack, env, 0.0, false, false, reward, terminated, truncated, S.needs_reset);
+        S.skip[env] = 1;
+        S.q_consumed[env] = k + 1;
     }
 }
 

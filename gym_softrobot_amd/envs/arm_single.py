@@ -65,7 +65,17 @@ class VecArmSingleEnv(VecRodEnvBase):
         self.n_seg = n_elems - 1
         self.policy_mode = policy_mode
 
-    def _reset_backend(self, mask, use_mask):
+    def _draw_reset(self, i):
+        return None                                   # build_arm draws nothing from the RNG
+
+    def _queue_from_draws(self, draws, counts):
+        n, m = self.num_envs, max(1, int(counts.max()))
+        start = np.zeros((n, m, 3))
+        direction = np.tile(np.array([1.0, 0.0, 0.0]), (n, m, 1))
+        normal = np.tile(np.array([0.0, 0.0, 1.0]), (n, m, 1))
+        self.backend.queue_push_straight(start, direction, normal, counts)
+
+    def _reset_backend(self, mask, use_mask, draws=None):
         # build_arm draws nothing from the RNG: every reset starts from the same straight arm
         n = self.num_envs
         start = np.zeros((n, 3))

@@ -8,9 +8,17 @@ SURVEY.md §8(f) N2:
                        terminated/truncated at step t is reset (instead of stepped) by the
                        call at t+1, which returns its reset observation, reward 0 and both
                        flags False.  Costs one small device->host read of the flags per step.
+  * `autoreset="device"`  the same semantics with no host round trip: the next
+                       `queue_depth` resets of every env are drawn ahead of time from the
+                       env's own NumPy stream (so the streams are the ones `autoreset=True`
+                       would consume, draw for draw) and staged on the device
+                       (softrod_queue_push*); the step applies them itself.  The host tops
+                       the queue up every `queue_depth` steps (one small read).  `infos`
+                       then carry device tensors.
 """
 from __future__ import annotations
 
+from collections import deque
 from typing import Any, Dict, List, Optional, Sequence, Union
 
 import numpy as np
@@ -89,7 +97,12 @@ class VecRodEnvBase:
         self.num_envs = int(num_envs)
         self.cfg = cfg
         self.numpy_output = numpy_output
-        self.autoreset = bool(autoreset)
+        if autoreset not in (False, True, "host", "device"):
+            raise ValueError("autoreset must be False, True/'host' or 'device'")
+        self.device_autoreset = autoreset == "device"
+        self.autoreset = bool(autoreset) and not self.device_autoreset
+        self.queue_depth = 16
+        self.top_up_every = self.queue_depth   # an env uses at most one record per two steps
         self.action_dim = _capi.config_action_dim(cfg)
         self.obs_dim = _capi.config_obs_dim(cfg)
         self.n_action = self.action_dim
@@ -107,12 +120,58 @@ class VecRodEnvBase:
         self._steps = np.zeros(self.num_envs, np.int64)  # env.steps since each env's reset
         self._time_tab = time_table(cfg, 8)
         self._needs_reset = np.zeros(self.num_envs, bool)
+        self._produced = np.zeros(self.num_envs, np.int64)   # reset records staged per env
+        self._staged = [deque() for _ in range(self.num_envs)]   # their draws, oldest first
+        self._popped = np.zeros(self.num_envs, np.int64)     # draws removed from _staged so far
+        self._since_top_up = 0
+        if self.device_autoreset:
+            self.backend.autoreset_enable(self.queue_depth)
 
     # -- hooks ---------------------------------------------------------------------
-    def _reset_backend(self, mask: np.ndarray, use_mask: bool) -> None:
-        """Draw what the env's build function draws from self._rngs[i] for masked envs and
-        reset those rods on the backend."""
+    def _reset_backend(self, mask: np.ndarray, use_mask: bool, draws: Optional[dict] = None) -> None:
+        """Reset the masked rods on the backend from what the env's build function draws from
+        self._rngs[i] (`self._draw(i, draws)`: a draw taken earlier for env i, if given)."""
         raise NotImplementedError
+
+    def _draw(self, i: int, draws: Optional[dict]):
+        return draws[i] if draws is not None and i in draws else self._draw_reset(i)
+
+    def _draw_reset(self, i: int):
+        """What one reset of env i draws from self._rngs[i], as the tuple of per-env arguments
+        `_reset_backend` / `_queue_from_draws` understand."""
+        raise NotImplementedError
+
+    def _queue_from_draws(self, draws, counts) -> None:
+        """backend.queue_push*(...) from draws[i] = list of counts[i] draws."""
+        raise NotImplementedError
+
+    def _top_up(self) -> None:
+        """Stage resets until every env has `queue_depth` unconsumed records (device mode)."""
+        from .. import _capi as capi
+
+        consumed = self._sync_staged()
+        counts = (self.queue_depth - (self._produced - consumed)).astype(np.int32)
+        if counts.max(initial=0) > 0:
+            draws = [[self._draw_reset(i) for _ in range(int(counts[i]))] for i in range(self.num_envs)]
+            self._queue_from_draws(draws, counts)
+            self._produced += counts
+            for i, d in enumerate(draws):
+                self._staged[i].extend(d)
+        self._since_top_up = 0
+
+    def _sync_staged(self) -> np.ndarray:
+        """Read how many staged records the device has used and forget their draws."""
+        from .. import _capi as capi
+
+        consumed, underflow = self.backend.queue_status()
+        if underflow:
+            raise capi.SoftrodError(
+                f"{underflow} auto-resets found no staged record: top up more often or raise queue_depth")
+        for i in np.nonzero(consumed > self._popped)[0]:
+            for _ in range(int(consumed[i] - self._popped[i])):
+                self._staged[i].popleft()
+            self._popped[i] = consumed[i]
+        return consumed
 
     def _infos(self, times: np.ndarray) -> Dict[str, Any]:
         return {"time": times, "TimeLimit.truncated": times > self.cfg.final_time}
@@ -138,9 +197,12 @@ class VecRodEnvBase:
             seeds = list(seed)
             if len(seeds) != n:
                 raise ValueError("need one seed per env")
+        reseeded = np.zeros(n, bool)
         for i in range(n):
             if mask[i] and (seeds[i] is not None or self._rngs[i] is None):
                 self._rngs[i], _ = np_random(seeds[i])
+                reseeded[i] = True
+        return reseeded
 
     # -- API -----------------------------------------------------------------------
     def reset(
@@ -152,14 +214,47 @@ class VecRodEnvBase:
     ):
         n = self.num_envs
         m = np.ones(n, bool) if mask is None else np.asarray(mask, bool).reshape(n)
-        self._seed_rngs(seed, m)
-        self._reset_backend(m, mask is not None)
+        reseeded = self._seed_rngs(seed, m)
+        draws = None
+        if self.device_autoreset and self._produced.any():
+            # The next draws of these envs' streams are already staged on the device.  A manual
+            # reset takes the env's NEXT draw, i.e. the oldest staged one (and marks it used);
+            # a re-seeded env starts a new stream, so everything staged for it is dropped.
+            self._sync_staged()
+            by = np.zeros(n, np.int32)
+            draws = {}
+            for i in np.nonzero(m)[0]:
+                if reseeded[i]:
+                    by[i] = -1
+                    self._popped[i] += len(self._staged[i])
+                    self._staged[i].clear()
+                elif self._staged[i]:
+                    by[i] = 1
+                    draws[i] = self._staged[i].popleft()
+                    self._popped[i] += 1
+            self.backend.queue_advance(by)
+        self._reset_backend(m, mask is not None, draws)
         self._steps[m] = 0
         self._needs_reset[m] = False
         # _prev_action lives with the resident state (softrod_state_view.prev_action): it
         # survives reset except where the reference clears it (soft_pendulum_3d.py:68)
         obs = self.backend.observe(None)
+        if self.device_autoreset:
+            self._top_up()
         return self._out(obs), {}
+
+    def _step_device_autoreset(self, a):
+        import torch
+
+        obs, reward, term, trunc = self.backend.step(a)    # auto-reset pass + step kernel
+        self._since_top_up += 1
+        if self._since_top_up >= self.top_up_every:
+            self._top_up()
+        if getattr(self, "_dev_time", None) is None:
+            self._dev_time = self.backend.state()["time"]
+        infos = {"time": self._out(self._dev_time), "TimeLimit.truncated": self._out(trunc.view(torch.bool))}
+        return (self._out(obs), self._out(reward), self._out(term.view(torch.bool)),
+                self._out(trunc.view(torch.bool)), infos)
 
     def step(self, actions):
         import torch
@@ -167,13 +262,21 @@ class VecRodEnvBase:
         self._validate_actions(actions)
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.backend.device)
         a = a.reshape(self.num_envs, self.action_dim)
+        if self.device_autoreset:
+            return self._step_device_autoreset(a)
         pending = self._needs_reset.copy() if self.autoreset else None
+        saved_prev = None
+        if pending is not None and pending.any():
+            # the action of a restarting env is ignored (NEXT_STEP): its _prev_action must stay
+            # the one of its last real step, as env.reset() would find it
+            saved_prev = self.backend.prev_action_rows()[torch.from_numpy(pending)].clone()
         obs, reward, term, trunc = self.backend.step(a)   # also records _prev_action[:] = action
         self._steps += 1
         if pending is not None and pending.any():
             # NEXT_STEP auto-reset: these envs finished on the previous call; their step above
             # is discarded, they restart and report their reset observation
             keep = obs.clone()
+            self.backend.prev_action_rows()[torch.from_numpy(pending)] = saved_prev
             self._seed_rngs(None, pending)
             self._reset_backend(pending, True)
             self._steps[pending] = 0
@@ -201,10 +304,15 @@ class VecRodEnvBase:
         import torch
 
         if self.autoreset:
-            raise NotImplementedError("step_packed does not auto-reset; use step()")
+            raise NotImplementedError("step_packed does not auto-reset on the host; use autoreset='device'")
         self._validate_actions(actions)
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.backend.device)
         packed = self.backend.step_packed(a.reshape(self.num_envs, self.action_dim))
+        if self.device_autoreset:
+            self._since_top_up += 1
+            if self._since_top_up >= self.top_up_every:
+                self._top_up()
+            return packed, {}
         self._steps += 1
         return packed, self._infos(self._times())
 

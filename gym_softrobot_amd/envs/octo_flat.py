@@ -74,10 +74,20 @@ class VecOctoFlatEnv(VecRodEnvBase):
         self.individual_shape = (n_arm, self.n_seg + (n_elems + 1) * 4 + n_action)
         self.targets = np.zeros((num_envs, 2), np.float64)
 
-    def _reset_backend(self, mask, use_mask):
+    def _draw_reset(self, i):
         # flat_env.py:221: self._target = (2 - 0.5) * self.np_random.random(2) + 0.5
+        return (2 - 0.5) * self._rngs[i].random(2) + 0.5
+
+    def _queue_from_draws(self, draws, counts):
+        tg = np.zeros((self.num_envs, max(1, int(counts.max())), 2))
+        for i, d in enumerate(draws):
+            for j, v in enumerate(d):
+                tg[i, j] = v
+        self.backend.queue_push_octo(tg, counts)
+
+    def _reset_backend(self, mask, use_mask, draws=None):
         for i in np.nonzero(mask)[0]:
-            self.targets[i] = (2 - 0.5) * self._rngs[i].random(2) + 0.5
+            self.targets[i] = self._draw(i, draws)
         self.backend.reset_octo(self.targets, mask.astype(np.uint8) if use_mask else None)
 
     def split_obs(self, obs):

@@ -65,11 +65,20 @@ class VecSoftPendulumEnv(VecRodEnvBase):
         self.n_elems = n_elems
         self.n_seg = n_elems - 1
 
-    def _reset_backend(self, mask, use_mask):
+    def _draw_reset(self, i):
+        return initial_angle(self._rngs[i])           # build.py:47-49
+
+    def _reset_backend(self, mask, use_mask, draws=None):
         theta0 = np.zeros(self.num_envs, np.float64)
         for i in np.nonzero(mask)[0]:
-            theta0[i] = initial_angle(self._rngs[i])  # build.py:47-49
+            theta0[i] = self._draw(i, draws)
         self.backend.reset(theta0, mask.astype(np.uint8) if use_mask else None)
+
+    def _queue_from_draws(self, draws, counts):
+        th = np.zeros((self.num_envs, max(1, int(counts.max()))))
+        for i, d in enumerate(draws):
+            th[i, : len(d)] = d
+        self.backend.queue_push(th, counts)
 
 
 class SoftPendulumEnv(_GymEnv):

@@ -61,13 +61,27 @@ class VecSoftPendulum3DEnv(VecRodEnvBase):
         self.base_step = 1e-3
         self.base_limit = 0.5
 
-    def _reset_backend(self, mask, use_mask):
+    def _draw_reset(self, i):
+        tilt = initial_tilt(self._rngs[i])
+        return [np.sin(tilt), 0.0, np.cos(tilt)]              # soft_pendulum_3d/build.py:52
+
+    def _queue_from_draws(self, draws, counts):
+        n, m = self.num_envs, max(1, int(counts.max()))
+        direction = np.zeros((n, m, 3))
+        direction[:, :, 2] = 1.0
+        for i, d in enumerate(draws):
+            for j, v in enumerate(d):
+                direction[i, j] = v
+        start = np.zeros((n, m, 3))
+        normal = np.tile(np.array([0.0, 1.0, 0.0]), (n, m, 1))
+        self.backend.queue_push_straight(start, direction, normal, counts)
+
+    def _reset_backend(self, mask, use_mask, draws=None):
         n = self.num_envs
         direction = np.zeros((n, 3))
         direction[:, 2] = 1.0
         for i in np.nonzero(mask)[0]:
-            tilt = initial_tilt(self._rngs[i])
-            direction[i] = [np.sin(tilt), 0.0, np.cos(tilt)]  # soft_pendulum_3d/build.py:52
+            direction[i] = self._draw(i, draws)
         start = np.zeros((n, 3))
         normal = np.tile(np.array([0.0, 1.0, 0.0]), (n, 1))   # :53
         self.backend.reset_straight(start, direction, normal, mask.astype(np.uint8) if use_mask else None)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 6
+#define SOFTROD_ABI_VERSION 7
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -315,6 +315,43 @@ int softrod_step(softrod_handle* h, const float* actions, float* obs,
  *     aligned) | terminated, truncated (bytes 0 and 1 of one word) | 0 ]       */
 int softrod_step_packed(softrod_handle* h, const float* actions, float* packed,
                         double* aux, void* stream);
+
+/* ---- Device-side auto-reset ---------------------------------
+ * The reference has no vector env and no auto-reset: a finished env is reset by its
+ * caller (gym_softrobot/debug/make.py:16-23).  For a resident batch that would cost a
+ * device->host read of the flags on every step.  Instead the caller stages, ahead of
+ * time, the next `depth` resets of every env — drawn on the host from the env's own
+ * NumPy stream exactly as the reference's build function draws them
+ * (build.py:47-49, soft_pendulum_3d/build.py:51, flat_env.py:221), so the streams stay
+ * bit-identical — and softrod_step / softrod_step_packed then apply Gymnasium-1.0
+ * VectorEnv NEXT_STEP semantics on the device: an env whose previous step returned
+ * terminated or truncated consumes its next staged reset INSTEAD of stepping; that call
+ * returns its reset observation, reward 0 and both flags clear.  An env that needs a
+ * record when none is staged stays finished and is counted in `underflow`.
+ *
+ *   softrod_autoreset_enable   once per handle; depth = records kept per env
+ *   softrod_queue_push*        stage counts[e] (<= max_count) more resets of env e; the
+ *                              arrays are host [n_envs][max_count]... with the per-reset
+ *                              layout of softrod_reset / _reset_straight / _reset_octo.
+ *                              Fails if staged-but-unconsumed + new records would exceed
+ *                              depth (as of the last softrod_queue_status).
+ *   softrod_queue_status       synchronises; consumed: host [n_envs] records used so far
+ *   softrod_queue_advance      mark by[e] staged records of env e as used (a manual reset
+ *                              took the env's next draw), or all of them if by[e] < 0
+ *                              (the env's stream was re-seeded); synchronises
+ * softrod_reset* of an env clears its pending auto-reset.                            */
+int softrod_autoreset_enable(softrod_handle* h, int depth);
+int softrod_queue_push(softrod_handle* h, const double* theta0, const int32_t* counts,
+                       int max_count, void* stream);
+int softrod_queue_push_straight(softrod_handle* h, const double* start,
+                                const double* direction, const double* normal,
+                                const int32_t* counts, int max_count, void* stream);
+int softrod_queue_push_octo(softrod_handle* h, const double* arm_start,
+                            const double* arm_direction, const double* target,
+                            const int32_t* counts, int max_count, void* stream);
+int softrod_queue_status(softrod_handle* h, int32_t* consumed, int32_t* underflow,
+                         void* stream);
+int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream);
 
 /* Replaces: get_state() at reset (soft_pendulum.py:145-161,
  * soft_pendulum_3d.py:93-98).  prev_action is device [n_envs][action_dim]

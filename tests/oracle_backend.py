@@ -33,11 +33,17 @@ class OracleBackend:
         self.truncated = torch.zeros(self.n_envs, dtype=torch.uint8)
         self.aux = torch.zeros((self.n_envs, 1), dtype=torch.float64) if self.is3d else None
         self._prev = np.zeros((self.n_envs, self.action_dim), np.float32)
+        self._queue = None          # device-side auto-reset emulation (softrod_queue_*)
+
+    def state(self):
+        return {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64)}
 
     def reset(self, theta0, mask=None):
         for i, r in enumerate(self.rods):
             if mask is None or mask[i]:
                 r.reset_pendulum(float(theta0[i]))
+                if self._queue is not None:
+                    self._need[i] = False
 
     def reset_straight(self, start, direction, normal, mask=None):
         for i, r in enumerate(self.rods):
@@ -48,6 +54,82 @@ class OracleBackend:
                     r.reset_arm()   # also re-arms prev_kappa_state / prev_com_state
                 else:
                     r.reset_straight(start[i], direction[i], normal[i])
+
+    # -- softrod_autoreset_enable / softrod_queue_* emulated on the host ----------------------
+    def autoreset_enable(self, depth):
+        from collections import deque
+
+        self.queue_depth = int(depth)
+        self._queue = [deque() for _ in range(self.n_envs)]
+        self._need = np.zeros(self.n_envs, bool)
+        self._consumed = np.zeros(self.n_envs, np.int32)
+        self._underflow = 0
+
+    def _push(self, records, counts):
+        for i in range(self.n_envs):
+            if len(self._queue[i]) + int(counts[i]) > self.queue_depth:
+                raise _capi.SoftrodError("reset queue overflow: staged + new records exceed depth")
+            self._queue[i].extend(records[i][: int(counts[i])])
+
+    def queue_push(self, theta0, counts):
+        th = np.asarray(theta0, np.float64).reshape(self.n_envs, -1)
+        self._push([[("theta", t) for t in row] for row in th], counts)
+
+    def queue_push_straight(self, start, direction, normal, counts):
+        s, d, nrm = (np.asarray(v, np.float64).reshape(self.n_envs, -1, 3) for v in (start, direction, normal))
+        self._push([[("straight", s[i, j], d[i, j], nrm[i, j]) for j in range(s.shape[1])]
+                    for i in range(self.n_envs)], counts)
+
+    def queue_push_octo(self, targets, counts):
+        tg = np.asarray(targets, np.float64).reshape(self.n_envs, -1, 2)
+        self._push([[("octo", t) for t in row] for row in tg], counts)
+
+    def queue_status(self):
+        return self._consumed.copy(), self._underflow
+
+    def queue_advance(self, by):
+        for i, b in enumerate(np.asarray(by)):
+            k = len(self._queue[i]) if b < 0 else min(int(b), len(self._queue[i]))
+            for _ in range(k):
+                self._queue[i].popleft()
+            self._consumed[i] += k
+
+    def _autoreset_pass(self):
+        """-> indices reset instead of stepped (obs/reward/flags already written)."""
+        done = []
+        for i in np.nonzero(self._need)[0]:
+            if not self._queue[i]:
+                self._underflow += 1
+                continue
+            rec = self._queue[i].popleft()
+            self._consumed[i] += 1
+            m = np.zeros(self.n_envs, bool)
+            m[i] = True
+            if rec[0] == "theta":
+                th = np.zeros(self.n_envs)
+                th[i] = rec[1]
+                self.reset(th, m)
+            elif rec[0] == "straight":
+                z = np.zeros((self.n_envs, 3))
+                s, d, nrm = z.copy(), z.copy(), z.copy()
+                s[i], d[i], nrm[i] = rec[1], rec[2], rec[3]
+                self.reset_straight(s, d, nrm, m)
+            else:
+                tg = np.zeros((self.n_envs, 2))
+                tg[i] = rec[1]
+                self.reset_octo(tg, m)
+            self._need[i] = False
+            done.append(i)
+        if done:
+            keep = self.obs.clone()
+            fresh = self.observe(None).clone()
+            self.obs[:] = keep
+            for i in done:
+                self.obs[i] = fresh[i]
+                self.reward[i] = 0.0
+                self.terminated[i] = 0
+                self.truncated[i] = 0
+        return done
 
     def reset_octo(self, targets, mask=None):
         for i, r in enumerate(self.rods):
@@ -82,10 +164,16 @@ class OracleBackend:
                 self.obs[i] = torch.from_numpy(r.observe())
         return self.obs
 
+    def prev_action_rows(self):
+        return torch.from_numpy(self._prev)      # shares memory with the resident copy
+
     def step(self, actions):
         a = torch.as_tensor(actions, dtype=torch.float32).reshape(self.n_envs, self.action_dim).numpy()
-        self._prev = a.copy()
+        skip = self._autoreset_pass() if self._queue is not None else []
         for i, r in enumerate(self.rods):
+            if i in skip:
+                continue
+            self._prev[i] = a[i]
             if self.isocto:
                 ob, rw, te, tr = r.env_step(a[i])
                 o = np.concatenate([ob["individual"].ravel(), ob["shared"]])
@@ -101,6 +189,8 @@ class OracleBackend:
             self.reward[i] = rw
             self.terminated[i] = int(te)
             self.truncated[i] = int(tr)
+            if self._queue is not None:
+                self._need[i] = bool(te) or bool(tr)
         return self.obs, self.reward, self.terminated, self.truncated
 
     def step_packed(self, actions):

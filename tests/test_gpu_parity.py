@@ -611,6 +611,70 @@ def test_autoreset_on_gpu(torch_gpu, hip_lib):
     env.close()
 
 
+@pytest.mark.parametrize("env_id,kw,amax", [
+    ("SoftPendulum-v0", dict(final_time=5e-4, time_step=1e-4, recording_fps=5000, n_elems=20), 5.0),
+    ("SoftPendulum-v0", dict(final_time=7e-4, time_step=1e-4, recording_fps=5000, n_elems=100), 5.0),
+    ("SoftPendulum3D-v0", dict(final_time=6e-4, time_step=1e-4, recording_fps=5000, n_elems=20), 1.0),
+    ("OctoArmSingle-v0", dict(final_time=3e-4, time_step=7e-5, recording_fps=7000, n_elems=20), 5.0),
+    ("OctoFlat-v0", dict(final_time=3e-4, time_step=7e-5, recording_fps=7000), 20.0),
+], ids=["pendulum", "pendulum-2-per-lane", "pendulum3d", "arm", "octo"])
+def test_device_autoreset_equals_host_autoreset(torch_gpu, hip_lib, env_id, kw, amax):
+    """autoreset="device" (staged reset records, no host read) must reproduce autoreset=True
+    (host reads the flags and resets) bit for bit: same NEXT_STEP semantics, and the staged
+    records are the draws the host path would have taken from each env's stream."""
+    import gym_softrobot_amd as gsa
+
+    n, T = 6, 23           # > queue_depth steps: the queue is topped up on the way
+    host = gsa.make_vec(env_id, n, device=0, autoreset=True, **kw)
+    dev = gsa.make_vec(env_id, n, device=0, autoreset="device", **kw)
+    oh, _ = host.reset(seed=3)
+    od, _ = dev.reset(seed=3)
+    assert torch_gpu.equal(oh, od)
+    acts = np.random.default_rng(0).uniform(-amax, amax, (T, n, host.action_dim)).astype(np.float32)
+    resets = 0
+    for t in range(T):
+        a = acts[t].copy()
+        if env_id == "SoftPendulum3D-v0":
+            a = np.clip(a, -1, 1)
+        o1, r1, te1, tr1, i1 = host.step(a)
+        o2, r2, te2, tr2, i2 = dev.step(a)
+        assert torch_gpu.equal(o1, o2), t
+        assert torch_gpu.equal(r1, r2) and torch_gpu.equal(te1, te2) and torch_gpu.equal(tr1, tr2), t
+        np.testing.assert_array_equal(i1["time"], i2["time"].cpu().numpy())
+        resets += int((host._steps == 0).sum())
+    assert resets >= 2 * n, "episodes were meant to end and restart several times"
+    cons, underflow = dev.backend.queue_status()
+    assert underflow == 0 and cons.min() >= 2
+    # a masked manual reset of a finished env clears its pending auto-reset and re-bases its queue
+    m = np.zeros(n, bool)
+    m[1] = True
+    oh, _ = host.reset(mask=m)
+    od, _ = dev.reset(mask=m)
+    assert torch_gpu.equal(oh, od)
+    for t in range(4):
+        o1, r1, te1, tr1, _ = host.step(acts[t])
+        o2, r2, te2, tr2, _ = dev.step(acts[t])
+        assert torch_gpu.equal(o1, o2) and torch_gpu.equal(r1, r2) and torch_gpu.equal(tr1, tr2)
+    host.close()
+    dev.close()
+
+
+def test_device_autoreset_underflow_is_reported(torch_gpu, hip_lib):
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd._capi import SoftrodError
+
+    kw = dict(final_time=1e-4, time_step=1e-4, recording_fps=10000, n_elems=10)   # every step truncates
+    env = gsa.make_vec("SoftPendulum-v0", 3, device=0, autoreset="device", **kw)
+    env.top_up_every = 10**9         # never top up on the way
+    env.reset(seed=0)
+    a = np.zeros(3, np.float32)
+    with pytest.raises(SoftrodError, match="no staged record"):
+        for _ in range(80):
+            env.step(a)
+        env._top_up()
+    env.close()
+
+
 # ---- rods longer than one node per lane (two per lane, softrod_long.hpp) ---------------------
 def test_long_rod_softpendulum_matches_oracle(torch_gpu, hip_lib, oracle_built):
     import gym_softrobot_amd as gsa

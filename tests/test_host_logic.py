@@ -319,3 +319,37 @@ def test_octo_action_basis_reproduces_padded_interp1d():
     ref = interp1d(np.linspace(0, 1, 5), k, kind="cubic", axis=-1)(np.linspace(0, 1, 9))   # flat_env.py:296-308
     np.testing.assert_allclose(W @ a.astype(np.float64), ref, rtol=0, atol=1e-13)
     assert np.all(W[0] == 0.0) and np.all(W[-1] == 0.0)              # clamped to zero at both ends
+
+
+def test_device_autoreset_host_logic_equals_host_autoreset(oracle_built):
+    """autoreset="device": reset draws are taken from each env's stream ahead of time and
+    staged; the trajectory must equal autoreset=True draw for draw — including top-ups, a
+    manual masked reset (takes the oldest staged draw) and a re-seed (drops what is staged)."""
+    kw = dict(final_time=5e-4, time_step=1e-4, recording_fps=5000, n_elems=6)   # 2 substeps/step
+    n = 3
+    envs = []
+    for mode in (True, "device"):
+        cfg = _capi.softpendulum_config(n, **kw)
+        envs.append(gsa.VecSoftPendulumEnv(n, backend=OracleBackend(cfg), numpy_output=True, autoreset=mode, **kw))
+    host, dev = envs
+    dev.queue_depth, dev.top_up_every = 3, 3
+    o1, _ = host.reset(seed=[5, 6, 7])
+    o2, _ = dev.reset(seed=[5, 6, 7])
+    np.testing.assert_array_equal(o1, o2)
+    rng = np.random.default_rng(0)
+    for t in range(30):
+        a = rng.uniform(-3, 3, n).astype(np.float32)
+        r1, r2 = host.step(a), dev.step(a)
+        for x, y in zip(r1[:4], r2[:4]):
+            np.testing.assert_array_equal(x, y)
+        if t == 11:     # manual reset of env 1 mid-episode: next draw of its stream, in both modes
+            m = np.array([False, True, False])
+            np.testing.assert_array_equal(host.reset(mask=m)[0], dev.reset(mask=m)[0])
+        if t == 19:     # re-seed env 2: staged draws of its old stream are dropped
+            m = np.array([False, False, True])
+            np.testing.assert_array_equal(host.reset(seed=[None, None, 99], mask=m)[0],
+                                          dev.reset(seed=[None, None, 99], mask=m)[0])
+    consumed, underflow = dev.backend.queue_status()
+    assert underflow == 0 and consumed.min() >= 5
+    host.close()
+    dev.close()
