@@ -280,6 +280,22 @@ class HipRodBackend:
             "arm_stride": int(v.arm_stride),
         }
 
+    def rod_snapshot(self, env_indices) -> Dict[str, np.ndarray]:
+        """Host copy of a few rods only (diagnostic taps): x, v (k,3,n+1); Q (k,3,3,n);
+        w (k,3,n); time (k,).  One small device->host copy per field."""
+        st = self.state()
+        idx = torch.as_tensor(list(env_indices), dtype=torch.long, device=self.device)
+        ne = int(self.cfg.n_elem)
+
+        def rows(name, width):
+            return st[name].index_select(1, idx)[:, :, :width].permute(1, 0, 2).cpu().numpy()
+
+        return {
+            "x": rows("position", ne + 1), "v": rows("velocity", ne + 1), "w": rows("omega", ne),
+            "Q": rows("director", ne).reshape(len(env_indices), 3, 3, ne),
+            "time": st["time"].index_select(0, idx).cpu().numpy(),
+        }
+
     def octo_state_numpy(self) -> Dict[str, np.ndarray]:
         """Host copy of an OctoFlat batch: arms as x,v (N,A,3,n+1), Q (N,A,3,3,n), w (N,A,3,n),
         kappa/rest_kappa (N,A,3,n-1); head as x,v,w (N,3), Q (N,3,3); target (N,2); time (N,)."""

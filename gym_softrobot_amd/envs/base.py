@@ -91,8 +91,7 @@ class VecRodEnvBase:
                  device: int, numpy_output: bool, autoreset: bool, backend):
         if render_mode not in {None, *self.metadata["render_modes"]}:
             raise ValueError(f"Unsupported render mode: {render_mode}")  # soft_pendulum.py:69-70
-        if config_generate_video:
-            raise NotImplementedError("diagnostic callbacks/video are outside the hot path (DESIGN.md)")
+        self.config_generate_video = bool(config_generate_video)
         self.render_mode = render_mode
         self.num_envs = int(num_envs)
         self.cfg = cfg
@@ -126,6 +125,11 @@ class VecRodEnvBase:
         self._since_top_up = 0
         if self.device_autoreset:
             self.backend.autoreset_enable(self.queue_depth)
+        # soft_pendulum.py:117-126: RodCallBack -> rod_parameters_dict, one sample per env.step.
+        # Video/plot generation from it stays out of scope; the data tap is here (env 0, or
+        # `record_envs` set before reset).
+        self.record_envs = (0,)
+        self.recorder = None
 
     # -- hooks ---------------------------------------------------------------------
     def _reset_backend(self, mask: np.ndarray, use_mask: bool, draws: Optional[dict] = None) -> None:
@@ -241,7 +245,20 @@ class VecRodEnvBase:
         obs = self.backend.observe(None)
         if self.device_autoreset:
             self._top_up()
+        if self.config_generate_video and not self.is_octo:
+            from ..diagnostics import RodRecorder
+
+            self.recorder = RodRecorder(self.backend, self.record_envs)   # fresh dict per reset (:118)
         return self._out(obs), {}
+
+    @property
+    def is_octo(self) -> bool:
+        return int(self.cfg.env_kind) == _capi.ENV_OCTO_FLAT
+
+    @property
+    def rod_parameters_dict(self):
+        """The reference's `rod_parameters_dict` for the first recorded env."""
+        return None if self.recorder is None else self.recorder.params[0]
 
     def _step_device_autoreset(self, a):
         import torch
@@ -288,6 +305,8 @@ class VecRodEnvBase:
             trunc = torch.where(pm, torch.zeros_like(trunc), trunc)
         if self.autoreset:
             self._needs_reset = (term | trunc).cpu().numpy().astype(bool)
+        if self.recorder is not None:
+            self.recorder.record()
         times = self._times()
         infos = self._infos(times)
         return (

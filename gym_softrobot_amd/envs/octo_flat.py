@@ -52,8 +52,8 @@ class VecOctoFlatEnv(VecRodEnvBase):
     ):
         if policy_mode != "centralized":
             raise NotImplementedError("only policy_mode='centralized' is implemented")
-        if config_save_head_data:
-            raise NotImplementedError("diagnostic callbacks are outside the hot path (DESIGN.md)")
+        if config_save_head_data or config_generate_video:
+            raise NotImplementedError("diagnostic taps exist for the single-rod envs only (diagnostics.py)")
         cfg = _capi.octo_flat_config(
             num_envs, final_time=final_time, time_step=time_step, recording_fps=recording_fps,
             n_elems=n_elems, n_arm=n_arm, n_action=n_action, math_mode=math_mode,

@@ -150,6 +150,11 @@ class SoftPendulumEnv(_GymEnv):
             info,
         )
 
+    @property
+    def rod_parameters_dict(self):
+        """RodCallBack's samples (soft_pendulum.py:117-126) when config_generate_video=True."""
+        return self._vec.rod_parameters_dict
+
     def render(self):
         if self.render_mode is None:
             return None

@@ -38,6 +38,12 @@ class OracleBackend:
     def state(self):
         return {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64)}
 
+    def rod_snapshot(self, env_indices):
+        rods = [self.rods[i] for i in env_indices]
+        return {"x": np.stack([r.get("x") for r in rods]), "v": np.stack([r.get("v") for r in rods]),
+                "w": np.stack([r.get("w") for r in rods]), "Q": np.stack([r.get("Q") for r in rods]),
+                "time": np.array([r.time for r in rods])}
+
     def reset(self, theta0, mask=None):
         for i, r in enumerate(self.rods):
             if mask is None or mask[i]:

@@ -675,6 +675,36 @@ def test_device_autoreset_underflow_is_reported(torch_gpu, hip_lib):
     env.close()
 
 
+def test_rod_recorder_on_gpu(torch_gpu, hip_lib, oracle_built):
+    """Diagnostic taps (RodCallBack fields) from the resident state of chosen envs."""
+    import gym_softrobot_amd as gsa
+
+    n = 4
+    env = gsa.make_vec("SoftPendulum-v0", n, device=0, config_generate_video=True)
+    env.record_envs = (0, 2)
+    env.reset(seed=0)
+    rods = {}
+    for i in env.record_envs:
+        rods[i] = oracle_built.OracleRod(env.cfg)
+        rods[i].reset_pendulum(_theta(i))
+    acts = np.random.default_rng(2).uniform(-22, 22, (2, n)).astype(np.float32)
+    for t in range(2):
+        env.step(acts[t])
+        for i, r in rods.items():
+            r.env_step(acts[t, i])
+    st = env.backend.state_numpy()
+    for k, i in enumerate(env.record_envs):
+        p = env.recorder.params[k]
+        assert len(p["time"]) == 2 and p["time"][-1] == pytest.approx(0.08, rel=1e-9)
+        np.testing.assert_array_equal(p["position"][-1], st["x"][i])
+        np.testing.assert_array_equal(p["omega"][-1], st["w"][i])
+        rods[i].refresh_strains()
+        np.testing.assert_allclose(p["kappa"][-1], rods[i].get("kappa"), rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(p["sigma"][-1], rods[i].get("sigma"), rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(p["radius"][-1], rods[i].get("radius"), rtol=1e-9)
+    env.close()
+
+
 # ---- rods longer than one node per lane (two per lane, softrod_long.hpp) ---------------------
 def test_long_rod_softpendulum_matches_oracle(torch_gpu, hip_lib, oracle_built):
     import gym_softrobot_amd as gsa

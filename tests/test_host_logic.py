@@ -353,3 +353,33 @@ def test_device_autoreset_host_logic_equals_host_autoreset(oracle_built):
     assert underflow == 0 and consumed.min() >= 5
     host.close()
     dev.close()
+
+
+def test_rod_recorder_matches_oracle_strains(oracle_built):
+    """config_generate_video=True: RodCallBack's fields (callback_func.py:23-41), one sample per
+    env.step, strains recomputed from the resident state."""
+    cfg = _capi.softpendulum_config(1, n_elems=12)
+    cfg.n_substeps = 30
+    be = OracleBackend(cfg)
+    env = gsa.SoftPendulumEnv(n_elems=12, config_generate_video=True, backend=be)
+    env._vec.cfg.n_substeps = 30
+    env.reset(seed=1)
+    for a in (5.0, -9.0, 3.0):
+        env.step(np.array([a], np.float32))
+    p = env.rod_parameters_dict
+    assert set(p) == {"time", "radius", "dilatation", "voronoi_dilatation", "position", "director",
+                      "velocity", "omega", "sigma", "kappa"}
+    assert all(len(v) == 3 for v in p.values())
+    rod = be.rods[0]
+    rod.refresh_strains()                      # the oracle's strains at the current state
+    np.testing.assert_array_equal(p["position"][-1], rod.get("x"))
+    np.testing.assert_array_equal(p["director"][-1], rod.get("Q"))
+    np.testing.assert_allclose(p["sigma"][-1], rod.get("sigma"), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(p["kappa"][-1], rod.get("kappa"), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(p["dilatation"][-1], rod.get("dilatation"), rtol=1e-13)
+    np.testing.assert_allclose(p["radius"][-1], rod.get("radius"), rtol=1e-13)
+    assert p["time"][-1] == pytest.approx(3 * 30 * 1e-4, rel=1e-12)
+    # a new reset starts a fresh dict, like the reference (soft_pendulum.py:118)
+    env.reset()
+    assert len(env.rod_parameters_dict["time"]) == 0
+    env.close()
