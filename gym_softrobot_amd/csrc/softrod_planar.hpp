@@ -17,6 +17,16 @@
 // that d1 is rebuilt from d3 instead of being rotated separately (they differ by the
 // rounding of one rotation, ~1e-16).
 //
+// One more consequence of planarity is used: element k turns about z at the rate s2 w_k, so
+// the bending angle D_k = angle(d3_{k+1}) - angle(d3_k) obeys dD_k/dt = s2 (w_{k+1} - w_k)
+// exactly, and kappa = -log(Q+ Q^T)/D^ reduces to s2 D_k / D^ (the theta/sin(theta) factor of
+// _inv_rotate cancels the sine it multiplies).  D_k is therefore carried as one more state
+// variable per Voronoi vertex — initialised from the directors with atan2 at kernel entry,
+// advanced with one subtraction and one FMA per kinematic step — instead of being recovered
+// from the directors every substep through sin D, cos D and the theta/sin(theta) series.  The
+// reference's `- 1e-10` inside arccos (a 3e-11 relative change of kappa) has no counterpart
+// on this path.
+//
 // The step kernel takes this path only if the loaded state IS planar (planar_from_lane:
 // exact zeros where the argument above needs them, d1 consistent with d3 to 1e-12); any
 // other state — e.g. one written through softrod_state_view — runs the general 3-D loop.
@@ -31,6 +41,7 @@ struct PlanarN {
     double s2[EPL];            // d2 = (0, 0, s2), s2 = +-1
     double w[EPL];             // omega = (0, w, 0) in the local frame
     double t[EPL][2];          // tangents as of the last force evaluation
+    double dl[EPL];            // bending angle between elements k and k+1
 };
 
 // exp(x) for the damper (see exp_pair)
@@ -67,6 +78,18 @@ __device__ __forceinline__ bool planar_from_lane(const RodParams& P, const BcTar
         Z.w[s] = L.w[s][1];
         Z.t[s][0] = L.t[s][0]; Z.t[s][1] = L.t[s][1];
     }
+    {
+        double cnx[EPL], snx[EPL];
+        shift_next<EPL>(Z.c, cnx);
+        shift_next<EPL>(Z.s, snx);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const bool vor_valid = (lane * EPL + s) < n - 1;
+            const double sinD = fma(snx[s], Z.c[s], -cnx[s] * Z.s[s]);
+            const double cosD = fma(cnx[s], Z.c[s], snx[s] * Z.s[s]);
+            Z.dl[s] = vor_valid ? atan2(sinD, cosD) : 0.0;
+        }
+    }
     return !__any(!ok);
 }
 
@@ -87,20 +110,25 @@ __device__ __forceinline__ void planar_to_lane(const PlanarN<EPL>& Z, LaneN<EPL>
 // the new d3 = sin * d1 + cos * d3.
 template <int EPL>
 __device__ __forceinline__ void planar_kinematic_n(double h, const ConstN<EPL>& C, PlanarN<EPL>& Z) {
+    double ra[EPL], ran[EPL];      // signed rotation angle of each element about z
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         const double hp = h * C.hx[s];
         Z.x[s][0] = fma(hp, Z.v[s][0], Z.x[s][0]);
         Z.x[s][1] = fma(hp, Z.v[s][1], Z.x[s][1]);
         const double a = (h * C.hq[s]) * Z.w[s];
+        ra[s] = a * Z.s2[s];
         const double t = a * a;
         double sc, cc;
         sinc_cosc(t, sc, cc);
-        const double sn = (sc * a) * Z.s2[s], cs = fma(-cc, t, 1.0);
+        const double sn = sc * ra[s], cs = fma(-cc, t, 1.0);
         const double c = Z.c[s], sv = Z.s[s];
         Z.c[s] = fma(-sn, sv, cs * c);
         Z.s[s] = fma(sn, c, cs * sv);
     }
+    shift_next<EPL>(ra, ran);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) Z.dl[s] += C.b01[s] != 0.0 ? ran[s] - ra[s] : 0.0;
 }
 
 // dynamic_n for SOFTROD_FEATURES_SOFTPENDULUM (gravity and the point force live in C.ca,
@@ -154,23 +182,16 @@ __device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const Const
 #pragma unroll
         for (int s = 0; s < EPL; ++s) f[s][c] = cs[s][c] - o[s];
     }
-    // bend: Q+ Q^T is a rotation about d2 by D = angle(d3+) - angle(d3); of _inv_rotate's
-    // vector only component 1 = RD(0,2) - RD(2,0) = -2 s2 sin D survives, trace = 1 + 2 cos D
-    double cnx[EPL], snx[EPL], len_n[EPL], up[EPL];
-    shift_next<EPL>(Z.c, cnx);
-    shift_next<EPL>(Z.s, snx);
+    // bend: kappa = s2 D / D^ with the carried bending angle D (see the header); the Voronoi
+    // couple B kappa / vd^3, and kappa x B kappa = 0 for a single component
+    double len_n[EPL], up[EPL];
     shift_next<EPL>(len, len_n);
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const bool vor_valid = (lane * EPL + s) < n - 1;
-        const double sinD = fma(snx[s], Z.c[s], -cnx[s] * Z.s[s]);
-        const double cosD = fma(cnx[s], Z.c[s], snx[s] * Z.s[s]);
-        const double y = fma(-0.5, cosD, 0.5 + 0.5 * P.acos_shift);
-        const double gk = theta_over_sin(y, vor_valid) * (-0.5 * P.inv_rest_vor);
-        const double k1 = (-2.0 * Z.s2[s] * sinD) * gk;
+        const double k1 = (Z.s2[s] * P.inv_rest_vor) * Z.dl[s];
         const double vd = (len_n[s] + len[s]) * (0.5 * P.inv_rest_vor);
         const double rvd = fast_rcp(vd);
-        up[s] = C.b01[s] * k1 * (rvd * rvd * rvd);       // B kappa / vd^3; kappa x B kappa = 0
+        up[s] = C.b01[s] * k1 * (rvd * rvd * rvd);
     }
     {
         double o[EPL];
