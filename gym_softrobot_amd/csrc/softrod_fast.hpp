@@ -34,6 +34,11 @@ namespace softrod {
 // when a simulation is blowing up) the angle is halved k times and rebuilt with
 //   sinc(2p) = sinc(p) cos(p),  cosc(2p) = sinc(p)^2 / 2,  cos(p) = 1 - cosc(p) p^2.
 __device__ __forceinline__ void sinc_cosc(double t, double& sc, double& cc) {
+    if (!__any(t >= 1.0e-3)) {     // the whole wave is in range: straight-line, one s_cbranch
+        sc = fma(t, fma(t, fma(t, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+        cc = fma(t, fma(t, fma(t, -1.0 / 40320.0, 1.0 / 720.0), -1.0 / 24.0), 0.5);
+        return;
+    }
     int k = 0;
     while (__any(t >= 1.0e-3) && k < 48) { t *= 0.25; ++k; }   // wave-uniform trip count
     sc = fma(t, fma(t, fma(t, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
@@ -91,6 +96,11 @@ __device__ __forceinline__ double theta_over_sin(double y, bool valid) {
 // exp(x) for the damper: |x| < 1e-3 -> degree-4 Taylor (remainder x^5/120 < 1e-17);
 // larger |x| (strong damping constants) are halved k times and squared back.
 __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid, double& e0, double& e2) {
+    if (!__any(valid && !(fmax(fabs(x0), fabs(x2)) < 1.0e-3))) {
+        e0 = fma(x0, fma(x0, fma(x0, fma(x0, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
+        e2 = fma(x2, fma(x2, fma(x2, fma(x2, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
+        return;
+    }
     int k = 0;
     while (__any(valid && !(fmax(fabs(x0), fabs(x2)) < 1.0e-3)) && k < 60) {
         x0 *= 0.5; x2 *= 0.5; ++k;
