@@ -127,7 +127,9 @@ def main() -> None:
     if args.autoreset != "off":
         extra["autoreset"] = True if args.autoreset == "host" else "device"
     local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode, **extra)
-    env = ShardedVecEnv(local, n_total)   # world > 1: kernel-packed rows + one all-gather per step
+    # world > 1: kernel-packed rows + one all-gather per step, issued asynchronously so that the
+    # next step's kernel does not wait for it (ShardedVecEnv overlap; the final sync is timed)
+    env = ShardedVecEnv(local, n_total, overlap=True)
     env.reset(seed=0)                      # global env i seeded i
     lo, hi = env.lo, env.hi
     adim = local.backend.action_dim
@@ -148,6 +150,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for t in range(W, T):
         obs, rew, term, trunc, _ = env.step(acts_dev[t])
+    env.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

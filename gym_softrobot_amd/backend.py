@@ -203,22 +203,25 @@ class HipRodBackend:
         )
         return self.obs, self.reward, self.terminated, self.truncated
 
-    def step_packed(self, actions) -> torch.Tensor:
-        """softrod_step_packed: (n_envs, packed_width(obs_dim)) float32 words per env."""
+    def step_packed(self, actions, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """softrod_step_packed: (n_envs, packed_width(obs_dim)) float32 words per env, into
+        `out` if given (the overlapped multi-GPU path alternates two buffers)."""
         from .distributed import packed_width
 
         a = self._actions(actions)
-        if getattr(self, "packed", None) is None:
-            self.packed = torch.empty((self.n_envs, packed_width(self.obs_dim)), dtype=torch.float32,
-                                      device=self.device)
+        if out is None:
+            if getattr(self, "packed", None) is None:
+                self.packed = torch.empty((self.n_envs, packed_width(self.obs_dim)), dtype=torch.float32,
+                                          device=self.device)
+            out = self.packed
         check(
             self._lib.softrod_step_packed(
-                self._h, a.data_ptr(), self.packed.data_ptr(),
+                self._h, a.data_ptr(), out.data_ptr(),
                 self.aux.data_ptr() if self.aux is not None else None, self._stream(),
             ),
             self._h,
         )
-        return self.packed
+        return out
 
     def substeps(self, actions, n: int) -> None:
         a = self._actions(actions) if actions is not None else None

@@ -16,6 +16,13 @@ the sharded env is exactly two device operations per rank: the kernel and the al
 Backend `nccl` is RCCL over xGMI on the MI355X node; `gloo` drives the same code in
 the CPU tests (tests/test_distributed_gloo.py).  `gather=False` leaves outputs sharded
 for a data-parallel consumer.
+
+`overlap=True` (what `bench.py --gpus N` uses) takes the collective off the critical path:
+the all-gather of step t is issued asynchronously (it starts when step t's kernel has
+finished) and step t+1's kernel is launched without waiting for it, on alternating buffers.
+The tensors returned by `step` are then complete once `sync()` — or the step after next —
+has been called; a policy that needs them immediately calls `sync()` and loses nothing
+compared with `overlap=False`.
 """
 from __future__ import annotations
 
@@ -74,7 +81,7 @@ class ShardedVecEnv:
     """
 
     def __init__(self, local_env, total_envs: int, group: Optional[dist.ProcessGroup] = None,
-                 gather: bool = True):
+                 gather: bool = True, overlap: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -88,6 +95,13 @@ class ShardedVecEnv:
         dev = local_env.backend.device
         w = packed_width(self.obs_dim)
         self._global = torch.empty((self.total_envs, w), dtype=torch.float32, device=dev)
+        self.overlap = bool(overlap) and self.world > 1 and gather
+        if self.overlap:
+            n_loc = self.hi - self.lo
+            self._packed2 = [torch.empty((n_loc, w), dtype=torch.float32, device=dev) for _ in range(2)]
+            self._global2 = [self._global, torch.empty_like(self._global)]
+            self._works = [None, None]
+            self._k = 0
 
     def _all_gather(self, packed: torch.Tensor) -> torch.Tensor:
         dist.all_gather_into_tensor(self._global, packed, group=self.group)
@@ -114,9 +128,31 @@ class ShardedVecEnv:
             a = a[self.lo : self.hi]
         if not self.gather or self.world == 1:
             return self.local.step(a)
+        if self.overlap:
+            return self._step_overlapped(a)
         packed, info = self.local.step_packed(a)
         o, r, te, tr = unpack_outputs(self._all_gather(packed), self.obs_dim)
         return o, r, te, tr, info
 
+    def _step_overlapped(self, a):
+        k = self._k
+        if self._works[k] is not None:
+            # buffers k were last used two steps ago: their gather has long finished; this only
+            # orders the kernel below after it (a stream-level wait, not a host block on RCCL)
+            self._works[k].wait()
+        packed, info = self.local.step_packed(a, self._packed2[k])
+        self._works[k] = dist.all_gather_into_tensor(self._global2[k], packed, group=self.group, async_op=True)
+        self._k = 1 - k
+        o, r, te, tr = unpack_outputs(self._global2[k], self.obs_dim)
+        return o, r, te, tr, info
+
+    def sync(self) -> None:
+        """Make the outputs of the latest step() complete (overlap=True)."""
+        if self.overlap:
+            for w in self._works:
+                if w is not None:
+                    w.wait()
+
     def close(self):
+        self.sync()
         self.local.close()

@@ -317,16 +317,17 @@ class VecRodEnvBase:
             infos,
         )
 
-    def step_packed(self, actions):
+    def step_packed(self, actions, out=None):
         """step() with every per-env output in one (N, packed_width) float32 buffer written
-        by the kernel itself (distributed.unpack_outputs gives views); no auto-reset."""
+        by the kernel itself (distributed.unpack_outputs gives views); no host auto-reset."""
         import torch
 
         if self.autoreset:
             raise NotImplementedError("step_packed does not auto-reset on the host; use autoreset='device'")
         self._validate_actions(actions)
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.backend.device)
-        packed = self.backend.step_packed(a.reshape(self.num_envs, self.action_dim))
+        a = a.reshape(self.num_envs, self.action_dim)
+        packed = self.backend.step_packed(a) if out is None else self.backend.step_packed(a, out)
         if self.device_autoreset:
             self._since_top_up += 1
             if self._since_top_up >= self.top_up_every:

@@ -199,11 +199,11 @@ class OracleBackend:
                 self._need[i] = bool(te) or bool(tr)
         return self.obs, self.reward, self.terminated, self.truncated
 
-    def step_packed(self, actions):
+    def step_packed(self, actions, out=None):
         from gym_softrobot_amd.distributed import pack_outputs
 
         o, r, te, tr = self.step(actions)
-        return pack_outputs(o, r, te, tr)
+        return pack_outputs(o, r, te, tr, out)
 
     def close(self):
         self.rods = []

@@ -48,7 +48,7 @@ def _octo_worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
-def _worker(rank, world, port, total, T, q):
+def _worker(rank, world, port, total, T, q, overlap=False):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -63,12 +63,13 @@ def _worker(rank, world, port, total, T, q):
     cfg.n_substeps = 40  # keep the CPU suite quick; the sharding logic does not depend on it
     local = gsa.VecSoftPendulumEnv(hi - lo, backend=OracleBackend(cfg))
     local.cfg.n_substeps = 40
-    env = ShardedVecEnv(local, total)
+    env = ShardedVecEnv(local, total, overlap=overlap)
     obs0, _ = env.reset(seed=7)
     acts = np.random.default_rng(5).uniform(-22, 22, (T, total)).astype(np.float32)
     out = [obs0.clone().numpy()]
     for t in range(T):
         o, r, te, tr, _ = env.step(acts[t])
+        env.sync()     # overlap=True: outputs are complete after sync()
         out.append((o.clone().numpy(), r.clone().numpy(), te.clone().numpy(), tr.clone().numpy()))
     if rank == 0:
         q.put(out)
@@ -123,12 +124,13 @@ def test_shard_bounds():
         shard_bounds(10, 4, 0)
 
 
-def test_world2_gloo_matches_single_process(oracle_built):
-    total, T, world = 6, 2, 2
+@pytest.mark.parametrize("overlap", [False, True], ids=["blocking", "overlapped"])
+def test_world2_gloo_matches_single_process(oracle_built, overlap):
+    total, T, world = 6, 4, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=240)
