@@ -160,8 +160,7 @@ void fill_params(const softrod_config& c, RodParams& P) {
         const double s1 = harea * harea / (4.0 * M_PI);
         const double smoa[3] = {s1, s1, 2.0 * s1};
         for (int i = 0; i < 3; ++i) {
-            P.head_J[i] = smoa[i] * c.head_density * hl;
-            P.head_invJ[i] = 1.0 / P.head_J[i];
+            P.head_invJ[i] = 1.0 / (smoa[i] * c.head_density * hl);
         }
         P.head_radius = hr;
         P.joint_k = c.joint_k;

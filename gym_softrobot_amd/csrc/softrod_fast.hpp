@@ -348,9 +348,6 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
 #ifndef SOFTROD_FAST_WAVES
 #define SOFTROD_FAST_WAVES 3
 #endif
-#ifndef SOFTROD_PLANAR_EPL_OK
-#define SOFTROD_PLANAR_EPL_OK(epl) true
-#endif
 #ifndef SOFTROD_CONTACT_WAVES
 #define SOFTROD_CONTACT_WAVES 2
 #endif
@@ -391,7 +388,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
 
     bool stepped = false;
-    if constexpr (F == SOFTROD_FEATURES_SOFTPENDULUM && SOFTROD_PLANAR_EPL_OK(EPL)) {
+    if constexpr (F == SOFTROD_FEATURES_SOFTPENDULUM) {
         // SoftPendulum-v0 lives in the x-y plane: same substep without the identically
         // zero out-of-plane terms (softrod_planar.hpp); any other state takes the 3-D loop
         PlanarN<EPL> Z;

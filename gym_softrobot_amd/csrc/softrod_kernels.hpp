@@ -78,7 +78,7 @@ struct RodParams {
     double r0_sqrt_rest_len;         // radius_k = r0 sqrt(l_rest / l_k)  (volume preserving)
     // OctoFlat-v0: n_arm rods per wave, `seg` slots apart (0 = one rod per wave), + rigid head
     int seg, n_arm, seg_shift, pad1;
-    double head_mass, head_J[3], head_invJ[3], head_radius;
+    double head_mass, head_invJ[3], head_radius;   // the planar head only ever turns about d3
     double joint_k, joint_nu, joint_kt;
 };
 

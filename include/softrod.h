@@ -207,7 +207,8 @@ typedef struct softrod_handle softrod_handle;
  * Layout (DESIGN.md "HBM layout"): structure-of-arrays, component-major, one
  * row of `lane_stride` entries per rod (64 for n_elem <= 63: lane k of the rod's
  * wavefront owns node k, element k and Voronoi vertex k; 128 for n_elem <= 126:
- * lane k owns indices 2k and 2k+1):
+ * lane k owns indices 2k and 2k+1; OctoFlat: 64 per wavefront of the env's
+ * workgroup, arms `arm_stride` slots apart):
  *     position[(c * n_envs + env) * lane_stride + node]        c = 0..2
  *     director[((r*3 + c) * n_envs + env) * lane_stride + elem]  row r of Q, lab comp. c
  * Mirrors rod.position_collection / velocity_collection / director_collection /
@@ -221,16 +222,17 @@ typedef struct softrod_state_view {
     double* velocity; /* [3][n_envs][lane_stride] */
     double* director; /* [9][n_envs][lane_stride] */
     double* omega;    /* [3][n_envs][lane_stride] */
-    double* tangents; /* [3][n_envs][64]  as of the last force evaluation   */
+    double* tangents; /* [3][n_envs][lane_stride]  as of the last force evaluation */
     double* time;     /* [n_envs]  simulated time (soft_pendulum.py:141,184) */
     double* control;  /* [4][n_envs]  MovingBaseController position x,y and
                          velocity x,y (soft_pendulum_3d/build.py:15-20)      */
-    double* kappa;    /* [3][n_envs][64]  rod.kappa as of the last force
-                         evaluation (arm_single_env.py:189)                  */
-    double* rest_kappa; /* [3][n_envs][64]  rod.rest_kappa (:235)            */
-    double* env_memory; /* [n_envs][64]  env-side memory between steps:
-                         prev_kappa_state[0..n-2], prev_com_state at 60,61
-                         (arm_single_env.py:172-173,190-198)                 */
+    double* kappa;    /* [3][n_envs][lane_stride]  rod.kappa as of the last force
+                         evaluation (arm_single_env.py:189); maintained by the
+                         feature sets with SOFTROD_FEAT_REST_KAPPA_ACTION     */
+    double* rest_kappa; /* [3][n_envs][lane_stride]  rod.rest_kappa (:235)    */
+    double* env_memory; /* [n_envs][lane_stride]  ArmSingle: prev_kappa_state
+                         [0..n-2] (arm_single_env.py:172,190-198); its
+                         prev_com_state lives in control[0..1]               */
     float* prev_action; /* [n_envs][7]  the env's _prev_action, written by
                          softrod_step (soft_pendulum.py:165), cleared by reset
                          only where the reference does (soft_pendulum_3d.py:68);

@@ -705,7 +705,7 @@ def test_rod_recorder_on_gpu(torch_gpu, hip_lib, oracle_built):
     env.close()
 
 
-# ---- rods longer than one node per lane (two per lane, softrod_long.hpp) ---------------------
+# ---- rods longer than one node per lane (two slots per lane, EPL = 2) -------------------------
 def test_long_rod_softpendulum_matches_oracle(torch_gpu, hip_lib, oracle_built):
     import gym_softrobot_amd as gsa
 
