@@ -27,6 +27,7 @@ struct ContactParams {
     double k, nu, slip_tol, surface_tol;
     double kin_mu[3], stat_mu[3];   // forward, backward, sideways
     double r0_sqrt_rest_len;        // r0 * sqrt(l_rest): radius = this / sqrt(len)
+    double inv_r0_sqrt_rest_len;
 };
 
 __device__ __forceinline__ double sign_of(double x) { return (double)((x > 0.0) - (x < 0.0)); }
@@ -77,19 +78,32 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
 #pragma unroll
         for (int s = 0; s < EPL; ++s) Fn[s][i] = o[s];
     }
+    double wa[EPL], wb[EPL], inv_radius[EPL];
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         const int idx = slot_local(P, lane * EPL + s);
         const bool first = (idx == 0), last = (idx == n - 1);
-        radius[s] = FM ? C.r0_sqrt_rest_len * fast_rsqrt(len[s]) : C.r0_sqrt_rest_len / sqrt(len[s]);
+        // node -> element: half of each end node, the rod's two end nodes in full
+        wa[s] = first ? 1.0 : 0.5;
+        wb[s] = last ? 1.0 : 0.5;
         double fel[3];
+        if constexpr (FM) {
+            const double rsl = fast_rsqrt(len[s]);
+            radius[s] = C.r0_sqrt_rest_len * rsl;
+            inv_radius[s] = (len[s] * rsl) * C.inv_r0_sqrt_rest_len;      // sqrt(len) / (r0 sqrt(l_rest))
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            fel[i] = 0.5 * (F[s][i] + Fn[s][i]);
-            fel[i] += first ? 0.5 * F[s][i] : 0.0;
-            fel[i] += last ? 0.5 * Fn[s][i] : 0.0;
+            for (int i = 0; i < 3; ++i) fel[i] = fma(wb[s], Fn[s][i], wa[s] * F[s][i]);
+        } else {
+            radius[s] = C.r0_sqrt_rest_len / sqrt(len[s]);
+            inv_radius[s] = 1.0 / radius[s];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                fel[i] = 0.5 * (F[s][i] + Fn[s][i]);
+                fel[i] += first ? 0.5 * F[s][i] : 0.0;
+                fel[i] += last ? 0.5 * Fn[s][i] : 0.0;
+            }
         }
-        const double inv_m = inv_of<FM>(K.mass_next[s] + K.mass[s]);
+        const double inv_m = FM ? K.inv_mass_pair[s] : 1.0 / (K.mass_next[s] + K.mass[s]);
         double vel[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -147,7 +161,8 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) v2 += vel[i] * vel[i];
-        const double axn = sqrt_of<FM>(axn2);
+        // |ax| after the normalisation = |ax_raw| / (|ax_raw| + 1e-14)
+        const double axn = FM ? sqrt_of<true>(a2) * itp : sqrt(axn2);
         const double ron = ZUP ? axn : sqrt_of<FM>(ron2);   // |ax x e_z| = |ax| term by term
         const double sgn = sign_of(vax);
         const double kmu = 0.5 * (C.kin_mu[0] * (1 + sgn) + C.kin_mu[1] * (1 - sgn));
@@ -232,14 +247,16 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
     }
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const int idx = slot_local(P, lane * EPL + s);
-        const bool first = (idx == 0), last = (idx == n - 1);
         double fel[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            fel[i] = 0.5 * (F2[s][i] + Fn[s][i]);
-            fel[i] += first ? 0.5 * F2[s][i] : 0.0;
-            fel[i] += last ? 0.5 * Fn[s][i] : 0.0;
+            if constexpr (FM) {
+                fel[i] = fma(wb[s], Fn[s][i], wa[s] * F2[s][i]);
+            } else {
+                fel[i] = 0.5 * (F2[s][i] + Fn[s][i]);
+                fel[i] += (wa[s] == 1.0) ? 0.5 * F2[s][i] : 0.0;
+                fel[i] += (wb[s] == 1.0) ? 0.5 * Fn[s][i] : 0.0;
+            }
         }
         double fax = 0.0, fro = 0.0, tax = 0.0;
         const double* Q = L.Q[s];
@@ -253,7 +270,7 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
         const double sg = sign_of(fax);
         const double smu = 0.5 * (C.stat_mu[0] * (1 + sg) + C.stat_mu[1] * (1 - sg));
         const double sa = contact[s] ? -(fmin(fabs(fax), slip_ax[s] * smu * nmag[s]) * sg) : 0.0;
-        const double noslip = FM ? -((radius[s] * fro - 2.0 * tax) * (1.0 / 3.0) * inv_of<true>(radius[s]))
+        const double noslip = FM ? -((radius[s] * fro - 2.0 * tax) * (1.0 / 3.0) * inv_radius[s])
                                  : -((radius[s] * fro - 2.0 * tax) / 3.0 / radius[s]);
         const double sr = contact[s]
             ? fmin(fabs(noslip), slip_ro[s] * C.stat_mu[2] * nmag[s]) * sign_of(noslip) : 0.0;

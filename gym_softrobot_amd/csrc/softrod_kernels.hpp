@@ -187,7 +187,7 @@ struct ConstN {
     double cw01[EPL], cw2[EPL];
     double s01[EPL], s2[EPL];
     double b01[EPL], bd[EPL];
-    double mass[EPL], mass_next[EPL];
+    double mass[EPL], mass_next[EPL], inv_mass_pair[EPL];   // 1 / (m_k + m_{k+1}): element velocity
 };
 
 // value of index+1 / index-1 for a per-slot array
@@ -391,6 +391,7 @@ __device__ __forceinline__ ContactParams contact_params(const RodParams& P) {
     }
     C.k = P.contact_k; C.nu = P.contact_nu; C.slip_tol = P.slip_tol; C.surface_tol = P.surface_tol;
     C.r0_sqrt_rest_len = P.r0_sqrt_rest_len;
+    C.inv_r0_sqrt_rest_len = 1.0 / P.r0_sqrt_rest_len;
     return C;
 }
 
@@ -652,6 +653,7 @@ __device__ __forceinline__ void build_const(const RodParams& P, int lane, const 
         const double mass = (idx == 0 || idx == n) ? 0.5 * P.mass_node : P.mass_node;
         C.mass[s] = mass;
         C.mass_next[s] = (idx + 1 == n) ? 0.5 * P.mass_node : P.mass_node;
+        C.inv_mass_pair[s] = 1.0 / (C.mass[s] + C.mass_next[s]);
         C.hx[s] = held_x ? 0.0 : 1.0;
         C.hq[s] = held_q ? 0.0 : 1.0;
         const double cdm = node_valid ? ct * P.dt / mass : 0.0;
@@ -858,6 +860,7 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     ConstN<1> CK;
     CK.mass[0] = mass;
     CK.mass_next[0] = mass_next;
+    CK.inv_mass_pair[0] = 1.0 / (mass + mass_next);
     const double len1[1] = {len};
     if (has_contact && P.contact_before_forcing) {
         const double F[1][3] = {{f0, f1, f2}};
