@@ -333,13 +333,13 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         L.w[s][0] = w0; L.w[s][1] = w1; L.w[s][2] = w2;
     }
     if (P.damp_before_constrain) {
-        if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) laplace_filter_rates_n<EPL>(P, lane, L);
+        if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) laplace_filter_rates_fast<EPL>(P, lane, L);
         constrain_rates_n<F, EPL>(P, B, lane, L);
     } else {
         BcTargets Bs = B;
         Bs.vel[0] *= P.damp_t; Bs.vel[1] *= P.damp_t; Bs.vel[2] *= P.damp_t;
         constrain_rates_n<F, EPL>(P, Bs, lane, L);
-        if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) laplace_filter_rates_n<EPL>(P, lane, L);
+        if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) laplace_filter_rates_fast<EPL>(P, lane, L);
     }
 }
 
@@ -352,9 +352,9 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
 #define SOFTROD_CONTACT_WAVES 2
 #endif
 // Two slots per lane need the whole 512-entry register file (1 wave per SIMD); the contact
-// instantiation trades a wave of occupancy for not spilling.
+// and Laplace-filter instantiations trade a wave of occupancy for not spilling in the loop.
 template <unsigned F, int E, int EPL>
-__global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & SOFTROD_FEAT_PLANE_CONTACT_ANISO)) ? SOFTROD_CONTACT_WAVES : SOFTROD_FAST_WAVES)))
+__global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER))) ? SOFTROD_CONTACT_WAVES : SOFTROD_FAST_WAVES)))
 softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,

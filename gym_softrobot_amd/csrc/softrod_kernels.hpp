@@ -357,6 +357,110 @@ __device__ __forceinline__ void laplace_filter_rates_n(const RodParams& P, int l
     }
 }
 
+// The same filter for the reference's order 7 (soft_pendulum_3d/build.py:82-85) with six of the
+// seven passes of the omega fields folded into ONE 13-tap stencil staged through LDS, while the
+// velocity fields keep their DPP passes: the two halves run on different pipes (LDS / VALU)
+// and overlap; all six fields through LDS, or none, measured 8 % slower (profiles/README.md).
+//
+// A pass is f <- q (2 f - S+ f - S- f) with q = 1/4 inside and 0 on the two boundary entries,
+// i.e. after the first pass f vanishes on the boundary and every further pass is the free
+// 3-point operator L = (2 - S+ - S-)/4 acting on the ODD extension of f about both
+// boundaries (f(-j) = -f(j), f(N+j) = -f(N-j)): oddness keeps the boundary at zero and the
+// interior sees exactly the masked passes.  So f_7 = L^6 f_1 = sum_j c_j f_1(k+j),
+// c_j = (-1)^j C(12, 6+j) / 4^6.  Pass 1 runs in registers (DPP shifts) as before; f_1 and
+// its reflections go to LDS once; each entry then reads its 13 taps.  Per field: 13 FMAs and
+// 13 LDS reads instead of 6 x (4 DPP moves + 3 fp64 ops); the block is one wavefront, so
+// the barrier between the writes and the reads costs nothing.  Needs N >= 6.
+template <int EPL>
+__device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, int lane, LaneN<EPL>& L) {
+    constexpr int M = 6, W = kLanes * EPL;
+    __shared__ double lds[3][W + 2 * M];
+    const int n = P.n_elem;
+    // c_j for j = 0..6: C(12, 6+j) / 4096 with alternating sign
+    constexpr double c[M + 1] = {924.0 / 4096.0, -792.0 / 4096.0, 495.0 / 4096.0, -220.0 / 4096.0,
+                                 66.0 / 4096.0, -12.0 / 4096.0, 1.0 / 4096.0};
+    double r[6][EPL], f1[6][EPL];
+    bool inner[2][EPL];        // [0]: nodes 1..n-1, [1]: elements 1..n-2
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = slot_local(P, lane * EPL + s);
+        inner[0][s] = (idx >= 1 && idx <= n - 1);
+        inner[1][s] = (idx >= 1 && idx <= n - 2);
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            r[c3][s] = (idx <= n) ? L.v[s][c3] : 0.0;
+            r[3 + c3][s] = (idx < n) ? L.w[s][c3] : 0.0;
+        }
+    }
+    // pass 1 in registers
+#pragma unroll
+    for (int fld = 0; fld < 6; ++fld) {
+        double nx[EPL], pv[EPL];
+        shift_next<EPL>(r[fld], nx);
+        shift_prev<EPL>(r[fld], pv);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s)
+            f1[fld][s] = inner[fld / 3][s] ? ((-nx[s] - pv[s]) + 2.0 * r[fld][s]) * 0.25 : 0.0;
+    }
+    // stage f_1 and its odd reflections
+#pragma unroll
+    for (int fld = 3; fld < 6; ++fld) {
+        const int N = (fld < 3) ? n : n - 1;
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const int idx = slot_local(P, lane * EPL + s);
+            if (idx <= N) lds[fld - 3][M + idx] = f1[fld][s];
+            if (idx >= 1 && idx <= M) lds[fld - 3][M - idx] = -f1[fld][s];
+            if (idx >= N - M && idx <= N - 1) lds[fld - 3][M + 2 * N - idx] = -f1[fld][s];
+        }
+    }
+    __syncthreads();
+    {   // v: the remaining six passes in registers while the LDS writes settle
+        double qn[EPL];
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) qn[s] = inner[0][s] ? 0.25 : 0.0;
+#pragma unroll
+        for (int fld = 0; fld < 3; ++fld) {
+            double f[EPL], nx[EPL], pv[EPL];
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) f[s] = f1[fld][s];
+            for (int i = 0; i < 6; ++i) {
+                shift_next<EPL>(f, nx);
+                shift_prev<EPL>(f, pv);
+#pragma unroll
+                for (int s = 0; s < EPL; ++s) f[s] = ((-nx[s] - pv[s]) + 2.0 * f[s]) * qn[s];
+            }
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) {
+                const int idx = slot_local(P, lane * EPL + s);
+                L.v[s][fld] = (idx <= n) ? r[fld][s] - f[s] : L.v[s][fld];
+            }
+        }
+    }
+#pragma unroll
+    for (int fld = 3; fld < 6; ++fld) {
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const int base = lane * EPL + s;        // tap j of entry idx sits at M + idx + j
+            const double* row = &lds[fld - 3][base];
+            double acc = c[0] * row[M];
+#pragma unroll
+            for (int j = 1; j <= M; ++j) acc = fma(c[j], row[M + j] + row[M - j], acc);
+            const double out = r[fld][s] - (inner[fld / 3][s] ? acc : 0.0);
+            const int idx = slot_local(P, base);
+            if (fld < 3) L.v[s][fld] = (idx <= n) ? out : L.v[s][fld];
+            else L.w[s][fld - 3] = (idx < n) ? out : L.w[s][fld - 3];
+        }
+    }
+    __syncthreads();     // the next substep overwrites the staging rows
+}
+
+template <int EPL>
+__device__ __forceinline__ void laplace_filter_rates_fast(const RodParams& P, int lane, LaneN<EPL>& L) {
+    if (P.filter_order == 7 && P.n_elem >= 8 && P.seg == 0) laplace_filter_rates_lds7<EPL>(P, lane, L);
+    else laplace_filter_rates_n<EPL>(P, lane, L);
+}
+
 // ---- SOFTROD_MATH_FAST primitives (softrod_fast.hpp explains where they are used) ----
 // 1/x: v_rcp_f64 seed (~2^-25) + two Newton steps -> <= 1 ulp for normal x.
 __device__ __forceinline__ double fast_rcp(double x) {
