@@ -282,13 +282,22 @@ def test_octo_lite_variant_one_arm_eight_knots(torch_gpu, hip_lib, oracle_built)
 
 def test_octo_other_shapes(torch_gpu, hip_lib, oracle_built):
     """Arm counts and lengths other than the reference's: 5 arms of 12 elements (ghost slots
-    past the last arm), 3 arms of 20 elements (32 slots per arm)."""
+    past the last arm), 3 arms of 16 elements (32 slots per arm), 8 arms of 16 elements (four
+    wavefronts per env: the wide instantiation of the step kernel), 2 arms of 40 elements (64
+    slots per arm).
+
+    The explicit joint spring limits the arm resolution: node 0 of an arm carries half an
+    element mass m0 on a spring of stiffness joint_k = 1e6, and PositionVerlet needs
+    dt * sqrt(joint_k / m0) < 2; at the reference's dt = 7e-5 that is 1.35 for 10 elements, 1.7
+    for 16 and 1.9 for 20, where the oracle itself amplifies a 1e-10 perturbation to overflow
+    within 90 substeps.  Longer arms are therefore tested with a softer joint."""
     from gym_softrobot_amd import _capi
     from gym_softrobot_amd.backend import HipRodBackend
 
-    for n_arm, n_elems, nk in ((5, 12, 3), (3, 20, 4)):
+    for n_arm, n_elems, nk, joint_k in ((5, 12, 3, 1e6), (3, 16, 4, 1e6), (8, 16, 3, 1e6), (2, 40, 3, 1e5)):
         cfg = _capi.octo_flat_config(2, n_elems=n_elems, n_arm=n_arm, n_action=nk)
         cfg.n_substeps = 150
+        cfg.joint_k = joint_k
         be = HipRodBackend(cfg, device=0)
         tg = _targets(2, 21)
         be.reset_octo(tg)

@@ -625,10 +625,14 @@ def test_device_autoreset_equals_host_autoreset(torch_gpu, hip_lib, env_id, kw, 
     import gym_softrobot_amd as gsa
 
     n, T = 6, 23           # > queue_depth steps: the queue is topped up on the way
+    from gym_softrobot_amd.distributed import unpack_outputs
+
     host = gsa.make_vec(env_id, n, device=0, autoreset=True, **kw)
     dev = gsa.make_vec(env_id, n, device=0, autoreset="device", **kw)
+    devp = gsa.make_vec(env_id, n, device=0, autoreset="device", **kw)   # packed rows (multi-GPU path)
     oh, _ = host.reset(seed=3)
     od, _ = dev.reset(seed=3)
+    devp.reset(seed=3)
     assert torch_gpu.equal(oh, od)
     acts = np.random.default_rng(0).uniform(-amax, amax, (T, n, host.action_dim)).astype(np.float32)
     resets = 0
@@ -638,6 +642,8 @@ def test_device_autoreset_equals_host_autoreset(torch_gpu, hip_lib, env_id, kw, 
             a = np.clip(a, -1, 1)
         o1, r1, te1, tr1, i1 = host.step(a)
         o2, r2, te2, tr2, i2 = dev.step(a)
+        o3, r3, te3, tr3 = unpack_outputs(devp.step_packed(a)[0], dev.obs_dim)
+        assert torch_gpu.equal(o2, o3) and torch_gpu.equal(r2, r3) and torch_gpu.equal(tr2, tr3), t
         assert torch_gpu.equal(o1, o2), t
         assert torch_gpu.equal(r1, r2) and torch_gpu.equal(te1, te2) and torch_gpu.equal(tr1, tr2), t
         np.testing.assert_array_equal(i1["time"], i2["time"].cpu().numpy())
@@ -657,6 +663,7 @@ def test_device_autoreset_equals_host_autoreset(torch_gpu, hip_lib, env_id, kw, 
         assert torch_gpu.equal(o1, o2) and torch_gpu.equal(r1, r2) and torch_gpu.equal(tr1, tr2)
     host.close()
     dev.close()
+    devp.close()
 
 
 def test_device_autoreset_underflow_is_reported(torch_gpu, hip_lib):
