@@ -327,7 +327,11 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
                w2 = fma(ce2, tq[s][2], L.w[s][2]);
         if (has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) {
             double ex0, ex2;
-            exp_pair(e[s] * P.damp_logr[0], e[s] * P.damp_logr[2], elem_valid, ex0, ex2);
+            // c_r^e = c_r * c_r^(e-1): the strain e-1 is small, so the exponent stays in the
+            // polynomial's range also where log c_r is not (octopus arms: log c_r = -0.057)
+            const double em1 = e[s] - 1.0;
+            exp_pair(em1 * P.damp_logr[0], em1 * P.damp_logr[2], elem_valid, ex0, ex2);
+            ex0 *= P.damp_r[0]; ex2 *= P.damp_r[2];
             w0 *= ex0; w1 *= ex0; w2 *= ex2;
         }
         L.w[s][0] = w0; L.w[s][1] = w1; L.w[s][2] = w2;
