@@ -30,6 +30,7 @@ struct softrod_handle {
     double* d_init = nullptr;     // [N][18] staging for reset
     uint8_t* d_mask = nullptr;    // [N]
     double* d_basis = nullptr;    // [(n_elem-1)][7] action basis (zero until set)
+    RodParams* d_params = nullptr;  // device copy of P
     bool basis_set = false;
     double* h_init = nullptr;     // pinned
     uint8_t* h_mask = nullptr;    // pinned
@@ -485,6 +486,10 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     alloc((void**)&h->S.envmem, rowb);
     alloc((void**)&h->S.prev_action, N * (adim > 7 ? adim : 7) * sizeof(float));
     alloc((void**)&h->S.head, 20 * N * sizeof(double));
+    alloc((void**)&h->d_params, sizeof(RodParams));
+    if (rc == SOFTROD_OK && hipMemcpy(h->d_params, &h->P, sizeof(RodParams), hipMemcpyHostToDevice) != hipSuccess)
+        rc = SOFTROD_EHIP;
+    h->S.params = h->d_params;
     alloc((void**)&h->d_basis, (size_t)2 * kLanes * 7 * sizeof(double));
     h->S.basis = h->d_basis;
     alloc((void**)&h->d_init, N * h->init_stride * sizeof(double));
@@ -843,7 +848,7 @@ int softrod_destroy(softrod_handle* h) {
     if (h->h_produced) (void)hipHostFree(h->h_produced);
     if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_basis, h->d_init, h->d_mask};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_basis, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

@@ -347,6 +347,35 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
     }
 }
 
+// The substeps of one launch on the general 3-D state.  `always_inline` for every kernel whose
+// only path it is; the SoftPendulum kernel keeps it OUT of line (cold fallback for non-planar
+// states) so that its register demand cannot leak spills into the planar hot loop.
+template <unsigned F, int EPL>
+__device__ __forceinline__ void general_substeps(const RodParams& P, const RodParams& Pk, const ConstN<EPL>& C,
+                                                 const BcTargets& B, int lane, LaneN<EPL>& L, double& time,
+                                                 int n_sub) {
+    kinematic_n<EPL>(P.half_dt, C, L);
+    if (P.time_two_half_adds) time += P.half_dt;
+    for (int s = 0; s < n_sub; ++s) {
+        dynamic_n<F, EPL>(Pk, C, B, lane, L);
+        const bool last = (s == n_sub - 1);
+        kinematic_n<EPL>(last ? P.half_dt : P.dt, C, L);
+        time += P.time_two_half_adds ? P.half_dt : P.dt;
+        if (!last && P.time_two_half_adds) time += P.half_dt;
+    }
+}
+// The cold path reads the parameters from their device-memory copy (StatePtrs.params) instead of
+// having the caller copy 1.6 KB of kernel arguments to the stack.
+template <unsigned F, int EPL>
+__device__ __attribute__((noinline)) void general_substeps_cold(const RodParams* __restrict__ params,
+                                                                const ConstN<EPL>& C, const BcTargets& B, int lane,
+                                                                LaneN<EPL>& L, double& time, int n_sub) {
+    const RodParams P = *params;
+    RodParams Pk = P;
+    if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
+    general_substeps<F, EPL>(P, Pk, C, B, lane, L, time, n_sub);
+}
+
 // SOFTROD_FAST_WAVES: minimum waves per SIMD the register allocator must leave room for
 // (2nd __launch_bounds__ argument = waves per EU on gfx950); tuned in profiles/README.md.
 #ifndef SOFTROD_FAST_WAVES
@@ -411,15 +440,10 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
         }
     }
     if (n_sub > 0 && !stepped) {
-        kinematic_n<EPL>(P.half_dt, C, L);
-        if (P.time_two_half_adds) time += P.half_dt;
-        for (int s = 0; s < n_sub; ++s) {
-            dynamic_n<F, EPL>(Pk, C, B, lane, L);
-            const bool last = (s == n_sub - 1);
-            kinematic_n<EPL>(last ? P.half_dt : P.dt, C, L);
-            time += P.time_two_half_adds ? P.half_dt : P.dt;
-            if (!last && P.time_two_half_adds) time += P.half_dt;
-        }
+        if constexpr (F == SOFTROD_FEATURES_SOFTPENDULUM)
+            general_substeps_cold<F, EPL>(S.params, C, B, lane, L, time, n_sub);
+        else
+            general_substeps<F, EPL>(P, Pk, C, B, lane, L, time, n_sub);
     }
     store_lane<EPL, F>(S, N, rod, lane, L);
     if (lane == 0) S.time[rod] = time;

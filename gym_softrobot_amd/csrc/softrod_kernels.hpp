@@ -106,6 +106,7 @@ struct StatePtrs {
     const int* q_produced;  // [N] records staged so far
     int* q_underflow;       // [1] envs that needed a record when none was staged
     int q_depth, q_record;
+    const struct RodParams* params;   // device copy of the kernel's RodParams (cold paths read it)
 };
 
 // ---------------------------------------------------------------------------------
