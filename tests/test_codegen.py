@@ -1,0 +1,56 @@
+"""Guards the headline kernel's code generation: the planar SoftPendulum hot loop must stay
+free of scratch (spill) traffic and within its instruction budget.  The register allocation
+of this kernel has been knocked over before by unrelated edits to the 3-D fallback path
+(profiles/README.md, r1g), which costs 15 % without failing any parity test."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "gym_softrobot_amd" / "csrc"
+
+
+def _loops(asm: str, mangled_substr: str):
+    lines = asm.split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN7softrod\w*:", l) and mangled_substr in l)
+    end = start
+    while not lines[end].strip().startswith("s_endpgm"):
+        end += 1
+    labels, ins = {}, []
+    for l in lines[start:end + 1]:
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        t = l.strip()
+        if l.startswith("\t") and t and not t.startswith((".", ";")):
+            ins.append(t)
+    out = []
+    for i, t in enumerate(ins):
+        m = re.match(r"s_cbranch\w*\s+(\.LBB\d+_\d+)|s_branch\s+(\.LBB\d+_\d+)", t)
+        if m:
+            tgt = labels.get(m.group(1) or m.group(2))
+            if tgt is not None and tgt < i and i - tgt > 100:
+                out.append(ins[tgt:i + 1])
+    return out
+
+
+def test_planar_hot_loop_has_no_scratch_traffic(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    asm = tmp_path / "capi.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    "-o", str(asm), str(CSRC / "softrod_capi.hip")], check=True, timeout=900,
+                   stderr=subprocess.DEVNULL)
+    loops = _loops(asm.read_text(), "fast_kernelILj15ELi1ELi1E")   # <SOFTPENDULUM, SOFTPENDULUM, EPL = 1>
+    assert loops, "no loop found in the SoftPendulum step kernel"
+    hot = loops[0]                                                   # the planar substep loop comes first
+    scratch = [x for x in hot if x.startswith("scratch")]
+    valu = [x for x in hot if x.startswith("v_")]
+    assert not scratch, f"{len(scratch)} scratch instructions inside the planar hot loop"
+    assert len(valu) <= 185, f"planar hot loop grew to {len(valu)} VALU instructions"
+    assert not any(x.startswith("s_swappc") for x in hot), "a function call inside the hot loop"
