@@ -36,6 +36,19 @@ def test_config_layout_and_defaults_match_c(hip_lib):
     assert py.shear_modulus == pytest.approx(1e6 / 3.0)
 
 
+def test_every_python_config_builder_matches_its_c_twin(hip_lib):
+    pairs = [("softrod_config_softpendulum", _capi.softpendulum_config),
+             ("softrod_config_softpendulum3d", _capi.softpendulum3d_config),
+             ("softrod_config_arm_single", _capi.arm_single_config),
+             ("softrod_config_octo_flat", _capi.octo_flat_config)]
+    for cname, pyfn in pairs:
+        c = _capi.SoftrodConfig()
+        assert getattr(hip_lib, cname)(C.byref(c), 5) == 0
+        assert bytes(c) == bytes(pyfn(5)), cname
+        assert hip_lib.softrod_config_action_dim(C.byref(c)) == _capi.config_action_dim(c)
+        assert hip_lib.softrod_config_obs_dim(C.byref(c)) == _capi.config_obs_dim(c)
+
+
 def test_create_rejects_bad_config_and_never_falls_back(hip_lib):
     h = C.c_void_p()
     cfg = _capi.softpendulum_config(4)
