@@ -24,8 +24,8 @@
 // variable per Voronoi vertex — initialised from the directors with atan2 at kernel entry,
 // advanced with one subtraction and one FMA per kinematic step — instead of being recovered
 // from the directors every substep through sin D, cos D and the theta/sin(theta) series.  The
-// reference's `- 1e-10` inside arccos (a 3e-11 relative change of kappa) has no counterpart
-// on this path.
+// reference's `- 1e-10` inside arccos turns theta^2 into D^2 + 2e-10, i.e. multiplies kappa by
+// (sin D / D)(theta / sin theta) = 1 + 1e-10/3 + O(1e-10 D^2); that constant factor is kept.
 //
 // The step kernel takes this path only if the loaded state IS planar (planar_from_lane:
 // exact zeros where the argument above needs them, d1 consistent with d3 to 1e-12); any
@@ -190,7 +190,7 @@ __device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const Const
     shift_next<EPL>(len, len_n);
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const double k1 = (Z.s2[s] * P.inv_rest_vor) * Z.dl[s];
+        const double k1 = (Z.s2[s] * (P.inv_rest_vor * (1.0 + P.acos_shift * (1.0 / 3.0)))) * Z.dl[s];
         const double vd = (len_n[s] + len[s]) * (0.5 * P.inv_rest_vor);
         const double rvd = fast_rcp(vd);
         up[s] = C.b01[s] * k1 * (rvd * rvd * rvd);
