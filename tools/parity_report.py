@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Achieved GPU-vs-oracle agreement ("report achieved"), written as JSON.
+
+For each env: N envs stepped with random actions on the GPU and by the CPU oracle; the
+largest |obs_gpu - obs_oracle| / (|obs_oracle| + floor) and reward error after 1, 3 and 10
+env.steps.  The tests assert rtol 1e-5; this records how far inside that the kernels are.
+
+    python tools/parity_report.py > profiles/parity_achieved.json      (on the MI355X box)
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+import gym_softrobot_amd as gsa  # noqa: E402
+from gym_softrobot_amd.seeding import initial_angle, np_random  # noqa: E402
+from gym_softrobot_amd.envs.soft_pendulum_3d import initial_tilt  # noqa: E402
+from oracle import oracle_c  # noqa: E402
+
+
+def rel(a, b, floor):
+    return float(np.max(np.abs(a - b) / (np.abs(b) + floor)))
+
+
+def run(env_id, n, steps, amax, make_rod, step_rod, floor, **kw):
+    env = gsa.make_vec(env_id, n, device=0, **kw)
+    env.reset(seed=0)
+    rods = [make_rod(env, i) for i in range(n)]
+    acts = np.random.default_rng(1).uniform(-amax, amax, (steps, n, env.action_dim)).astype(np.float32)
+    out = {}
+    for t in range(steps):
+        obs, rew, term, trunc, _ = env.step(acts[t])
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        eo = er = 0.0
+        for i, r in enumerate(rods):
+            o, rw = step_rod(r, acts[t, i])
+            eo = max(eo, rel(obs[i], o, floor))
+            er = max(er, abs(rew[i] - rw) / (abs(rw) + floor))
+        if t + 1 in (1, 3, 10):
+            out[f"after_{t + 1}_steps"] = {"obs_max_rel_err": eo, "reward_max_rel_err": er}
+    env.close()
+    return out
+
+
+def main():
+    doc = {"note": "max over envs and observation entries of |gpu - oracle| / (|oracle| + floor); "
+                   "tests assert 1e-5 (BASELINE.json north_star)", "floor": 1e-3}
+    f = 1e-3
+
+    def pend(env, i):
+        r = oracle_c.OracleRod(env.cfg)
+        r.reset_pendulum(initial_angle(np_random(i)[0]))
+        return r
+
+    doc["SoftPendulum-v0"] = run("SoftPendulum-v0", 16, 10, 22.0, pend,
+                                 lambda r, a: r.env_step(float(a[0]))[:2], f)
+    doc["SoftPendulum-v0 (100 elements)"] = run("SoftPendulum-v0", 8, 10, 22.0, pend,
+                                                 lambda r, a: r.env_step(float(a[0]))[:2], f, n_elems=100)
+
+    def pend3(env, i):
+        r = oracle_c.OracleRod(env.cfg)
+        r.reset_pendulum3d(initial_tilt(np_random(i)[0]))
+        return r
+
+    doc["SoftPendulum3D-v0"] = run("SoftPendulum3D-v0", 16, 10, 1.0, pend3, lambda r, a: r.env_step3d(a)[:2], f)
+
+    def arm(env, i):
+        r = oracle_c.OracleRod(env.cfg)
+        r.reset_arm()
+        return r
+
+    doc["OctoArmSingle-v0"] = run("OctoArmSingle-v0", 8, 10, 6.0, arm, lambda r, a: r.env_step_arm(a)[:2], f)
+
+    def octo(env, i):
+        o = oracle_c.OracleOcto(env.cfg)
+        o.reset(env.targets[i])
+        return o
+
+    def octo_step(o, a):
+        ob, rw, _, _ = o.env_step(a)
+        return np.concatenate([ob["individual"].ravel(), ob["shared"]]), rw
+
+    doc["OctoFlat-v0 (200 substeps per step; whole rollouts are chaotic at rounding level, DESIGN.md §3)"] = run(
+        "OctoFlat-v0", 4, 3, 22.0, octo, octo_step, f, recording_fps=71)
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()
