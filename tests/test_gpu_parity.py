@@ -487,6 +487,35 @@ def test_softpendulum3d_rollout_matches_oracle(torch_gpu, hip_lib, oracle_built,
     env.close()
 
 
+@pytest.mark.parametrize("n_elems", [6, 8, 63, 100], ids=lambda n: f"n{n}")
+def test_softpendulum3d_filter_paths_by_rod_size(torch_gpu, hip_lib, oracle_built, n_elems):
+    """The order-7 Laplace filter runs as DPP passes for rods shorter than 8 elements, as the
+    LDS stencil otherwise (one or two slots per lane); all against the oracle's seven passes."""
+    import gym_softrobot_amd as gsa
+
+    n, T = 4, 3
+    env = gsa.make_vec("SoftPendulum3D-v0", n, device=0, n_elems=n_elems)
+    env.reset(seed=0)
+    acts = np.random.default_rng(6).uniform(-1, 1, (T, n, 2)).astype(np.float32)
+    rods = []
+    for i in range(n):
+        r = oracle_built.OracleRod(env.cfg)
+        r.reset_pendulum3d(_tilt(i))
+        rods.append(r)
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(acts[t])
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for i, r in enumerate(rods):
+            o, rw, te, tr, tl = r.env_step3d(acts[t, i])
+            np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=1e-7)
+            np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-9)
+    st = env.backend.state_numpy()
+    for i, r in enumerate(rods):
+        np.testing.assert_allclose(st["v"][i], r.get("v"), rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(st["w"][i], r.get("w"), rtol=RTOL, atol=1e-6)
+    env.close()
+
+
 def test_softpendulum3d_single_env_and_truncation(torch_gpu, hip_lib):
     import gym_softrobot_amd as gsa
 
