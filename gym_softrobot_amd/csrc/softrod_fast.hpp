@@ -15,14 +15,18 @@
 //     by a previous step are handled exactly like the reference;
 //   * sin/cos of the Rodrigues angle, theta/sin(theta) of _inv_rotate and the damper's
 //     pow() are short polynomials in their (tiny) arguments with wave-uniform range
-//     checks; outside the range the argument is halved until it fits and the result
-//     rebuilt with double-angle / squaring identities (no libm calls, which keeps the
-//     register budget small enough for several waves per SIMD);
+//     checks (one s_cbranch on the fast path); outside the range the argument is halved
+//     until it fits and the result rebuilt with double-angle / squaring identities (no libm
+//     calls, which keeps the register budget small enough for several waves per SIMD);
+//     the damper's c_r^e is evaluated as c_r * c_r^(e-1) so that only the strain e-1, not
+//     log c_r, has to be small;
 //   * divisions become one Newton-refined v_rcp_f64 / v_rsq_f64 each; circular cross
 //     sections (I1 = I2, always true for CosseratRod.straight_rod) are exploited;
 //   * lane-validity masks are folded into per-lane stiffness / time-step constants;
 //   * everything is written over EPL slots per lane (softrod_kernels.hpp), so the same
-//     code serves rods of up to 63 (EPL = 1) and 126 (EPL = 2) elements.
+//     code serves rods of up to 63 (EPL = 1) and 126 (EPL = 2) elements;
+//   * SoftPendulum's rod is planar: its instantiation runs softrod_planar.hpp and keeps the
+//     general loop as an out-of-line cold call for states that are not.
 // All of these are ulp-level reorderings; tests/test_gpu_parity.py holds the kernel to
 // the same rtol 1e-5 against the oracle as the LIBM kernel.
 #pragma once

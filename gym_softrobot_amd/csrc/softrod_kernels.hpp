@@ -6,15 +6,21 @@
 // loop of `env.step` (soft_pendulum.py:183-184: step_skip x PositionVerlet.step) runs
 // register-resident: HBM is read once and written once per env.step.  Every
 // nearest-neighbour stencil of the discretisation (x[k+1]-x[k], n[k]-n[k-1],
-// Q[k+1]Q[k]^T, 1/2(a[k]+a[k-1]), the Laplace filter) is a DPP wave shift
+// Q[k+1]Q[k]^T, 1/2(a[k]+a[k-1]), the first pass of the Laplace filter) is a DPP wave shift
 // (v_mov_b32_dpp wave_shl:1 / wave_shr:1, 2 per fp64 value) — no LDS round trip, no
-// barrier.
+// barrier.  LDS appears in two places only: the 13-tap stencil that replaces six passes of
+// the order-7 Laplace filter (laplace_filter_rates_lds7) and OctoFlat's head (softrod_octo.hpp).
 //
 // Lane k owns nodes EPL*k .. EPL*k+EPL-1 (and the elements / Voronoi vertices of the same
 // indices): EPL = 1 for rods of up to 63 elements, EPL = 2 up to 126 (BASELINE config 3,
 // "100 elements").  Neighbours inside a lane are plain registers; only the last slot's
 // "next" and the first slot's "previous" cross lanes, so the DPP count per substep does not
 // grow with EPL.  Global rows are 64*EPL wide, index = node index.
+//
+// File map: softrod_contact.hpp (rod-plane contact), softrod_fast.hpp (the default step
+// kernel), softrod_planar.hpp (SoftPendulum's planar substep), softrod_octo.hpp (OctoFlat: one
+// env per workgroup); this file holds the state layout, the env prologues/epilogues, the reset /
+// observe / auto-reset kernels and the LIBM kernel.
 //
 // Two step kernels share this file's state layout and env prologue/epilogue:
 //   softrod_step_libm_kernel  SOFTROD_MATH_LIBM (EPL = 1): the substep exactly as PyElastica
@@ -25,8 +31,9 @@
 //                             reorganised for the fp64 VALU (softrod_fast.hpp).
 //
 // The arithmetic restates PyElastica's PositionVerlet substep for the simulators that
-// build_soft_pendulum (gym_softrobot/envs/soft_pendulum/build.py:29-115) and
-// build_soft_pendulum_3d (gym_softrobot/envs/soft_pendulum_3d/build.py:43-86) assemble;
+// build_soft_pendulum (gym_softrobot/envs/soft_pendulum/build.py:29-115),
+// build_soft_pendulum_3d (gym_softrobot/envs/soft_pendulum_3d/build.py:43-86), build_arm and
+// build_octopus (gym_softrobot/envs/octopus/build.py:220-292, 52-217) assemble;
 // the order of operations is documented in DESIGN.md "substep order" and mirrored by
 // the CPU oracle (oracle/softrod_oracle.c), against which tests/ check this file.
 #pragma once
