@@ -516,6 +516,56 @@ def test_softpendulum3d_filter_paths_by_rod_size(torch_gpu, hip_lib, oracle_buil
     env.close()
 
 
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+@pytest.mark.parametrize("which", ["damp_before_constrain", "contact_before_forcing", "single_time_add"])
+def test_operator_order_switches_match_oracle(torch_gpu, hip_lib, oracle_built, which, math_mode):
+    """The softrod_config switches that exist so that a session with pyelastica importable can
+    re-pin the operator order must mean the same thing on both sides."""
+    from gym_softrobot_amd import _capi
+
+    n = 3
+    if which == "contact_before_forcing":
+        cfg = _capi.arm_single_config(n, math_mode=math_mode)
+        cfg.contact_before_forcing = 1
+        cfg.n_substeps = 200
+    else:
+        cfg = _capi.softpendulum3d_config(n, math_mode=math_mode)
+        cfg.n_substeps = 120
+        if which == "damp_before_constrain":
+            cfg.damp_before_constrain = 1
+        else:
+            cfg.time_two_half_adds = 0
+    be = _backend(cfg)
+    rods = [oracle_built.OracleRod(cfg) for _ in range(n)]
+    if which == "contact_before_forcing":
+        be.reset_straight(np.zeros((n, 3)), np.tile([1.0, 0, 0], (n, 1)), np.tile([0, 0, 1.0], (n, 1)))
+        for r in rods:
+            r.reset_arm()
+        acts = np.random.default_rng(3).uniform(-6, 6, (2, n, 7)).astype(np.float32)
+    else:
+        tilts = [_tilt(i) for i in range(n)]
+        d = np.array([[np.sin(t), 0.0, np.cos(t)] for t in tilts])
+        be.reset_straight(np.zeros((n, 3)), d, np.tile([0, 1.0, 0], (n, 1)))
+        for r, t in zip(rods, tilts):
+            r.reset_pendulum3d(t)
+        acts = np.random.default_rng(3).uniform(-1, 1, (2, n, 2)).astype(np.float32)
+    be.observe(None)
+    for t in range(2):
+        obs, rew, term, trunc = (x.cpu().numpy() for x in be.step(acts[t]))
+        for i, r in enumerate(rods):
+            if which == "contact_before_forcing":
+                o, rw, te, tr = r.env_step_arm(acts[t, i])
+            else:
+                o, rw, te, tr, _ = r.env_step3d(acts[t, i])
+            np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=2e-6)
+            np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-7)
+    st = be.state_numpy()
+    for i, r in enumerate(rods):
+        np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-8)
+        assert st["time"][i] == r.time
+    be.close()
+
+
 def test_softpendulum3d_single_env_and_truncation(torch_gpu, hip_lib):
     import gym_softrobot_amd as gsa
 
