@@ -43,8 +43,10 @@ __device__ __forceinline__ void sinc_cosc(double t, double& sc, double& cc) {
         cc = fma(t, fma(t, fma(t, -1.0 / 40320.0, 1.0 / 720.0), -1.0 / 24.0), 0.5);
         return;
     }
+    // up to 4^16 * 1e-3: more than 250 rad per (sub)step — beyond that the state is garbage on
+    // its way to NaN and only the cost of getting there matters
     int k = 0;
-    while (__any(t >= 1.0e-3) && k < 48) { t *= 0.25; ++k; }   // wave-uniform trip count
+    while (__any(t >= 1.0e-3) && k < 16) { t *= 0.25; ++k; }   // wave-uniform trip count
     sc = fma(t, fma(t, fma(t, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
     cc = fma(t, fma(t, fma(t, -1.0 / 40320.0, 1.0 / 720.0), -1.0 / 24.0), 0.5);
     for (; k > 0; --k) {
@@ -105,8 +107,8 @@ __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid, doubl
         e2 = fma(x2, fma(x2, fma(x2, fma(x2, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
         return;
     }
-    int k = 0;
-    while (__any(valid && !(fmax(fabs(x0), fabs(x2)) < 1.0e-3)) && k < 60) {
+    int k = 0;   // 2^24 * 1e-3 > 16000: exp underflows long before
+    while (__any(valid && !(fmax(fabs(x0), fabs(x2)) < 1.0e-3)) && k < 24) {
         x0 *= 0.5; x2 *= 0.5; ++k;
     }
     e0 = fma(x0, fma(x0, fma(x0, fma(x0, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
@@ -351,6 +353,37 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
     }
 }
 
+// Wave-uniform: does the rod's dynamic state hold a NaN in a valid node / element?
+template <int EPL>
+__device__ __forceinline__ bool rod_has_nan(const RodParams& P, int lane, const LaneN<EPL>& L) {
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = slot_local(P, lane * EPL + s);
+        bool b = false, q = false;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            b = b || isnan(L.x[s][c]) || isnan(L.v[s][c]);
+            q = q || isnan(L.w[s][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) q = q || isnan(L.Q[s][c]);
+        bad = bad || (idx <= P.n_elem && b) || (idx < P.n_elem && q);
+    }
+    return __any(bad);
+}
+template <int EPL>
+__device__ __forceinline__ void poison_rod(LaneN<EPL>& L) {
+    const double nan = __builtin_nan("");
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { L.x[s][c] = nan; L.v[s][c] = nan; L.w[s][c] = nan; L.t[s][c] = nan; }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) L.Q[s][c] = nan;
+    }
+}
+
 // The substeps of one launch on the general 3-D state.  `always_inline` for every kernel whose
 // only path it is; the SoftPendulum kernel keeps it OUT of line (cold fallback for non-planar
 // states) so that its register demand cannot leak spills into the planar hot loop.
@@ -425,11 +458,24 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
 
     bool stepped = false;
+    // A rod whose state already holds a NaN (an env that blew up and was not reset — the
+    // reference reports terminated and -50 for it on every further step, soft_pendulum.py:
+    // 196-208) would only smear that NaN over all of its nodes while dragging every
+    // range-reduction loop to its iteration cap.  It is not integrated: its state becomes NaN
+    // throughout (where the reference's would end up after a few substeps), its clock advances.
+    if (n_sub > 0 && epilogue && rod_has_nan<EPL>(P, lane, L)) {
+        poison_rod<EPL>(L);
+        for (int s = 0; s < n_sub; ++s) {
+            if (P.time_two_half_adds) { time += P.half_dt; time += P.half_dt; }
+            else time += P.dt;
+        }
+        stepped = true;
+    }
     if constexpr (F == SOFTROD_FEATURES_SOFTPENDULUM) {
         // SoftPendulum-v0 lives in the x-y plane: same substep without the identically
         // zero out-of-plane terms (softrod_planar.hpp); any other state takes the 3-D loop
         PlanarN<EPL> Z;
-        if (n_sub > 0 && planar_from_lane<EPL>(P, B, lane, L, Z)) {
+        if (n_sub > 0 && !stepped && planar_from_lane<EPL>(P, B, lane, L, Z)) {
             planar_kinematic_n<EPL>(P.half_dt, C, Z);
             if (P.time_two_half_adds) time += P.half_dt;
             for (int s = 0; s < n_sub; ++s) {

@@ -292,7 +292,27 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         H.w[2] = fma(P.dt, P.head_invJ[2] * (-tot[2]), H.w[2]);
     };
 
-    if (n_sub > 0) {
+    // an env that already holds a NaN is not integrated (see softrod_step_fast_kernel)
+    bool dead = false;
+    if (n_sub > 0 && epilogue) {
+        bool bad = isnan(H.x[0]) || isnan(H.x[1]) || isnan(H.v[0]) || isnan(H.v[1]) || isnan(H.w[2]) ||
+                   isnan(H.Q[0]) || isnan(H.Q[1]) || isnan(H.Q[3]) || isnan(H.Q[4]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            bad = bad || (arm_ok && r <= n && (isnan(L.x[0][c]) || isnan(L.v[0][c]))) ||
+                  (arm_ok && r < n && isnan(L.w[0][c]));
+#pragma unroll
+        for (int c = 0; c < 9; ++c) bad = bad || (arm_ok && r < n && isnan(L.Q[0][c]));
+        dead = __syncthreads_or(bad ? 1 : 0) != 0;
+        if (dead) {
+            poison_rod<1>(L);
+            for (int s = 0; s < n_sub; ++s) {
+                if (P.time_two_half_adds) { time += P.half_dt; time += P.half_dt; }
+                else time += P.dt;
+            }
+        }
+    }
+    if (n_sub > 0 && !dead) {
         kinematic_n<1>(P.half_dt, C, L);
         head_kinematic(P.half_dt, H);
         if (P.time_two_half_adds) time += P.half_dt;

@@ -49,7 +49,7 @@ __device__ __forceinline__ double exp_one(double x, bool valid) {
     if (!__any(valid && !(fabs(x) < 1.0e-3)))
         return fma(x, fma(x, fma(x, fma(x, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
     int k = 0;
-    while (__any(valid && !(fabs(x) < 1.0e-3)) && k < 60) { x *= 0.5; ++k; }
+    while (__any(valid && !(fabs(x) < 1.0e-3)) && k < 24) { x *= 0.5; ++k; }
     double e = fma(x, fma(x, fma(x, fma(x, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
     for (; k > 0; --k) e *= e;
     return e;

@@ -195,6 +195,13 @@ def test_nan_state_terminates_with_penalty(torch_gpu, hip_lib):
     term, rew = term.cpu().numpy(), rew.cpu().numpy()
     assert term.tolist() == [False, True, False]
     assert rew[1] == -50.0 and rew[0] >= 0.0   # soft_pendulum.py:205-208,231
+    # a dead env is not integrated any more: its state is NaN throughout (what the substeps
+    # would smear it to), its clock keeps running, its neighbours are untouched
+    sn = env.backend.state_numpy()
+    assert np.isnan(sn["x"][1]).all() and np.isfinite(sn["x"][0]).all() and np.isfinite(sn["x"][2]).all()
+    assert sn["time"][1] == sn["time"][0]
+    obs, rew, term, trunc, _ = env.step(np.zeros(3, np.float32))
+    assert term.cpu().numpy().tolist() == [False, True, False] and float(rew[1]) == -50.0
     env.close()
 
 
