@@ -48,6 +48,35 @@ def _octo_worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
+def _autoreset_worker(rank, world, port, total, T, q):
+    """Sharded env over device-side auto-reset (staged reset records), overlapped gather."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.distributed import ShardedVecEnv, shard_bounds
+    from tests.oracle_backend import OracleBackend
+
+    kw = dict(final_time=5e-4, time_step=1e-4, recording_fps=5000, n_elems=6)   # 3-step episodes
+    lo, hi = shard_bounds(total, world, rank)
+    cfg = _capi.softpendulum_config(hi - lo, **kw)
+    local = gsa.VecSoftPendulumEnv(hi - lo, backend=OracleBackend(cfg), autoreset="device", **kw)
+    env = ShardedVecEnv(local, total, overlap=True)
+    env.reset(seed=11)
+    acts = np.random.default_rng(2).uniform(-5, 5, (T, total)).astype(np.float32)
+    out = []
+    for t in range(T):
+        o, r, te, tr, _ = env.step(acts[t])
+        env.sync()
+        out.append((o.clone().numpy(), r.clone().numpy(), te.clone().numpy(), tr.clone().numpy()))
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, total, T, q, overlap=False):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -170,3 +199,33 @@ def test_world2_gloo_octoflat_matches_single_process(oracle_built):
     assert got[0].shape == (total, 461)
     for a, b in zip(got, ref):
         np.testing.assert_array_equal(a, b)
+
+
+def test_world2_gloo_device_autoreset_matches_single_process(oracle_built):
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from tests.oracle_backend import OracleBackend
+
+    total, T, world = 4, 9, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_autoreset_worker, args=(r, world, port, total, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kw = dict(final_time=5e-4, time_step=1e-4, recording_fps=5000, n_elems=6)
+    cfg = _capi.softpendulum_config(total, **kw)
+    env = gsa.VecSoftPendulumEnv(total, backend=OracleBackend(cfg), numpy_output=True, autoreset=True, **kw)
+    env.reset(seed=11)
+    acts = np.random.default_rng(2).uniform(-5, 5, (T, total)).astype(np.float32)
+    restarted = 0
+    for t in range(T):
+        o, r, te, tr, _ = env.step(acts[t])
+        restarted += int((env._steps == 0).sum())
+        for a, b in zip(got[t], (o, r, te, tr)):
+            np.testing.assert_array_equal(a, b)
+    assert restarted >= total       # episodes really ended and restarted on the way
