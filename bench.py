@@ -85,6 +85,9 @@ def main() -> None:
                     choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0", "OctoFlat-v0"],
                     help="headline metric is SoftPendulum-v0; the others are the widened §8 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, BASELINE configs[3]): --envs-per-gpu envs on every GPU; "
+                         "strong: that many envs in total, split over the GPUs (SURVEY.md §8d cfg 4)")
     ap.add_argument("--autoreset", choices=["auto", "off", "host", "device"], default="auto",
                     help="NEXT_STEP auto-reset of finished envs.  auto (default): off while warmup + steps "
                          "stay inside one SoftPendulum episode (125 steps), else 'device' (staged reset "
@@ -122,6 +125,10 @@ def main() -> None:
             dist.init_process_group(backend)
 
     n_local = args.envs_per_gpu or (1024 if args.env == "OctoFlat-v0" else ENVS_PER_GPU)
+    if args.scaling == "strong":
+        if n_local % world:
+            raise SystemExit(f"--scaling strong: {n_local} envs do not split over {world} GPUs")
+        n_local //= world
     n_total = n_local * world
     K, W = args.steps, args.warmup
     math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
@@ -204,7 +211,7 @@ def main() -> None:
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
