@@ -63,6 +63,17 @@ def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
         batch.env_step(acts[1 + steps])
         steps += 1
     dt = time.perf_counter() - t0
+    # one rod on one thread, for reading the threaded figure (cgroup quotas and SMT siblings make
+    # "cores" an upper bound of what the box really gives the process)
+    one = oracle_c.OracleRod(cfg)
+    one.reset_pendulum(initial_angle(np_random(0)[0]))
+    one.env_step(float(acts[0, 0]))
+    t1 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t1 < 1.0:
+        one.env_step(float(acts[1 + k % 60, 0]))
+        k += 1
+    dt1 = time.perf_counter() - t1
     return {
         "value": n_rods * steps / dt,
         "unit": "env-steps/s",
@@ -70,6 +81,7 @@ def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
         "kind": "port",
         "sample": f"{n_rods} rods x {steps} env.steps (400 substeps, 50 elements, fp64 C oracle, "
                   f"OpenMP {cores} threads, {dt:.1f} s)",
+        "single_thread_value": k / dt1,
     }
 
 
