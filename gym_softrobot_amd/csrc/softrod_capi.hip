@@ -25,6 +25,8 @@ struct softrod_handle {
     int epl = 1;            // nodes/elements per lane: 1 (n_elem <= 63) or 2 (<= 126)
     int nw = 1;             // wavefronts per env: 1, or ceil(n_arm*seg/64) for OctoFlat
     size_t init_stride = 18;  // doubles of reset staging per env
+    int window_refresh = 0;   // > 0: the rod runs on two overlapping wave windows (softrod_window.hpp),
+                              // halo refreshed every so many substeps
     RodParams P{};
     StatePtrs S{};
     double* d_init = nullptr;     // [N][18] staging for reset
@@ -200,6 +202,14 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
         else     { if (h->nw <= 2) SR_OCTO(SOFTROD_FEATURES_OCTO_FLAT, 2);
                    else SR_OCTO(SOFTROD_FEATURES_OCTO_FLAT, 8); }
 #undef SR_OCTO
+    } else if (h->window_refresh > 0 && epilogue) {
+        // substeps on two overlapping one-node-per-lane windows, then reward / observation by the
+        // two-slot kernel with n_sub = 0 on the same rows (the timing events bracket both)
+        hipLaunchKernelGGL((softrod_step_window_kernel<SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup>), grid,
+                           dim3(2 * kLanes), 0, st, h->P, h->S, actions, n_sub, h->window_refresh);
+        hipLaunchKernelGGL((softrod_step_fast_kernel<SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup,
+                                                     SOFTROD_ENV_ARM_SINGLE, 2>),
+                           grid, dim3(kLanes), 0, st, h->P, h->S, actions, obs, reward, term, trunc, aux, 0, 1, pack);
     } else if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
         // instantiations specialised for the registered envs' feature sets (one or two
         // slots per lane); anything else (known-answer tests, custom feature mixes) takes
@@ -463,6 +473,15 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     if (octo) {
         h->nw = (cfg->n_arm * h->P.seg + kLanes - 1) / kLanes;
         h->init_stride = (size_t)cfg->n_arm * 18 + 2;
+    }
+    {   // two-window form: ArmSingle with the e_z contact, 64..102 elements
+        const int halo = kLanes - (cfg->n_elem + 2) / 2;     // the narrower of the two halos
+        const char* off = std::getenv("SOFTROD_NO_WINDOW");  // A/B switch for profiling and tests
+        if (h->epl == 2 && cfg->features == SOFTROD_FEATURES_ARM_SINGLE && cfg->env_kind == SOFTROD_ENV_ARM_SINGLE &&
+            cfg->math_mode == SOFTROD_MATH_FAST && (h->P.features & kFeatPlaneZup) && !(off && off[0] == '1') &&
+            halo >= 3 * kWindowRho)
+            h->window_refresh = halo / kWindowRho;    // the front (< 3.25 nodes per substep) stays in the halo
+        if (const char* r = std::getenv("SOFTROD_WINDOW_REFRESH")) if (h->window_refresh > 0) h->window_refresh = std::atoi(r);
     }
     const size_t adim = (size_t)softrod_config_action_dim(cfg);
     const size_t rowb = N * kLanes * h->epl * h->nw * sizeof(double);

@@ -702,8 +702,9 @@ def test_autoreset_on_gpu(torch_gpu, hip_lib):
     ("SoftPendulum-v0", dict(final_time=7e-4, time_step=1e-4, recording_fps=5000, n_elems=100), 5.0),
     ("SoftPendulum3D-v0", dict(final_time=6e-4, time_step=1e-4, recording_fps=5000, n_elems=20), 1.0),
     ("OctoArmSingle-v0", dict(final_time=3e-4, time_step=7e-5, recording_fps=7000, n_elems=20), 5.0),
+    ("OctoArmSingle-v0", dict(final_time=3e-4, time_step=7e-5, recording_fps=7000, n_elems=100), 5.0),
     ("OctoFlat-v0", dict(final_time=3e-4, time_step=7e-5, recording_fps=7000), 20.0),
-], ids=["pendulum", "pendulum-2-per-lane", "pendulum3d", "arm", "octo"])
+], ids=["pendulum", "pendulum-2-per-lane", "pendulum3d", "arm", "arm-two-windows", "octo"])
 def test_device_autoreset_equals_host_autoreset(torch_gpu, hip_lib, env_id, kw, amax):
     """autoreset="device" (staged reset records, no host read) must reproduce autoreset=True
     (host reads the flags and resets) bit for bit: same NEXT_STEP semantics, and the staged
@@ -857,6 +858,53 @@ def test_arm_single_100_elements_matches_oracle(torch_gpu, hip_lib, oracle_built
         np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-7)
         np.testing.assert_allclose(st["rest_kappa"][i][0], r.get("rest_kappa")[0], rtol=1e-12, atol=1e-12)
     env.close()
+
+
+@pytest.mark.parametrize("n_elems", [64, 80, 100, 102], ids=lambda n: f"n{n}")
+def test_two_window_kernel_for_long_arms(torch_gpu, hip_lib, oracle_built, n_elems, monkeypatch):
+    """OctoArmSingle rods of 64..102 elements run on two overlapping one-node-per-lane windows
+    (softrod_window.hpp).  Against the oracle, and against the two-slots-per-lane kernel the same
+    rods use when the window form is switched off: the owned halves must not see the halo."""
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    n = 3
+    acts = np.random.default_rng(n_elems).uniform(-6, 6, (2, n, 7)).astype(np.float32)
+    cfg = _capi.arm_single_config(n, n_elems=n_elems)
+    cfg.n_substeps = 300
+    rods = [oracle_built.OracleRod(cfg) for _ in range(n)]
+    for r in rods:
+        r.reset_arm()
+    outs = {}
+    for name, env in (("window", {}), ("two-slot", {"SOFTROD_NO_WINDOW": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        be = HipRodBackend(cfg, 0)
+        be.reset_straight(np.zeros((n, 3)), np.tile([1.0, 0, 0], (n, 1)), np.tile([0, 0, 1.0], (n, 1)))
+        be.observe(None)
+        res = []
+        for t in range(2):
+            o, r, te, tr = (x.cpu().numpy().copy() for x in be.step(acts[t]))
+            res.append((o, r, te, tr))
+        outs[name] = (res, be.state_numpy())
+        be.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for t in range(2):
+        for i, r in enumerate(rods):
+            o, rw, te, tr = r.env_step_arm(acts[t, i])
+            np.testing.assert_allclose(outs["window"][0][t][0][i], o, rtol=RTOL, atol=2e-6)
+            np.testing.assert_allclose(outs["window"][0][t][1][i], rw, rtol=RTOL, atol=1e-7)
+            assert bool(outs["window"][0][t][2][i]) == te and bool(outs["window"][0][t][3][i]) == tr
+    sw, ss = outs["window"][1], outs["two-slot"][1]
+    for i, r in enumerate(rods):
+        np.testing.assert_allclose(sw["x"][i], r.get("x"), rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(sw["Q"][i], r.get("Q"), rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(sw["x"], ss["x"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sw["w"], ss["w"], rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(sw["time"], ss["time"])
+    for a, b in zip(outs["window"][0], outs["two-slot"][0]):
+        np.testing.assert_array_equal(a[0], b[0])          # float32 observations: identical
 
 
 @pytest.mark.parametrize("env_id,amax", [("SoftPendulum-v0", 22.0), ("SoftPendulum3D-v0", 1.0), ("OctoArmSingle-v0", 8.0)])
