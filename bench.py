@@ -249,6 +249,9 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "kernel": "softrod_octo_step_kernel" if octo else
+                          "softrod_step_window_kernel + softrod_step_fast_kernel (epilogue only)"
+                          if (args.env == "OctoArmSingle-v0" and 64 <= int(cfg.n_elem) <= 102
+                              and args.math_mode == "fast") else
                           ("softrod_step_fast_kernel" if args.math_mode == "fast" else "softrod_step_libm_kernel"),
                 "fp64_valu": {
                     "note": "the binding unit: wave64 fp64 VALU ops issue in 4 cycles (78.6 TFLOP/s); "
