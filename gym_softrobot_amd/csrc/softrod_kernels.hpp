@@ -19,7 +19,8 @@
 //
 // File map: softrod_contact.hpp (rod-plane contact), softrod_fast.hpp (the default step
 // kernel), softrod_planar.hpp (SoftPendulum's planar substep), softrod_octo.hpp (OctoFlat: one
-// env per workgroup); this file holds the state layout, the env prologues/epilogues, the reset /
+// env per workgroup), softrod_window.hpp (64..102-element arms on two overlapping windows);
+// this file holds the state layout, the env prologues/epilogues, the reset /
 // observe / auto-reset kernels and the LIBM kernel.
 //
 // Two step kernels share this file's state layout and env prologue/epilogue:
