@@ -74,6 +74,8 @@ def main():
         return r
 
     doc["OctoArmSingle-v0"] = run("OctoArmSingle-v0", 8, 10, 6.0, arm, lambda r, a: r.env_step_arm(a)[:2], f)
+    doc["OctoArmSingle-v0 (100 elements, two-window kernel)"] = run(
+        "OctoArmSingle-v0", 4, 10, 6.0, arm, lambda r, a: r.env_step_arm(a)[:2], f, n_elems=100)
 
     def octo(env, i):
         o = oracle_c.OracleOcto(env.cfg)
