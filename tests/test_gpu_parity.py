@@ -99,6 +99,64 @@ def test_golden_oracle_rollout_fixture(torch_gpu, hip_lib, math_mode):
     env.close()
 
 
+def test_other_envs_golden_fixtures(torch_gpu, hip_lib):
+    """The committed fixtures of the other envs (tests/golden/other_envs_*): reference-derived
+    reset observations and the oracle's regression pins, without the oracle at run time."""
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    vec = json.loads((GOLD / "other_envs_reset.json").read_text())
+    v3 = vec["SoftPendulum3D-v0"]
+    env = gsa.make_vec("SoftPendulum3D-v0", len(v3), device=0)
+    obs, _ = env.reset(seed=[v["seed"] for v in v3])
+    np.testing.assert_allclose(obs.cpu().numpy(), np.array([v["obs"] for v in v3], np.float32), rtol=1e-6, atol=1e-9)
+    env.close()
+    env = gsa.make_vec("OctoArmSingle-v0", 1, device=0)
+    obs, _ = env.reset(seed=0)
+    np.testing.assert_allclose(obs.cpu().numpy()[0], np.array(vec["OctoArmSingle-v0"][0]["obs"], np.float32),
+                               rtol=1e-6, atol=1e-7)
+    env.close()
+    vo = vec["OctoFlat-v0"]
+    env = gsa.make_vec("OctoFlat-v0", len(vo), device=0)
+    obs, _ = env.reset(seed=[v["seed"] for v in vo])
+    d = env.split_obs(obs.cpu().numpy())
+    for i, v in enumerate(vo):
+        np.testing.assert_allclose(d["individual"][i], np.array(v["individual"], np.float32), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(d["shared"][i], np.array(v["shared"], np.float32), rtol=1e-6, atol=1e-7)
+    env.close()
+
+    z = np.load(GOLD / "other_envs_oracle_rollout.npz")
+    be = HipRodBackend(_capi.softpendulum3d_config(1), 0)
+    t0 = np.deg2rad(0.37)
+    be.reset_straight([[0, 0, 0]], [[np.sin(t0), 0.0, np.cos(t0)]], [[0, 1.0, 0]])
+    for t in range(3):
+        o, r, *_ = be.step(z["p3d_actions"][t][None])
+        np.testing.assert_allclose(o.cpu().numpy()[0], z["p3d_obs"][t], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(float(r[0]), z["p3d_reward"][t], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(be.state_numpy()["x"][0], z["p3d_x"], rtol=RTOL, atol=1e-8)
+    be.close()
+    be = HipRodBackend(_capi.arm_single_config(1), 0)
+    be.reset_straight([[0, 0, 0]], [[1.0, 0, 0]], [[0, 0, 1.0]])
+    be.observe(None)
+    for t in range(3):
+        o, r, *_ = be.step(z["arm_actions"][t][None])
+        np.testing.assert_allclose(o.cpu().numpy()[0], z["arm_obs"][t], rtol=RTOL, atol=2e-6)
+        np.testing.assert_allclose(float(r[0]), z["arm_reward"][t], rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(be.state_numpy()["x"][0], z["arm_x"], rtol=RTOL, atol=1e-7)
+    be.close()
+    cfg = _capi.octo_flat_config(1)
+    cfg.n_substeps = 200
+    be = HipRodBackend(cfg, 0)
+    be.reset_octo(z["octo_target"][None])
+    for t in range(2):
+        o, r, *_ = be.step(z["octo_actions"][t][None])
+        ref = np.concatenate([z["octo_individual"][t].ravel(), z["octo_shared"][t]])
+        np.testing.assert_allclose(o.cpu().numpy()[0], ref, rtol=RTOL, atol=5e-7)
+        np.testing.assert_allclose(float(r[0]), z["octo_reward"][t], rtol=RTOL, atol=1e-8)
+    be.close()
+
+
 def test_fast_and_libm_modes_agree(torch_gpu, hip_lib):
     n, T = 64, 10
     acts = np.random.default_rng(3).uniform(-22, 22, (T, n)).astype(np.float32)

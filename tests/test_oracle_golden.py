@@ -133,3 +133,59 @@ def test_truncation_step_and_time(oracle_built):
     for k in range(1, 4):
         rod.env_step(0.0)
         assert rod.time == tab[k]
+
+
+# ---- the other envs: reference-derived reset observations and oracle regression pins ----------
+def test_other_envs_reset_vectors_match_oracle_and_host(oracle_built):
+    """tests/golden/other_envs_reset.json is computed from gym-softrobot's own reset code with
+    NumPy/SciPy (tools/make_golden.py); the oracle and the host-side draws must reproduce it."""
+    import json
+
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.envs.soft_pendulum_3d import initial_tilt
+    from gym_softrobot_amd.seeding import np_random
+
+    vec = json.loads((GOLD / "other_envs_reset.json").read_text())
+    for v in vec["SoftPendulum3D-v0"]:
+        tilt = initial_tilt(np_random(v["seed"])[0])
+        assert tilt == v["tilt"]
+        r = oracle_built.OracleRod(_capi.softpendulum3d_config(1))
+        r.reset_pendulum3d(tilt)
+        np.testing.assert_allclose(r.observe3d(), np.array(v["obs"], np.float32), rtol=1e-6, atol=1e-9)
+    for v in vec["OctoFlat-v0"]:
+        rng, _ = np_random(v["seed"])
+        target = (2 - 0.5) * rng.random(2) + 0.5
+        np.testing.assert_array_equal(target, v["target"])
+        o = oracle_built.OracleOcto(_capi.octo_flat_config(1))
+        ob = o.reset(target)
+        np.testing.assert_allclose(ob["individual"], np.array(v["individual"], np.float32), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(ob["shared"], np.array(v["shared"], np.float32), rtol=1e-6, atol=1e-7)
+
+
+def test_other_envs_oracle_regression_pins(oracle_built):
+    from gym_softrobot_amd import _capi
+
+    z = np.load(GOLD / "other_envs_oracle_rollout.npz")
+    r = oracle_built.OracleRod(_capi.softpendulum3d_config(1))
+    r.reset_pendulum3d(np.deg2rad(0.37))
+    for t in range(3):
+        o, rw, *_ = r.env_step3d(z["p3d_actions"][t])
+        np.testing.assert_array_equal(o, z["p3d_obs"][t])
+        assert rw == z["p3d_reward"][t]
+    np.testing.assert_array_equal(r.get("x"), z["p3d_x"])
+    r = oracle_built.OracleRod(_capi.arm_single_config(1))
+    r.reset_arm()
+    for t in range(3):
+        o, rw, *_ = r.env_step_arm(z["arm_actions"][t])
+        np.testing.assert_array_equal(o, z["arm_obs"][t])
+        assert rw == z["arm_reward"][t]
+    np.testing.assert_array_equal(r.get("x"), z["arm_x"])
+    cfg = _capi.octo_flat_config(1)
+    cfg.n_substeps = 200
+    o = oracle_built.OracleOcto(cfg)
+    o.reset(z["octo_target"])
+    for t in range(2):
+        ob, rw, *_ = o.env_step(z["octo_actions"][t])
+        np.testing.assert_array_equal(ob["individual"], z["octo_individual"][t])
+        np.testing.assert_array_equal(ob["shared"], z["octo_shared"][t])
+        assert rw == z["octo_reward"][t]

@@ -63,9 +63,91 @@ def oracle_rollout():
     return dict(seeds=np.array(seeds), actions=acts, obs=obs, reward=rew, x_final=np.stack(xfin))
 
 
+def reset_vectors_other_envs():
+    """REFERENCE-DERIVED reset observations of the other envs (gym-softrobot's code + NumPy/SciPy
+    only; straight rods at rest, so no PyElastica arithmetic is involved)."""
+    from scipy.spatial.transform import Rotation as Rot
+
+    out = {}
+    # SoftPendulum3D-v0: soft_pendulum_3d/build.py:51-53, soft_pendulum_3d.py:60-98
+    v3 = []
+    for seed in (0, 1, 42, 123):
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        tilt = np.deg2rad(rng.uniform(-1.0, 1.0))
+        direction = np.array([np.sin(tilt), 0.0, np.cos(tilt)])
+        tangent = np.mean(np.repeat(direction[:, None], 50, axis=1), axis=1)
+        tangent /= np.linalg.norm(tangent)
+        ang = float(np.arccos(np.clip(tangent[2], -1.0, 1.0)))
+        obs = np.concatenate([np.zeros(3), np.zeros(3), np.zeros(2), [ang]]).astype(np.float32)
+        v3.append({"seed": seed, "tilt": float(tilt), "obs": [float(x) for x in obs]})
+    out["SoftPendulum3D-v0"] = v3
+    # OctoArmSingle-v0: arm_single_env.py:160-219 on a straight arm at rest (kappa = 0, rates = 0,
+    # com rate = 0, _prev_action = 0, target (1, 0)); do_normalization = (x - lo) / (hi - lo)
+    kr, krr = (-49.33508476187419, 49.33545827754751), (-21.063520620377012, 24.664591289161944)
+    obs = np.hstack([np.full(7, (0.0 - kr[0]) / (kr[1] - kr[0])), np.full(7, (0.0 - krr[0]) / (krr[1] - krr[0])),
+                     np.zeros(2), np.zeros(7), [1.0, 0.0]]).astype(np.float32)
+    out["OctoArmSingle-v0"] = [{"seed": 0, "obs": [float(x) for x in obs]}]
+    # OctoFlat-v0: flat_env.py:171-286, octopus/build.py:73-105 (8 arms of 10 elements, L0 = 0.35)
+    vo = []
+    n_arm, n_el, L0, head_r = 8, 10, 0.35, 0.04
+    for seed in (0, 1, 42):
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        target = (2 - 0.5) * rng.random(2) + 0.5
+        rows = []
+        for arm_i in range(n_arm):
+            rot = Rot.from_euler("z", 360 / n_arm * arm_i, degrees=True)
+            start, direction = rot.apply([head_r, 0.0, 0.0]), rot.apply([1.0, 0.0, 0.0])
+            end = start + direction * L0
+            pos = np.stack([np.linspace(start[i], end[i], n_el + 1) for i in range(3)])   # straight_rod
+            rows.append(np.hstack([np.zeros(n_el - 1), pos[0] - 0.0, pos[1] - 0.0, np.zeros(n_el + 1),
+                                   np.zeros(n_el + 1), np.zeros(3)]))
+        shared = np.concatenate([target - np.zeros(2), np.zeros(2),
+                                 np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]).ravel()])
+        vo.append({"seed": seed, "target": [float(x) for x in target],
+                   "individual": np.vstack(rows).astype(np.float32).tolist(),
+                   "shared": shared.astype(np.float32).tolist()})
+    out["OctoFlat-v0"] = vo
+    return out
+
+
+def oracle_rollouts_other_envs():
+    """REGRESSION pins of this repo's oracle for the other envs (not reference outputs)."""
+    from gym_softrobot_amd import _capi
+    from oracle.oracle_c import OracleOcto, OracleRod
+
+    out = {}
+    rng = np.random.default_rng(11)
+    cfg = _capi.softpendulum3d_config(1)
+    r = OracleRod(cfg)
+    r.reset_pendulum3d(np.deg2rad(0.37))
+    a = rng.uniform(-1, 1, (3, 2)).astype(np.float32)
+    res = [r.env_step3d(a[t]) for t in range(3)]
+    out.update(p3d_actions=a, p3d_obs=np.stack([x[0] for x in res]), p3d_reward=np.array([x[1] for x in res]),
+               p3d_x=r.get("x"))
+    cfg = _capi.arm_single_config(1)
+    r = OracleRod(cfg)
+    r.reset_arm()
+    a = rng.uniform(-6, 6, (3, 7)).astype(np.float32)
+    res = [r.env_step_arm(a[t]) for t in range(3)]
+    out.update(arm_actions=a, arm_obs=np.stack([x[0] for x in res]), arm_reward=np.array([x[1] for x in res]),
+               arm_x=r.get("x"))
+    cfg = _capi.octo_flat_config(1)
+    cfg.n_substeps = 200          # short windows: whole OctoFlat rollouts are chaotic (DESIGN.md §3)
+    o = OracleOcto(cfg)
+    o.reset([1.0, 1.3])
+    a = rng.uniform(-22, 22, (2, 24)).astype(np.float32)
+    res = [o.env_step(a[t]) for t in range(2)]
+    out.update(octo_actions=a, octo_target=np.array([1.0, 1.3]),
+               octo_individual=np.stack([x[0]["individual"] for x in res]),
+               octo_shared=np.stack([x[0]["shared"] for x in res]), octo_reward=np.array([x[1] for x in res]))
+    return out
+
+
 if __name__ == "__main__":
     g = ROOT / "tests" / "golden"
     g.mkdir(parents=True, exist_ok=True)
     (g / "softpendulum_reset.json").write_text(json.dumps(reset_vectors(), indent=1))
     np.savez(g / "softpendulum_oracle_rollout.npz", **oracle_rollout())
+    (g / "other_envs_reset.json").write_text(json.dumps(reset_vectors_other_envs(), indent=1))
+    np.savez(g / "other_envs_oracle_rollout.npz", **oracle_rollouts_other_envs())
     print("wrote", sorted(p.name for p in g.iterdir()))
