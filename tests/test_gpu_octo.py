@@ -1,6 +1,8 @@
 """OctoFlat-v0 (8 arms + rigid head, BASELINE.json configs[4]) parity: the HIP path through the
 C-ABI against oracle/octoflat_oracle.inc.c on the same targets and actions.  rtol 1e-5 on
 observations/rewards, exact flags and crossing counts."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -357,3 +359,33 @@ def test_octo_determinism_masked_reset_and_packed(torch_gpu, hip_lib):
     assert not np.array_equal(after["target"][1], before["target"][1])
     env_a.close()
     env_b.close()
+
+
+def test_octo_crossing_count_against_the_reference_function(torch_gpu, hip_lib):
+    """The kernel's crossing count against outputs of the reference's own intersection()
+    (tests/golden/intersection_vectors.npz): arm shapes are written into the resident state of
+    a two-arm env, one substep of negligible length runs, and the count is read off the reward
+    (survive_reward = -0.02 * crossings, flat_env.py:372)."""
+    import torch
+
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    z = np.load(Path(__file__).parent / "golden" / "intersection_vectors.npz")
+    n = len(z["count"])
+    cfg = _capi.octo_flat_config(n, n_arm=2)
+    cfg.n_substeps = 1
+    cfg.dt = 1e-13            # the arms do not move: forward reward ~ 0
+    be = HipRodBackend(cfg, device=0)
+    be.reset_octo(np.tile([[1.0, 1.0]], (n, 1)))
+    st = be.state()
+    seg = st["arm_stride"]
+    for a, key in ((1, "p1"), (0, "p2")):
+        st["position"][0:2, :, a * seg : a * seg + 11] = torch.from_numpy(
+            np.ascontiguousarray(z[key].transpose(1, 0, 2))).to(st["position"].device)
+    obs, rew, term, trunc = be.step(np.zeros((n, 6), np.float32))
+    rew = rew.cpu().numpy()
+    got = np.rint(-rew / 0.02).astype(int)
+    assert np.all(np.abs(rew + 0.02 * got) < 1e-3)
+    np.testing.assert_array_equal(got, z["count"])
+    be.close()

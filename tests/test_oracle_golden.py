@@ -189,3 +189,21 @@ def test_other_envs_oracle_regression_pins(oracle_built):
         np.testing.assert_array_equal(ob["individual"], z["octo_individual"][t])
         np.testing.assert_array_equal(ob["shared"], z["octo_shared"][t])
         assert rw == z["octo_reward"][t]
+
+
+def test_crossing_count_against_the_reference_function(oracle_built):
+    """tests/golden/intersection_vectors.npz holds outputs of the reference's own
+    gym_softrobot/utils/intersection.py (tools/make_intersection_golden.py); FlatEnv counts
+    len(intersection(arm[i-1], arm[i])[0]) (flat_env.py:347-357)."""
+    from gym_softrobot_amd import _capi
+
+    z = np.load(GOLD / "intersection_vectors.npz")
+    o = oracle_built.OracleOcto(_capi.octo_flat_config(1, n_arm=2))
+    o.reset([1.0, 1.0])
+    for p1, p2, cnt in zip(z["p1"], z["p2"], z["count"]):
+        # the pair counted for n_arm = 2 is (arm[-1], arm[0]) = (arm 1, arm 0)
+        for a, p in ((1, p1), (0, p2)):
+            x = o.arm(a).get("x")
+            x[:2] = p
+            o.arm(a).set("x", x)
+        assert o.crossings() == int(cnt)
