@@ -371,6 +371,31 @@ int oracle_octo_crossings(oracle_octo* o)
         c += count_intersections(o->arm[(i - 1 + o->n_arm) % o->n_arm], o->arm[i]);
     return c;
 }
+/* test probes: ONE joint, or the head constraint, evaluated on the current state
+ * (tests/golden/octo_operator_vectors.npz holds what the reference's own joint.py /
+ * constraint.py give for the same inputs).  out: head force, head torque, arm node-0 force,
+ * arm element-0 torque. */
+void oracle_octo_joint_probe(oracle_octo* o, int a, double angle_deg, double* out)
+{
+    oracle_rod* r = o->arm[a];
+    for (int i = 0; i < 3; ++i) {
+        o->head.f_ext[i] = 0.0; o->head.t_ext[i] = 0.0; r->f_ext[i][0] = 0.0; r->t_ext[i][0] = 0.0;
+    }
+    const double keep = o->angle[a];
+    o->angle[a] = angle_deg;
+    joint_apply(o, a);
+    o->angle[a] = keep;
+    for (int i = 0; i < 3; ++i) {
+        out[i] = o->head.f_ext[i]; out[3 + i] = o->head.t_ext[i];
+        out[6 + i] = r->f_ext[i][0]; out[9 + i] = r->t_ext[i][0];
+        o->head.f_ext[i] = 0.0; o->head.t_ext[i] = 0.0; r->f_ext[i][0] = 0.0; r->t_ext[i][0] = 0.0;
+    }
+}
+void oracle_octo_head_constrain_probe(oracle_octo* o)
+{
+    head_constrain_values(&o->head);
+    head_constrain_rates(&o->head);
+}
 /* state injection for the windowed parity tests: x[3], v[3], Q[9], w[3] ; time */
 void oracle_octo_set_head(oracle_octo* o, const double* in)
 {

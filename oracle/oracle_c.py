@@ -65,6 +65,8 @@ def _load(omp: bool) -> C.CDLL:
     lib.oracle_octo_crossings.argtypes = [C.c_void_p]
     lib.oracle_octo_head.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_octo_set_head.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_octo_joint_probe.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    lib.oracle_octo_head_constrain_probe.argtypes = [C.c_void_p]
     lib.oracle_octo_set_time.argtypes = [C.c_void_p, C.c_double]
     lib.oracle_get.restype = C.c_int
     lib.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
@@ -294,6 +296,16 @@ class OracleOcto:
         buf = np.ascontiguousarray(np.concatenate([np.ravel(x), np.ravel(v), np.ravel(Q), np.ravel(w)]),
                                    dtype=np.float64)
         self._lib.oracle_octo_set_head(self._h, buf.ctypes.data)
+
+    def joint_probe(self, arm: int, angle_deg: float):
+        """FixedJoint2Rigid of one arm on the current state -> head force, head torque, arm node-0
+        force, arm element-0 torque."""
+        out = np.empty(12, np.float64)
+        self._lib.oracle_octo_joint_probe(self._h, int(arm), float(angle_deg), out.ctypes.data)
+        return out[0:3], out[3:6], out[6:9], out[9:12]
+
+    def head_constrain_probe(self) -> None:
+        self._lib.oracle_octo_head_constrain_probe(self._h)
 
     def copy_state_from(self, other: "OracleOcto") -> None:
         """Overwrite the dynamic state (arms, head, time) with `other`'s."""

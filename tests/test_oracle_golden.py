@@ -207,3 +207,43 @@ def test_crossing_count_against_the_reference_function(oracle_built):
             x[:2] = p
             o.arm(a).set("x", x)
         assert o.crossings() == int(cnt)
+
+
+def test_joint_and_head_constraint_against_the_reference_operators(oracle_built):
+    """tests/golden/octo_operator_vectors.npz: outputs of the reference's own FixedJoint2Rigid
+    (utils/custom_elastica/joint.py) and BodyBoundaryCondition (constraint.py) on random states
+    (tools/make_octo_operator_golden.py); the oracle's joint_apply / head_constrain_* must
+    reproduce them."""
+    from gym_softrobot_amd import _capi
+
+    z = np.load(GOLD / "octo_operator_vectors.npz")
+    cfg = _capi.octo_flat_config(1, n_arm=2)
+    k, nu, kt, radius = z["joint_params"]
+    assert (cfg.joint_k, cfg.joint_nu, cfg.joint_kt, cfg.head_radius) == (k, nu, kt, radius)
+    o = oracle_built.OracleOcto(cfg)
+    o.reset([1.0, 1.0])
+    arm = o.arm(0)
+    assert arm.get("rest_lengths")[0] == pytest.approx(float(z["joint_rest_len"][0]), rel=1e-15)
+    for c in range(len(z["joint_angle"])):
+        o.set_head(z["joint_head_x"][c], z["joint_head_v"][c], z["joint_head_Q"][c], np.zeros(3))
+        x, v, Q = arm.get("x"), arm.get("v"), arm.get("Q")
+        x[:, 0:3] = z["joint_arm_x"][c]
+        v[:, 0:3] = z["joint_arm_v"][c]
+        Q[:, :, 0:2] = z["joint_arm_Q"][c]
+        arm.set("x", x); arm.set("v", v); arm.set("Q", Q)
+        hf, ht, af, at = o.joint_probe(0, float(z["joint_angle"][c]))
+        # every third case sits exactly on its attachment point: the spring term there is
+        # k * (rounding of a 0.04-sized position), so the floor is k * 1e-15
+        scale_f = max(np.abs(z["joint_head_f"][c]).max(), k * 1e-5)
+        np.testing.assert_allclose(hf, z["joint_head_f"][c], rtol=1e-10, atol=1e-10 * scale_f)
+        np.testing.assert_allclose(af, z["joint_arm_f"][c], rtol=1e-10, atol=1e-10 * scale_f)
+        np.testing.assert_allclose(ht, z["joint_head_t"][c], rtol=1e-10, atol=1e-16)
+        np.testing.assert_allclose(at, z["joint_arm_t"][c], rtol=1e-10, atol=1e-16)
+    for c in range(len(z["bc_x_in"])):
+        o.set_head(z["bc_x_in"][c], z["bc_v_in"][c], z["bc_Q_in"][c], z["bc_w_in"][c])
+        o.head_constrain_probe()
+        h = o.head()
+        np.testing.assert_allclose(h["x"], z["bc_x_out"][c], rtol=0, atol=1e-16)
+        np.testing.assert_allclose(h["Q"], z["bc_Q_out"][c], rtol=1e-14, atol=1e-16)
+        np.testing.assert_array_equal(h["v"], z["bc_v_out"][c])
+        np.testing.assert_array_equal(h["w"], z["bc_w_out"][c])
