@@ -476,15 +476,23 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
         // zero out-of-plane terms (softrod_planar.hpp); any other state takes the 3-D loop
         PlanarN<EPL> Z;
         if (n_sub > 0 && !stepped && planar_from_lane<EPL>(P, B, lane, L, Z)) {
-            planar_kinematic_n<EPL>(P.half_dt, C, Z);
-            if (P.time_two_half_adds) time += P.half_dt;
-            for (int s = 0; s < n_sub; ++s) {
-                planar_dynamic_n<EPL>(Pk, C, lane, Z);
-                const bool last = (s == n_sub - 1);
-                planar_kinematic_n<EPL>(last ? P.half_dt : P.dt, C, Z);
-                time += P.time_two_half_adds ? P.half_dt : P.dt;
-                if (!last && P.time_two_half_adds) time += P.half_dt;
+            PlanarC<EPL> K;
+            planar_build_const<EPL>(Pk, C, lane, K);
+            // the clock takes the reference's additions in the reference's order: 2 n_sub times
+            // +dt/2, or n_sub times +dt (then tb = 0 and x + 0 = x)
+            const double ta = P.time_two_half_adds ? P.half_dt : P.dt;
+            const double tb = P.time_two_half_adds ? P.half_dt : 0.0;
+            // two half kinematic steps between force evaluations are one whole step; the last
+            // substep (half a step) is peeled so that the loop's step length is a constant
+            planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
+            for (int s = 0; s + 1 < n_sub; ++s) {
+                planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
+                planar_kinematic_n<EPL>(P.dt, K.hq_dt, C, K, Z);
+                time = (time + ta) + tb;
             }
+            planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
+            planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
+            time = (time + ta) + tb;
             planar_to_lane<EPL>(Z, L);
             stepped = true;
         }

@@ -30,6 +30,18 @@
 // The step kernel takes this path only if the loaded state IS planar (planar_from_lane:
 // exact zeros where the argument above needs them, d1 consistent with d3 to 1e-12); any
 // other state — e.g. one written through softrod_state_view — runs the general 3-D loop.
+//
+// The loop is VALU-issue bound, so what is left is written to the instruction:
+//   * the state carries the rotation rate about z, wz = s2 w, instead of w: every s2 in the
+//     formulas multiplies another s2 or cancels against it (multiplying by +-1 is exact, so
+//     this is bit-identical), and d1 never has to be formed;
+//   * products of loop-invariant factors are folded into per-lane constants (PlanarC);
+//   * masks are folded into those constants instead of being applied with selects: the pinned
+//     v_y of node 0 has a zero force coefficient, an invalid slot has |d|^2 clamped from below
+//     (its stiffnesses are zero) and may carry a finite, unused bending angle;
+//   * the Taylor coefficients are handed to the compiler as opaque registers: as immediates it
+//     turns every Horner step into v_mov + v_fmac instead of one v_fma;
+//   * 1/x and 1/sqrt(x) take one third-order correction of the 2^-23 hardware seed.
 #pragma once
 
 namespace softrod {
@@ -38,18 +50,72 @@ template <int EPL>
 struct PlanarN {
     double x[EPL][2], v[EPL][2];
     double c[EPL], s[EPL];     // d3 = (c, s, 0)
-    double s2[EPL];            // d2 = (0, 0, s2), s2 = +-1
-    double w[EPL];             // omega = (0, w, 0) in the local frame
+    double s2;                 // d2 = (0, 0, s2), s2 = +-1, the same for every element
+    double wz[EPL];            // rotation rate about z: omega = (0, s2 wz, 0) in the local frame
     double t[EPL][2];          // tangents as of the last force evaluation
     double dl[EPL];            // bending angle between elements k and k+1
 };
 
+// loop-invariant per-lane products (see the header) and the opaque polynomial coefficients
+template <int EPL>
+struct PlanarC {
+    double cfy[EPL], cay[EPL];     // C.cf, C.ca[1] with node 0 (v_y pinned) zeroed
+    double cwl[EPL];               // C.cw01 / rest_len:   cw01 * e = cwl * len
+    double bk[EPL];                // C.b01 * kappa scale * (2 rest_vor)^3:  B kappa / vd^3 = bk D / (l + l+)^3
+    double xl[EPL];                // damp_logr / rest_len:  e * logr = xl * len  (0 on invalid slots)
+    double hq_dt[EPL], hq_hdt[EPL];  // C.hq * dt, C.hq * dt/2
+    double jr;                     // J * rest_len:          J / e = jr / len
+    double s3, s2, s1, c3, c2, e4, e3;
+};
+
+__device__ __forceinline__ double opaque_s(double k) { asm("" : "+s"(k)); return k; }
+__device__ __forceinline__ double opaque_v(double k) { asm("" : "+v"(k)); return k; }
+// x = m * x + a written over x (the compiler's v_fmac would put it over a and copy it back)
+__device__ __forceinline__ void fma_inplace(double& x, double m, double a) {
+    asm("v_fma_f64 %0, %1, %0, %2" : "+v"(x) : "v"(m), "v"(a));
+}
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+// third-order refinements of the hardware seeds (relative error 2^-23 -> 2^-69)
+__device__ __forceinline__ double rcp3(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
+__device__ __forceinline__ double rsqrt3(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(0.5 * x) * r, r, 0.5);          // -(d + d^2/2) for r = (1 + d)/sqrt(x)
+    return fma(r, e * fma(1.5, e, 1.0), r);                // 1 + e + 3/2 e^2 = 1/(1 + d) + O(d^3)
+}
+
+template <int EPL>
+__device__ __forceinline__ void planar_build_const(const RodParams& P, const ConstN<EPL>& C, int lane,
+                                                   PlanarC<EPL>& K) {
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const bool pinned = (lane * EPL + s) == 0;
+        K.cfy[s] = pinned ? 0.0 : C.cf[s];
+        K.cay[s] = pinned ? 0.0 : C.ca[s][1];
+        K.cwl[s] = C.cw01[s] * P.inv_rest_len;
+        const double two_vor = 2.0 * P.rest_vor;
+        K.bk[s] = C.b01[s] * (P.inv_rest_vor * (1.0 + P.acos_shift * (1.0 / 3.0))) * (two_vor * two_vor * two_vor);
+        K.xl[s] = (lane * EPL + s) < P.n_elem ? P.damp_logr[0] * P.inv_rest_len : 0.0;
+        K.hq_dt[s] = C.hq[s] * P.dt;
+        K.hq_hdt[s] = C.hq[s] * P.half_dt;
+    }
+    K.jr = P.J[0] * P.rest_len;
+    K.s3 = opaque_s(-1.0 / 5040.0); K.s2 = opaque_v(1.0 / 120.0); K.s1 = opaque_s(-1.0 / 6.0);
+    K.c3 = opaque_s(-1.0 / 720.0); K.c2 = opaque_v(1.0 / 24.0);
+    K.e4 = opaque_s(1.0 / 24.0); K.e3 = opaque_v(1.0 / 6.0);
+}
+
 // exp(x) for the damper (see exp_pair)
-__device__ __forceinline__ double exp_one(double x, bool valid) {
-    if (!__any(valid && !(fabs(x) < 1.0e-3)))
-        return fma(x, fma(x, fma(x, fma(x, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
+template <int EPL>
+__device__ __forceinline__ double exp_one(const PlanarC<EPL>& K, double x) {
+    if (!wave_any(!(fabs(x) < 1.0e-3)))
+        return fma(x, fma(x, fma(x, fma(x, K.e4, K.e3), 0.5), 1.0), 1.0);
     int k = 0;
-    while (__any(valid && !(fabs(x) < 1.0e-3)) && k < 24) { x *= 0.5; ++k; }
+    while (wave_any(!(fabs(x) < 1.0e-3)) && k < 24) { x *= 0.5; ++k; }
     double e = fma(x, fma(x, fma(x, fma(x, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
     for (; k > 0; --k) e *= e;
     return e;
@@ -61,23 +127,24 @@ __device__ __forceinline__ bool planar_from_lane(const RodParams& P, const BcTar
                                                  const LaneN<EPL>& L, PlanarN<EPL>& Z) {
     const int n = P.n_elem;
     bool ok = (P.gravity[2] == 0.0) && (B.pos[2] == 0.0) && (B.Q[2] == 0.0) && (B.Q[8] == 0.0);
+    // d2_z = -(cos^2 + sin^2) as straight_rod's cross product rounds it: +-1 to an ulp; the
+    // planar update leaves row 1 of Q untouched, exactly like the 3-D one (R4 = 1)
+    Z.s2 = __shfl((L.Q[0][5] < 0.0) ? -1.0 : 1.0, 0);
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         const int idx = lane * EPL + s;
         const double* Q = L.Q[s];
-        // d2_z = -(cos^2 + sin^2) as straight_rod's cross product rounds it: +-1 to an ulp;
-        // the planar update leaves row 1 of Q untouched, exactly like the 3-D one (R4 = 1)
         const double s2 = (Q[5] < 0.0) ? -1.0 : 1.0, c = Q[6], sn = Q[7];
         const bool node_ok = (L.x[s][2] == 0.0) && (L.v[s][2] == 0.0);
-        const bool elem_ok = (Q[2] == 0.0) && (Q[3] == 0.0) && (Q[4] == 0.0) && (Q[8] == 0.0) &&
+        const bool elem_ok = (Q[2] == 0.0) && (Q[3] == 0.0) && (Q[4] == 0.0) && (Q[8] == 0.0) && (s2 == Z.s2) &&
                              (fabs(fabs(Q[5]) - 1.0) <= 1.0e-12) && (L.w[s][0] == 0.0) && (L.w[s][2] == 0.0) &&
                              (fabs(fma(s2, sn, Q[0])) <= 1.0e-12) && (fabs(fma(-s2, c, Q[1])) <= 1.0e-12) &&
                              (fabs(fma(c, c, fma(sn, sn, -1.0))) <= 1.0e-12);
         ok = ok && (idx > n || node_ok) && (idx >= n || elem_ok);
         Z.x[s][0] = L.x[s][0]; Z.x[s][1] = L.x[s][1];
         Z.v[s][0] = L.v[s][0]; Z.v[s][1] = L.v[s][1];
-        Z.c[s] = c; Z.s[s] = sn; Z.s2[s] = (idx < n) ? s2 : 1.0;
-        Z.w[s] = L.w[s][1];
+        Z.c[s] = c; Z.s[s] = sn;
+        Z.wz[s] = (idx < n) ? Z.s2 * L.w[s][1] : 0.0;
         Z.t[s][0] = L.t[s][0]; Z.t[s][1] = L.t[s][1];
     }
     {
@@ -101,46 +168,56 @@ __device__ __forceinline__ void planar_to_lane(const PlanarN<EPL>& Z, LaneN<EPL>
     for (int s = 0; s < EPL; ++s) {
         L.x[s][0] = Z.x[s][0]; L.x[s][1] = Z.x[s][1];
         L.v[s][0] = Z.v[s][0]; L.v[s][1] = Z.v[s][1];
-        L.Q[s][0] = -Z.s2[s] * Z.s[s]; L.Q[s][1] = Z.s2[s] * Z.c[s];
+        L.Q[s][0] = -Z.s2 * Z.s[s]; L.Q[s][1] = Z.s2 * Z.c[s];
         L.Q[s][6] = Z.c[s]; L.Q[s][7] = Z.s[s];
-        L.w[s][1] = Z.w[s];
+        L.w[s][1] = Z.s2 * Z.wz[s];
         L.t[s][0] = Z.t[s][0]; L.t[s][1] = Z.t[s][1]; L.t[s][2] = 0.0;
     }
 }
 
 // kinematic_n with a = (0, h w, 0): R0 = R8 = cos, R6 = -R2 = sin, R4 = 1, the rest 0, so
-// the new d3 = sin * d1 + cos * d3.
+// the new d3 = sin * d1 + cos * d3 — the rotation of (c, s) about z by h wz.
 template <int EPL>
-__device__ __forceinline__ void planar_kinematic_n(double h, const ConstN<EPL>& C, PlanarN<EPL>& Z) {
-    double ra[EPL], ran[EPL];      // signed rotation angle of each element about z
+__device__ __forceinline__ void planar_kinematic_n(double h, const double (&hq_h)[EPL], const ConstN<EPL>& C,
+                                                   const PlanarC<EPL>& K, PlanarN<EPL>& Z) {
+    double ra[EPL], ran[EPL];      // rotation angle of each element about z
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         const double hp = h * C.hx[s];
         Z.x[s][0] = fma(hp, Z.v[s][0], Z.x[s][0]);
         Z.x[s][1] = fma(hp, Z.v[s][1], Z.x[s][1]);
-        const double a = (h * C.hq[s]) * Z.w[s];
-        ra[s] = a * Z.s2[s];
+        const double a = hq_h[s] * Z.wz[s];
+        ra[s] = a;
         const double t = a * a;
-        double sc, cc;
-        sinc_cosc(t, sc, cc);
-        const double sn = sc * ra[s], cs = fma(-cc, t, 1.0);
-        const double c = Z.c[s], sv = Z.s[s];
-        Z.c[s] = fma(-sn, sv, cs * c);
-        Z.s[s] = fma(sn, c, cs * sv);
+        double sc, cs;
+        if (!wave_any(t >= 1.0e-3)) {      // sinc_cosc's range, on the opaque coefficients; the
+            sc = fma(t, fma(t, fma(t, K.s3, K.s2), K.s1), 1.0);       // cosine directly (t^4/8! < 3e-17)
+            cs = fma(t, fma(t, fma(t, K.c3, K.c2), -0.5), 1.0);
+        } else {
+            double cc;
+            sinc_cosc(t, sc, cc);
+            cs = fma(-cc, t, 1.0);
+        }
+        const double sn = sc * a;
+        // both products of the old c first, so that c and s are then updated in place
+        const double p = cs * Z.c[s], q = sn * Z.c[s];
+        Z.c[s] = fma(-sn, Z.s[s], p);
+        fma_inplace(Z.s[s], cs, q);
     }
+    // invalid slots turn by exactly 0 (hq wz = 0 there), so the angle of the vertex after the
+    // last element only collects a finite value that its zero stiffness never lets out
     shift_next<EPL>(ra, ran);
 #pragma unroll
-    for (int s = 0; s < EPL; ++s) Z.dl[s] += C.b01[s] != 0.0 ? ran[s] - ra[s] : 0.0;
+    for (int s = 0; s < EPL; ++s) Z.dl[s] += ran[s] - ra[s];
 }
 
 // dynamic_n for SOFTROD_FEATURES_SOFTPENDULUM (gravity and the point force live in C.ca,
 // the analytical damper is fused, the pendulum constraint pins v_y of node 0).
 template <int EPL>
-__device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const ConstN<EPL>& C, int lane,
-                                                 PlanarN<EPL>& Z) {
-    const int n = P.n_elem;
+__device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const ConstN<EPL>& C,
+                                                 const PlanarC<EPL>& K, int lane, PlanarN<EPL>& Z) {
     double xn[EPL][2], vn[EPL][2], d[EPL][2];
-    double len[EPL], il[EPL], e[EPL], ie[EPL];
+    double len[EPL], il[EPL];
     double qt0[EPL], qt2[EPL], np0[EPL], np2[EPL], cs[EPL][2], f[EPL][2], tq[EPL];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -152,28 +229,26 @@ __device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const Const
 #pragma unroll
         for (int s = 0; s < EPL; ++s) { xn[s][c] = o[s]; vn[s][c] = ov[s]; }
     }
-    // geometry and shear/stretch: qt = Q t has no d2 component, so n = S (Q t - z/e) has none
+    // geometry and shear/stretch in the frame (d1', d3) with d1' = s2 d1 = (-s, c): Q t has no
+    // d2 component, so n = S (Q t - z/e) has none; qt0, np0 are s2 times the 3-D ones
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const bool elem_valid = (lane * EPL + s) < n;
         d[s][0] = xn[s][0] - Z.x[s][0];
         d[s][1] = xn[s][1] - Z.x[s][1];
-        double dd = fma(d[s][1], d[s][1], d[s][0] * d[s][0]);
-        dd = elem_valid ? dd : 1.0;
-        const double r = fast_rsqrt(dd);
+        // slots past the last element have d = 0: clamped, they stay finite and their zero
+        // stiffnesses keep them out of every sum
+        const double dd = fmax(fma(d[s][1], d[s][1], d[s][0] * d[s][0]), 1.0e-20);
+        const double r = rsqrt3(dd);
         len[s] = fma(dd, r, P.eps_length);
         il[s] = fma(-P.eps_length * r, r, r);
         Z.t[s][0] = d[s][0] * il[s];
         Z.t[s][1] = d[s][1] * il[s];
-        e[s] = len[s] * P.inv_rest_len;
-        ie[s] = P.rest_len * il[s];
-        const double d1x = -Z.s2[s] * Z.s[s], d1y = Z.s2[s] * Z.c[s];
-        qt0[s] = fma(d1y, Z.t[s][1], d1x * Z.t[s][0]);
+        qt0[s] = fma(Z.c[s], Z.t[s][1], -Z.s[s] * Z.t[s][0]);
         qt2[s] = fma(Z.s[s], Z.t[s][1], Z.c[s] * Z.t[s][0]);
         np0[s] = C.s01[s] * qt0[s];
-        np2[s] = C.s2[s] * (qt2[s] - ie[s]);
-        cs[s][0] = fma(Z.c[s], np2[s], d1x * np0[s]);
-        cs[s][1] = fma(Z.s[s], np2[s], d1y * np0[s]);
+        np2[s] = C.s2[s] * fma(-P.rest_len, il[s], qt2[s]);
+        cs[s][0] = fma(Z.c[s], np2[s], -Z.s[s] * np0[s]);
+        cs[s][1] = fma(Z.s[s], np2[s], Z.c[s] * np0[s]);
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -185,15 +260,13 @@ __device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const Const
         for (int s = 0; s < EPL; ++s) f[s][c] = cs[s][c] - o[s];
     }
     // bend: kappa = s2 D / D^ with the carried bending angle D (see the header); the Voronoi
-    // couple B kappa / vd^3, and kappa x B kappa = 0 for a single component
+    // couple B kappa / vd^3 about z, and kappa x B kappa = 0 for a single component
     double len_n[EPL], up[EPL];
     shift_next<EPL>(len, len_n);
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const double k1 = (Z.s2[s] * (P.inv_rest_vor * (1.0 + P.acos_shift * (1.0 / 3.0)))) * Z.dl[s];
-        const double vd = (len_n[s] + len[s]) * (0.5 * P.inv_rest_vor);
-        const double rvd = fast_rcp(vd);
-        up[s] = C.b01[s] * k1 * (rvd * rvd * rvd);
+        const double rl = rcp3(len_n[s] + len[s]);          // vd = (l + l+) / (2 rest_vor), folded into bk
+        up[s] = (K.bk[s] * Z.dl[s]) * (rl * rl * rl);
     }
     {
         double o[EPL];
@@ -206,20 +279,19 @@ __device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const Const
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         tq[s] = fma(len[s], fma(qt2[s], np0[s], -qt0[s] * np2[s]), tq[s]);
-        const double num = fma(d[s][1], vn[s][1] - Z.v[s][1], d[s][0] * (vn[s][0] - Z.v[s][0]));
-        const double sdil = num * il[s] * il[s];
-        tq[s] = fma((P.J[0] * ie[s]) * sdil, Z.w[s], tq[s]);
+        // (J / e) (de/dt / e) = J rest_len (t . dv) / l^2
+        const double tdv = fma(Z.t[s][1], vn[s][1] - Z.v[s][1], Z.t[s][0] * (vn[s][0] - Z.v[s][0]));
+        tq[s] = fma((K.jr * il[s] * il[s]) * tdv, Z.wz[s], tq[s]);
     }
-    // rate update fused with the analytical damper, then constrain_rates (v_y of node 0)
+    // rate update fused with the analytical damper; constrain_rates (v_y of node 0) is the zero
+    // in cfy / cay
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const bool elem_valid = (lane * EPL + s) < n;
-        Z.v[s][0] = fma(P.damp_t, Z.v[s][0], fma(C.cf[s], f[s][0], C.ca[s][0]));
-        Z.v[s][1] = fma(P.damp_t, Z.v[s][1], fma(C.cf[s], f[s][1], C.ca[s][1]));
-        const double w = fma(C.cw01[s] * e[s], tq[s], Z.w[s]);
-        Z.w[s] = w * exp_one(e[s] * P.damp_logr[0], elem_valid);
+        Z.v[s][0] = fma(C.cf[s], f[s][0], fma(P.damp_t, Z.v[s][0], C.ca[s][0]));
+        Z.v[s][1] = fma(K.cfy[s], f[s][1], fma(P.damp_t, Z.v[s][1], K.cay[s]));
+        const double w = fma(K.cwl[s] * len[s], tq[s], Z.wz[s]);
+        Z.wz[s] = w * exp_one<EPL>(K, K.xl[s] * len[s]);
     }
-    Z.v[0][1] = (lane == 0) ? 0.0 : Z.v[0][1];
 }
 
 }  // namespace softrod

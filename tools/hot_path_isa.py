@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Counts the instructions one substep of a step kernel actually executes when every
+range-reduction check passes (the normal case): walks the kernel's ISA from the substep
+loop's header round to the header again, taking at each wave-uniform branch the side the
+in-range case takes (vcc == 0 after an `any lane out of range` compare, exec != 0, loop
+not finished).  This is the number SQ_INSTS_VALU / (rods x substeps) measures
+(tools/pmc_valu_per_substep.sh).
+
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o capi.s softrod_capi.hip
+  python tools/hot_path_isa.py capi.s fast_kernelILj15ELi1ELi1E [-v]
+"""
+import re
+import sys
+
+
+def function_body(asm: str, name: str):
+    lines = asm.split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN7softrod\w*:", l) and name in l)
+    end = start
+    while not lines[end].strip().startswith("s_endpgm"):
+        end += 1
+    labels, ins = {}, []
+    for l in lines[start:end + 1]:
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        t = l.strip()
+        if l.startswith("\t") and t and not t.startswith((".", ";")):
+            ins.append(t.split(";")[0].strip())
+    return ins, labels
+
+
+def hot_path(ins, labels):
+    # the substep loop: the first backward branch that spans more than 100 instructions
+    head = None
+    for i, t in enumerate(ins):
+        m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", t)
+        if m and labels.get(m.group(1), i) < i - 100:
+            head = labels[m.group(1)]
+            break
+    if head is None:
+        raise SystemExit("no loop found")
+    path, pc, seen = [], head, 0
+    while True:
+        t = ins[pc]
+        m = re.match(r"(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", t)
+        if m:
+            kind, tgt = m.group(1), labels[m.group(2)]
+            taken = kind in ("s_branch", "s_cbranch_vccz", "s_cbranch_execnz")
+            path.append(t)
+            pc = tgt if taken else pc + 1
+        else:
+            path.append(t)
+            pc += 1
+        if pc == head:
+            return path
+        seen += 1
+        if seen > 5000:
+            raise SystemExit("did not return to the loop header")
+
+
+def main():
+    asm = open(sys.argv[1]).read()
+    ins, labels = function_body(asm, sys.argv[2])
+    path = hot_path(ins, labels)
+    valu = [x for x in path if x.startswith("v_")]
+    dpp = [x for x in valu if "dpp" in x]
+    print(f"{sys.argv[2]}: {len(path)} instructions per substep, {len(valu)} VALU "
+          f"({len(dpp)} DPP moves, {sum(x.startswith('v_mov_b64') for x in valu)} v_mov_b64, "
+          f"{sum(x.startswith('v_cndmask') for x in valu)} v_cndmask), "
+          f"{sum(x.startswith(('scratch', 'buffer', 'global', 'flat')) for x in path)} memory")
+    if "-v" in sys.argv:
+        for x in path:
+            print("   ", x.replace(" row_mask:0xf bank_mask:0xf bound_ctrl:1", ""))
+
+
+if __name__ == "__main__":
+    main()
