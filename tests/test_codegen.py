@@ -18,7 +18,7 @@ def _loops(asm: str, mangled_substr: str):
     lines = asm.split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN7softrod\w*:", l) and mangled_substr in l)
     end = start
-    while not lines[end].strip().startswith("s_endpgm"):
+    while not lines[end].startswith(".Lfunc_end"):
         end += 1
     labels, ins = {}, []
     for l in lines[start:end + 1]:

@@ -17,7 +17,7 @@ def function_body(asm: str, name: str):
     lines = asm.split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN7softrod\w*:", l) and name in l)
     end = start
-    while not lines[end].strip().startswith("s_endpgm"):
+    while not lines[end].startswith(".Lfunc_end"):      # (a kernel may hold several s_endpgm)
         end += 1
     labels, ins = {}, []
     for l in lines[start:end + 1]:
