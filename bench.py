@@ -128,8 +128,12 @@ def main() -> None:
     if os.environ.get("SOFTROD_BENCH_ALL_RANKS_ON_DEVICE0") == "1":
         local_rank = 0   # smoke-testing the N>1 code path on a 1-GPU box (not a measurement)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("SOFTROD_BENCH_FORCE_DIST") == "1"   # RCCL smoke test in a world of one
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("SOFTROD_BENCH_DIST_BACKEND", "nccl")   # "gloo": 1-GPU smoke test only
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -152,7 +156,7 @@ def main() -> None:
     local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode, **extra)
     # world > 1: kernel-packed rows + one all-gather per step, issued asynchronously so that the
     # next step's kernel does not wait for it (ShardedVecEnv overlap; the final sync is timed)
-    env = ShardedVecEnv(local, n_total, overlap=True)
+    env = ShardedVecEnv(local, n_total, overlap=True, force_collective=force_dist)
     env.reset(seed=0)                      # global env i seeded i
     lo, hi = env.lo, env.hi
     adim = local.backend.action_dim
@@ -168,7 +172,7 @@ def main() -> None:
         env.step(acts_dev[t])
     local.backend.set_timing(K)
     restarts_before = int(local.backend.queue_status()[0].sum()) if args.autoreset == "device" else 0
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -176,10 +180,10 @@ def main() -> None:
         obs, rew, term, trunc, _ = env.step(acts_dev[t])
     env.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         el = torch.tensor([elapsed], dtype=torch.float64, device=local.backend.device)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
@@ -190,11 +194,13 @@ def main() -> None:
     restarts = 0
     if args.autoreset == "device":
         restarts = int(local.backend.queue_status()[0].sum()) - restarts_before
-    if world > 1:
+    if world > 1 or force_dist:
         rs = torch.tensor([restarts], dtype=torch.int64, device=local.backend.device)
         dist.all_reduce(rs)
         restarts = int(rs.item())
     n_bad = int((~torch.isfinite(obs).all(dim=1)).sum().item())
+    # what the last step returned, over ALL envs (gathered rows included): lets two runs be compared
+    obs_checksum = float(torch.nan_to_num(obs.double()).sum().item()) + float(torch.nan_to_num(rew.double()).sum().item())
 
     if rank == 0:
         cfg = local.cfg
@@ -239,7 +245,7 @@ def main() -> None:
                 "episode_restarts_not_counted": restarts,
                 "sharding": "contiguous env blocks per rank; one packed all_gather per step" if world > 1 else "single GPU",
                 "rod_substeps_per_sec": (n_total * K - restarts) * rods_per_env * nsub / elapsed,
-                "non_finite_envs_at_end": n_bad,
+                "non_finite_envs_at_end": n_bad, "last_step_checksum": obs_checksum,
             },
             "roofline": {
                 "bound": "hbm",
@@ -273,7 +279,7 @@ def main() -> None:
         print(json.dumps(line), flush=True)
 
     env.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -81,7 +81,8 @@ class ShardedVecEnv:
     """
 
     def __init__(self, local_env, total_envs: int, group: Optional[dist.ProcessGroup] = None,
-                 gather: bool = True, overlap: bool = False):
+                 gather: bool = True, overlap: bool = False, force_collective: bool = False,
+                 overlap_depth: int = 2):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -91,16 +92,20 @@ class ShardedVecEnv:
         if local_env.num_envs != self.hi - self.lo:
             raise ValueError("local env size does not match this rank's shard")
         self.gather = gather
+        # force_collective: run the all-gather also in a world of one (exercises the RCCL path
+        # on a single-GPU box: `SOFTROD_BENCH_FORCE_DIST=1 torchrun --nproc-per-node 1 bench.py`)
+        self._collective = gather and (self.world > 1 or (force_collective and dist.is_initialized()))
         self.obs_dim = local_env.obs_dim
         dev = local_env.backend.device
         w = packed_width(self.obs_dim)
         self._global = torch.empty((self.total_envs, w), dtype=torch.float32, device=dev)
-        self.overlap = bool(overlap) and self.world > 1 and gather
+        self.overlap = bool(overlap) and self._collective
         if self.overlap:
             n_loc = self.hi - self.lo
-            self._packed2 = [torch.empty((n_loc, w), dtype=torch.float32, device=dev) for _ in range(2)]
-            self._global2 = [self._global, torch.empty_like(self._global)]
-            self._works = [None, None]
+            d = max(2, int(overlap_depth))
+            self._packed2 = [torch.empty((n_loc, w), dtype=torch.float32, device=dev) for _ in range(d)]
+            self._global2 = [self._global] + [torch.empty_like(self._global) for _ in range(d - 1)]
+            self._works = [None] * d
             self._k = 0
 
     def _all_gather(self, packed: torch.Tensor) -> torch.Tensor:
@@ -112,7 +117,7 @@ class ShardedVecEnv:
         seeds = None if seed is None else [int(seed) + i for i in range(self.lo, self.hi)]
         m = None if mask is None else np.asarray(mask)[self.lo : self.hi]
         obs, info = self.local.reset(seed=seeds, mask=m)
-        if not self.gather or self.world == 1:
+        if not self._collective:
             return obs, info
         n = obs.shape[0]
         zeros64 = torch.zeros(n, dtype=torch.float64, device=obs.device)
@@ -126,7 +131,7 @@ class ShardedVecEnv:
         a = torch.as_tensor(actions, dtype=torch.float32).reshape(-1, adim)
         if a.shape[0] == self.total_envs and self.world > 1:
             a = a[self.lo : self.hi]
-        if not self.gather or self.world == 1:
+        if not self._collective:
             return self.local.step(a)
         if self.overlap:
             return self._step_overlapped(a)
@@ -142,7 +147,7 @@ class ShardedVecEnv:
             self._works[k].wait()
         packed, info = self.local.step_packed(a, self._packed2[k])
         self._works[k] = dist.all_gather_into_tensor(self._global2[k], packed, group=self.group, async_op=True)
-        self._k = 1 - k
+        self._k = (k + 1) % len(self._works)
         o, r, te, tr = unpack_outputs(self._global2[k], self.obs_dim)
         return o, r, te, tr, info
 
