@@ -94,7 +94,7 @@ def main() -> None:
                     help=f"default {ENVS_PER_GPU}; OctoFlat-v0: 1024 (BASELINE configs[4]: 8192 envs on 8 GPUs)")
     ap.add_argument("--math-mode", choices=["fast", "libm"], default="fast")
     ap.add_argument("--env", default="SoftPendulum-v0",
-                    choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0", "OctoFlat-v0"],
+                    choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0", "OctoFlat-v0", "SoftArmTracking-v0"],
                     help="headline metric is SoftPendulum-v0; the others are the widened §8 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -161,7 +161,7 @@ def main() -> None:
     lo, hi = env.lo, env.hi
     adim = local.backend.action_dim
     amax = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
-            "OctoFlat-v0": 22.0}[args.env]
+            "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0}[args.env]
     # the truncation flag of SoftPendulum first fires on env.step #126; the default window
     # (55 steps) stays inside one episode
     T = W + K

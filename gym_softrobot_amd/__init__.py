@@ -4,10 +4,12 @@ from . import _capi
 from .envs import (
     ArmSingleEnv,
     FlatEnv,
+    SoftArmTrackingEnv,
     SoftPendulum3DEnv,
     SoftPendulumEnv,
     VecArmSingleEnv,
     VecOctoFlatEnv,
+    VecSoftArmTrackingEnv,
     VecSoftPendulum3DEnv,
     VecSoftPendulumEnv,
 )
@@ -22,12 +24,15 @@ register(id="OctoArmSingle-v0", entry_point=ArmSingleEnv)
 # gym_softrobot/__init__.py:6-15
 register(id="OctoFlat-v0", entry_point=FlatEnv)
 register(id="OctoFlatLite-v0", entry_point=FlatEnv, kwargs=dict(n_arm=1, n_action=8))
+# gym_softrobot/__init__.py:60-63
+register(id="SoftArmTracking-v0", entry_point=SoftArmTrackingEnv)
 
 _VEC = {
     "SoftPendulum-v0": VecSoftPendulumEnv,
     "SoftPendulum3D-v0": VecSoftPendulum3DEnv,
     "OctoArmSingle-v0": VecArmSingleEnv,
     "OctoFlat-v0": VecOctoFlatEnv,
+    "SoftArmTracking-v0": VecSoftArmTrackingEnv,
 }
 
 
@@ -40,5 +45,5 @@ def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
 
 __all__ = [
     "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
-    "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv", "make", "make_vec", "register", "registered", "_capi",
+    "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv", "SoftArmTrackingEnv", "VecSoftArmTrackingEnv", "make", "make_vec", "register", "registered", "_capi",
 ]

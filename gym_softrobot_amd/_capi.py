@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -24,6 +24,7 @@ FEAT_LAPLACE_FILTER = 1 << 7
 FEAT_PLANE_CONTACT_ANISO = 1 << 8
 FEAT_REST_KAPPA_ACTION = 1 << 9
 FEAT_OCTO_HEAD = 1 << 10
+FEAT_SPLINE_MUSCLE_TORQUES = 1 << 11
 FEATURES_SOFTPENDULUM = (
     FEAT_GRAVITY | FEAT_POINT_FORCE_NODE0_X | FEAT_PENDULUM_BC | FEAT_ANALYTICAL_DAMPER
 )
@@ -40,17 +41,21 @@ ENV_SOFTPENDULUM = 1
 ENV_SOFTPENDULUM3D = 2
 ENV_ARM_SINGLE = 3
 ENV_OCTO_FLAT = 4
+ENV_SOFT_ARM = 5
 FEATURES_OCTO_FLAT = FEATURES_ARM_SINGLE | FEAT_OCTO_HEAD
+FEATURES_SOFT_ARM = FEAT_FIXED_BC | FEAT_ANALYTICAL_DAMPER | FEAT_SPLINE_MUSCLE_TORQUES
 
 MATH_LIBM = 0
 MATH_FAST = 1
 
 LANE_STRIDE = 64  # one wavefront row per rod (softrod_state_view.lane_stride)
 
-_ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2, ENV_ARM_SINGLE: 7, ENV_OCTO_FLAT: 24}
+_ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2, ENV_ARM_SINGLE: 7, ENV_OCTO_FLAT: 24,
+               ENV_SOFT_ARM: 8}
 _OBS_DIM = {ENV_NONE: 4, ENV_SOFTPENDULUM: 4, ENV_SOFTPENDULUM3D: 9, ENV_ARM_SINGLE: 25,
-            ENV_OCTO_FLAT: 8 * 56 + 13}
-_AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1, ENV_ARM_SINGLE: 0, ENV_OCTO_FLAT: 0}
+            ENV_OCTO_FLAT: 8 * 56 + 13, ENV_SOFT_ARM: 14}
+_AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1, ENV_ARM_SINGLE: 0, ENV_OCTO_FLAT: 0,
+            ENV_SOFT_ARM: 0}
 
 
 def action_dim(env_kind: int) -> int:
@@ -117,6 +122,11 @@ class SoftrodConfig(C.Structure):
         ("joint_k", C.c_double),
         ("joint_nu", C.c_double),
         ("joint_kt", C.c_double),
+        ("n_ctrl", C.c_int32),
+        ("n_spline_pieces", C.c_int32),
+        ("muscle_torque_scale", C.c_double),
+        ("max_activation_rate", C.c_double),
+        ("arm_target", C.c_double * 3),
     ]
 
     def copy(self) -> "SoftrodConfig":
@@ -295,6 +305,59 @@ def octo_flat_config(
     return cfg
 
 
+def soft_arm_config(n_envs: int = 1, *, n_elems: int = 40, math_mode: int = MATH_FAST) -> SoftrodConfig:
+    """`softrod_config_soft_arm`: SoftArmTrackingEnv.__init__ (soft_arm/soft_arm_tracking.py:
+    107-158) and the simulator its reset builds (:261-383), game_mode 1 (the registered
+    SoftArmTracking-v0).  Lengths are in millimetres there (base_length 1000, radius 50,
+    density 1000e-6)."""
+    cfg = SoftrodConfig()
+    sim_dt, rl_interval = 2.0e-4, 0.01                       # :117-118
+    _common(cfg, n_envs, 5.0, sim_dt, 1, n_elems, math_mode)  # max_episode_final_time = 5  :127
+    cfg.n_substeps = int(np_rint(rl_interval / sim_dt))      # num_steps_per_update, :119-121
+    cfg.features = FEATURES_SOFT_ARM
+    cfg.env_kind = ENV_SOFT_ARM
+    cfg.base_length = 1000.0                                 # :129
+    cfg.base_radius = 50.0                                   # :130
+    cfg.density = 1000 * 1e-6                                # :280
+    cfg.youngs_modulus = 2e6                                 # :122
+    cfg.shear_modulus = 2e6 / (2.0 * (1.0 + 0.5))            # not passed at :272-283: PyElastica's default
+    cfg.damping_constant = 2e6 * 1e-7 * 1                    # :269
+    cfg.n_ctrl = 4                                           # :133
+    cfg.n_spline_pieces = 3
+    cfg.muscle_torque_scale = 10 * 50.0 * 2e6                # alpha, :350
+    cfg.max_activation_rate = float("inf")                   # :143
+    cfg.arm_target[0], cfg.arm_target[1], cfg.arm_target[2] = 500.0, 500.0, 500.0   # :147
+    return cfg
+
+
+def np_rint(x: float) -> float:
+    import numpy as np
+
+    return float(np.rint(x))
+
+
+def spline_table(base_length: float, n_ctrl: int):
+    """(breaks, coef) for softrod_set_spline_table: the cubic interpolating spline of
+    muscle_torques_with_bspline.py:150-152 — `make_interp_spline` through n_ctrl + 2 equidistant
+    points whose two end values are zero — as the piecewise-cubic form of its n_ctrl cardinal
+    functions (scipy BSpline -> PPoly)."""
+    import numpy as np
+    from scipy.interpolate import PPoly, make_interp_spline
+
+    x = np.linspace(0.0, base_length, n_ctrl + 2)
+    breaks, coef = None, None
+    for j in range(n_ctrl):
+        y = np.zeros(n_ctrl + 2)
+        y[1 + j] = 1.0
+        pp = PPoly.from_spline(make_interp_spline(x, y))
+        keep = np.nonzero(np.diff(pp.x) > 0)[0]               # drop the zero-length end pieces
+        if coef is None:
+            breaks = np.concatenate([pp.x[keep], pp.x[keep[-1] + 1:keep[-1] + 2]])
+            coef = np.zeros((len(keep), n_ctrl, 4))
+        coef[:, j, :] = pp.c[::-1, keep].T                    # ascending powers of (s - breaks[p])
+    return np.ascontiguousarray(breaks, np.float64), np.ascontiguousarray(coef, np.float64)
+
+
 def action_basis(n_elems: int, n_action: int = 7):
     """W with rest_kappa[0,:] = W @ action: set_action's cubic `interp1d`
     (octopus/arm_single_env.py:226-235) applied to unit vectors."""
@@ -362,6 +425,8 @@ _EXPORTS = {
     "softrod_config_softpendulum3d": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_arm_single": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_octo_flat": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_config_soft_arm": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_set_spline_table": (C.c_int, [_VP, _VP, _VP]),
     "softrod_config_action_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),
     "softrod_config_obs_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),
     "softrod_reset_octo": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),

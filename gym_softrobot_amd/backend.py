@@ -53,6 +53,11 @@ class HipRodBackend:
             else:
                 basis = _capi.action_basis(int(cfg.n_elem), self.action_dim)
             check(self._lib.softrod_set_action_basis(self._h, basis.ctypes.data), self._h)
+        if self.cfg.features & _capi.FEAT_SPLINE_MUSCLE_TORQUES:
+            breaks, coef = _capi.spline_table(float(cfg.base_length), int(cfg.n_ctrl))
+            if len(breaks) != int(cfg.n_spline_pieces) + 1:
+                raise _capi.SoftrodError("n_spline_pieces does not match the interpolant")
+            check(self._lib.softrod_set_spline_table(self._h, breaks.ctypes.data, coef.ctypes.data), self._h)
         n = self.n_envs
         with torch.cuda.device(self.device):
             self.obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=self.device)

@@ -32,6 +32,8 @@ struct softrod_handle {
     double* d_init = nullptr;     // [N][18] staging for reset
     uint8_t* d_mask = nullptr;    // [N]
     double* d_basis = nullptr;    // [(n_elem-1)][7] action basis (zero until set)
+    double* d_spline = nullptr;   // breaks[MAX_PIECES + 1], coef[pieces][n_ctrl][4] (softrod_set_spline_table)
+    bool spline_set = false;
     RodParams* d_params = nullptr;  // device copy of P
     bool basis_set = false;
     double* h_init = nullptr;     // pinned
@@ -170,6 +172,13 @@ void fill_params(const softrod_config& c, RodParams& P) {
         P.joint_nu = c.joint_nu;
         P.joint_kt = c.joint_kt;
     }
+    // SoftArmTracking-v0
+    P.n_ctrl = c.n_ctrl;
+    P.n_pieces = c.n_spline_pieces;
+    P.muscle_scale = c.muscle_torque_scale;
+    P.max_rate = c.max_activation_rate;
+    P.base_length = c.base_length;
+    for (int i = 0; i < 3; ++i) P.arm_target[i] = c.arm_target[i];
 }
 
 bool is_octo(const softrod_handle* h) { return (h->cfg.features & SOFTROD_FEAT_OCTO_HEAD) != 0; }
@@ -227,6 +236,8 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
                 SR_LAUNCH(SOFTROD_FEATURES_SOFTPENDULUM3D, SOFTROD_ENV_SOFTPENDULUM3D, EPL);        \
             else if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE && zup)        \
                 SR_LAUNCH(SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup, SOFTROD_ENV_ARM_SINGLE, EPL); \
+            else if (f == SOFTROD_FEATURES_SOFT_ARM && e == SOFTROD_ENV_SOFT_ARM)                   \
+                SR_LAUNCH(SOFTROD_FEATURES_SOFT_ARM, SOFTROD_ENV_SOFT_ARM, EPL);                    \
             else                                                                                    \
                 SR_LAUNCH(kRuntimeFeatures, kRuntimeEnv, EPL);                                      \
         } while (0)
@@ -312,18 +323,20 @@ int softrod_abi_version(void) { return SOFTROD_ABI_VERSION; }
 
 int softrod_action_dim(int env_kind) {
     return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 2 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 7
-         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 24 : 1;
+         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 24 : env_kind == SOFTROD_ENV_SOFT_ARM ? 8 : 1;
 }
 int softrod_obs_dim(int env_kind) {
     return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 9 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 25
-         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 8 * 56 + 13 : 4;
+         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 8 * 56 + 13 : env_kind == SOFTROD_ENV_SOFT_ARM ? 14 : 4;
 }
 int softrod_config_action_dim(const softrod_config* cfg) {
     if (!cfg) return 0;
+    if (cfg->env_kind == SOFTROD_ENV_SOFT_ARM) return 2 * cfg->n_ctrl;     // soft_arm_tracking.py:152-157
     return cfg->env_kind == SOFTROD_ENV_OCTO_FLAT ? cfg->n_arm * cfg->n_knots : softrod_action_dim(cfg->env_kind);
 }
 int softrod_config_obs_dim(const softrod_config* cfg) {
     if (!cfg) return 0;
+    if (cfg->env_kind == SOFTROD_ENV_SOFT_ARM) return 2 * cfg->n_ctrl + 6;  // :158-163
     if (cfg->env_kind != SOFTROD_ENV_OCTO_FLAT) return softrod_obs_dim(cfg->env_kind);
     return cfg->n_arm * ((cfg->n_elem - 1) + 4 * (cfg->n_elem + 1) + cfg->n_knots) + 13;
 }
@@ -417,6 +430,29 @@ int softrod_config_octo_flat(softrod_config* cfg, int n_envs) {
     return SOFTROD_OK;
 }
 
+int softrod_config_soft_arm(softrod_config* cfg, int n_envs) {
+    if (!cfg || n_envs < 1) return fail(nullptr, SOFTROD_EINVAL, "bad argument");
+    config_common(cfg, n_envs);
+    cfg->features = SOFTROD_FEATURES_SOFT_ARM;
+    cfg->env_kind = SOFTROD_ENV_SOFT_ARM;
+    cfg->n_elem = 40;                                    // soft_arm/soft_arm_tracking.py:116
+    cfg->dt = 2.0e-4;                                    // sim_dt, :117
+    cfg->n_substeps = (int)std::rint(0.01 / cfg->dt);    // num_steps_per_update, :118-121
+    cfg->final_time = 5.0;                               // max_episode_final_time, :127
+    cfg->base_length = 1000.0;                           // :129 (millimetres)
+    cfg->base_radius = 50.0;                             // :130
+    cfg->density = 1000 * 1e-6;                          // :280
+    cfg->youngs_modulus = 2e6;                           // :122
+    cfg->shear_modulus = 2e6 / (2.0 * (1.0 + 0.5));      // not passed at :272-283: PyElastica's default
+    cfg->damping_constant = 2e6 * 1e-7 * 1;              // :269
+    cfg->n_ctrl = 4;                                     // :132
+    cfg->n_spline_pieces = 3;                            // 4 + 2 points, not-a-knot
+    cfg->muscle_torque_scale = 10 * 50.0 * 2e6;          // alpha, :350
+    cfg->max_activation_rate = INFINITY;                 // :143
+    cfg->arm_target[0] = cfg->arm_target[1] = cfg->arm_target[2] = 500.0;   // :147
+    return SOFTROD_OK;
+}
+
 int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) {
     if (!cfg || !out) return fail(nullptr, SOFTROD_EINVAL, "null argument");
     *out = nullptr;
@@ -431,8 +467,20 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "need n_substeps >= 0 and dt > 0");
     if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
-    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_OCTO_FLAT)
+    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_SOFT_ARM)
         return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
+    {
+        const bool muscles = (cfg->features & SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) != 0;
+        if (muscles != (cfg->env_kind == SOFTROD_ENV_SOFT_ARM))
+            return fail(nullptr, SOFTROD_EINVAL,
+                        "SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES and SOFTROD_ENV_SOFT_ARM go together");
+        if (muscles && (cfg->math_mode != SOFTROD_MATH_FAST || cfg->n_ctrl < 1 || cfg->n_ctrl > 4 ||
+                        cfg->n_spline_pieces < 1 || cfg->n_spline_pieces > SOFTROD_MAX_SPLINE_PIECES ||
+                        cfg->n_elem - 1 < cfg->n_ctrl || !(cfg->max_activation_rate > 0.0)))
+            return fail(nullptr, SOFTROD_EINVAL,
+                        "spline muscles need SOFTROD_MATH_FAST, 1 <= n_ctrl <= 4, 1 <= n_spline_pieces <= 8, "
+                        "max_activation_rate > 0");
+    }
     const bool octo = (cfg->features & SOFTROD_FEAT_OCTO_HEAD) != 0;
     if (octo != (cfg->env_kind == SOFTROD_ENV_OCTO_FLAT))
         return fail(nullptr, SOFTROD_EINVAL, "SOFTROD_FEAT_OCTO_HEAD and SOFTROD_ENV_OCTO_FLAT go together");
@@ -505,6 +553,8 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     alloc((void**)&h->S.envmem, rowb);
     alloc((void**)&h->S.prev_action, N * (adim > 7 ? adim : 7) * sizeof(float));
     alloc((void**)&h->S.head, 20 * N * sizeof(double));
+    alloc((void**)&h->d_spline, (size_t)(SOFTROD_MAX_SPLINE_PIECES + 1 + SOFTROD_MAX_SPLINE_PIECES * 4 * 4) * sizeof(double));
+    h->P.spline = h->d_spline;
     alloc((void**)&h->d_params, sizeof(RodParams));
     if (rc == SOFTROD_OK && hipMemcpy(h->d_params, &h->P, sizeof(RodParams), hipMemcpyHostToDevice) != hipSuccess)
         rc = SOFTROD_EHIP;
@@ -734,6 +784,22 @@ int softrod_reset_straight(softrod_handle* h, const double* start, const double*
     return upload_and_reset(h, (hipStream_t)stream, mask != nullptr);
 }
 
+int softrod_set_spline_table(softrod_handle* h, const double* breaks, const double* coef) {
+    if (!h || !breaks || !coef) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (!(h->cfg.features & SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))
+        return fail(h, SOFTROD_EINVAL, "this handle has no spline muscles");
+    const int np = h->cfg.n_spline_pieces, nc = h->cfg.n_ctrl;
+    for (int p = 0; p < np; ++p)
+        if (!(breaks[p + 1] > breaks[p])) return fail(h, SOFTROD_EINVAL, "breaks must ascend");
+    std::vector<double> buf((size_t)SOFTROD_MAX_SPLINE_PIECES + 1 + (size_t)np * nc * 4, 0.0);
+    for (int p = 0; p <= np; ++p) buf[p] = breaks[p];
+    for (int i = 0; i < np * nc * 4; ++i) buf[SOFTROD_MAX_SPLINE_PIECES + 1 + i] = coef[i];
+    SR_HIP(h, hipSetDevice(h->device));
+    SR_HIP(h, hipMemcpy(h->d_spline, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->spline_set = true;
+    return SOFTROD_OK;
+}
+
 int softrod_set_action_basis(softrod_handle* h, const double* basis) {
     if (!h || !basis) return fail(h, SOFTROD_EINVAL, "null argument");
     SR_HIP(h, hipSetDevice(h->device));
@@ -749,6 +815,8 @@ int softrod_step(softrod_handle* h, const float* actions, float* obs, double* re
         return fail(h, SOFTROD_EINVAL, "null argument");
     if ((h->cfg.features & SOFTROD_FEAT_REST_KAPPA_ACTION) && !h->basis_set)
         return fail(h, SOFTROD_EINVAL, "softrod_set_action_basis must be called before softrod_step");
+    if ((h->cfg.features & SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) && !h->spline_set)
+        return fail(h, SOFTROD_EINVAL, "softrod_set_spline_table must be called before softrod_step");
     if (h->cfg.env_kind == SOFTROD_ENV_NONE)
         return fail(h, SOFTROD_EINVAL, "env_kind NONE has no step epilogue; use softrod_substeps");
     SR_HIP(h, hipSetDevice(h->device));
@@ -762,6 +830,8 @@ int softrod_step_packed(softrod_handle* h, const float* actions, float* packed, 
         return fail(h, SOFTROD_EINVAL, "env_kind NONE has no step epilogue; use softrod_substeps");
     if ((h->cfg.features & SOFTROD_FEAT_REST_KAPPA_ACTION) && !h->basis_set)
         return fail(h, SOFTROD_EINVAL, "softrod_set_action_basis must be called before softrod_step");
+    if ((h->cfg.features & SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) && !h->spline_set)
+        return fail(h, SOFTROD_EINVAL, "softrod_set_spline_table must be called before softrod_step");
     SR_HIP(h, hipSetDevice(h->device));
     return launch_step(h, actions, packed, nullptr, nullptr, nullptr, aux, h->cfg.n_substeps, 1, 1,
                        (hipStream_t)stream);
@@ -867,7 +937,7 @@ int softrod_destroy(softrod_handle* h) {
     if (h->h_produced) (void)hipHostFree(h->h_produced);
     if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_basis, h->d_init, h->d_mask};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_basis, h->d_spline, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

@@ -250,7 +250,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         const double vd = (len_n[s] + len[s]) * (0.5 * P.inv_rest_vor);
         const double rvd = fast_rcp(vd);
         const double e3 = rvd * rvd * rvd;
-        if (F == kRuntimeFeatures || (F & SOFTROD_FEAT_REST_KAPPA_ACTION)) {
+        if (F == kRuntimeFeatures || (F & (SOFTROD_FEAT_REST_KAPPA_ACTION | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))) {
             L.kap[s][0] = k0; L.kap[s][1] = k1; L.kap[s][2] = k2;
         }
         if (has<F>(P, SOFTROD_FEAT_REST_KAPPA_ACTION)) {
@@ -298,6 +298,13 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         tq[s][0] = fma(js01, w[0], tq[s][0]);
         tq[s][1] = fma(js01, w[1], tq[s][1]);
         tq[s][2] = fma(js2, w[2], tq[s][2]);
+    }
+    // forcing on the torques: the two spline muscles add their profiles to external_torques
+    // (compute_muscle_torques, muscle_torques_with_bspline.py:199-201), normal then binormal
+    if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)) {
+        if (L.mflag & 3) spline_muscle_rebuild<EPL>(P, lane, len, L);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) { tq[s][0] += L.rk[s][0]; tq[s][1] += L.rk[s][1]; }
     }
     connect(f, tq, L, xn);
     // plane contact
@@ -424,7 +431,7 @@ __device__ __attribute__((noinline)) void general_substeps_cold(const RodParams*
 // Two slots per lane need the whole 512-entry register file (1 wave per SIMD); the contact
 // and Laplace-filter instantiations trade a wave of occupancy for not spilling in the loop.
 template <unsigned F, int E, int EPL>
-__global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER))) ? SOFTROD_CONTACT_WAVES : SOFTROD_FAST_WAVES)))
+__global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))) ? SOFTROD_CONTACT_WAVES : SOFTROD_FAST_WAVES)))
 softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
@@ -443,6 +450,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     load_bc(S, N, rod, B);
     EnvAction A;
     set_action_n<F, E, EPL>(P, S, N, rod, lane, actions, A, B, L);
+    if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)) muscle_load<EPL>(P, S, rod, actions != nullptr, A, L);
     {
         BcTargets B0 = B;
         if (has<F>(P, SOFTROD_FEAT_MOVING_BASE_BC)) {
@@ -504,6 +512,9 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             general_substeps<F, EPL>(P, Pk, C, B, lane, L, time, n_sub);
     }
     store_lane<EPL, F>(S, N, rod, lane, L);
+    if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)) muscle_store<EPL>(P, S, rod, lane, L);
+    if (env_of<E>(P) == SOFTROD_ENV_SOFT_ARM && lane == 0)   // self.tick += 1 per substep, soft_arm_tracking.py:222
+        S.ctrl[(size_t)0 * N + rod] += (double)n_sub;
     if (lane == 0) S.time[rod] = time;
     if (epilogue)
         env_epilogue_n<E, EPL>(P, S, N, rod, lane, C, L, time, A, obs, reward, terminated, truncated, aux, pack);

@@ -87,6 +87,10 @@ struct RodParams {
     // OctoFlat-v0: n_arm rods per wave, `seg` slots apart (0 = one rod per wave), + rigid head
     int seg, n_arm, seg_shift, pad1;
     double head_mass, head_invJ[3], head_radius;   // the planar head only ever turns about d3
+    // SoftArmTracking: the two spline muscles (muscle_torques_with_bspline.py:98-126)
+    int n_ctrl, n_pieces;
+    double muscle_scale, max_rate, base_length, arm_target[3];
+    const double* spline;   // device: breaks[SOFTROD_MAX_SPLINE_PIECES + 1], then coef[p][j][4] (j < n_ctrl)
     double joint_k, joint_nu, joint_kt;
 };
 
@@ -187,6 +191,12 @@ struct LaneN {
     double Q[EPL][9], w[EPL][3];
     double t[EPL][3];
     double kap[EPL][3], rk[EPL][3];
+    // SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES (wave-uniform; dead code elsewhere): points_cached of the
+    // normal / binormal muscle, the control points of this env.step, and bits 0-1 "profile d
+    // must be rebuilt", bits 2-3 initial_call_flag d.  rk[.][0..1] hold the two torque profiles.
+    double pc[8];
+    float pin[8];
+    int mflag;
 };
 
 template <int EPL>
@@ -225,7 +235,7 @@ __device__ __forceinline__ void load_lane(const StatePtrs& S, size_t N, int rod,
             L.v[s][c] = S.vel[c * N * W + base + s];
             L.w[s][c] = S.omg[c * N * W + base + s];
             L.t[s][c] = S.tan[c * N * W + base + s];
-            if (F == kRuntimeFeatures || (F & SOFTROD_FEAT_REST_KAPPA_ACTION)) {
+            if (F == kRuntimeFeatures || (F & (SOFTROD_FEAT_REST_KAPPA_ACTION | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))) {
                 L.kap[s][c] = S.kap[c * N * W + base + s];
                 L.rk[s][c] = S.rkap[c * N * W + base + s];
             } else {
@@ -250,7 +260,7 @@ __device__ __forceinline__ void store_lane(const StatePtrs& S, size_t N, int rod
             S.vel[c * N * W + base + s] = L.v[s][c];
             S.omg[c * N * W + base + s] = L.w[s][c];
             S.tan[c * N * W + base + s] = L.t[s][c];
-            if (F == kRuntimeFeatures || (F & SOFTROD_FEAT_REST_KAPPA_ACTION))
+            if (F == kRuntimeFeatures || (F & (SOFTROD_FEAT_REST_KAPPA_ACTION | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)))
                 S.kap[c * N * W + base + s] = L.kap[s][c];
         }
 #pragma unroll
@@ -267,7 +277,7 @@ struct BcTargets {
 
 // Per-env action handling done once per env.step before the substeps.
 struct EnvAction {
-    float a[7];         // raw action (float32), as many as the env has
+    float a[8];         // raw action (float32), as many as the env has
     double force;       // SoftPendulum: point_force[0] (float32 value held in float64)
 };
 
@@ -619,6 +629,39 @@ __device__ __forceinline__ void arm_get_state_n(const RodParams& P, const StateP
     }
 }
 
+// SoftArmTrackingEnv.get_state (soft_arm/soft_arm_tracking.py:160-207): segment means of
+// kappa[0], kappa[1] as of the last force evaluation, scaled by base_length / 2 pi; the tip
+// position / base_length; the target / 1000.  st: [2 n_ctrl + 6], valid in every lane.
+template <int EPL>
+__device__ __forceinline__ void soft_arm_get_state_n(const RodParams& P, const StatePtrs& S, size_t N, int rod,
+                                                     int lane, const LaneN<EPL>& L, double (&st)[14]) {
+    const int n = P.n_elem, ns = P.n_ctrl, nv = n - 1, avg = nv / ns;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) st[i] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= ns) continue;
+            const int lo = avg * i, hi = (i == ns - 1) ? nv : avg * (i + 1);
+            double part = 0.0;
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) {
+                const int idx = lane * EPL + s;
+                part += (idx >= lo && idx < hi) ? L.kap[s][c] : 0.0;
+            }
+            st[c * ns + i] = (wave_sum(part) / (double)(hi - lo)) * P.base_length / (2.0 * M_PI);
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double xs = 0.0;
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) xs = (n % EPL == s) ? L.x[s][c] : xs;
+        st[2 * ns + c] = __shfl(xs, n / EPL) / P.base_length;
+        st[2 * ns + 3 + c] = S.ctrl[(size_t)(1 + c) * N + rod] / 1000.0;
+    }
+}
+
 template <int EPL>
 __device__ __forceinline__ double theta_n(const RodParams& P, int lane, const LaneN<EPL>& L) {
     double tm[3];
@@ -654,6 +697,11 @@ __device__ __forceinline__ void env_observe_n(const RodParams& P, const StatePtr
         }
     } else if (env == SOFTROD_ENV_ARM_SINGLE) {
         arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, pa, o);
+    } else if (env == SOFTROD_ENV_SOFT_ARM) {
+        double st[14];
+        soft_arm_get_state_n<EPL>(P, S, N, rod, lane, L, st);
+        if (lane == 0)
+            for (int i = 0; i < 2 * P.n_ctrl + 6; ++i) o[i] = (float)st[i];
     } else {
         const double th = theta_n<EPL>(P, lane, L);
         if (lane == 0) {
@@ -683,7 +731,7 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
     }
     const bool invalid = __any(bad);
     const int env = env_of<E>(P);
-    if (lane == 0) {   // set_action: self._prev_action[:] = action
+    if (lane == 0 && env != SOFTROD_ENV_SOFT_ARM) {   // set_action: self._prev_action[:] = action
 #pragma unroll
         for (int i = 0; i < 7; ++i) S.prev_action[7 * (size_t)rod + i] = A.a[i];
     }
@@ -704,6 +752,33 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
             o[3] = (float)L.v[0][0]; o[4] = (float)L.v[0][1]; o[5] = (float)L.v[0][2];
             o[6] = A.a[0]; o[7] = A.a[1];
             o[8] = (float)tilt;
+        }
+    } else if (env == SOFTROD_ENV_SOFT_ARM) {
+        // step(), soft_arm_tracking.py:226-259
+        double st[14];
+        soft_arm_get_state_n<EPL>(P, S, N, rod, lane, L, st);
+        const int od = 2 * P.n_ctrl + 6;
+        if (lane == 0) {
+            double d2 = 0.0;
+            bool nan = false;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double d = (st[2 * P.n_ctrl + 3 + c] * 1000.0 - st[2 * P.n_ctrl + c] * P.base_length) / 1000.0;
+                d2 += d * d;
+            }
+            for (int i = 0; i < od; ++i) nan = nan || isnan(st[i]);
+            const double nrm = sqrt(d2);
+            double r = -(nrm * nrm);
+            if (nan) r = -100.0;
+            float* o = out_row(obs, rod, od, pack);
+            const double tick = S.ctrl[(size_t)0 * N + rod];
+            emit_scalars(o, od, pack, rod, r, nan, tick * P.dt >= P.final_time, reward, terminated, truncated,
+                         S.needs_reset);
+            for (int i = 0; i < od; ++i) {
+                double v = st[i];
+                if (nan) v = isnan(v) ? 0.0 : (isinf(v) ? copysign(1.7976931348623157e308, v) : v);   // np.nan_to_num
+                o[i] = (float)v;
+            }
         }
     } else if (env == SOFTROD_ENV_ARM_SINGLE) {
         double pw = 0.0;
@@ -795,7 +870,7 @@ __device__ __forceinline__ void set_action_n(const RodParams& P, const StatePtrs
                                              BcTargets& B, LaneN<EPL>& L) {
     constexpr size_t W = (size_t)kLanes * EPL;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
+    for (int i = 0; i < 8; ++i) A.a[i] = 0.0f;
     A.force = 0.0;
     const int env = env_of<E>(P);
     if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
@@ -838,9 +913,115 @@ __device__ __forceinline__ void set_action_n(const RodParams& P, const StatePtrs
                 }
             }
         }
+    } else if (env == SOFTROD_ENV_SOFT_ARM) {
+        // step(): spline_points_func_array_*[:] = action halves (soft_arm_tracking.py:211-216)
+        if (actions) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) A.a[i] = (i < 2 * P.n_ctrl) ? actions[(size_t)(2 * P.n_ctrl) * rod + i] : 0.0f;
+        }
     } else {
         if (actions) A.a[0] = actions[rod];
         A.force = (double)A.a[0];
+    }
+}
+
+// ---- SoftArmTracking: MuscleTorquesWithVaryingBetaSplines x 2 --------------------------------
+// State of the two forcing objects between launches lives in the env-memory row:
+// [0 .. 2 n_ctrl) points_cached, [8 .. 8 + 2 n_ctrl) the control points last set, [16], [17]
+// initial_call_flag; the torque profiles in rest-kappa rows 0 and 1.
+template <int EPL>
+__device__ __forceinline__ void muscle_load(const RodParams& P, const StatePtrs& S, int rod, bool have_action,
+                                            const EnvAction& A, LaneN<EPL>& L) {
+    const double* row = S.envmem + (size_t)rod * kLanes * EPL;
+    const int nc = P.n_ctrl;
+    int flag = 0;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = j < nc;
+            L.pc[4 * d + j] = on ? row[d * nc + j] : 0.0;
+            L.pin[4 * d + j] = on ? (have_action ? A.a[d * nc + j] : (float)row[8 + d * nc + j]) : 0.0f;
+            same = same && (L.pc[4 * d + j] == (double)L.pin[4 * d + j]);
+        }
+        const bool init = row[16 + d] != 0.0;
+        flag |= (init ? 4 : 0) << d;
+        flag |= ((!same || !init) ? 1 : 0) << d;          // muscle_torques_with_bspline.py:137-140
+    }
+    L.mflag = flag;
+}
+template <int EPL>
+__device__ __forceinline__ void muscle_store(const RodParams& P, const StatePtrs& S, int rod, int lane,
+                                             const LaneN<EPL>& L) {
+    double* row = S.envmem + (size_t)rod * kLanes * EPL;
+    const int nc = P.n_ctrl;
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nc) { row[d * nc + j] = L.pc[4 * d + j]; row[8 + d * nc + j] = (double)L.pin[4 * d + j]; }
+            row[16 + d] = ((L.mflag >> (2 + d)) & 1) ? 1.0 : 0.0;
+        }
+    }
+    constexpr size_t W = (size_t)kLanes * EPL;
+    const size_t N = (size_t)P.n_envs;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const size_t m = (size_t)rod * W + (size_t)lane * EPL + s;
+        S.rkap[0 * N * W + m] = L.rk[s][0];
+        S.rkap[1 * N * W + m] = L.rk[s][1];
+    }
+}
+// apply_torques' rebuild branch (:137-158): rate filter on points_cached, then the interpolant
+// (piecewise-cubic form, softrod_set_spline_table) at np.cumsum(system.lengths).  Rare — once
+// per env.step, twice when the filter's rounding leaves points_cached one ulp off the input.
+template <int EPL>
+__device__ __forceinline__ void spline_muscle_rebuild(const RodParams& P, int lane, const double (&len)[EPL],
+                                                   LaneN<EPL>& L) {
+    const int n = P.n_elem, nc = P.n_ctrl, np = P.n_pieces;
+    double run[EPL], tot = 0.0;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        tot += (lane * EPL + s < n) ? len[s] : 0.0;
+        run[s] = tot;
+    }
+    double inc = tot;
+#pragma unroll
+    for (int off = 1; off < kLanes; off <<= 1) {
+        const double y = __shfl_up(inc, off);
+        inc += (lane >= off) ? y : 0.0;
+    }
+    const double excl = inc - tot;
+    const double* breaks = P.spline;
+    const double* coef = P.spline + (SOFTROD_MAX_SPLINE_PIECES + 1);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        if (!((L.mflag >> d) & 1)) continue;
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double in = (double)L.pin[4 * d + j];
+            const double diff = in - L.pc[4 * d + j];
+            const double sg = (double)((diff > 0.0) - (diff < 0.0));
+            L.pc[4 * d + j] += sg * fmin(P.max_rate, fabs(diff));              // filter_activation, :221-225
+            same = same && (L.pc[4 * d + j] == in);
+        }
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const double cum = excl + run[s];
+            int p = 0;
+            for (int q = 1; q < np; ++q) p += (cum >= breaks[q]) ? 1 : 0;
+            const double ds = cum - breaks[p];
+            double val = 0.0;
+            for (int j = 0; j < nc; ++j) {
+                const double* c = coef + (size_t)(p * nc + j) * 4;
+                val += L.pc[4 * d + j] * fma(fma(fma(c[3], ds, c[2]), ds, c[1]), ds, c[0]);
+            }
+            L.rk[s][d] = (lane * EPL + s < n) ? P.muscle_scale * val : 0.0;     // :156-158
+        }
+        L.mflag = (L.mflag & ~(1 << d)) | (4 << d) | ((same ? 0 : 1) << d);
     }
 }
 
@@ -1093,11 +1274,12 @@ softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __rest
     ConstN<EPL> C;
     build_const<kRuntimeFeatures, EPL>(P, lane, A, C);
     const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2
-                   : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : 1;
+                   : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 0 : 1;
     float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = 0; i < adim; ++i)
         pa[i] = prev_action ? prev_action[adim * (size_t)rod + i] : S.prev_action[7 * (size_t)rod + i];
-    const int od = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 9 : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 25 : 4;
+    const int od = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 9 : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 25
+                 : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 2 * P.n_ctrl + 6 : 4;
     env_observe_n<kRuntimeEnv, EPL>(P, S, N, rod, lane, C, L, pa, obs + (size_t)od * rod);
 }
 
@@ -1167,6 +1349,10 @@ __device__ __forceinline__ void reset_rod(const RodParams& P, const StatePtrs& S
         for (int i = 0; i < 9; ++i) S.bc[(size_t)(3 + i) * N + rod] = in[9 + i];
 #pragma unroll
         for (int i = 0; i < 4; ++i) S.ctrl[(size_t)i * N + rod] = (i < 2) ? com[i] : 0.0;
+        if (P.env_kind == SOFTROD_ENV_SOFT_ARM) {   // tick = 0, wsol[0] (soft_arm_tracking.py:386,407-412)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) S.ctrl[(size_t)(1 + i) * N + rod] = P.arm_target[i];
+        }
     }
 }
 

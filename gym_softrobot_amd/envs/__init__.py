@@ -1,9 +1,11 @@
 from .arm_single import ArmSingleEnv, VecArmSingleEnv
 from .octo_flat import FlatEnv, VecOctoFlatEnv
+from .soft_arm import SoftArmTrackingEnv, VecSoftArmTrackingEnv
 from .soft_pendulum import SoftPendulumEnv, VecSoftPendulumEnv
 from .soft_pendulum_3d import SoftPendulum3DEnv, VecSoftPendulum3DEnv
 
 __all__ = [
     "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
     "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv",
+    "SoftArmTrackingEnv", "VecSoftArmTrackingEnv",
 ]

@@ -1,0 +1,125 @@
+"""SoftArmTracking-v0 on the MI355X batched Cosserat-rod stepper.
+
+Mirrors gym_softrobot/envs/soft_arm/soft_arm_tracking.py:104-483 (game_mode 1, the registered
+SoftArmTracking-v0): a 40-element arm clamped at its base (OneEndFixedBC), damped
+(AnalyticalLinearDamper), bent by two MuscleTorquesWithVaryingBetaSplines (normal and
+binormal, 4 control points each = the 8-dim action), reaching for a fixed target with its tip;
+50 PositionVerlet substeps per env.step, 500 steps per episode.  The target Sphere is appended
+to the reference's simulator without any connection and its state is overwritten every substep
+(:223-224, :428-436), so it does not act on the rod: here it is just the three numbers that
+enter the reward and the observation.
+
+The reference's observation and action spaces are float64; the C-ABI hands observations over
+as float32 (include/softrod.h), which this wrapper widens again — values agree to float32
+rounding (6e-8 relative, against the 1e-5 the parity tests allow).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .. import _capi
+from ..spaces import Box
+from .base import GymEnv as _GymEnv
+from .base import VecRodEnvBase
+
+
+class VecSoftArmTrackingEnv(VecRodEnvBase):
+    """N parallel SoftArmTracking-v0 envs resident on one GPU (see VecRodEnvBase)."""
+
+    metadata = {"render_modes": ["rgb_array", "human"], "render_fps": 30}
+    action_low, action_high = -1.0, 1.0               # soft_arm_tracking.py:152-157
+
+    def __init__(self, num_envs: int, game_mode: int = 1, render_mode: Optional[str] = None, *,
+                 n_elems: int = 40, device: int = 0, math_mode: int = _capi.MATH_FAST,
+                 numpy_output: bool = False, autoreset: bool = False, backend=None):
+        if game_mode != 1:
+            raise NotImplementedError("game_mode 2 (moving target) is not registered by the reference "
+                                      "(gym_softrobot/__init__.py:64-72) and is not built here")
+        cfg = _capi.soft_arm_config(num_envs, n_elems=n_elems, math_mode=math_mode)
+        super().__init__(num_envs, cfg, render_mode=render_mode, config_generate_video=False, device=device,
+                         numpy_output=numpy_output, autoreset=autoreset, backend=backend)
+        self.n_elem = n_elems
+        self.sim_dt = float(cfg.dt)
+        self.num_steps_per_update = int(cfg.n_substeps)
+        self.max_episode_final_time = float(cfg.final_time)
+        self.mode = game_mode
+
+    def _draw_reset(self, i):
+        return None                                   # game_mode 1 draws nothing from the RNG
+
+    def _queue_from_draws(self, draws, counts):
+        n, m = self.num_envs, max(1, int(counts.max()))
+        start = np.zeros((n, m, 3))
+        direction = np.tile(np.array([0.0, 1.0, 0.0]), (n, m, 1))
+        normal = np.tile(np.array([0.0, 0.0, 1.0]), (n, m, 1))
+        self.backend.queue_push_straight(start, direction, normal, counts)
+
+    def _reset_backend(self, mask, use_mask, draws=None):
+        n = self.num_envs
+        start = np.zeros((n, 3))
+        direction = np.tile(np.array([0.0, 1.0, 0.0]), (n, 1))   # rod pointing upwards, :266-268
+        normal = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1))
+        self.backend.reset_straight(start, direction, normal, mask.astype(np.uint8) if use_mask else None)
+
+    def _infos(self, times):
+        # truncation is `tick * sim_dt >= max_episode_final_time` (:253): an integer count, not
+        # the accumulated float time
+        ticks = self._steps * self.num_steps_per_update
+        return {"time": times, "ctime": times, "TimeLimit.truncated": ticks * self.sim_dt >= self.max_episode_final_time}
+
+
+class SoftArmTrackingEnv(_GymEnv):
+    """Drop-in for gym_softrobot's SoftArmTrackingEnv (soft_arm/soft_arm_tracking.py:104-548), N = 1."""
+
+    metadata = {"render_modes": ["rgb_array", "human"], "render_fps": 30}
+
+    def __init__(self, game_mode: int = 1, render_mode: Optional[str] = None, *, device: int = 0,
+                 math_mode: int = _capi.MATH_FAST, backend=None):
+        super().__init__()
+        if render_mode not in {None, *self.metadata["render_modes"]}:
+            raise ValueError(f"Unsupported render mode: {render_mode}")
+        self.render_mode = render_mode
+        self._vec = VecSoftArmTrackingEnv(1, game_mode, None, device=device, math_mode=math_mode,
+                                          numpy_output=True, backend=backend)
+        self.n_elem = 40
+        self.sim_dt = 2.0e-4
+        self.RL_update_interval = 0.01
+        self.num_steps_per_update = self._vec.num_steps_per_update
+        self.youngs_modulus = 2e6
+        self.torque_scale = 10
+        self.max_episode_final_time = 5
+        self.base_length = 1000
+        self.radius = 50
+        self.number_of_control_points = 4
+        self.number_of_observation_segments = 4
+        self.mode = game_mode
+        self.target_location = np.array([500, 500.0, 500])
+        self.action_space = Box(-1.0, 1.0, shape=(8,), dtype=np.float64)
+        self.observation_space = Box(-np.inf, np.inf, shape=(14,), dtype=np.float64)
+        self.tick = 0
+        self.time_tracker = np.float64(0.0)
+
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
+        super().reset(seed=seed)
+        obs, _ = self._vec.reset()
+        self.tick = 0
+        self.time_tracker = np.float64(0.0)
+        return np.asarray(obs[0], dtype=np.float64), {}
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float32).reshape(1, 8)
+        obs, reward, term, trunc, infos = self._vec.step(a)
+        self.tick += self.num_steps_per_update
+        self.time_tracker = np.float64(infos["time"][0])
+        return (np.asarray(obs[0], dtype=np.float64), float(reward[0]), bool(term[0]), bool(trunc[0]),
+                {"ctime": self.time_tracker})
+
+    def render(self):
+        if self.render_mode is None:
+            return None
+        raise NotImplementedError("rendering is outside the hot path (DESIGN.md, out of scope)")
+
+    def close(self):
+        self._vec.close()

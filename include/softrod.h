@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 7
+#define SOFTROD_ABI_VERSION 8
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -92,6 +92,12 @@ enum softrod_feature {
      *   octopus/build.py:52-132, utils/custom_elastica/joint.py:20-225,
      *   utils/custom_elastica/constraint.py:8-85                               */
     SOFTROD_FEAT_OCTO_HEAD = 1u << 10,
+    /* two MuscleTorquesWithVaryingBetaSplines ("normal", "binormal"): control points from the
+     * action, rate-limited, a cubic interpolating spline through them evaluated at the
+     * cumulative element lengths whenever the points changed, added to external_torques
+     *   soft_arm/soft_arm_tracking.py:352-383,
+     *   utils/custom_elastica/muscle_torque/muscle_torques_with_bspline.py:128-225       */
+    SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES = 1u << 11,
 };
 
 #define SOFTROD_FEATURES_SOFTPENDULUM                                             \
@@ -105,6 +111,9 @@ enum softrod_feature {
      SOFTROD_FEAT_ANALYTICAL_DAMPER | SOFTROD_FEAT_REST_KAPPA_ACTION)
 #define SOFTROD_FEATURES_OCTO_FLAT                                                \
     (SOFTROD_FEATURES_ARM_SINGLE | SOFTROD_FEAT_OCTO_HEAD)
+#define SOFTROD_FEATURES_SOFT_ARM                                                 \
+    (SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_ANALYTICAL_DAMPER |                    \
+     SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)
 
 /* env_kind: which env's set_action / NaN check / reward / observation the step
  * kernel's prologue and epilogue implement.                                     */
@@ -113,6 +122,7 @@ enum softrod_feature {
 #define SOFTROD_ENV_SOFTPENDULUM3D 2 /* soft_pendulum_3d/soft_pendulum_3d.py:93-174 */
 #define SOFTROD_ENV_ARM_SINGLE 3     /* octopus/arm_single_env.py:186-316           */
 #define SOFTROD_ENV_OCTO_FLAT 4      /* octopus/flat_env.py:231-408                 */
+#define SOFTROD_ENV_SOFT_ARM 5       /* soft_arm/soft_arm_tracking.py:160-259       */
 
 /* math_mode (HIP library only; the oracle always uses libm). */
 #define SOFTROD_MATH_LIBM 0 /* sqrt/sin/cos/acos/pow evaluated as written   */
@@ -187,12 +197,22 @@ typedef struct softrod_config {
     double joint_k;           /* body_arm_k  1e6        :36                     */
     double joint_nu;          /* 1e-3                   :128                    */
     double joint_kt;          /* body_arm_kt 1e0        :37                     */
+    /* ---- SoftArmTracking-v0 (soft_arm/soft_arm_tracking.py:107-158,261-383) ---- */
+    int32_t n_ctrl;           /* number_of_control_points per direction: 4  :132 */
+    int32_t n_spline_pieces;  /* polynomial pieces of the interpolant (3 for 4 + 2
+                                 points, not-a-knot); see softrod_set_spline_table */
+    double muscle_torque_scale; /* alpha = torque_scale * radius * E   :350        */
+    double max_activation_rate; /* max_rate_of_change_of_activation: inf  :143     */
+    double arm_target[3];     /* target_location (game_mode 1)          :147      */
 } softrod_config;
+
+#define SOFTROD_MAX_CTRL 8           /* control points per direction             */
+#define SOFTROD_MAX_SPLINE_PIECES 8
 
 /* Per-env I/O widths implied by env_kind (OctoFlat: at the reference's n_arm = 8,
  * n_elem = 10, n_knots = 3). */
-int softrod_action_dim(int env_kind); /* 1, 2, 7, 24                        */
-int softrod_obs_dim(int env_kind);    /* 4, 9, 25, 8*56 + 13 = 461          */
+int softrod_action_dim(int env_kind); /* 1, 2, 7, 24, 8                     */
+int softrod_obs_dim(int env_kind);    /* 4, 9, 25, 8*56 + 13 = 461, 14      */
 int softrod_aux_dim(int env_kind);    /* 0, 1 (info["tilt"], float64), 0    */
 /* The same for a given configuration: OctoFlat widths follow n_arm, n_elem and n_knots
  * (flat_env.py:112-141): action n_arm*n_knots; obs n_arm*((n-1) + 4(n+1) + n_knots) + 13,
@@ -225,14 +245,20 @@ typedef struct softrod_state_view {
     double* tangents; /* [3][n_envs][lane_stride]  as of the last force evaluation */
     double* time;     /* [n_envs]  simulated time (soft_pendulum.py:141,184) */
     double* control;  /* [4][n_envs]  MovingBaseController position x,y and
-                         velocity x,y (soft_pendulum_3d/build.py:15-20)      */
+                         velocity x,y (soft_pendulum_3d/build.py:15-20);
+                         SoftArmTracking: tick (substeps since reset, :222) and
+                         the target position x,y,z (wsol[tick], :218-219)     */
     double* kappa;    /* [3][n_envs][lane_stride]  rod.kappa as of the last force
                          evaluation (arm_single_env.py:189); maintained by the
                          feature sets with SOFTROD_FEAT_REST_KAPPA_ACTION     */
-    double* rest_kappa; /* [3][n_envs][lane_stride]  rod.rest_kappa (:235)    */
+    double* rest_kappa; /* [3][n_envs][lane_stride]  rod.rest_kappa (:235);
+                         SoftArmTracking: rows 0, 1 = torque_magnitude_cache of the
+                         normal / binormal muscle (muscle_torques_with_bspline.py:156) */
     double* env_memory; /* [n_envs][lane_stride]  ArmSingle: prev_kappa_state
                          [0..n-2] (arm_single_env.py:172,190-198); its
-                         prev_com_state lives in control[0..1]               */
+                         prev_com_state lives in control[0..1].  SoftArmTracking:
+                         [0 .. 2 n_ctrl) points_cached[1, 1:-1] of the two muscles,
+                         [16], [17] their initial_call_flag                    */
     float* prev_action; /* [n_envs][7]  the env's _prev_action, written by
                          softrod_step (soft_pendulum.py:165), cleared by reset
                          only where the reference does (soft_pendulum_3d.py:68);
@@ -254,6 +280,22 @@ int softrod_config_arm_single(softrod_config* cfg, int n_envs);
 /* Same for FlatEnv (octopus/flat_env.py:55-110) and build_octopus
  * (octopus/build.py:30-217): 8 arms of 10 elements, rigid head, joints.     */
 int softrod_config_octo_flat(softrod_config* cfg, int n_envs);
+/* Same for SoftArmTrackingEnv (soft_arm/soft_arm_tracking.py:107-158) and the
+ * simulator its reset builds (:261-383), game_mode 1.                       */
+int softrod_config_soft_arm(softrod_config* cfg, int n_envs);
+
+/* Replaces the constant part of
+ *   make_interp_spline(points_cached[0], points_cached[1])(cumsum(system.lengths))
+ * (muscle_torques_with_bspline.py:150-158): the interpolant through the n_ctrl + 2 control
+ * points (the two end values are zero) is linear in the control values,
+ *   S(s) = sum_j y_j phi_j(s),
+ * and every phi_j is a piecewise cubic on fixed breakpoints.  The caller passes that form:
+ *   breaks: host [n_spline_pieces + 1] float64, ascending
+ *   coef:   host [n_spline_pieces][n_ctrl][4] float64, ascending powers of (s - breaks[p])
+ * (scipy: PPoly.from_spline(make_interp_spline(x, e_j)); s outside the breaks uses the end
+ * pieces, as BSpline's default extrapolation does).  Needed before the first softrod_step
+ * of a handle with SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES.                          */
+int softrod_set_spline_table(softrod_handle* h, const double* breaks, const double* coef);
 
 /* Replaces the constant part of set_action's
  *   interp1d(linspace(0,1,n_action), action, kind="cubic")(linspace(0,1,n_seg))

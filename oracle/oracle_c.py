@@ -51,6 +51,11 @@ def _load(omp: bool) -> C.CDLL:
     lib.oracle_env_step3d.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     lib.oracle_reset_arm.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_env_step_arm.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    lib.oracle_set_spline_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_reset_soft_arm.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_spline_torque_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    lib.oracle_set_arm_target.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_env_step_soft_arm.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     lib.oracle_octo_create.restype = C.c_void_p
     lib.oracle_octo_create.argtypes = [C.POINTER(SoftrodConfig)]
     lib.oracle_octo_destroy.argtypes = [C.c_void_p]
@@ -195,6 +200,40 @@ class OracleRod:
             self._h, a.ctypes.data, rk.ctypes.data, obs.ctypes.data, rew.ctypes.data,
             term.ctypes.data, trunc.ctypes.data,
         )
+        return obs, float(rew[0]), bool(term[0]), bool(trunc[0])
+
+    # -- SoftArmTracking-v0 ----------------------------------------------------------
+    def reset_soft_arm(self) -> np.ndarray:
+        """The interpolant's table is built with scipy, exactly as the host side of the HIP
+        library gets it (gym_softrobot_amd._capi.spline_table)."""
+        from gym_softrobot_amd._capi import spline_table
+
+        br, cf = spline_table(float(self.cfg.base_length), int(self.cfg.n_ctrl))
+        assert len(br) == int(self.cfg.n_spline_pieces) + 1
+        self._lib.oracle_set_spline_table(self._h, br.ctypes.data, cf.ctypes.data)
+        obs = np.empty(2 * int(self.cfg.n_ctrl) + 6, np.float64)
+        self._lib.oracle_reset_soft_arm(self._h, obs.ctypes.data)
+        return obs
+
+    def spline_torque_probe(self, points, lengths):
+        nc = int(self.cfg.n_ctrl)
+        p = np.ascontiguousarray(points, np.float64).reshape(2 * nc)
+        ln = np.ascontiguousarray(lengths, np.float64).reshape(self.n)
+        tq = np.empty((3, self.n), np.float64)
+        cached = np.empty(2 * nc, np.float64)
+        self._lib.oracle_spline_torque_probe(self._h, p.ctypes.data, ln.ctypes.data, tq.ctypes.data,
+                                             cached.ctypes.data)
+        return tq, cached
+
+    def env_step_soft_arm(self, action):
+        nc = int(self.cfg.n_ctrl)
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(2 * nc)
+        obs = np.empty(2 * nc + 6, np.float64)
+        rew = np.empty(1, np.float64)
+        term = np.empty(1, np.uint8)
+        trunc = np.empty(1, np.uint8)
+        self._lib.oracle_env_step_soft_arm(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data,
+                                           term.ctypes.data, trunc.ctypes.data)
         return obs, float(rew[0]), bool(term[0]), bool(trunc[0])
 
     def get(self, name: str) -> np.ndarray:

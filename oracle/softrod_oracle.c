@@ -70,6 +70,16 @@ typedef struct oracle_rod {
     /* MovingBaseController, soft_pendulum_3d/build.py:15-20 */
     double ctrl_pos[3], ctrl_vel[3];
     float prev_action2[2]; /* SoftPendulum3DEnv._prev_action */
+    /* SoftArmTracking: the two MuscleTorquesWithVaryingBetaSplines (normal, binormal)
+     * muscle_torques_with_bspline.py:98-126 — points_array, points_cached[1,1:-1],
+     * initial_call_flag, torque_magnitude_cache; the interpolant's piecewise-cubic form */
+    double pts_input[2][SOFTROD_MAX_CTRL], pts_cached[2][SOFTROD_MAX_CTRL];
+    int pts_init[2];
+    double torque_mag[2][NMAX];
+    double spline_breaks[SOFTROD_MAX_SPLINE_PIECES + 1];
+    double spline_coef[SOFTROD_MAX_SPLINE_PIECES][SOFTROD_MAX_CTRL][4];
+    long tick;             /* soft_arm_tracking.py:222 */
+    double arm_target[3];  /* wsol[tick] */
 } oracle_rod;
 
 /* ------------------------------------------------------------------------- */
@@ -581,6 +591,40 @@ static void plane_contact(oracle_rod* r)
 
 /* synchronize(): forcing in registration order — GravityForces (build.py:88-91)
  * then PendulumPointForces which ASSIGNS (build.py:100-101) */
+/* MuscleTorquesWithVaryingBetaSplines.apply_torques, muscle_torques_with_bspline.py:128-176,
+ * for the two instances SoftArmTrackingEnv.reset registers (soft_arm_tracking.py:352-383:
+ * "normal" then "binormal").  `my_spline(cumulative_lengths)` is evaluated in the
+ * piecewise-cubic form of the interpolant (oracle_set_spline_table). */
+static void spline_muscle_torques(oracle_rod* r)
+{
+    const int n = r->n, nc = r->cfg.n_ctrl, np = r->cfg.n_spline_pieces;
+    for (int d = 0; d < 2; ++d) {
+        int same = 1;                                     /* np.array_equal(points_cached, points_array) :137 */
+        for (int j = 0; j < nc; ++j) same = same && (r->pts_cached[d][j] == r->pts_input[d][j]);
+        if (!same || !r->pts_init[d]) {
+            r->pts_init[d] = 1;
+            for (int j = 0; j < nc; ++j) {                /* filter_activation, :221-225 */
+                const double diff = r->pts_input[d][j] - r->pts_cached[d][j];
+                r->pts_cached[d][j] += sign_of(diff) * fmin(r->cfg.max_activation_rate, fabs(diff));
+            }
+            double cum = 0.0;
+            for (int k = 0; k < n; ++k) {                 /* np.cumsum(system.lengths), :153 */
+                cum += r->len[k];
+                int p = 0;
+                while (p + 1 < np && cum >= r->spline_breaks[p + 1]) ++p;
+                const double ds = cum - r->spline_breaks[p];
+                double val = 0.0;
+                for (int j = 0; j < nc; ++j) {
+                    const double* c = r->spline_coef[p][j];
+                    val += r->pts_cached[d][j] * (((c[3] * ds + c[2]) * ds + c[1]) * ds + c[0]);
+                }
+                r->torque_mag[d][k] = r->cfg.muscle_torque_scale * val;   /* :156-158 */
+            }
+        }
+        for (int k = 0; k < n; ++k) r->t_ext[d][k] += r->torque_mag[d][k];   /* compute_muscle_torques :199-201 */
+    }
+}
+
 static void apply_forcing(oracle_rod* r)
 {
     const int n = r->n;
@@ -590,6 +634,7 @@ static void apply_forcing(oracle_rod* r)
     if (r->cfg.features & SOFTROD_FEAT_POINT_FORCE_NODE0_X) r->f_ext[0][0] = r->point_force;
     if (r->cfg.features & SOFTROD_FEAT_TIP_FORCE)
         for (int i = 0; i < 3; ++i) r->f_ext[i][n] += r->cfg.tip_force[i];
+    if (r->cfg.features & SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) spline_muscle_torques(r);
 }
 
 /* _update_accelerations + overload_operator_dynamic_numba (v += dt*a) */
@@ -1039,6 +1084,103 @@ int oracle_set(oracle_rod* r, const char* name, const double* in)
         return 0;
     }
     return -1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SoftArmTracking-v0 (game_mode 1): soft_arm/soft_arm_tracking.py              */
+/* ------------------------------------------------------------------------- */
+void oracle_set_spline_table(oracle_rod* r, const double* breaks, const double* coef)
+{
+    const int np = r->cfg.n_spline_pieces, nc = r->cfg.n_ctrl;
+    for (int p = 0; p <= np; ++p) r->spline_breaks[p] = breaks[p];
+    for (int p = 0; p < np; ++p)
+        for (int j = 0; j < nc; ++j)
+            for (int q = 0; q < 4; ++q) r->spline_coef[p][j][q] = coef[(p * nc + j) * 4 + q];
+}
+
+/* get_state, :160-207 (float64, as the reference's observation space) */
+static void get_state_soft_arm(const oracle_rod* r, double* obs)
+{
+    const int n = r->n, ns = r->cfg.n_ctrl;       /* number_of_observation_segments = control points */
+    const int avg_length = (n - 1) / ns;
+    for (int c = 0; c < 2; ++c)
+        for (int i = 0; i < ns; ++i) {
+            const int lo = avg_length * i, hi = (i == ns - 1) ? (n - 1) : avg_length * (i + 1);
+            double s = 0.0;
+            for (int k = lo; k < hi; ++k) s += r->kappa[c][k];
+            obs[c * ns + i] = (s / (double)(hi - lo)) * r->cfg.base_length / (2.0 * M_PI);
+        }
+    for (int i = 0; i < 3; ++i) {
+        obs[2 * ns + i] = r->x[i][n] / r->cfg.base_length;
+        obs[2 * ns + 3 + i] = r->arm_target[i] / 1000.0;
+    }
+}
+
+void oracle_reset_soft_arm(oracle_rod* r, double* obs)   /* reset, :261-282,386-483 */
+{
+    const double start[3] = { 0.0, 0.0, 0.0 }, direction[3] = { 0.0, 1.0, 0.0 }, normal[3] = { 0.0, 0.0, 1.0 };
+    oracle_reset_straight(r, start, direction, normal);
+    r->time = 0.0;
+    r->tick = 0;
+    for (int d = 0; d < 2; ++d) {
+        r->pts_init[d] = 0;
+        for (int j = 0; j < SOFTROD_MAX_CTRL; ++j) r->pts_cached[d][j] = r->pts_input[d][j] = 0.0;
+        for (int k = 0; k < NMAX; ++k) r->torque_mag[d][k] = 0.0;
+    }
+    for (int i = 0; i < 3; ++i) r->arm_target[i] = r->cfg.arm_target[i];
+    get_state_soft_arm(r, obs);
+}
+
+/* test probe: one call of the two muscles' apply_torques with the given control points and
+ * element lengths (tests/golden/softarm_vectors.npz holds what the reference's own class gives) */
+void oracle_spline_torque_probe(oracle_rod* r, const double* points, const double* lengths,
+                                double* torques /* [3][n] */, double* cached /* [2 n_ctrl] */)
+{
+    const int n = r->n, nc = r->cfg.n_ctrl;
+    for (int j = 0; j < nc; ++j) { r->pts_input[0][j] = points[j]; r->pts_input[1][j] = points[nc + j]; }
+    for (int k = 0; k < n; ++k) r->len[k] = lengths[k];
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < n; ++k) r->t_ext[i][k] = 0.0;
+    spline_muscle_torques(r);
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < n; ++k) { torques[i * n + k] = r->t_ext[i][k]; r->t_ext[i][k] = 0.0; }
+    for (int j = 0; j < nc; ++j) { cached[j] = r->pts_cached[0][j]; cached[nc + j] = r->pts_cached[1][j]; }
+}
+
+void oracle_set_arm_target(oracle_rod* r, const double t[3]) { for (int i = 0; i < 3; ++i) r->arm_target[i] = t[i]; }
+
+/* step, :209-259.  The target sphere does not interact with the rod (it is appended to the
+ * simulator without a connection, :428-436, and its state is overwritten every substep,
+ * :223-224), so only its position enters — through the reward and the observation. */
+void oracle_env_step_soft_arm(oracle_rod* r, const float* action, double* obs, double* reward,
+                              uint8_t* terminated, uint8_t* truncated)
+{
+    const softrod_config* c = &r->cfg;
+    const int n = r->n, nc = c->n_ctrl;
+    for (int j = 0; j < nc; ++j) {
+        r->pts_input[0][j] = (double)action[j];
+        r->pts_input[1][j] = (double)action[nc + j];
+    }
+    for (int s = 0; s < c->n_substeps; ++s) {
+        position_verlet_step(r);
+        r->tick += 1;
+    }
+    double d2 = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        const double d = (r->arm_target[i] - r->x[i][n]) / 1000.0;
+        d2 += d * d;
+    }
+    const double nrm = sqrt(d2);                  /* -np.square(np.linalg.norm(tip_to_target)) */
+    *reward = -(nrm * nrm);
+    get_state_soft_arm(r, obs);
+    *terminated = 0;
+    int invalid = 0;
+    for (int i = 0; i < 2 * nc + 6; ++i) invalid = invalid || isnan(obs[i]);
+    if (invalid) {
+        *reward = -100.0;
+        for (int i = 0; i < 2 * nc + 6; ++i)      /* np.nan_to_num */
+            obs[i] = isnan(obs[i]) ? 0.0 : (isinf(obs[i]) ? copysign(1.7976931348623157e308, obs[i]) : obs[i]);
+        *terminated = 1;
+    }
+    *truncated = ((double)r->tick * c->dt >= c->final_time) ? 1 : 0;
 }
 
 size_t oracle_config_size(void) { return sizeof(softrod_config); }
