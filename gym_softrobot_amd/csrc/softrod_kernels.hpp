@@ -681,6 +681,12 @@ __device__ __forceinline__ double tilt_n(const RodParams& P, int lane, const Lan
     return acos(fmin(fmax(tm[2] / nrm, -1.0), 1.0));
 }
 
+// observation width of the single-rod envs (softrod_obs_dim)
+__device__ __forceinline__ int env_obs_dim(const RodParams& P) {
+    return (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 9 : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 25
+         : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 2 * P.n_ctrl + 6 : 4;
+}
+
 template <int E, int EPL>
 __device__ __forceinline__ void env_observe_n(const RodParams& P, const StatePtrs& S, size_t N, int rod,
                                               int lane, const ConstN<EPL>& C, const LaneN<EPL>& L,
@@ -1278,8 +1284,7 @@ softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __rest
     float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = 0; i < adim; ++i)
         pa[i] = prev_action ? prev_action[adim * (size_t)rod + i] : S.prev_action[7 * (size_t)rod + i];
-    const int od = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 9 : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 25
-                 : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 2 * P.n_ctrl + 6 : 4;
+    const int od = env_obs_dim(P);
     env_observe_n<kRuntimeEnv, EPL>(P, S, N, rod, lane, C, L, pa, obs + (size_t)od * rod);
 }
 
@@ -1399,7 +1404,7 @@ softrod_autoreset_kernel(const RodParams P, const StatePtrs S, float* __restrict
     float pa[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) pa[i] = S.prev_action[7 * (size_t)rod + i];
-    const int od = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 9 : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 25 : 4;
+    const int od = env_obs_dim(P);
     float* o = out_row(obs, rod, od, pack);
     env_observe_n<kRuntimeEnv, EPL>(P, S, N, rod, lane, C, L, pa, o);
     if (lane == 0) {

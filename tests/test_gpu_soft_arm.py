@@ -90,3 +90,30 @@ def test_truncation_after_five_seconds_and_determinism(torch_gpu, hip_lib):
     # the bent arm has moved its tip off the axis, the relaxed one has not
     assert abs(final[0, 8]) < 1e-6 and abs(final[1, 8]) + abs(final[1, 10]) > 1e-3
     env.close()
+
+
+def test_autoreset_host_and_device_agree(torch_gpu, hip_lib):
+    """NEXT_STEP auto-reset over the episode boundary (step 500 truncates, step 501 restarts):
+    the host-driven and the device-side form must give the same stream, bit for bit."""
+    import gym_softrobot_amd as gsa
+
+    rng = np.random.default_rng(5)
+    acts = (0.2 * rng.uniform(-1, 1, (8, 2, 8))).astype(np.float32)   # gentle: no blow-up before the time limit
+    outs = []
+    for mode in (True, "device"):
+        env = gsa.make_vec("SoftArmTracking-v0", 2, numpy_output=True, autoreset=mode)
+        env.reset(seed=0)
+        rows = []
+        for t in range(506):
+            obs, rew, term, trunc, _ = env.step(acts[t % 8])
+            if t >= 496:
+                rows.append((obs.copy(), rew.copy(), term.copy(), trunc.copy()))
+        outs.append(rows)
+        env.close()
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    # step 500 (index 3 of the kept rows) truncates; the step after it returns the reset observation
+    assert outs[0][3][3].all() and not outs[0][4][3].any()
+    z = np.load(GOLD / "softarm_vectors.npz")
+    np.testing.assert_allclose(outs[0][4][0][0], z["reset_obs"], rtol=0, atol=1e-7)
