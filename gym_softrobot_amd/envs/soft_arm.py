@@ -25,6 +25,30 @@ from .base import GymEnv as _GymEnv
 from .base import VecRodEnvBase
 
 
+def target_trajectory(final_time: float, sim_dt: float, target_v_scale: float, rng, every: int = 1):
+    """generate_trajectory (soft_arm_tracking.py:46-101) at every `every`-th sample: a product of
+    three sines per axis with frequencies, sign and a start time drawn from the env's RNG, in
+    millimetres, inside [-800, 800] x [-400 + 0.4, 400 + 0.4] x [-800, 800] (the reference adds
+    its 0.4 offset to y AFTER the scaling to millimetres, :85-86; kept).  Draw order as there:
+    the start time, then per axis three frequencies and the sign."""
+    end_time = final_time * 1.1
+    numpoints = int(np.rint(1 / sim_dt * end_time))
+    idx = np.arange(0, numpoints, every, dtype=np.float64)
+    t = end_time * idx / (numpoints - 1)
+    t += rng.random() * 3600
+    out = np.zeros((len(idx), 3))
+    for axis, amp in ((0, 0.8), (1, 0.4), (2, 0.8)):
+        f1 = rng.uniform(2, 5) * 0.025 * target_v_scale
+        f2 = rng.uniform(2, 5) * 0.025 * target_v_scale
+        f3 = rng.uniform(2, 5) * 0.025 * target_v_scale
+        direction = rng.integers(0, 2) * 2 - 1
+        out[:, axis] = (direction * amp * np.sin(2 * np.pi * f1 * t) * np.sin(2 * np.pi * f2 * t)
+                        * np.sin(2 * np.pi * f3 * t) * 1000)
+        if axis == 1:
+            out[:, 1] += 0.4
+    return out
+
+
 class VecSoftArmTrackingEnv(VecRodEnvBase):
     """N parallel SoftArmTracking-v0 envs resident on one GPU (see VecRodEnvBase)."""
 
@@ -34,9 +58,10 @@ class VecSoftArmTrackingEnv(VecRodEnvBase):
     def __init__(self, num_envs: int, game_mode: int = 1, render_mode: Optional[str] = None, *,
                  n_elems: int = 40, device: int = 0, math_mode: int = _capi.MATH_FAST,
                  numpy_output: bool = False, autoreset: bool = False, backend=None):
-        if game_mode != 1:
-            raise NotImplementedError("game_mode 2 (moving target) is not registered by the reference "
-                                      "(gym_softrobot/__init__.py:64-72) and is not built here")
+        if game_mode not in (1, 2):
+            raise ValueError("game_mode is 1 (fixed target) or 2 (moving target), soft_arm_tracking.py:386-412")
+        if game_mode == 2 and autoreset == "device":
+            raise NotImplementedError("game_mode 2 draws a trajectory per episode on the host: use autoreset=True")
         cfg = _capi.soft_arm_config(num_envs, n_elems=n_elems, math_mode=math_mode)
         super().__init__(num_envs, cfg, render_mode=render_mode, config_generate_video=False, device=device,
                          numpy_output=numpy_output, autoreset=autoreset, backend=backend)
@@ -45,9 +70,14 @@ class VecSoftArmTrackingEnv(VecRodEnvBase):
         self.num_steps_per_update = int(cfg.n_substeps)
         self.max_episode_final_time = float(cfg.final_time)
         self.mode = game_mode
+        self.target_v_scale = 0.1                     # :144
+        self._traj = None                             # game_mode 2: wsol at the env.step boundaries, (N, K, 3)
 
     def _draw_reset(self, i):
-        return None                                   # game_mode 1 draws nothing from the RNG
+        if self.mode == 1:
+            return None                               # game_mode 1 draws nothing from the RNG
+        return target_trajectory(self.max_episode_final_time, self.sim_dt, self.target_v_scale, self._rngs[i],
+                                 every=self.num_steps_per_update)
 
     def _queue_from_draws(self, draws, counts):
         n, m = self.num_envs, max(1, int(counts.max()))
@@ -62,6 +92,31 @@ class VecSoftArmTrackingEnv(VecRodEnvBase):
         direction = np.tile(np.array([0.0, 1.0, 0.0]), (n, 1))   # rod pointing upwards, :266-268
         normal = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1))
         self.backend.reset_straight(start, direction, normal, mask.astype(np.uint8) if use_mask else None)
+        if self.mode == 2:
+            import torch
+
+            if self._traj is None:
+                self._traj = np.zeros((n, int(np.rint(self.max_episode_final_time * 1.1 / self.sim_dt))
+                                       // self.num_steps_per_update + 1, 3))
+            for i in np.nonzero(mask)[0]:
+                tr = self._draw(int(i), draws)
+                self._traj[i, : len(tr)] = tr
+            # wsol[0] is what the reset observation shows (:476-477)
+            ctrl = self.backend.state()["control"]
+            tgt = torch.from_numpy(np.ascontiguousarray(self._traj[:, 0, :].T)).to(ctrl.device)
+            m = torch.from_numpy(np.asarray(mask, bool)).to(ctrl.device)
+            ctrl[1:4] = torch.where(m[None, :], tgt, ctrl[1:4])
+
+    def step(self, actions):
+        if self.mode == 2:
+            # the sphere follows wsol[tick] (:223): after this env.step tick = 50 (steps + 1)
+            import torch
+
+            k = np.minimum(self._steps + 1, self._traj.shape[1] - 1)
+            tgt = self._traj[np.arange(self.num_envs), k, :]
+            ctrl = self.backend.state()["control"]
+            ctrl[1:4] = torch.from_numpy(np.ascontiguousarray(tgt.T)).to(ctrl.device)
+        return super().step(actions)
 
     def _infos(self, times):
         # truncation is `tick * sim_dt >= max_episode_final_time` (:253): an integer count, not
@@ -96,6 +151,7 @@ class SoftArmTrackingEnv(_GymEnv):
         self.number_of_observation_segments = 4
         self.mode = game_mode
         self.target_location = np.array([500, 500.0, 500])
+        self.target_v_scale = 0.1
         self.action_space = Box(-1.0, 1.0, shape=(8,), dtype=np.float64)
         self.observation_space = Box(-np.inf, np.inf, shape=(14,), dtype=np.float64)
         self.tick = 0
@@ -103,7 +159,8 @@ class SoftArmTrackingEnv(_GymEnv):
 
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
         super().reset(seed=seed)
-        obs, _ = self._vec.reset()
+        self._vec._rngs[0] = self.np_random       # env-owned stream, as soft_arm_tracking.py:402-407
+        obs, _ = self._vec.reset(seed=None)
         self.tick = 0
         self.time_tracker = np.float64(0.0)
         return np.asarray(obs[0], dtype=np.float64), {}

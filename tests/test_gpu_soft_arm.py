@@ -117,3 +117,36 @@ def test_autoreset_host_and_device_agree(torch_gpu, hip_lib):
     assert outs[0][3][3].all() and not outs[0][4][3].any()
     z = np.load(GOLD / "softarm_vectors.npz")
     np.testing.assert_allclose(outs[0][4][0][0], z["reset_obs"], rtol=0, atol=1e-7)
+
+
+def test_game_mode_2_moving_target(torch_gpu, hip_lib, oracle_built):
+    """game_mode 2: the target follows the trajectory drawn from the env's RNG at reset
+    (pinned against the reference's generate_trajectory in tests/test_oracle_golden.py); it
+    enters the observation and the reward only.  Oracle: same rod, target set per step."""
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+
+    z = np.load(GOLD / "softarm_trajectory.npz")
+    env = gsa.make_vec("SoftArmTracking-v0", 2, game_mode=2, numpy_output=True)
+    obs, _ = env.reset(seed=[0, 42])
+    np.testing.assert_allclose(obs[0, 11:14], z["every50_0"][0] / 1000, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(obs[1, 11:14], z["every50_42"][0] / 1000, rtol=1e-6, atol=1e-7)
+    rng = np.random.default_rng(3)
+    o = oracle_built.OracleRod(_capi.soft_arm_config(1))
+    o.reset_soft_arm()
+    for t in range(10):
+        a = (0.5 * rng.uniform(-1, 1, (2, 8))).astype(np.float32)
+        obs, rew, term, trunc, _ = env.step(a)
+        np.testing.assert_allclose(obs[0, 11:14], z["every50_0"][t + 1] / 1000, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(obs[1, 11:14], z["every50_42"][t + 1] / 1000, rtol=1e-6, atol=1e-7)
+        tgt = np.ascontiguousarray(z["every50_0"][t + 1], np.float64)     # (kept alive across the call)
+        o._lib.oracle_set_arm_target(o._h, tgt.ctypes.data)
+        r_obs, r_rew, r_term, r_trunc = o.env_step_soft_arm(a[0])
+        np.testing.assert_allclose(obs[0], r_obs, rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(rew[0], r_rew, rtol=RTOL, atol=ATOL)
+    env.close()
+    # the single-env class takes the keyword like the reference's
+    e1 = gsa.make("SoftArmTracking-v0", game_mode=2)
+    ob, _ = e1.reset(seed=42)
+    np.testing.assert_allclose(ob[11:14], z["every50_42"][0] / 1000, rtol=1e-6, atol=1e-7)
+    e1.close()

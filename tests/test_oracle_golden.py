@@ -290,3 +290,22 @@ def test_soft_arm_reset_observation(oracle_built):
     avg = (n - 1) // ns
     seg = [(avg * i, avg * (i + 1) if i < ns - 1 else n - 1) for i in range(ns)]
     np.testing.assert_array_equal(np.array(seg), z["obs_segments"])
+
+
+def test_soft_arm_target_trajectory_against_the_reference_function():
+    """tests/golden/softarm_trajectory.npz: the reference's own generate_trajectory
+    (soft_arm_tracking.py:46-101, executed from its syntax tree by
+    tools/make_softarm_trajectory_golden.py) at the env.step boundaries; the host-side
+    restatement must give the same numbers and leave the RNG stream where the reference does."""
+    from gym_softrobot_amd.envs.soft_arm import target_trajectory
+
+    z = np.load(GOLD / "softarm_trajectory.npz")
+    for seed in z["seeds"]:
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(seed))))
+        w = target_trajectory(5, 2.0e-4, 0.1, rng, every=50)
+        np.testing.assert_allclose(w, z[f"every50_{seed}"], rtol=0, atol=1e-9)
+        assert rng.random() == z[f"next_draw_{seed}"][0]
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(seed))))
+        full = target_trajectory(5, 2.0e-4, 0.1, rng)
+        assert full.shape == tuple(z["shape"])
+        np.testing.assert_allclose(full[[1, 7, 12345, 27499]], z[f"probe_{seed}"], rtol=0, atol=1e-9)
