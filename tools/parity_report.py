@@ -77,6 +77,14 @@ def main():
     doc["OctoArmSingle-v0 (100 elements, two-window kernel)"] = run(
         "OctoArmSingle-v0", 4, 10, 6.0, arm, lambda r, a: r.env_step_arm(a)[:2], f, n_elems=100)
 
+    def softarm(env, i):
+        r = oracle_c.OracleRod(env.cfg)
+        r.reset_soft_arm()
+        return r
+
+    doc["SoftArmTracking-v0"] = run("SoftArmTracking-v0", 8, 10, 1.0, softarm,
+                                    lambda r, a: r.env_step_soft_arm(a)[:2], f)
+
     def octo(env, i):
         o = oracle_c.OracleOcto(env.cfg)
         o.reset(env.targets[i])
