@@ -88,8 +88,11 @@ def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: 20 + 100 env.steps stay inside one SoftPendulum episode (truncation fires on step
+    # 126), and the warm-up covers the ~20 launches the GPU clock takes to settle after the reset
+    # (profiles/README.md r1f: 0.38 ms per launch at first, 0.34 ms from then on)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=None,
                     help=f"default {ENVS_PER_GPU}; OctoFlat-v0: 1024 (BASELINE configs[4]: 8192 envs on 8 GPUs)")
     ap.add_argument("--math-mode", choices=["fast", "libm"], default="fast")
@@ -163,7 +166,7 @@ def main() -> None:
     amax = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
             "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0}[args.env]
     # the truncation flag of SoftPendulum first fires on env.step #126; the default window
-    # (55 steps) stays inside one episode
+    # (120 steps) stays inside one episode
     T = W + K
     acts = np.random.default_rng(1).uniform(-amax, amax, (T, n_total, adim)).astype(np.float32)
     acts_dev = torch.from_numpy(acts[:, lo:hi].copy()).to(local.backend.device)
