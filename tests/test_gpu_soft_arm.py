@@ -38,18 +38,22 @@ def test_reset_observation_and_spaces(torch_gpu, hip_lib):
     env.close()
 
 
-@pytest.mark.parametrize("n_envs,steps", [(3, 12), (1, 40)])
-def test_rollout_matches_oracle(torch_gpu, hip_lib, oracle_built, n_envs, steps):
+@pytest.mark.parametrize("n_envs,steps,n_elems", [(3, 12, 40), (1, 40, 40), (2, 6, 20), (2, 6, 80)])
+def test_rollout_matches_oracle(torch_gpu, hip_lib, oracle_built, n_envs, steps, n_elems):
+    """40 elements as the reference; 20 and 80 (two slots per lane) exercise the slot-generic
+    prefix sum and segment means."""
     import gym_softrobot_amd as gsa
     from gym_softrobot_amd import _capi
 
     rng = np.random.default_rng(11 + n_envs)
     acts = rng.uniform(-1, 1, (steps, n_envs, 8)).astype(np.float32)
+    if n_elems == 80:
+        acts *= 0.2                       # dt = 2e-4 is near the stability limit of 12.5 mm elements
     acts[3] = acts[2]                     # unchanged control points: the cached profile is kept
-    env = gsa.make_vec("SoftArmTracking-v0", n_envs, numpy_output=True)
+    env = gsa.make_vec("SoftArmTracking-v0", n_envs, numpy_output=True, n_elems=n_elems)
     obs0, _ = env.reset(seed=0)
     got = [env.step(acts[t]) for t in range(steps)]
-    cfg1 = _capi.soft_arm_config(1)
+    cfg1 = _capi.soft_arm_config(1, n_elems=n_elems)
     for i in range(n_envs):
         o, ref = _oracle_rollout(oracle_built, cfg1, acts[:, i])
         np.testing.assert_allclose(obs0[i], ref[0][0], rtol=RTOL, atol=ATOL)
