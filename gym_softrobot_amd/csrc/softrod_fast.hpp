@@ -492,10 +492,12 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             const double tb = P.time_two_half_adds ? P.half_dt : 0.0;
             // two half kinematic steps between force evaluations are one whole step; the last
             // substep (half a step) is peeled so that the loop's step length is a constant
+            // (the step length as a vector register where scalar ones are short: uniform_k)
+            const double step_dt = EPL > 1 ? opaque_v(P.dt) : P.dt;
             planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
             for (int s = 0; s + 1 < n_sub; ++s) {
                 planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
-                planar_kinematic_n<EPL>(P.dt, K.hq_dt, C, K, Z);
+                planar_kinematic_n<EPL>(step_dt, K.hq_dt, C, K, Z);
                 time = (time + ta) + tb;
             }
             planar_dynamic_n<EPL>(Pk, C, K, lane, Z);

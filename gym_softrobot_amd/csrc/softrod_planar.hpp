@@ -54,6 +54,8 @@ struct PlanarN {
     double wz[EPL];            // rotation rate about z: omega = (0, s2 wz, 0) in the local frame
     double t[EPL][2];          // tangents as of the last force evaluation
     double dl[EPL];            // bending angle between elements k and k+1
+    double d[EPL][2];          // edge vector x_{k+1} - x_k, carried: dd/dt = v_{k+1} - v_k
+    double dv[EPL][2];         // v_{k+1} - v_k of the current velocities
 };
 
 // loop-invariant per-lane products (see the header) and the opaque polynomial coefficients
@@ -66,10 +68,17 @@ struct PlanarC {
     double hq_dt[EPL], hq_hdt[EPL];  // C.hq * dt, C.hq * dt/2
     double jr;                     // J * rest_len:          J / e = jr / len
     double s3, s2, s1, c3, c2, e4, e3;
+    double eps_length, rest_len, damp_t;   // RodParams values the loop uses (see uniform_k)
 };
 
 __device__ __forceinline__ double opaque_s(double k) { asm("" : "+s"(k)); return k; }
 __device__ __forceinline__ double opaque_v(double k) { asm("" : "+v"(k)); return k; }
+// A wave-uniform constant for the loop: a scalar register at one slot per lane; a vector
+// register at two — that instantiation has 512 vector registers and runs out of the 102 scalar
+// ones (64 v_readlane per substep of spilled scalars otherwise).
+template <int EPL>
+__device__ __forceinline__ double uniform_k(double k) { return EPL > 1 ? opaque_v(k) : opaque_s(k); }
+
 // x = m * x + a written over x (the compiler's v_fmac would put it over a and copy it back)
 __device__ __forceinline__ void fma_inplace(double& x, double m, double a) {
     asm("v_fma_f64 %0, %1, %0, %2" : "+v"(x) : "v"(m), "v"(a));
@@ -101,12 +110,17 @@ __device__ __forceinline__ void planar_build_const(const RodParams& P, const Con
         K.bk[s] = C.b01[s] * (P.inv_rest_vor * (1.0 + P.acos_shift * (1.0 / 3.0))) * (two_vor * two_vor * two_vor);
         K.xl[s] = (lane * EPL + s) < P.n_elem ? P.damp_logr[0] * P.inv_rest_len : 0.0;
         K.hq_dt[s] = C.hq[s] * P.dt;
+        if (EPL > 1) K.hq_dt[s] = opaque_v(K.hq_dt[s]);     // (or it is recomputed in the loop from a spilled dt)
         K.hq_hdt[s] = C.hq[s] * P.half_dt;
     }
     K.jr = P.J[0] * P.rest_len;
-    K.s3 = opaque_s(-1.0 / 5040.0); K.s2 = opaque_v(1.0 / 120.0); K.s1 = opaque_s(-1.0 / 6.0);
-    K.c3 = opaque_s(-1.0 / 720.0); K.c2 = opaque_v(1.0 / 24.0);
-    K.e4 = opaque_s(1.0 / 24.0); K.e3 = opaque_v(1.0 / 6.0);
+    K.s3 = uniform_k<EPL>(-1.0 / 5040.0); K.s2 = opaque_v(1.0 / 120.0); K.s1 = uniform_k<EPL>(-1.0 / 6.0);
+    K.c3 = uniform_k<EPL>(-1.0 / 720.0); K.c2 = opaque_v(1.0 / 24.0);
+    K.e4 = uniform_k<EPL>(1.0 / 24.0); K.e3 = opaque_v(1.0 / 6.0);
+    K.eps_length = EPL > 1 ? opaque_v(P.eps_length) : P.eps_length;
+    K.rest_len = EPL > 1 ? opaque_v(P.rest_len) : P.rest_len;
+    K.damp_t = EPL > 1 ? opaque_v(P.damp_t) : P.damp_t;
+    if (EPL > 1) K.jr = opaque_v(K.jr);
 }
 
 // exp(x) for the damper (see exp_pair)
@@ -147,6 +161,16 @@ __device__ __forceinline__ bool planar_from_lane(const RodParams& P, const BcTar
         Z.wz[s] = (idx < n) ? Z.s2 * L.w[s][1] : 0.0;
         Z.t[s][0] = L.t[s][0]; Z.t[s][1] = L.t[s][1];
     }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        double a[EPL], o[EPL], av[EPL], ov[EPL];
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) { a[s] = Z.x[s][c]; av[s] = Z.v[s][c]; }
+        shift_next<EPL>(a, o);
+        shift_next<EPL>(av, ov);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) { Z.d[s][c] = o[s] - a[s]; Z.dv[s][c] = ov[s] - av[s]; }
+    }
     {
         double cnx[EPL], snx[EPL];
         shift_next<EPL>(Z.c, cnx);
@@ -186,6 +210,11 @@ __device__ __forceinline__ void planar_kinematic_n(double h, const double (&hq_h
         const double hp = h * C.hx[s];
         Z.x[s][0] = fma(hp, Z.v[s][0], Z.x[s][0]);
         Z.x[s][1] = fma(hp, Z.v[s][1], Z.x[s][1]);
+        // the edge vectors move with the velocity differences (no node is held in x or y by a
+        // position constraint in this feature set: hx = 1), so the next force evaluation needs
+        // no neighbour positions
+        Z.d[s][0] = fma(h, Z.dv[s][0], Z.d[s][0]);
+        Z.d[s][1] = fma(h, Z.dv[s][1], Z.d[s][1]);
         const double a = hq_h[s] * Z.wz[s];
         ra[s] = a;
         const double t = a * a;
@@ -216,37 +245,27 @@ __device__ __forceinline__ void planar_kinematic_n(double h, const double (&hq_h
 template <int EPL>
 __device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const ConstN<EPL>& C,
                                                  const PlanarC<EPL>& K, int lane, PlanarN<EPL>& Z) {
-    double xn[EPL][2], vn[EPL][2], d[EPL][2];
+    double d[EPL][2];
     double len[EPL], il[EPL];
     double qt0[EPL], qt2[EPL], np0[EPL], np2[EPL], cs[EPL][2], f[EPL][2], tq[EPL];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        double a[EPL], o[EPL], av[EPL], ov[EPL];
-#pragma unroll
-        for (int s = 0; s < EPL; ++s) { a[s] = Z.x[s][c]; av[s] = Z.v[s][c]; }
-        shift_next<EPL>(a, o);
-        shift_next<EPL>(av, ov);
-#pragma unroll
-        for (int s = 0; s < EPL; ++s) { xn[s][c] = o[s]; vn[s][c] = ov[s]; }
-    }
     // geometry and shear/stretch in the frame (d1', d3) with d1' = s2 d1 = (-s, c): Q t has no
     // d2 component, so n = S (Q t - z/e) has none; qt0, np0 are s2 times the 3-D ones
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        d[s][0] = xn[s][0] - Z.x[s][0];
-        d[s][1] = xn[s][1] - Z.x[s][1];
+        d[s][0] = Z.d[s][0];
+        d[s][1] = Z.d[s][1];
         // slots past the last element have d = 0: clamped, they stay finite and their zero
         // stiffnesses keep them out of every sum
         const double dd = fmax(fma(d[s][1], d[s][1], d[s][0] * d[s][0]), 1.0e-20);
         const double r = rsqrt3(dd);
-        len[s] = fma(dd, r, P.eps_length);
-        il[s] = fma(-P.eps_length * r, r, r);
+        len[s] = fma(dd, r, K.eps_length);
+        il[s] = fma(-K.eps_length * r, r, r);
         Z.t[s][0] = d[s][0] * il[s];
         Z.t[s][1] = d[s][1] * il[s];
         qt0[s] = fma(Z.c[s], Z.t[s][1], -Z.s[s] * Z.t[s][0]);
         qt2[s] = fma(Z.s[s], Z.t[s][1], Z.c[s] * Z.t[s][0]);
         np0[s] = C.s01[s] * qt0[s];
-        np2[s] = C.s2[s] * fma(-P.rest_len, il[s], qt2[s]);
+        np2[s] = C.s2[s] * fma(-K.rest_len, il[s], qt2[s]);
         cs[s][0] = fma(Z.c[s], np2[s], -Z.s[s] * np0[s]);
         cs[s][1] = fma(Z.s[s], np2[s], Z.c[s] * np0[s]);
     }
@@ -280,17 +299,28 @@ __device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const Const
     for (int s = 0; s < EPL; ++s) {
         tq[s] = fma(len[s], fma(qt2[s], np0[s], -qt0[s] * np2[s]), tq[s]);
         // (J / e) (de/dt / e) = J rest_len (t . dv) / l^2
-        const double tdv = fma(Z.t[s][1], vn[s][1] - Z.v[s][1], Z.t[s][0] * (vn[s][0] - Z.v[s][0]));
+        const double tdv = fma(Z.t[s][1], Z.dv[s][1], Z.t[s][0] * Z.dv[s][0]);
         tq[s] = fma((K.jr * il[s] * il[s]) * tdv, Z.wz[s], tq[s]);
     }
     // rate update fused with the analytical damper; constrain_rates (v_y of node 0) is the zero
     // in cfy / cay
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        Z.v[s][0] = fma(C.cf[s], f[s][0], fma(P.damp_t, Z.v[s][0], C.ca[s][0]));
-        Z.v[s][1] = fma(K.cfy[s], f[s][1], fma(P.damp_t, Z.v[s][1], K.cay[s]));
+        Z.v[s][0] = fma(C.cf[s], f[s][0], fma(K.damp_t, Z.v[s][0], C.ca[s][0]));
+        Z.v[s][1] = fma(K.cfy[s], f[s][1], fma(K.damp_t, Z.v[s][1], K.cay[s]));
         const double w = fma(K.cwl[s] * len[s], tq[s], Z.wz[s]);
         Z.wz[s] = w * exp_one<EPL>(K, K.xl[s] * len[s]);
+    }
+    // velocity differences of the new velocities: for the edge vectors' step and the next
+    // dilatation rate
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        double av[EPL], ov[EPL];
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) av[s] = Z.v[s][c];
+        shift_next<EPL>(av, ov);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) Z.dv[s][c] = ov[s] - av[s];
     }
 }
 
