@@ -8,7 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"
+# bench.py's own defaults (20 warm-up + 100 timed steps): the profile is of the SAME command
+ARGS="--no-cpu-baseline $*"
 
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- \
     python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1

@@ -44,6 +44,17 @@ def kernel_stats(root):
     return out
 
 
+def timed_launches(root):
+    """Durations (ns) of the step kernel's launches in start order, from the kernel trace."""
+    rows = []
+    for p in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        for r in read_csv(p):
+            if is_step_kernel(r.get("Kernel_Name", "")):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows.sort()
+    return [d for _, d in rows]
+
+
 def counters(root, sub):
     """-> {counter_name: [per-dispatch values of the step kernel]} and register info"""
     vals = defaultdict(list)
@@ -97,6 +108,22 @@ def main(root):
                         }
                     except Exception:  # noqa: BLE001
                         pass
+    # the launches bench.py times are the LAST `steps` ones (the warm-up runs at a lower clock):
+    # their average is the number to hold against roofline.kernel_ms_avg of the same command
+    dur = timed_launches(root)
+    steps = None
+    p = os.path.join(root, "bench_trace.log")
+    if os.path.exists(p):
+        for line in open(p):
+            if line.startswith("{"):
+                try:
+                    steps = int(json.loads(line)["steps"])
+                except Exception:  # noqa: BLE001
+                    pass
+    if dur and steps and len(dur) >= steps:
+        doc["step_kernel_timed_launches"] = steps
+        doc["step_kernel_timed_avg_ms"] = sum(dur[-steps:]) / steps / 1e6
+        doc["step_kernel_warmup_avg_ms"] = (sum(dur[:-steps]) / max(1, len(dur) - steps)) / 1e6
     print(json.dumps(doc, indent=1))
 
 
