@@ -85,17 +85,8 @@ __device__ __forceinline__ void fma_inplace(double& x, double m, double a) {
 }
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
-// third-order refinements of the hardware seeds (relative error 2^-23 -> 2^-69)
-__device__ __forceinline__ double rcp3(double x) {
-    const double r = __builtin_amdgcn_rcp(x);
-    const double e = fma(-x, r, 1.0);
-    return fma(r, fma(e, e, e), r);
-}
-__device__ __forceinline__ double rsqrt3(double x) {
-    const double r = __builtin_amdgcn_rsq(x);
-    const double e = fma(-(0.5 * x) * r, r, 0.5);          // -(d + d^2/2) for r = (1 + d)/sqrt(x)
-    return fma(r, e * fma(1.5, e, 1.0), r);                // 1 + e + 3/2 e^2 = 1/(1 + d) + O(d^3)
-}
+__device__ __forceinline__ double rcp3(double x) { return fast_rcp(x); }       // (third order, softrod_kernels.hpp)
+__device__ __forceinline__ double rsqrt3(double x) { return fast_rsqrt(x); }
 
 template <int EPL>
 __device__ __forceinline__ void planar_build_const(const RodParams& P, const ConstN<EPL>& C, int lane,
