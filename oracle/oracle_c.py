@@ -55,6 +55,7 @@ def _load(omp: bool) -> C.CDLL:
     lib.oracle_reset_soft_arm.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_spline_torque_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     lib.oracle_set_arm_target.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_observe_soft_arm.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_env_step_soft_arm.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     lib.oracle_octo_create.restype = C.c_void_p
     lib.oracle_octo_create.argtypes = [C.POINTER(SoftrodConfig)]
@@ -213,6 +214,15 @@ class OracleRod:
         self._lib.oracle_set_spline_table(self._h, br.ctypes.data, cf.ctypes.data)
         obs = np.empty(2 * int(self.cfg.n_ctrl) + 6, np.float64)
         self._lib.oracle_reset_soft_arm(self._h, obs.ctypes.data)
+        return obs
+
+    def set_arm_target(self, target) -> None:
+        t = np.ascontiguousarray(target, np.float64).reshape(3)
+        self._lib.oracle_set_arm_target(self._h, t.ctypes.data)
+
+    def observe_soft_arm(self) -> np.ndarray:
+        obs = np.empty(2 * int(self.cfg.n_ctrl) + 6, np.float64)
+        self._lib.oracle_observe_soft_arm(self._h, obs.ctypes.data)
         return obs
 
     def spline_torque_probe(self, points, lengths):

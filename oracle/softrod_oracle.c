@@ -1146,6 +1146,7 @@ void oracle_spline_torque_probe(oracle_rod* r, const double* points, const doubl
 }
 
 void oracle_set_arm_target(oracle_rod* r, const double t[3]) { for (int i = 0; i < 3; ++i) r->arm_target[i] = t[i]; }
+void oracle_observe_soft_arm(const oracle_rod* r, double* obs) { get_state_soft_arm(r, obs); }
 
 /* step, :209-259.  The target sphere does not interact with the rod (it is appended to the
  * simulator without a connection, :428-436, and its state is overwritten every substep,

@@ -20,6 +20,9 @@ class OracleBackend:
         self.is3d = cfg.env_kind == _capi.ENV_SOFTPENDULUM3D
         self.isarm = cfg.env_kind == _capi.ENV_ARM_SINGLE
         self.isocto = cfg.env_kind == _capi.ENV_OCTO_FLAT
+        self.issoftarm = cfg.env_kind == _capi.ENV_SOFT_ARM
+        # softrod_state_view.control: SoftArmTracking keeps tick and the target there
+        self._ctrl = torch.zeros((4, int(cfg.n_envs)), dtype=torch.float64)
         self.action_dim = _capi.config_action_dim(cfg)
         self.obs_dim = _capi.config_obs_dim(cfg)
         if self.isocto:
@@ -36,7 +39,7 @@ class OracleBackend:
         self._queue = None          # device-side auto-reset emulation (softrod_queue_*)
 
     def state(self):
-        return {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64)}
+        return {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64), "control": self._ctrl}
 
     def rod_snapshot(self, env_indices):
         rods = [self.rods[i] for i in env_indices]
@@ -58,6 +61,10 @@ class OracleBackend:
                     self._prev[i] = 0.0   # SoftPendulum3DEnv.reset clears _prev_action
                 if self.isarm:
                     r.reset_arm()   # also re-arms prev_kappa_state / prev_com_state
+                elif self.issoftarm:
+                    r.reset_soft_arm()
+                    self._ctrl[0, i] = 0.0
+                    self._ctrl[1:4, i] = torch.tensor(list(self.cfg.arm_target), dtype=torch.float64)
                 else:
                     r.reset_straight(start[i], direction[i], normal[i])
 
@@ -156,6 +163,9 @@ class OracleBackend:
                 o = r.observe3d()
                 o[6:8] = pa[i]   # the env owns _prev_action; the rod only sees it at step time
                 self.obs[i] = torch.from_numpy(o)
+            elif self.issoftarm:
+                r.set_arm_target(self._ctrl[1:4, i].numpy())
+                self.obs[i] = torch.from_numpy(r.observe_soft_arm().astype(np.float32))
             elif self.isarm:
                 # get_state at reset: rates are zero, kappa is zero (straight arm)
                 o = np.zeros(25, np.float32)
@@ -189,6 +199,11 @@ class OracleBackend:
                 self.aux[i, 0] = tilt
             elif self.isarm:
                 o, rw, te, tr = r.env_step_arm(a[i])
+            elif self.issoftarm:
+                r.set_arm_target(self._ctrl[1:4, i].numpy())
+                o, rw, te, tr = r.env_step_soft_arm(a[i])
+                o = o.astype(np.float32)
+                self._ctrl[0, i] += int(self.cfg.n_substeps)
             else:
                 o, rw, te, tr = r.env_step(a[i, 0])
             self.obs[i] = torch.from_numpy(o)

@@ -383,3 +383,52 @@ def test_rod_recorder_matches_oracle_strains(oracle_built):
     env.reset()
     assert len(env.rod_parameters_dict["time"]) == 0
     env.close()
+
+
+def test_soft_arm_env_host_logic_on_the_oracle_backend(oracle_built):
+    """SoftArmTracking's Gymnasium classes driven by the CPU oracle instead of the HIP library
+    (tests/oracle_backend.py): spaces and dtypes of the single-env class, game_mode 2's
+    per-step target upload (the trajectory is pinned against the reference's function in
+    test_oracle_golden.py), and the host-driven NEXT_STEP auto-reset drawing a NEW trajectory
+    from the env's stream."""
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.envs.soft_arm import target_trajectory
+    from gym_softrobot_amd.seeding import np_random
+    from tests.oracle_backend import OracleBackend
+
+    env = gsa.SoftArmTrackingEnv(backend=OracleBackend(_capi.soft_arm_config(1)))
+    assert env.observation_space.shape == (14,) and env.observation_space.dtype == np.float64
+    assert env.action_space.shape == (8,)
+    ob, info = env.reset(seed=1)
+    assert ob.dtype == np.float64 and info == {} and env.observation_space.contains(ob)
+    np.testing.assert_allclose(ob[8:14], [0, 1, 0, 0.5, 0.5, 0.5], atol=1e-7)
+    ob, rew, term, trunc, info = env.step(env.action_space.sample())
+    assert isinstance(rew, float) and isinstance(term, bool) and isinstance(trunc, bool) and "ctime" in info
+    assert rew == pytest.approx(-np.sum((ob[11:14] - ob[8:11]) ** 2), rel=1e-5)
+    env.close()
+
+    # game_mode 2 on a short episode (final_time 0.03 s = 3 env.steps) with host auto-reset
+    cfg = _capi.soft_arm_config(2)
+    cfg.final_time = 0.03
+    vec = gsa.VecSoftArmTrackingEnv(2, game_mode=2, backend=OracleBackend(cfg), numpy_output=True, autoreset=True)
+    vec.max_episode_final_time = 0.03
+    obs, _ = vec.reset(seed=[5, 6])
+    rng5, _ = np_random(5)
+    tr_a = target_trajectory(0.03, 2.0e-4, 0.1, rng5, every=50)
+    np.testing.assert_allclose(obs[0, 11:14], tr_a[0] / 1000, rtol=1e-6, atol=1e-7)
+    a = np.zeros((2, 8), np.float32)
+    for k in range(1, 4):
+        obs, rew, term, trunc, _ = vec.step(a)
+        np.testing.assert_allclose(obs[0, 11:14], tr_a[k] / 1000, rtol=1e-6, atol=1e-7)
+    assert trunc.all() and not term.any()                     # tick * dt >= 0.03 after 3 steps
+    obs, rew, term, trunc, _ = vec.step(a)                    # NEXT_STEP: restart, new trajectory, same stream
+    tr_b = target_trajectory(0.03, 2.0e-4, 0.1, rng5, every=50)
+    assert not trunc.any() and (rew == 0).all()
+    np.testing.assert_allclose(obs[0, 11:14], tr_b[0] / 1000, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(obs[0, 8:11], [0, 1, 0], atol=1e-7)
+    obs, *_ = vec.step(a)
+    np.testing.assert_allclose(obs[0, 11:14], tr_b[1] / 1000, rtol=1e-6, atol=1e-7)
+    vec.close()
+    with pytest.raises(NotImplementedError):
+        gsa.VecSoftArmTrackingEnv(1, game_mode=2, backend=OracleBackend(_capi.soft_arm_config(1)), autoreset="device")
