@@ -33,6 +33,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+# SQ_INSTS_VALU per rod-substep measured with rocprofv3 --pmc (profiles/README.md), by (env, n_elem)
+VALU_PER_ROD_SUBSTEP = {("SoftPendulum-v0", 50): 99.5, ("SoftPendulum3D-v0", 50): 596.0,
+                        ("OctoArmSingle-v0", 50): 597.0, ("SoftArmTracking-v0", 40): 349.0}
 ENVS_PER_GPU = 4096
 N_ELEM = 50
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -267,6 +270,14 @@ def main() -> None:
                             "SIMD-cycles per rod-substep below vs ~4 x fp64 instruction count (profiles/README.md)",
                     "simd_cycles_per_rod_substep_at_2.4GHz":
                         kernel_ms * 1e-3 * 2.4e9 * 1024 / (n_local * rods_per_env * nsub),
+                    # measured SQ_INSTS_VALU per rod-substep of this workload's kernel (profiles/README.md;
+                    # tools/pmc_valu_per_substep.sh), and the share of the VALU issue slots they fill
+                    # at the nominal 2.4 GHz — the roofline of the unit that actually bounds the kernel
+                    "valu_instructions_per_rod_substep": VALU_PER_ROD_SUBSTEP.get((args.env, int(cfg.n_elem))),
+                    "valu_issue_frac_at_2.4GHz":
+                        None if (args.env, int(cfg.n_elem)) not in VALU_PER_ROD_SUBSTEP else
+                        4.0 * VALU_PER_ROD_SUBSTEP[(args.env, int(cfg.n_elem))]
+                        / (kernel_ms * 1e-3 * 2.4e9 * 1024 / (n_local * rods_per_env * nsub)),
                 },
                 "kernel_ms_avg": kernel_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
