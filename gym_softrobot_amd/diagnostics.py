@@ -72,3 +72,50 @@ class RodRecorder:
             p["omega"].append(snap["w"][k].copy())
             p["sigma"].append(s["sigma"])
             p["kappa"].append(s["kappa"])
+
+
+class OctoRecorder:
+    """FlatEnv's taps (octopus/flat_env.py:188-206): one RodCallBack dict per arm
+    (`rod_parameters_dict_list`, when config_generate_video) and the head's
+    RigidCylinderCallBack dict (`head_dict`: time, step, position, velocity —
+    callback_func.py:4-20 — when config_save_head_data), for ONE env of the batch, sampled
+    once per env.step like the reference's `current_step % step_skip == 0`."""
+
+    def __init__(self, backend, env_index: int = 0, rods: bool = True, head: bool = True):
+        self.backend = backend
+        self.env_index = int(env_index)
+        cfg = backend.cfg
+        self.n_arm = int(cfg.n_arm)
+        self.rest_length = float(cfg.base_length) / int(cfg.n_elem)
+        self.base_radius = float(cfg.base_radius)
+        self.acos_shift = float(cfg.acos_shift)
+        self.eps_sin = float(cfg.eps_sin)
+        self.n_substeps = int(cfg.n_substeps)
+        self.rod_parameters_dict_list = [defaultdict(list) for _ in range(self.n_arm)] if rods else None
+        self.head_dict = defaultdict(list) if head else None
+        self._steps = 0
+
+    def record(self) -> None:
+        st = self.backend.octo_state_numpy()
+        e = self.env_index
+        self._steps += 1
+        t = float(st["time"][e])
+        if self.rod_parameters_dict_list is not None:
+            for a, p in enumerate(self.rod_parameters_dict_list):
+                x, Q = st["x"][e, a], st["Q"][e, a]
+                s = rod_strains(x, Q, self.rest_length, self.base_radius, self.acos_shift, self.eps_sin)
+                p["time"].append(t)
+                p["radius"].append(s["radius"])
+                p["dilatation"].append(s["dilatation"])
+                p["voronoi_dilatation"].append(s["voronoi_dilatation"])
+                p["position"].append(x.copy())
+                p["director"].append(Q.copy())
+                p["velocity"].append(st["v"][e, a].copy())
+                p["omega"].append(st["w"][e, a].copy())
+                p["sigma"].append(s["sigma"])
+                p["kappa"].append(s["kappa"])
+        if self.head_dict is not None:
+            self.head_dict["time"].append(t)
+            self.head_dict["step"].append(self._steps * self.n_substeps)
+            self.head_dict["position"].append(st["head_x"][e].reshape(3, 1).copy())
+            self.head_dict["velocity"].append(st["head_v"][e].reshape(3, 1).copy())

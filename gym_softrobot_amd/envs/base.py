@@ -249,6 +249,12 @@ class VecRodEnvBase:
             from ..diagnostics import RodRecorder
 
             self.recorder = RodRecorder(self.backend, self.record_envs)   # fresh dict per reset (:118)
+        elif self.is_octo and (self.config_generate_video or getattr(self, "config_save_head_data", False)):
+            from ..diagnostics import OctoRecorder
+
+            # flat_env.py:188-206: per-arm RodCallBack dicts and the head's dict, fresh per reset
+            self.recorder = OctoRecorder(self.backend, self.record_envs[0], rods=self.config_generate_video,
+                                         head=self.config_save_head_data)
         return self._out(obs), {}
 
     @property
@@ -258,7 +264,17 @@ class VecRodEnvBase:
     @property
     def rod_parameters_dict(self):
         """The reference's `rod_parameters_dict` for the first recorded env."""
-        return None if self.recorder is None else self.recorder.params[0]
+        return None if self.recorder is None or self.is_octo else self.recorder.params[0]
+
+    @property
+    def rod_parameters_dict_list(self):
+        """FlatEnv.rod_parameters_dict_list (octopus/flat_env.py:190-198): one dict per arm."""
+        return getattr(self.recorder, "rod_parameters_dict_list", None)
+
+    @property
+    def head_dict(self):
+        """FlatEnv.head_dict (octopus/flat_env.py:199-206)."""
+        return getattr(self.recorder, "head_dict", None)
 
     def _step_device_autoreset(self, a):
         import torch

@@ -52,8 +52,7 @@ class VecOctoFlatEnv(VecRodEnvBase):
     ):
         if policy_mode != "centralized":
             raise NotImplementedError("only policy_mode='centralized' is implemented")
-        if config_save_head_data or config_generate_video:
-            raise NotImplementedError("diagnostic taps exist for the single-rod envs only (diagnostics.py)")
+        self.config_save_head_data = bool(config_save_head_data)
         cfg = _capi.octo_flat_config(
             num_envs, final_time=final_time, time_step=time_step, recording_fps=recording_fps,
             n_elems=n_elems, n_arm=n_arm, n_action=n_action, math_mode=math_mode,
@@ -181,6 +180,16 @@ class FlatEnv(_GymEnv):
         if self.render_mode is None:
             return None
         raise NotImplementedError("rendering is outside the hot path (DESIGN.md, out of scope)")
+
+    @property
+    def rod_parameters_dict_list(self):
+        """One RodCallBack dict per arm (flat_env.py:190-198), with config_generate_video=True."""
+        return self._vec.rod_parameters_dict_list
+
+    @property
+    def head_dict(self):
+        """The head's RigidCylinderCallBack dict (flat_env.py:199-206), with config_save_head_data=True."""
+        return self._vec.head_dict
 
     def close(self):
         self._vec.close()

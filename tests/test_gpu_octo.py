@@ -389,3 +389,34 @@ def test_octo_crossing_count_against_the_reference_function(torch_gpu, hip_lib):
     assert np.all(np.abs(rew + 0.02 * got) < 1e-3)
     np.testing.assert_array_equal(got, z["count"])
     be.close()
+
+
+def test_octo_diagnostic_taps(hip_lib):
+    """FlatEnv(config_generate_video=True, config_save_head_data=True): one RodCallBack dict per
+    arm and the head's dict, one sample per env.step (octopus/flat_env.py:188-206,
+    utils/custom_elastica/callback_func.py:4-41)."""
+    import gym_softrobot_amd as gsa
+
+    env = gsa.make("OctoFlat-v0", config_generate_video=True, config_save_head_data=True, recording_fps=71)
+    env.reset(seed=0)
+    assert len(env.rod_parameters_dict_list) == 8 and len(env.head_dict["time"]) == 0
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        obs, *_ = env.step(rng.uniform(-5, 5, 24).astype(np.float32))
+    n = 10
+    for p in env.rod_parameters_dict_list:
+        assert set(p) == {"time", "radius", "dilatation", "voronoi_dilatation", "position", "director",
+                          "velocity", "omega", "sigma", "kappa"}
+        assert len(p["time"]) == 3 and p["position"][-1].shape == (3, n + 1)
+        assert p["director"][-1].shape == (3, 3, n) and p["kappa"][-1].shape == (3, n - 1)
+        assert np.all(np.isfinite(p["kappa"][-1])) and np.allclose(p["dilatation"][-1], 1.0, atol=0.05)
+    hd = env.head_dict
+    assert set(hd) == {"time", "step", "position", "velocity"} and hd["step"] == [201, 402, 603]
+    assert hd["position"][-1].shape == (3, 1) and hd["time"][-1] == pytest.approx(3 * 201 * 7.0e-5, rel=1e-9)
+    # every arm's base node stays on the head's rim (joint springs): |x_arm0 - x_head| ~ head radius
+    for p in env.rod_parameters_dict_list:
+        d = p["position"][-1][:2, 0] - hd["position"][-1][:2, 0]
+        assert np.hypot(*d) == pytest.approx(0.04, abs=2e-3)
+    env.reset(seed=0)
+    assert len(env.head_dict["time"]) == 0           # fresh dicts per reset
+    env.close()
