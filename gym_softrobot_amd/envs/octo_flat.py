@@ -50,8 +50,8 @@ class VecOctoFlatEnv(VecRodEnvBase):
         autoreset: bool = False,
         backend=None,
     ):
-        if policy_mode != "centralized":
-            raise NotImplementedError("only policy_mode='centralized' is implemented")
+        if policy_mode not in ("centralized", "decentralized"):
+            raise NotImplementedError                   # flat_env.py:131-132
         self.config_save_head_data = bool(config_save_head_data)
         cfg = _capi.octo_flat_config(
             num_envs, final_time=final_time, time_step=time_step, recording_fps=recording_fps,
@@ -90,9 +90,21 @@ class VecOctoFlatEnv(VecRodEnvBase):
         self.backend.reset_octo(self.targets, mask.astype(np.uint8) if use_mask else None)
 
     def split_obs(self, obs):
-        """(N, obs_dim) -> {"individual": (N, n_arm, width), "shared": (N, 13)} (views)."""
+        """(N, obs_dim) -> {"individual": (N, n_arm, width), "shared": (N, 13)} (views).
+        policy_mode "decentralized" (flat_env.py:248-260) appends the one-hot arm index to every
+        arm's row; the kernel's rows are the centralized ones, the identity is added here."""
         na, w = self.individual_shape
-        return {"individual": obs[:, : na * w].reshape(-1, na, w), "shared": obs[:, na * w:]}
+        ind = obs[:, : na * w].reshape(-1, na, w)
+        if self.policy_mode == "decentralized":
+            if isinstance(ind, np.ndarray):
+                eye = np.broadcast_to(np.eye(na, dtype=ind.dtype), (ind.shape[0], na, na))
+                ind = np.concatenate([ind, eye], axis=-1)
+            else:
+                import torch
+
+                eye = torch.eye(na, dtype=ind.dtype, device=ind.device).expand(ind.shape[0], na, na)
+                ind = torch.cat([ind, eye], dim=-1)
+        return {"individual": ind, "shared": obs[:, na * w:]}
 
 
 class FlatEnv(_GymEnv):
@@ -136,10 +148,17 @@ class FlatEnv(_GymEnv):
         self.n_seg = n_elems - 1
         self.n_action = n_action
         self.policy_mode = policy_mode
-        lo = np.repeat(np.ones(n_action) * (-22), n_arm)
-        hi = np.repeat(np.ones(n_action) * (22), n_arm)
-        self.action_space = Box(lo, hi, shape=(n_arm * n_action,), dtype=np.float32)
-        self._observation_size = self._vec.individual_shape
+        if policy_mode == "centralized":
+            lo = np.repeat(np.ones(n_action) * (-22), n_arm)
+            hi = np.repeat(np.ones(n_action) * (22), n_arm)
+            self.action_space = Box(lo, hi, shape=(n_arm * n_action,), dtype=np.float32)
+            self._observation_size = self._vec.individual_shape
+        else:
+            # flat_env.py:111-130: the declared spaces are ONE arm's; step() still takes all
+            # n_arm * n_action values (set_action reshapes them, :288-289)
+            self.action_space = Box(np.ones(n_action) * (-22), np.ones(n_action) * 22, shape=(n_action,),
+                                    dtype=np.float32)
+            self._observation_size = (self._vec.individual_shape[1] + n_arm,)
         self.observation_space = Dict({
             "individual": Box(-np.inf, np.inf, shape=self._observation_size, dtype=np.float32),
             "shared": Box(-np.inf, np.inf, shape=(13,), dtype=np.float32),
