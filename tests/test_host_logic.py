@@ -282,8 +282,15 @@ def test_octo_flat_config_and_spaces(oracle_built):
     np.testing.assert_array_equal(ob3["individual"][:, -3:], a.reshape(8, 3))
     assert not np.array_equal(env._target, tgt)                     # next draw of the same stream
     with pytest.raises(NotImplementedError):
-        gsa.FlatEnv(policy_mode="decentralized", backend=OracleBackend(cfg))
+        gsa.FlatEnv(policy_mode="hierarchical", backend=OracleBackend(cfg))          # flat_env.py:131-132
     env.close()
+    # decentralized: one arm's declared spaces, the one-hot arm index appended per row (:111-130,248-260)
+    dec = gsa.FlatEnv(policy_mode="decentralized", backend=OracleBackend(cfg))
+    assert dec.action_space.shape == (3,) and dec.observation_space["individual"].shape == (64,)
+    obd, _ = dec.reset(seed=0)
+    np.testing.assert_array_equal(obd["individual"][:, :56], ob["individual"][:, :56])
+    np.testing.assert_array_equal(obd["individual"][:, 56:], np.eye(8, dtype=np.float32))
+    dec.close()
 
 
 def test_octo_flat_lite_and_vec(oracle_built):
