@@ -195,6 +195,35 @@ class FlatEnv(_GymEnv):
             {"time": self.time, "TimeLimit.truncated": bool(infos["TimeLimit.truncated"][0])},
         )
 
+    def get_state(self):
+        """Current observation dict (flat_env.py:231-286)."""
+        obs = self._vec.backend.observe(None)
+        return self._state(obs.cpu().numpy() if hasattr(obs, "cpu") else obs)
+
+    def summary(self):
+        """As the reference's summary() (octopus/flat_env.py:153-170)."""
+        print(
+            f"""
+        {self.final_time=}
+        {self.time_step=}
+        {self.total_steps=}
+        {self.step_skip=}
+        simulation time per action: {1.0/self.step_skip=}
+        max number of action per episode: {self.total_steps / self.step_skip}
+
+        {self.n_elems=}
+        {self.action_space=}
+        {self.observation_space=}
+        {self.reward_range=}
+        """
+        )
+
+    def save_data(self, filename_video, fps):
+        """The reference renders `rod_parameters_dict` to a video here (flat_env.py:410-420); drawing is out of
+        scope: the data is in `rod_parameters_dict`, nothing is written."""
+        if getattr(self._vec, "config_generate_video", False):
+            raise NotImplementedError("video generation is outside the hot path; use rod_parameters_dict")
+
     def render(self):
         if self.render_mode is None:
             return None

@@ -173,6 +173,11 @@ class SoftArmTrackingEnv(_GymEnv):
         return (np.asarray(obs[0], dtype=np.float64), float(reward[0]), bool(term[0]), bool(trunc[0]),
                 {"ctime": self.time_tracker})
 
+    def get_state(self):
+        """Current observation (soft_arm_tracking.py:160-207)."""
+        obs = self._vec.backend.observe(None)
+        return np.asarray(obs[0].cpu().numpy() if hasattr(obs, "cpu") else obs[0], dtype=np.float64)
+
     def render(self):
         if self.render_mode is None:
             return None

@@ -155,6 +155,17 @@ class SoftPendulumEnv(_GymEnv):
         """RodCallBack's samples (soft_pendulum.py:117-126) when config_generate_video=True."""
         return self._vec.rod_parameters_dict
 
+    def get_state(self):
+        """Current observation (soft_pendulum.py:149-161)."""
+        obs = self._vec.backend.observe(None)
+        return np.asarray(obs[0].cpu().numpy() if hasattr(obs, "cpu") else obs[0], dtype=np.float32).copy()
+
+    def save_data(self, filename_video, fps):
+        """The reference renders `rod_parameters_dict` to a video here (soft_pendulum.py:253-256); drawing is out of
+        scope: the data is in `rod_parameters_dict`, nothing is written."""
+        if getattr(self._vec, "config_generate_video", False):
+            raise NotImplementedError("video generation is outside the hot path; use rod_parameters_dict")
+
     def render(self):
         if self.render_mode is None:
             return None

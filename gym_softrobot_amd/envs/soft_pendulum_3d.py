@@ -162,6 +162,11 @@ class SoftPendulum3DEnv(_GymEnv):
             {"time": self.time, "tilt": float(infos["tilt"][0])},
         )
 
+    def get_state(self):
+        """Current observation (soft_pendulum_3d.py:93-98)."""
+        obs = self._vec.backend.observe(None)
+        return np.asarray(obs[0].cpu().numpy() if hasattr(obs, "cpu") else obs[0], dtype=np.float32).copy()
+
     def render(self):
         if self.render_mode is None:
             return None

@@ -439,3 +439,23 @@ def test_soft_arm_env_host_logic_on_the_oracle_backend(oracle_built):
     vec.close()
     with pytest.raises(NotImplementedError):
         gsa.VecSoftArmTrackingEnv(1, game_mode=2, backend=OracleBackend(_capi.soft_arm_config(1)), autoreset="device")
+
+
+def test_single_env_get_state_summary_save_data(oracle_built, capsys):
+    """The public helpers of the reference's env classes: get_state() is the observation of the
+    current state; summary() prints the episode arithmetic; save_data() writes nothing unless
+    video generation (out of scope) was asked for."""
+    env = gsa.SoftPendulumEnv(backend=OracleBackend(_capi.softpendulum_config(1)))
+    ob, _ = env.reset(seed=3)
+    np.testing.assert_array_equal(env.get_state(), ob)
+    ob, *_ = env.step(np.array([5.0], np.float32))
+    np.testing.assert_array_equal(env.get_state(), ob)
+    assert env.save_data("x.mp4", 25) is None
+    env.close()
+    arm = gsa.ArmSingleEnv(backend=OracleBackend(_capi.arm_single_config(1)))
+    arm.reset(seed=0)
+    arm.summary()
+    out = capsys.readouterr().out
+    assert "self.final_time=10.0" in out and "self.step_skip=714" in out and "self.n_elems=50" in out
+    assert arm.get_state().shape == (25,)
+    arm.close()
