@@ -225,9 +225,10 @@ class FlatEnv(_GymEnv):
             raise NotImplementedError("video generation is outside the hot path; use rod_parameters_dict")
 
     def render(self):
-        if self.render_mode is None:
-            return None
-        raise NotImplementedError("rendering is outside the hot path (DESIGN.md, out of scope)")
+        """None without a render mode; an (H, W, 3) uint8 frame for "rgb_array" (render.py)."""
+        from ..render import render_env
+
+        return render_env(self)
 
     @property
     def rod_parameters_dict_list(self):
@@ -240,4 +241,7 @@ class FlatEnv(_GymEnv):
         return self._vec.head_dict
 
     def close(self):
+        from ..render import close_env
+
+        close_env(self)
         self._vec.close()

@@ -179,9 +179,13 @@ class SoftArmTrackingEnv(_GymEnv):
         return np.asarray(obs[0].cpu().numpy() if hasattr(obs, "cpu") else obs[0], dtype=np.float64)
 
     def render(self):
-        if self.render_mode is None:
-            return None
-        raise NotImplementedError("rendering is outside the hot path (DESIGN.md, out of scope)")
+        """None without a render mode; an (H, W, 3) uint8 frame for "rgb_array" (render.py)."""
+        from ..render import render_env
+
+        return render_env(self)
 
     def close(self):
+        from ..render import close_env
+
+        close_env(self)
         self._vec.close()

@@ -167,9 +167,13 @@ class SoftPendulumEnv(_GymEnv):
             raise NotImplementedError("video generation is outside the hot path; use rod_parameters_dict")
 
     def render(self):
-        if self.render_mode is None:
-            return None
-        raise NotImplementedError("rendering is outside the hot path (DESIGN.md, out of scope)")
+        """None without a render mode; an (H, W, 3) uint8 frame for "rgb_array" (render.py)."""
+        from ..render import render_env
+
+        return render_env(self)
 
     def close(self):
+        from ..render import close_env
+
+        close_env(self)
         self._vec.close()

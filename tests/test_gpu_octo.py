@@ -442,3 +442,15 @@ def test_octo_decentralized_policy_mode(hip_lib):
         np.testing.assert_array_equal(d[k]["individual"][:, 56:], np.eye(8, dtype=np.float32))
         np.testing.assert_array_equal(d[k]["shared"], c[k]["shared"])
     assert c[2] == d[2]
+
+
+def test_octo_render_rgb_array(hip_lib):
+    import gym_softrobot_amd as gsa
+
+    env = gsa.make("OctoFlat-v0", render_mode="rgb_array", recording_fps=71)
+    env.reset(seed=0)
+    f0 = env.render()
+    assert f0.shape == (600, 800, 3) and f0.dtype == np.uint8
+    env.step(np.full(24, 10.0, np.float32))
+    assert (env.render() != f0).any()
+    env.close()

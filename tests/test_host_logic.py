@@ -459,3 +459,32 @@ def test_single_env_get_state_summary_save_data(oracle_built, capsys):
     assert "self.final_time=10.0" in out and "self.step_skip=714" in out and "self.n_elems=50" in out
     assert arm.get_state().shape == (25,)
     arm.close()
+
+
+def test_render_rgb_array(oracle_built):
+    """render(): None without a mode, a frame for "rgb_array" (matplotlib, as the reference's
+    MATPLOTLIB session), NotImplementedError for the pyglet window of "human"."""
+    env = gsa.SoftPendulumEnv(backend=OracleBackend(_capi.softpendulum_config(1)))
+    env.reset(seed=0)
+    assert env.render() is None
+    env.close()
+    env = gsa.SoftPendulumEnv(render_mode="rgb_array", backend=OracleBackend(_capi.softpendulum_config(1)))
+    env.reset(seed=0)
+    f0 = env.render()
+    assert f0.shape == (600, 800, 3) and f0.dtype == np.uint8 and f0.min() < 128 < f0.max()
+    for _ in range(3):
+        env.step(np.array([22.0], np.float32))
+    f1 = env.render()
+    assert f1.shape == f0.shape and (f1 != f0).any()          # the rod has moved
+    env.close()
+    env = gsa.SoftArmTrackingEnv(render_mode="rgb_array", backend=OracleBackend(_capi.soft_arm_config(1)))
+    env.reset(seed=0)
+    assert env.render().shape == (600, 800, 3)
+    env.close()
+    env = gsa.ArmSingleEnv(render_mode="human", backend=OracleBackend(_capi.arm_single_config(1)))
+    env.reset(seed=0)
+    with pytest.raises(NotImplementedError):
+        env.render()
+    env.close()
+    with pytest.raises(ValueError):
+        gsa.SoftPendulumEnv(render_mode="ascii", backend=OracleBackend(_capi.softpendulum_config(1)))
