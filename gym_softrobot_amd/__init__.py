@@ -16,6 +16,12 @@ from .envs import (
 from .registration import make, register, registered
 
 __version__ = "0.2.0"
+VERSION = __version__                       # gym_softrobot/version.py
+
+from .render import RendererType  # noqa: E402
+
+# gym_softrobot/__init__.py:83 sets POVRAY; the matplotlib session is the one provided here
+RENDERER_CONFIG = RendererType.MATPLOTLIB
 
 # gym_softrobot/__init__.py:27-30,74-80
 register(id="SoftPendulum-v0", entry_point=SoftPendulumEnv)

@@ -7,9 +7,18 @@ pyglet window of render_mode="human" are not provided.
 """
 from __future__ import annotations
 
+import enum
 from typing import Callable, List, Optional
 
 import numpy as np
+
+
+class RendererType(enum.Enum):
+    """Which renderer `render()` uses (the reference keeps this choice in `RENDERER_CONFIG`,
+    gym_softrobot/__init__.py:83); only MATPLOTLIB is provided here."""
+
+    POVRAY = 1
+    MATPLOTLIB = 2
 
 
 class MatplotlibSession:
