@@ -311,3 +311,33 @@ def test_k12_arm_crossing_count(oracle_built):
     o.arm(0).set("x", zig + np.array([[5.0], [0.0], [0.0]]))
     o.arm(7).set("x", line + np.array([[5.0], [0.0], [0.0]]))
     assert o.crossings() == 2 * n                        # pair (7, 0) is tested (index -1 wraps)
+
+
+def test_k13_spline_muscle_static_curvature(oracle_built):
+    """A clamped arm under the spline muscle torques settles where the bending couple balances
+    them: with torques tau_j on the elements and a free tip, the couple at Voronoi vertex k is
+    sum_{j > k} tau_j and kappa_k = that / (E I) (Euler-Bernoulli; shear is negligible here).
+    This ties sign, frame and scale of the forcing (muscle_torques_with_bspline.py:199-201)
+    to the rod's bending law."""
+    from gym_softrobot_amd import _capi
+
+    cfg = _capi.soft_arm_config(1)
+    cfg.damping_constant = 20.0                     # settles within 1500 env.steps
+    o = oracle_built.OracleRod(cfg)
+    o.reset_soft_arm()
+    a = np.zeros(8, np.float32)
+    a[:4] = 0.02
+    for _ in range(1500):
+        o.env_step_soft_arm(a)
+    assert np.abs(o.get("v")).max() < 1e-3          # mm/s: at rest
+    br, cf = _capi.spline_table(float(cfg.base_length), int(cfg.n_ctrl))
+    cum = np.cumsum(o.get("lengths"))
+    piece = (cum >= br[1]).astype(int) + (cum >= br[2]).astype(int)
+    ds = cum - br[piece]
+    c = np.einsum("kjq,j->kq", cf[piece], a[:4].astype(np.float64))
+    tau = float(cfg.muscle_torque_scale) * (((c[:, 3] * ds + c[:, 2]) * ds + c[:, 1]) * ds + c[:, 0])
+    EI = float(cfg.youngs_modulus) * np.pi * float(cfg.base_radius) ** 4 / 4
+    couple = np.array([tau[k + 1:].sum() for k in range(len(tau) - 1)])
+    kappa = o.get("kappa")
+    np.testing.assert_allclose(kappa[0][:-1], (couple / EI)[:-1], rtol=1e-4)
+    assert np.abs(kappa[1]).max() < 1e-12 and np.abs(kappa[2]).max() < 1e-12
