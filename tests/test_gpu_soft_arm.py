@@ -154,3 +154,19 @@ def test_game_mode_2_moving_target(torch_gpu, hip_lib, oracle_built):
     ob, _ = e1.reset(seed=42)
     np.testing.assert_allclose(ob[11:14], z["every50_42"][0] / 1000, rtol=1e-6, atol=1e-7)
     e1.close()
+
+
+def test_golden_oracle_rollout_fixture(torch_gpu, hip_lib):
+    """The committed oracle rollout (tests/golden/softarm_oracle_rollout.npz): parity without
+    the oracle at run time."""
+    import gym_softrobot_amd as gsa
+
+    z = np.load(GOLD / "softarm_oracle_rollout.npz")
+    env = gsa.make_vec("SoftArmTracking-v0", 1, numpy_output=True)
+    env.reset(seed=0)
+    for t in range(len(z["actions"])):
+        obs, rew, term, trunc, _ = env.step(z["actions"][t][None])
+        np.testing.assert_allclose(obs[0], z["obs"][t], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(rew[0], z["reward"][t], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(env.backend.rod_snapshot([0])["x"][0], z["x"], rtol=RTOL, atol=1e-4)
+    env.close()

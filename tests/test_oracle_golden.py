@@ -309,3 +309,17 @@ def test_soft_arm_target_trajectory_against_the_reference_function():
         full = target_trajectory(5, 2.0e-4, 0.1, rng)
         assert full.shape == tuple(z["shape"])
         np.testing.assert_allclose(full[[1, 7, 12345, 27499]], z[f"probe_{seed}"], rtol=0, atol=1e-9)
+
+
+def test_soft_arm_oracle_regression_pin(oracle_built):
+    from gym_softrobot_amd import _capi
+
+    z = np.load(GOLD / "softarm_oracle_rollout.npz")
+    r = oracle_built.OracleRod(_capi.soft_arm_config(1))
+    r.reset_soft_arm()
+    for t in range(len(z["actions"])):
+        o, rw, te, tr = r.env_step_soft_arm(z["actions"][t])
+        np.testing.assert_array_equal(o, z["obs"][t])
+        assert rw == z["reward"][t] and not te and not tr
+    np.testing.assert_array_equal(r.get("x"), z["x"])
+    np.testing.assert_array_equal(r.get("kappa"), z["kappa"])

@@ -143,6 +143,22 @@ def oracle_rollouts_other_envs():
     return out
 
 
+def oracle_rollout_soft_arm():
+    """REGRESSION pin of this repo's oracle for SoftArmTracking-v0 (not reference outputs; the
+    actuation itself is pinned against reference code in softarm_vectors.npz)."""
+    from gym_softrobot_amd import _capi
+    from oracle.oracle_c import OracleRod
+
+    rng = np.random.default_rng(21)
+    r = OracleRod(_capi.soft_arm_config(1))
+    r.reset_soft_arm()
+    a = rng.uniform(-1, 1, (6, 8)).astype(np.float32)
+    a[3] = a[2]
+    res = [r.env_step_soft_arm(a[t]) for t in range(6)]
+    return dict(actions=a, obs=np.stack([x[0] for x in res]), reward=np.array([x[1] for x in res]),
+                x=r.get("x"), kappa=r.get("kappa"))
+
+
 if __name__ == "__main__":
     g = ROOT / "tests" / "golden"
     g.mkdir(parents=True, exist_ok=True)
@@ -150,4 +166,5 @@ if __name__ == "__main__":
     np.savez(g / "softpendulum_oracle_rollout.npz", **oracle_rollout())
     (g / "other_envs_reset.json").write_text(json.dumps(reset_vectors_other_envs(), indent=1))
     np.savez(g / "other_envs_oracle_rollout.npz", **oracle_rollouts_other_envs())
+    np.savez(g / "softarm_oracle_rollout.npz", **oracle_rollout_soft_arm())
     print("wrote", sorted(p.name for p in g.iterdir()))
