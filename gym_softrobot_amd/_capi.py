@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -155,6 +155,7 @@ class SoftrodStateView(C.Structure):
         ("env_memory", C.c_void_p),
         ("prev_action", C.c_void_p),
         ("head", C.c_void_p),
+        ("bc_targets", C.c_void_p),
     ]
 
 

@@ -285,8 +285,28 @@ class HipRodBackend:
             "prev_action": torch.as_tensor(_DevArray(v.prev_action, (n, max(7, self.action_dim)), "<f4", self),
                                            device=self.device),
             "head": torch.as_tensor(_DevArray(v.head, (20, n), "<f8", self), device=self.device),
+            "bc_targets": torch.as_tensor(_DevArray(v.bc_targets, (12, n), "<f8", self), device=self.device),
             "arm_stride": int(v.arm_stride),
         }
+
+    _SNAPSHOT_KEYS = ("position", "velocity", "director", "omega", "tangents", "time", "control", "kappa",
+                      "rest_kappa", "env_memory", "prev_action", "head", "bc_targets")
+
+    def snapshot(self) -> Dict[str, torch.Tensor]:
+        """Host copy of the whole resident batch (every array of softrod_state_view): what
+        `restore` needs to put the batch back exactly — checkpoint / resume, or branching a
+        rollout.  The reference has no counterpart (its env state is never serialised)."""
+        st = self.state()
+        torch.cuda.synchronize(self.device)
+        return {k: st[k].cpu().clone() for k in self._SNAPSHOT_KEYS}
+
+    def restore(self, snap: Dict[str, torch.Tensor]) -> None:
+        st = self.state()
+        for k in self._SNAPSHOT_KEYS:
+            if tuple(snap[k].shape) != tuple(st[k].shape):
+                raise ValueError(f"snapshot field {k!r} has shape {tuple(snap[k].shape)}, expected {tuple(st[k].shape)}")
+            st[k].copy_(snap[k].to(self.device))
+        torch.cuda.synchronize(self.device)
 
     def rod_snapshot(self, env_indices) -> Dict[str, np.ndarray]:
         """Host copy of a few rods only (diagnostic taps): x, v (k,3,n+1); Q (k,3,3,n);

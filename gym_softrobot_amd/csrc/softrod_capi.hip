@@ -881,6 +881,7 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->env_memory = h->S.envmem;
     out->prev_action = h->S.prev_action;
     out->head = h->S.head;
+    out->bc_targets = h->S.bc;
     return SOFTROD_OK;
 }
 

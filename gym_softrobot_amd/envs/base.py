@@ -352,6 +352,38 @@ class VecRodEnvBase:
         self._steps += 1
         return packed, self._infos(self._times())
 
+    # -- checkpoint / resume ----------------------------------------------------------
+    def state_dict(self) -> Dict[str, Any]:
+        """Everything needed to continue this batch exactly where it is: the resident state
+        (backend.snapshot()) and the host bookkeeping (steps since reset, pending auto-resets,
+        every env's RNG state).  The reference never serialises an env; this is
+        an addition.  Not available with autoreset="device" (reset records staged on the device
+        belong to the RNG streams' future)."""
+        if self.device_autoreset:
+            raise NotImplementedError("state_dict() with autoreset='device': staged reset records are not captured")
+        extra = {k: np.array(getattr(self, k)) for k in ("targets", "_traj") if getattr(self, k, None) is not None}
+        return {
+            "backend": self.backend.snapshot(),
+            "steps": self._steps.copy(),
+            "needs_reset": self._needs_reset.copy(),
+            "rng": [None if g is None else g.bit_generator.state for g in self._rngs],
+            "extra": extra,
+        }
+
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        self.backend.restore(sd["backend"])
+        self._steps[:] = sd["steps"]
+        self._needs_reset[:] = sd["needs_reset"]
+        for i, st in enumerate(sd["rng"]):
+            if st is None:
+                self._rngs[i] = None
+            else:
+                if self._rngs[i] is None:
+                    self._rngs[i], _ = np_random(0)
+                self._rngs[i].bit_generator.state = st
+        for k, v in sd.get("extra", {}).items():
+            setattr(self, k, np.array(v))
+
     def close(self):
         if self.backend is not None and hasattr(self.backend, "close"):
             self.backend.close()

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 8
+#define SOFTROD_ABI_VERSION 9
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -266,6 +266,12 @@ typedef struct softrod_state_view {
     double* head;     /* [20][n_envs]  OctoFlat rigid head (octopus/build.py:103-105):
                          position[3], velocity[3], directors[9] (row-major),
                          omega[3], target[2] (flat_env.py:221); else unused    */
+    double* bc_targets; /* [12][n_envs]  what the boundary condition holds node 0 / element 0
+                         to: fixed_position[3], fixed_directors[9] (row-major), captured at
+                         reset (build.py:81-85: constrained_position_idx=(0,),
+                         constrained_director_idx=(0,)).  With the rows above it makes the
+                         view a complete snapshot: copying every array out and back in
+                         restores a batch exactly (checkpoint / resume).            */
 } softrod_state_view;
 
 /* Fill `cfg` with SoftPendulumEnv.__init__ defaults (soft_pendulum.py:59-78)

@@ -986,3 +986,34 @@ def test_packed_step_equals_separate_outputs(torch_gpu, hip_lib, env_id, amax):
         assert pr.dtype == torch_gpu.float64 and pte.dtype == torch_gpu.bool
     a_env.close()
     b_env.close()
+
+
+@pytest.mark.parametrize("env_id,kw,amax", [("SoftPendulum-v0", {}, 22.0), ("OctoArmSingle-v0", {}, 6.0),
+                                            ("SoftArmTracking-v0", {"game_mode": 2}, 0.5),
+                                            ("OctoFlat-v0", {"recording_fps": 71}, 10.0)])
+def test_checkpoint_resume_is_exact(torch_gpu, hip_lib, env_id, kw, amax):
+    """state_dict() / load_state_dict(): a batch put back from its snapshot continues bit for bit
+    — also across a host auto-reset (the RNG streams are part of the snapshot) and into a FRESH
+    env object."""
+    import gym_softrobot_amd as gsa
+
+    n = 3
+    env = gsa.make_vec(env_id, n, numpy_output=True, autoreset=True, **kw)
+    env.reset(seed=7)
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-amax, amax, (8, n, env.action_dim)).astype(np.float32)
+    for t in range(3):
+        env.step(acts[t])
+    sd = env.state_dict()
+    first = [env.step(acts[t])[:4] for t in range(3, 8)]
+    other = gsa.make_vec(env_id, n, numpy_output=True, autoreset=True, **kw)
+    other.reset(seed=99)                       # a different history, then overwritten by the snapshot
+    other.step(acts[0])
+    for e in (env, other):
+        e.load_state_dict(sd)
+        again = [e.step(acts[t])[:4] for t in range(3, 8)]
+        for a, b in zip(first, again):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+    env.close()
+    other.close()
