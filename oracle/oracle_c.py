@@ -7,6 +7,7 @@ its parity with pyelastica==1.0.0 is unpinned.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -29,6 +30,8 @@ def _load(omp: bool) -> C.CDLL:
     if key in _libs:
         return _libs[key]
     path = _DIR / ("libsoftrod_oracle_omp.so" if omp else "libsoftrod_oracle.so")
+    if not omp and os.environ.get("SOFTROD_ORACLE_LIB"):      # e.g. the ASan/UBSan build (oracle/Makefile: asan)
+        path = Path(os.environ["SOFTROD_ORACLE_LIB"])
     if not path.exists():
         build()
     lib = C.CDLL(str(path))
