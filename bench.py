@@ -10,16 +10,28 @@ one kernel launch, plus (N>1) one packed RCCL all-gather of the per-env outputs.
 Inputs (state, pre-staged float32 actions) are resident in HBM when the timed region
 starts.  Rank 0 prints ONE JSON line.
 
-roofline: algorithmic bytes per launch = rods x substeps x 2*(18n+6)*8 B (SURVEY.md
-§8(d): every substep reads+writes x, v, Q, omega once) divided by the step kernel's
-average duration, measured with HIP events recorded on the launch stream around every
-timed launch (softrod_set_timing / softrod_kernel_times_ms).  The kernel is
-register-resident (HBM is touched once per env.step), so measured `traffic` is far below
-the algorithmic figure — see DESIGN.md "roofline".
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches itself:
+the parent starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+process before anything in the parent touches the GPU (never an exec), relays rank 0's JSON
+line and exits with the child's return code.  Launched under torchrun (WORLD_SIZE set) it
+runs as one rank, as before.
+
+roofline: the kernel is register-resident (HBM is touched once per env.step, not once per
+substep), so what bounds it is the fp64 VALU issue rate: a wave64 fp64 instruction occupies
+its SIMD for 4 cycles (1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s = 78.6 TFLOP/s
+of FMAs).  `roofline.achieved` = VALU wave-instructions per launch (SQ_INSTS_VALU of this
+workload's kernel from the tracked PMC pass, profiles/valu_counts.json, which names the
+rocprofv3 output it came from) / the step kernel's average duration measured live with HIP
+events on the launch stream (softrod_set_timing / softrod_kernel_times_ms); `frac` =
+achieved / peak.  `roofline.traffic` = measured HBM bytes per launch (FETCH_SIZE/WRITE_SIZE
+passes, profiles/hbm_traffic.json); `roofline.hbm` carries the measured-traffic bandwidth
+and, labelled as a model, SURVEY.md §8(d)'s algorithmic-bytes streaming figure (rods x
+substeps x 2*(18n+6)*8 B / kernel time), which a fused kernel exceeds by construction.
 
 cpu_baseline: the repo's fp64 C oracle (a port/restatement, NOT PyElastica — see
 oracle/softrod_oracle.c) timed on this box's host cores with OpenMP over rods, rank 0,
-N=1 only, on a bounded sample of the same workload.
+N=1 only, on a bounded sample of the same workload.  `cores` = the CPUs the process may
+really use (cgroup quota, else affinity), which is also the OpenMP thread count.
 """
 from __future__ import annotations
 
@@ -33,16 +45,38 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-# SQ_INSTS_VALU per rod-substep measured with rocprofv3 --pmc (profiles/README.md), by (env, n_elem)
-VALU_PER_ROD_SUBSTEP = {("SoftPendulum-v0", 50): 99.5, ("SoftPendulum3D-v0", 50): 596.0,
-                        ("OctoArmSingle-v0", 50): 597.0, ("SoftArmTracking-v0", 40): 349.0}
 ENVS_PER_GPU = 4096
 N_ELEM = 50
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+N_SIMD = 1024                # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9             # MI355X_MICROARCH.md peak engine clock
+CYCLES_PER_FP64_WAVE_INSTR = 4.0   # wave64 fp64 op: 16 lanes per clock per SIMD
+VALU_PEAK_GINSTR = N_SIMD * CLOCK_HZ / CYCLES_PER_FP64_WAVE_INSTR / 1e9   # 614.4
 
 
 def algorithmic_bytes_per_rod_substep(n_elem: int, sizeof_real: int = 8) -> int:
     return 2 * (18 * n_elem + 6) * sizeof_real  # 14 496 B for n = 50, fp64
+
+
+def usable_cpus() -> int:
+    """CPUs this process can really run on: the cgroup CPU quota when there is one (a box that
+    shows 256 CPUs in its affinity mask may grant a dozen), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
@@ -66,8 +100,8 @@ def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
         batch.env_step(acts[1 + steps])
         steps += 1
     dt = time.perf_counter() - t0
-    # one rod on one thread, for reading the threaded figure (cgroup quotas and SMT siblings make
-    # "cores" an upper bound of what the box really gives the process)
+    # one rod on one thread: the threaded figure divided by this one is the parallel speed-up the
+    # box really delivered (SMT siblings and quotas make `cores` an upper bound)
     one = oracle_c.OracleRod(cfg)
     one.reset_pendulum(initial_angle(np_random(0)[0]))
     one.env_step(float(acts[0, 0]))
@@ -77,18 +111,21 @@ def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
         one.env_step(float(acts[1 + k % 60, 0]))
         k += 1
     dt1 = time.perf_counter() - t1
+    value, single = n_rods * steps / dt, k / dt1
     return {
-        "value": n_rods * steps / dt,
+        "value": value,
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
         "sample": f"{n_rods} rods x {steps} env.steps (400 substeps, 50 elements, fp64 C oracle, "
                   f"OpenMP {cores} threads, {dt:.1f} s)",
-        "single_thread_value": k / dt1,
+        "single_thread_value": single,
+        "measured_parallel_speedup": value / single,
+        "affinity_cpus": len(os.sched_getaffinity(0)),
     }
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 20 + 100 env.steps stay inside one SoftPendulum episode (truncation fires on step
@@ -111,8 +148,63 @@ def main() -> None:
                          "stay inside one SoftPendulum episode (125 steps), else 'device' (staged reset "
                          "records, no host read) — the reference's own loop resets a truncated env, and "
                          "a pendulum driven by random forces for more than ~7 s of simulated time blows up")
+    ap.add_argument("--actions", choices=["random", "zero"], default="random",
+                    help="random (default): uniform in the action box; zero: SURVEY.md §8(d)'s zero-action run")
     ap.add_argument("--n-elems", type=int, default=None, help="elements per rod (env default if omitted)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1, not under torchrun): start the N ranks as a CHILD
+    `python -m torch.distributed.run` — this parent has not imported torch or touched the GPU,
+    and it never exec()s — relay rank 0's JSON line on stdout, everything else on stderr, and
+    return the child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    n_json = 0
+    for ln in proc.stdout:
+        txt = ln.strip()
+        is_line = False
+        if txt.startswith("{") and '"metric"' in txt:
+            try:
+                json.loads(txt)
+                is_line = True
+            except ValueError:
+                pass
+        if is_line:
+            n_json += 1
+            print(txt, flush=True)
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and n_json != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, saw {n_json}\n")
+        return 1
+    return rc
+
+
+def load_profile_table(name: str, key: str):
+    """profiles/<name>.json[key] or None — tracked rocprofv3 evidence keyed by workload."""
+    f = ROOT / "profiles" / name
+    try:
+        return json.loads(f.read_text()).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def main() -> int:
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
 
     import numpy as np
     import torch
@@ -122,25 +214,35 @@ def main() -> None:
     from gym_softrobot_amd import _capi
     from gym_softrobot_amd.distributed import ShardedVecEnv
 
+    # CPU tests of this file's argument handling / launch / sharding logic swap the device layer
+    # for a module under tests/ (an oracle-backed double over gloo); such a run labels its line
+    # "data": "TEST-SHIM" and is not a measurement.  Nothing under oracle/ is reachable from here
+    # otherwise (cpu_baseline excepted, which only times it).
+    shim = None
+    if os.environ.get("SOFTROD_BENCH_TEST_SHIM"):
+        import importlib
+
+        shim = importlib.import_module(os.environ["SOFTROD_BENCH_TEST_SHIM"])
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a MI355X: the hot path has no CPU fallback")
-    if os.environ.get("SOFTROD_BENCH_ALL_RANKS_ON_DEVICE0") == "1":
-        local_rank = 0   # smoke-testing the N>1 code path on a 1-GPU box (not a measurement)
-    torch.cuda.set_device(local_rank)
+    if shim is None:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a MI355X: the hot path has no CPU fallback")
+        if os.environ.get("SOFTROD_BENCH_ALL_RANKS_ON_DEVICE0") == "1":
+            local_rank = 0   # smoke-testing the N>1 code path on a 1-GPU box (not a measurement)
+        torch.cuda.set_device(local_rank)
+    device_sync = torch.cuda.synchronize if shim is None else (lambda: None)
     force_dist = os.environ.get("SOFTROD_BENCH_FORCE_DIST") == "1"   # RCCL smoke test in a world of one
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        backend = os.environ.get("SOFTROD_BENCH_DIST_BACKEND", "nccl")   # "gloo": 1-GPU smoke test only
+        backend = os.environ.get("SOFTROD_BENCH_DIST_BACKEND", "nccl" if shim is None else "gloo")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -159,7 +261,10 @@ def main() -> None:
         args.autoreset = "off" if (args.steps + args.warmup <= 120 or args.env != "SoftPendulum-v0") else "device"
     if args.autoreset != "off":
         extra["autoreset"] = True if args.autoreset == "host" else "device"
-    local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode, **extra)
+    if shim is None:
+        local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode, **extra)
+    else:
+        local = shim.make_vec(args.env, n_local, **extra)
     # world > 1: kernel-packed rows + one all-gather per step, issued asynchronously so that the
     # next step's kernel does not wait for it (ShardedVecEnv overlap; the final sync is timed)
     env = ShardedVecEnv(local, n_total, overlap=True, force_collective=force_dist)
@@ -168,6 +273,8 @@ def main() -> None:
     adim = local.backend.action_dim
     amax = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
             "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0}[args.env]
+    if args.actions == "zero":
+        amax = 0.0
     # the truncation flag of SoftPendulum first fires on env.step #126; the default window
     # (120 steps) stays inside one episode
     T = W + K
@@ -176,16 +283,18 @@ def main() -> None:
 
     for t in range(W):
         env.step(acts_dev[t])
-    local.backend.set_timing(K)
+    timed = hasattr(local.backend, "set_timing")
+    if timed:
+        local.backend.set_timing(K)
     restarts_before = int(local.backend.queue_status()[0].sum()) if args.autoreset == "device" else 0
     if world > 1 or force_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for t in range(W, T):
         obs, rew, term, trunc, _ = env.step(acts_dev[t])
     env.sync()
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1 or force_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -194,7 +303,7 @@ def main() -> None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
 
-    kt = local.backend.kernel_times_ms()
+    kt = local.backend.kernel_times_ms() if timed else np.full(K, elapsed / K * 1e3)
     assert len(kt) == K or args.autoreset != "off"
     # env-steps that restarted an episode instead of integrating are not counted as work
     restarts = 0
@@ -213,19 +322,19 @@ def main() -> None:
         nsub = int(cfg.n_substeps)
         octo = args.env == "OctoFlat-v0"
         rods_per_env = int(cfg.n_arm) if octo else 1
+        rod_substeps = n_local * rods_per_env * nsub
         # OctoFlat: n_arm rods + the rigid head (x, v, Q, w = 18 doubles read and written)
         bytes_per_launch = n_local * nsub * (rods_per_env * algorithmic_bytes_per_rod_substep(int(cfg.n_elem))
                                              + (2 * 18 * 8 if octo else 0))
         kernel_ms = float(np.mean(kt))
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tf = ROOT / "profiles" / "hbm_traffic.json"
-        if tf.exists():  # measured with rocprofv3 --pmc (separate passes), see profiles/README.md
-            try:   # keyed by workload: only a measurement of THIS env / size / batch is reported
-                key = f"{args.env}|n_elem={int(cfg.n_elem)}|envs={n_local}"
-                traffic = json.loads(tf.read_text()).get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        kernel_s = kernel_ms * 1e-3
+        # tracked rocprofv3 evidence, keyed by workload: only a measurement of THIS env / size is used
+        traffic_rec = load_profile_table("hbm_traffic.json", f"{args.env}|n_elem={int(cfg.n_elem)}|envs={n_local}")
+        traffic = (traffic_rec or {}).get("hbm_bytes_per_launch")
+        valu_rec = load_profile_table("valu_counts.json", f"{args.env}|n_elem={int(cfg.n_elem)}") \
+            if args.math_mode == "fast" else None
+        valu_per = (valu_rec or {}).get("valu_instr_per_rod_substep")
+        achieved = None if valu_per is None else valu_per * rod_substeps / kernel_s / 1e9
         line = {
             "metric": "env_steps_per_sec",
             "value": (n_total * K - restarts) / elapsed,
@@ -238,7 +347,7 @@ def main() -> None:
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if shim is None else "TEST-SHIM",
             "config": {
                 "workload": f"{args.env}, {n_local} envs x "
                             + (f"{rods_per_env} arms x " if octo else "") + f"{int(cfg.n_elem)} elements per GPU "
@@ -247,6 +356,7 @@ def main() -> None:
                 "envs_total": n_total,
                 "substeps_per_env_step": nsub,
                 "math_mode": args.math_mode,
+                "actions": args.actions,
                 "autoreset": args.autoreset,
                 "episode_restarts_not_counted": restarts,
                 "sharding": "contiguous env blocks per rank; one packed all_gather per step" if world > 1 else "single GPU",
@@ -254,40 +364,42 @@ def main() -> None:
                 "non_finite_envs_at_end": n_bad, "last_step_checksum": obs_checksum,
             },
             "roofline": {
-                "bound": "hbm",
+                # what bounds a register-resident kernel: fp64 VALU issue slots
+                "bound": "fp64_valu",
                 "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "peak": VALU_PEAK_GINSTR,
+                "unit": "G wave64-VALU-instr/s",
+                "frac": None if achieved is None else achieved / VALU_PEAK_GINSTR,
                 "traffic": traffic,
                 "kernel": "softrod_octo_step_kernel" if octo else
                           "softrod_step_window_kernel + softrod_step_fast_kernel (epilogue only)"
                           if (args.env == "OctoArmSingle-v0" and 64 <= int(cfg.n_elem) <= 102
                               and args.math_mode == "fast") else
                           ("softrod_step_fast_kernel" if args.math_mode == "fast" else "softrod_step_libm_kernel"),
-                "fp64_valu": {
-                    "note": "the binding unit: wave64 fp64 VALU ops issue in 4 cycles (78.6 TFLOP/s); "
-                            "SIMD-cycles per rod-substep below vs ~4 x fp64 instruction count (profiles/README.md)",
-                    "simd_cycles_per_rod_substep_at_2.4GHz":
-                        kernel_ms * 1e-3 * 2.4e9 * 1024 / (n_local * rods_per_env * nsub),
-                    # measured SQ_INSTS_VALU per rod-substep of this workload's kernel (profiles/README.md;
-                    # tools/pmc_valu_per_substep.sh), and the share of the VALU issue slots they fill
-                    # at the nominal 2.4 GHz — the roofline of the unit that actually bounds the kernel
-                    "valu_instructions_per_rod_substep": VALU_PER_ROD_SUBSTEP.get((args.env, int(cfg.n_elem))),
-                    "valu_issue_frac_at_2.4GHz":
-                        None if (args.env, int(cfg.n_elem)) not in VALU_PER_ROD_SUBSTEP else
-                        4.0 * VALU_PER_ROD_SUBSTEP[(args.env, int(cfg.n_elem))]
-                        / (kernel_ms * 1e-3 * 2.4e9 * 1024 / (n_local * rods_per_env * nsub)),
-                },
                 "kernel_ms_avg": kernel_ms,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": "algorithmic bytes = rods x substeps x 2(18n+6) x 8 B (SURVEY 8d); the kernel keeps "
-                        "the state in registers for all substeps, so real HBM traffic is ~1/400 of that",
+                "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz / {CYCLES_PER_FP64_WAVE_INSTR:g} cycles per "
+                                   "wave64 fp64 instruction (= 78.6 TFLOP/s of FMAs, MI355X_MICROARCH.md)",
+                "valu_instr_per_rod_substep": valu_per,
+                "valu_instr_source": (valu_rec or {}).get("source"),
+                "rod_substeps_per_launch": rod_substeps,
+                # the same fraction from the profiler's own cycle counter (clock-independent), if tracked
+                "profiled_valu_busy_frac": (valu_rec or {}).get("valu_busy_frac"),
+                "hbm": {
+                    "measured_traffic_GBs": None if traffic is None else traffic / kernel_s / 1e9,
+                    "measured_traffic_frac_of_8TBs": None if traffic is None else traffic / kernel_s / 1e9 / HBM_PEAK_GBS,
+                    "traffic_source": (traffic_rec or {}).get("source"),
+                    "minimum_bytes_per_launch": n_local * rods_per_env * (18 * int(cfg.n_elem) + 6) * 8 * 2,
+                    "streaming_model_GBs": bytes_per_launch / kernel_s / 1e9,
+                    "streaming_model_bytes_per_launch": bytes_per_launch,
+                    "streaming_model_note": "SURVEY 8d's algorithmic bytes (rods x substeps x 2(18n+6) x 8 B) / kernel "
+                                            "time: what a one-substep-per-pass implementation would have to move; this "
+                                            "kernel keeps the state in registers for all substeps, so the figure exceeds "
+                                            "the 8 TB/s peak by construction and is NOT a fraction of anything",
+                },
             },
         }
-        if world == 1 and not args.no_cpu_baseline and args.env == "SoftPendulum-v0":
-            cores = len(os.sched_getaffinity(0))
-            line["cpu_baseline"] = cpu_baseline(cfg, cores)
+        if world == 1 and not args.no_cpu_baseline and args.env == "SoftPendulum-v0" and shim is None:
+            line["cpu_baseline"] = cpu_baseline(cfg, usable_cpus())
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
@@ -295,7 +407,8 @@ def main() -> None:
     env.close()
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

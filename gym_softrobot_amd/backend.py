@@ -292,15 +292,35 @@ class HipRodBackend:
     _SNAPSHOT_KEYS = ("position", "velocity", "director", "omega", "tangents", "time", "control", "kappa",
                       "rest_kappa", "env_memory", "prev_action", "head", "bc_targets")
 
+    def config_fingerprint(self) -> bytes:
+        """What a snapshot is only valid for: the ABI and every field of softrod_config except the
+        batch size (checked through the shapes) — a snapshot taken under another dt, substep
+        count, feature set or material continues with the wrong physics otherwise."""
+        c = self.cfg.copy()
+        c.n_envs = 0
+        return bytes([_capi.ABI_VERSION]) + bytes(memoryview(c).cast("B"))
+
     def snapshot(self) -> Dict[str, torch.Tensor]:
         """Host copy of the whole resident batch (every array of softrod_state_view): what
         `restore` needs to put the batch back exactly — checkpoint / resume, or branching a
         rollout.  The reference has no counterpart (its env state is never serialised)."""
+        if getattr(self, "queue_depth", 0):
+            raise _capi.SoftrodError("snapshot/restore of a handle with device-side auto-reset is not supported: "
+                                     "the pending-reset flags and the staged queue are not part of the state view")
         st = self.state()
         torch.cuda.synchronize(self.device)
-        return {k: st[k].cpu().clone() for k in self._SNAPSHOT_KEYS}
+        snap = {k: st[k].cpu().clone() for k in self._SNAPSHOT_KEYS}
+        snap["config_fingerprint"] = torch.frombuffer(bytearray(self.config_fingerprint()), dtype=torch.uint8).clone()
+        return snap
 
     def restore(self, snap: Dict[str, torch.Tensor]) -> None:
+        if getattr(self, "queue_depth", 0):
+            raise _capi.SoftrodError("snapshot/restore of a handle with device-side auto-reset is not supported: "
+                                     "stale needs_reset / skip flags would reset or skip the wrong envs")
+        fp = snap.get("config_fingerprint")
+        if fp is None or bytes(fp.numpy().tobytes()) != self.config_fingerprint():
+            raise ValueError("snapshot was taken under a different softrod_config / ABI version "
+                             "(dt, n_substeps, features, env_kind, material ...): refusing to load it")
         st = self.state()
         for k in self._SNAPSHOT_KEYS:
             if tuple(snap[k].shape) != tuple(st[k].shape):

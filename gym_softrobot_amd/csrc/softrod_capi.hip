@@ -64,6 +64,26 @@ int fail(softrod_handle* h, int code, const std::string& msg) {
     return code;
 }
 
+// Every entry point runs on the handle's device and leaves the caller's current device as it
+// found it (a process may hold handles on several GPUs, or have torch's current device elsewhere).
+struct DeviceGuard {
+    int prev = -1, want = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) : want(device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != want) err = hipSetDevice(want);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != want) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define SR_ON_DEVICE(h)                                                                  \
+    DeviceGuard guard_((h)->device);                                                     \
+    if (guard_.err != hipSuccess)                                                        \
+        return fail(h, SOFTROD_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err))
+
 #define SR_HIP(h, call)                                                                 \
     do {                                                                                \
         hipError_t e_ = (call);                                                         \
@@ -539,7 +559,8 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         if (hipMalloc(p, bytes) != hipSuccess) { rc = SOFTROD_ENOMEM; return; }
         if (hipMemset(*p, 0, bytes) != hipSuccess) rc = SOFTROD_EHIP;
     };
-    if (hipSetDevice(device) != hipSuccess) rc = SOFTROD_EHIP;
+    DeviceGuard guard_(device);
+    if (guard_.err != hipSuccess) rc = SOFTROD_EHIP;
     alloc((void**)&h->S.pos, 3 * rowb);
     alloc((void**)&h->S.vel, 3 * rowb);
     alloc((void**)&h->S.dir, 9 * rowb);
@@ -579,7 +600,7 @@ int softrod_reset_octo(softrod_handle* h, const double* arm_start, const double*
                        const double* target, const uint8_t* mask, void* stream) {
     if (!h || !arm_start || !arm_direction || !target) return fail(h, SOFTROD_EINVAL, "null argument");
     if (!is_octo(h)) return fail(h, SOFTROD_EINVAL, "softrod_reset_octo is for SOFTROD_ENV_OCTO_FLAT");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     SR_HIP(h, hipEventSynchronize(h->ev_reset));
     const int N = h->cfg.n_envs, na = h->cfg.n_arm;
     const double normal[3] = {0.0, 0.0, 1.0};             // octopus/build.py:82
@@ -602,7 +623,7 @@ int softrod_autoreset_enable(softrod_handle* h, int depth) {
     if (!h || depth < 1 || depth > 4096) return fail(h, SOFTROD_EINVAL, "need 1 <= depth <= 4096");
     if (h->q_depth) return fail(h, SOFTROD_EINVAL, "auto-reset is already enabled");
     if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no episodes");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     const size_t N = (size_t)h->cfg.n_envs;
     const size_t qb = (size_t)depth * N * h->init_stride * sizeof(double);
     SR_HIP(h, hipMalloc((void**)&h->d_queue, qb));
@@ -644,7 +665,6 @@ int queue_begin(softrod_handle* h, const int32_t* counts, int max_count) {
         if (h->h_produced[e] + counts[e] - h->seen_consumed[e] > h->q_depth)
             return fail(h, SOFTROD_EINVAL, "reset queue overflow: staged + new records exceed depth");
     }
-    SR_HIP(h, hipSetDevice(h->device));
     SR_HIP(h, hipEventSynchronize(h->ev_queue));   // previous upload out of the pinned mirror
     return SOFTROD_OK;
 }
@@ -665,6 +685,7 @@ int softrod_queue_push(softrod_handle* h, const double* theta0, const int32_t* c
                        void* stream) {
     if (!h || !theta0) return fail(h, SOFTROD_EINVAL, "null argument");
     if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat stages resets through softrod_queue_push_octo");
+    SR_ON_DEVICE(h);
     const int rc = queue_begin(h, counts, max_count);
     if (rc != SOFTROD_OK) return rc;
     for (int e = 0; e < h->cfg.n_envs; ++e)
@@ -682,6 +703,7 @@ int softrod_queue_push_straight(softrod_handle* h, const double* start, const do
                                 const double* normal, const int32_t* counts, int max_count, void* stream) {
     if (!h || !start || !direction || !normal) return fail(h, SOFTROD_EINVAL, "null argument");
     if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat stages resets through softrod_queue_push_octo");
+    SR_ON_DEVICE(h);
     const int rc = queue_begin(h, counts, max_count);
     if (rc != SOFTROD_OK) return rc;
     for (int e = 0; e < h->cfg.n_envs; ++e)
@@ -696,6 +718,7 @@ int softrod_queue_push_octo(softrod_handle* h, const double* arm_start, const do
                             const double* target, const int32_t* counts, int max_count, void* stream) {
     if (!h || !arm_start || !arm_direction || !target) return fail(h, SOFTROD_EINVAL, "null argument");
     if (!is_octo(h)) return fail(h, SOFTROD_EINVAL, "softrod_queue_push_octo is for SOFTROD_ENV_OCTO_FLAT");
+    SR_ON_DEVICE(h);
     const int rc = queue_begin(h, counts, max_count);
     if (rc != SOFTROD_OK) return rc;
     const int na = h->cfg.n_arm;
@@ -716,7 +739,7 @@ int softrod_queue_push_octo(softrod_handle* h, const double* arm_start, const do
 int softrod_queue_status(softrod_handle* h, int32_t* consumed, int32_t* underflow, void* stream) {
     if (!h || !consumed) return fail(h, SOFTROD_EINVAL, "null argument");
     if (!h->q_depth) return fail(h, SOFTROD_EINVAL, "call softrod_autoreset_enable first");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     const size_t N = (size_t)h->cfg.n_envs;
     int uf = 0;
     SR_HIP(h, hipMemcpyAsync(consumed, h->d_consumed, N * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -730,7 +753,7 @@ int softrod_queue_status(softrod_handle* h, int32_t* consumed, int32_t* underflo
 int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream) {
     if (!h || !by) return fail(h, SOFTROD_EINVAL, "null argument");
     if (!h->q_depth) return fail(h, SOFTROD_EINVAL, "call softrod_autoreset_enable first");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     const int N = h->cfg.n_envs;
     // consumed += by (by < 0: := produced).  The device counters are only ever written by the
     // auto-reset pass, which is stream-ordered with these copies.
@@ -753,7 +776,7 @@ int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream) {
 int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask, void* stream) {
     if (!h || !theta0) return fail(h, SOFTROD_EINVAL, "null argument");
     if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat resets through softrod_reset_octo");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     SR_HIP(h, hipEventSynchronize(h->ev_reset));  // previous upload out of the pinned buffers
     const int N = h->cfg.n_envs;
     for (int e = 0; e < N; ++e) {
@@ -773,7 +796,7 @@ int softrod_reset_straight(softrod_handle* h, const double* start, const double*
                            const double* normal, const uint8_t* mask, void* stream) {
     if (!h || !start || !direction || !normal) return fail(h, SOFTROD_EINVAL, "null argument");
     if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat resets through softrod_reset_octo");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     SR_HIP(h, hipEventSynchronize(h->ev_reset));
     const int N = h->cfg.n_envs;
     for (int e = 0; e < N; ++e) {
@@ -794,7 +817,7 @@ int softrod_set_spline_table(softrod_handle* h, const double* breaks, const doub
     std::vector<double> buf((size_t)SOFTROD_MAX_SPLINE_PIECES + 1 + (size_t)np * nc * 4, 0.0);
     for (int p = 0; p <= np; ++p) buf[p] = breaks[p];
     for (int i = 0; i < np * nc * 4; ++i) buf[SOFTROD_MAX_SPLINE_PIECES + 1 + i] = coef[i];
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     SR_HIP(h, hipMemcpy(h->d_spline, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
     h->spline_set = true;
     return SOFTROD_OK;
@@ -802,7 +825,7 @@ int softrod_set_spline_table(softrod_handle* h, const double* breaks, const doub
 
 int softrod_set_action_basis(softrod_handle* h, const double* basis) {
     if (!h || !basis) return fail(h, SOFTROD_EINVAL, "null argument");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     const size_t bytes = (size_t)(h->cfg.n_elem - 1) * (is_octo(h) ? h->cfg.n_knots : 7) * sizeof(double);
     SR_HIP(h, hipMemcpy(h->d_basis, basis, bytes, hipMemcpyHostToDevice));
     h->basis_set = true;
@@ -819,7 +842,7 @@ int softrod_step(softrod_handle* h, const float* actions, float* obs, double* re
         return fail(h, SOFTROD_EINVAL, "softrod_set_spline_table must be called before softrod_step");
     if (h->cfg.env_kind == SOFTROD_ENV_NONE)
         return fail(h, SOFTROD_EINVAL, "env_kind NONE has no step epilogue; use softrod_substeps");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     return launch_step(h, actions, obs, reward, terminated, truncated, aux, h->cfg.n_substeps, 1, 0,
                        (hipStream_t)stream);
 }
@@ -832,7 +855,7 @@ int softrod_step_packed(softrod_handle* h, const float* actions, float* packed, 
         return fail(h, SOFTROD_EINVAL, "softrod_set_action_basis must be called before softrod_step");
     if ((h->cfg.features & SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) && !h->spline_set)
         return fail(h, SOFTROD_EINVAL, "softrod_set_spline_table must be called before softrod_step");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     return launch_step(h, actions, packed, nullptr, nullptr, nullptr, aux, h->cfg.n_substeps, 1, 1,
                        (hipStream_t)stream);
 }
@@ -841,14 +864,14 @@ int softrod_substeps(softrod_handle* h, const float* actions, int n, void* strea
     if (!h || n < 0) return fail(h, SOFTROD_EINVAL, "bad argument");
     if (actions && h->cfg.env_kind != SOFTROD_ENV_SOFTPENDULUM && h->cfg.env_kind != SOFTROD_ENV_NONE)
         return fail(h, SOFTROD_EINVAL, "softrod_substeps takes no actions for this env_kind");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     return launch_step(h, actions, nullptr, nullptr, nullptr, nullptr, nullptr, n, 0, 0, (hipStream_t)stream);
 }
 
 int softrod_observe(softrod_handle* h, const float* prev_action, float* obs, void* stream) {
     if (!h || !obs) return fail(h, SOFTROD_EINVAL, "null argument");
     if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no observation");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
     if (is_octo(h))
         hipLaunchKernelGGL(softrod_octo_observe_kernel, grid, dim3(kLanes * h->nw), 0, (hipStream_t)stream,
@@ -887,7 +910,7 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
 
 int softrod_set_timing(softrod_handle* h, int n_launches) {
     if (!h || n_launches < 0 || n_launches > (1 << 20)) return fail(h, SOFTROD_EINVAL, "bad argument");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     while ((int)h->ev_start.size() < n_launches) {
         hipEvent_t a = nullptr, b = nullptr;
         SR_HIP(h, hipEventCreate(&a));
@@ -907,7 +930,7 @@ int softrod_set_timing(softrod_handle* h, int n_launches) {
 
 int softrod_kernel_times_ms(softrod_handle* h, float* out_ms, int cap, int* count) {
     if (!h || !out_ms || !count || cap < 0) return fail(h, SOFTROD_EINVAL, "bad argument");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     const int n = h->timed < cap ? h->timed : cap;
     for (int i = 0; i < n; ++i) {
         SR_HIP(h, hipEventSynchronize(h->ev_stop[i]));
@@ -920,7 +943,7 @@ int softrod_kernel_times_ms(softrod_handle* h, float* out_ms, int cap, int* coun
 int softrod_last_kernel_ms(softrod_handle* h, float* ms) {
     if (!h || !ms) return fail(h, SOFTROD_EINVAL, "null argument");
     if (h->timed < 1) return fail(h, SOFTROD_EINVAL, "timing not enabled or no timed launch yet");
-    SR_HIP(h, hipSetDevice(h->device));
+    SR_ON_DEVICE(h);
     SR_HIP(h, hipEventSynchronize(h->ev_stop[h->timed - 1]));
     SR_HIP(h, hipEventElapsedTime(ms, h->ev_start[h->timed - 1], h->ev_stop[h->timed - 1]));
     return SOFTROD_OK;
@@ -930,7 +953,7 @@ const char* softrod_last_error(softrod_handle* h) { return h ? h->err.c_str() : 
 
 int softrod_destroy(softrod_handle* h) {
     if (!h) return SOFTROD_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard_(h->device);
     (void)hipDeviceSynchronize();
     void* qbufs[] = {h->d_queue, h->d_consumed, h->d_produced, h->d_underflow, h->d_flags};
     for (void* p : qbufs) (void)hipFree(p);

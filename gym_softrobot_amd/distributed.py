@@ -114,6 +114,10 @@ class ShardedVecEnv:
 
     def reset(self, *, seed: Optional[int] = None, mask=None):
         """Global env i is seeded seed + i regardless of the sharding."""
+        if self.overlap:      # no all-gather of an earlier step may still be writing the buffers
+            self.sync()
+            self._works = [None] * len(self._works)
+            self._k = 0
         seeds = None if seed is None else [int(seed) + i for i in range(self.lo, self.hi)]
         m = None if mask is None else np.asarray(mask)[self.lo : self.hi]
         obs, info = self.local.reset(seed=seeds, mask=m)

@@ -177,7 +177,8 @@ class FlatEnv(_GymEnv):
 
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
         super().reset(seed=seed)
-        obs, _ = self._vec.reset(seed=seed)
+        self._vec._rngs[0] = self.np_random   # env-owned stream: the target draw advances env.np_random (flat_env.py:171,221)
+        obs, _ = self._vec.reset(seed=None)
         self.time = np.float64(0.0)
         self.counter = 0
         return self._state(obs), {}

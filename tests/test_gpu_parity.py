@@ -1017,3 +1017,43 @@ def test_checkpoint_resume_is_exact(torch_gpu, hip_lib, env_id, kw, amax):
                 np.testing.assert_array_equal(x, y)
     env.close()
     other.close()
+
+
+def test_restore_refuses_a_snapshot_of_other_physics(torch_gpu, hip_lib):
+    """A snapshot carries the fingerprint of the softrod_config (and ABI) it was taken under:
+    same shapes but another dt / substep count / feature set must not load silently; and a
+    handle with device-side auto-reset refuses snapshot/restore (its pending-reset flags and
+    staged queue are outside the state view)."""
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+
+    a = gsa.make_vec("SoftPendulum-v0", 3)
+    a.reset(seed=1)
+    snap = a.backend.snapshot()
+    a.backend.restore(snap)                                   # same config: fine
+    b = gsa.make_vec("SoftPendulum-v0", 3, time_step=5e-5)    # same shapes, other physics
+    b.reset(seed=1)
+    with pytest.raises(ValueError, match="different softrod_config"):
+        b.backend.restore(snap)
+    c = gsa.make_vec("SoftPendulum-v0", 3, autoreset="device")
+    c.reset(seed=1)
+    with pytest.raises(_capi.SoftrodError, match="auto-reset"):
+        c.backend.restore(snap)
+    with pytest.raises(_capi.SoftrodError, match="auto-reset"):
+        c.backend.snapshot()
+    for e in (a, b, c):
+        e.close()
+
+
+def test_capi_calls_leave_the_current_device_alone(torch_gpu, hip_lib):
+    """Every extern "C" entry point switches to the handle's device under a guard and restores
+    the caller's: torch's current device is what it was after a reset / step / observe / destroy."""
+    import gym_softrobot_amd as gsa
+
+    before = torch_gpu.cuda.current_device()
+    env = gsa.make_vec("SoftPendulum-v0", 2, device=0)
+    env.reset(seed=0)
+    env.step(np.zeros((2, 1), np.float32))
+    env.backend.observe(None)
+    env.close()
+    assert torch_gpu.cuda.current_device() == before

@@ -13,7 +13,8 @@ env_id = sys.argv[1] if len(sys.argv) > 1 else "SoftPendulum-v0"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 amax = float(sys.argv[4]) if len(sys.argv) > 4 else 22.0
-env = gsa.make_vec(env_id, n, device=0)
+n_elems = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+env = gsa.make_vec(env_id, n, device=0, **({"n_elems": n_elems} if n_elems else {}))
 env.reset(seed=0)
 adim = env.action_dim
 acts = torch.from_numpy(np.random.default_rng(1).uniform(-amax, amax, (T, n, adim)).astype(np.float32)).cuda()
