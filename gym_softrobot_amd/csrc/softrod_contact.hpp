@@ -151,7 +151,7 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
             ro[s][1] = ax[s][2] * nr[0] - ax[s][0] * nr[2];
             ro[s][2] = ax[s][0] * nr[1] - ax[s][1] * nr[0];
         }
-        double vax = 0.0, vroll = 0.0, axn2 = 0.0, ron2 = 0.0, v2 = 0.0;
+        double vax = 0.0, vroll = 0.0, axn2 = 0.0, ron2 = 0.0;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             vax += vel[i] * ax[s][i];
@@ -159,8 +159,6 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
             axn2 += ax[s][i] * ax[s][i];
             ron2 += ro[s][i] * ro[s][i];
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) v2 += vel[i] * vel[i];
         // |ax| after the normalisation = |ax_raw| / (|ax_raw| + 1e-14)
         const double axn = FM ? sqrt_of<true>(a2) * itp : sqrt(axn2);
         const double ron = ZUP ? axn : sqrt_of<FM>(ron2);   // |ax x e_z| = |ax| term by term
@@ -186,11 +184,18 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
         }
         const double sroll = vroll + vrot;
         slip_ro[s] = slip_function<FM>(fabs(sroll) * ron, C.slip_tol, inv_slip);
-        const double ivm = inv_of<FM>(sqrt_of<FM>(v2) + 1e-14);
+        // unit vector of the total slip velocity in the plane, sroll ro + vax ax, with PyElastica's
+        // 1e-14 added to every component before the norm (all three: a zero component adds 1e-28)
+        double tot[3] = {0.0, 0.0, 0.0}, m2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) tot[i] = sroll * ro[s][i] + vax * ax[s][i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const double te = tot[i] + 1e-14; m2 += te * te; }
+        const double ivm = FM ? fast_rsqrt(m2) : 1.0 / sqrt(m2);
         double uax = 0.0, uro = 0.0;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            const double u = FM ? vel[i] * ivm : vel[i] / (sqrt(v2) + 1e-14);
+            const double u = FM ? tot[i] * ivm : tot[i] / sqrt(m2);
             uax += u * ax[s][i];
             uro += u * ro[s][i];
         }

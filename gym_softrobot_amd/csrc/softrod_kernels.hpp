@@ -804,7 +804,10 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
                 forward = exp(-dist / 0.35) - 0.096;
                 if (dist < 0.1) { survive = 5.0; term = true; }
             }
-            emit_scalars(out_row(obs, rod, 25, pack), 25, pack, rod, forward - (double)pen + survive, term,
+            // blown: forward_reward is still the Python float 0.0, so the reference's sum
+            // `0.0 - np.float32 + (-1.0)` is float32 arithmetic (NumPy 2 promotion)
+            const double rw = blown ? (double)((0.0f - pen) + (-1.0f)) : forward - (double)pen + survive;
+            emit_scalars(out_row(obs, rod, 25, pack), 25, pack, rod, rw, term,
                          time > P.final_time, reward, terminated, truncated, S.needs_reset);
         }
         arm_get_state_n<EPL>(P, S, N, rod, lane, C, L, A.a, out_row(obs, rod, 25, pack));
@@ -1035,10 +1038,12 @@ __device__ __forceinline__ void spline_muscle_rebuild(const RodParams& P, int la
 __device__ __forceinline__ void libm_kinematic_step(const RodParams& P, double h, LaneN<1>& L) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) L.x[0][i] += h * L.v[0][i];
-    double a0 = h * L.w[0][0], a1 = h * L.w[0][1], a2 = h * L.w[0][2];
-    const double th = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-    const double den = th + P.eps_rot_axis;
+    // _get_rotation_matrix(scale = h, omega): axis = omega / (|omega| + eps), angle = h |omega|
+    double a0 = L.w[0][0], a1 = L.w[0][1], a2 = L.w[0][2];
+    const double th0 = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+    const double den = th0 + P.eps_rot_axis;
     a0 /= den; a1 /= den; a2 /= den;
+    const double th = th0 * h;
     double up, cs;
     sincos(th, &up, &cs);
     const double usq = 1.0 - cs;

@@ -63,9 +63,10 @@ static void cylinder_init(rigid_head* h, const double start[3], const double dir
 static void head_kinematic(rigid_head* h, double prefac, double eps)
 {
     for (int i = 0; i < 3; ++i) h->x[i] += prefac * h->v[i];
-    double v0 = prefac * h->w[0], v1 = prefac * h->w[1], v2 = prefac * h->w[2];
+    double v0 = h->w[0], v1 = h->w[1], v2 = h->w[2];      /* _get_rotation_matrix(prefac, omega) */
     double theta = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
     v0 /= theta + eps; v1 /= theta + eps; v2 /= theta + eps;
+    theta *= prefac;
     const double up = sin(theta), usq = 1.0 - cos(theta);
     double R[3][3];
     R[0][0] = 1.0 - usq * (v1 * v1 + v2 * v2);
@@ -324,17 +325,12 @@ void oracle_octo_reset(oracle_octo* o, const double* arm_pos, const double* arm_
 
 /* FlatEnv.step, flat_env.py:315-408.  rest_kappa0 [n_arm][n_elem-1] is the interp1d output
  * of set_action (:288-311), computed by the caller with scipy exactly as the reference. */
-void oracle_octo_env_step(oracle_octo* o, const float* action, const double* rest_kappa0,
-                          float* individual, float* shared, double* reward, uint8_t* terminated,
-                          uint8_t* truncated)
+/* FlatEnv.step after the substep loop, flat_env.py:330-408; `before` = xposbefore (:321) */
+static void octo_epilogue(oracle_octo* o, const double before[2], float* individual, float* shared,
+                          double* reward, uint8_t* terminated, uint8_t* truncated)
 {
     const softrod_config* c = &o->cfg;
     const int na = o->n_arm, n = o->arm[0]->n;
-    for (int i = 0; i < na * c->n_knots; ++i) o->prev_action[i] = action[i];
-    for (int a = 0; a < na; ++a)
-        for (int k = 0; k < n - 1; ++k) o->arm[a]->rest_kappa[0][k] = rest_kappa0[a * (n - 1) + k];
-    const double before[2] = { o->head.x[0], o->head.x[1] };
-    for (int s = 0; s < c->n_substeps; ++s) octo_substep(o);
     int invalid = 0;
     for (int a = 0; a < na; ++a)
         for (int i = 0; i < 3; ++i)
@@ -360,6 +356,32 @@ void oracle_octo_env_step(oracle_octo* o, const float* action, const double* res
     *reward = rew;
     octo_get_state(o, individual, shared);
 }
+
+void oracle_octo_env_step(oracle_octo* o, const float* action, const double* rest_kappa0,
+                          float* individual, float* shared, double* reward, uint8_t* terminated,
+                          uint8_t* truncated)
+{
+    const softrod_config* c = &o->cfg;
+    const int na = o->n_arm, n = o->arm[0]->n;
+    for (int i = 0; i < na * c->n_knots; ++i) o->prev_action[i] = action[i];
+    for (int a = 0; a < na; ++a)
+        for (int k = 0; k < n - 1; ++k) o->arm[a]->rest_kappa[0][k] = rest_kappa0[a * (n - 1) + k];
+    const double before[2] = { o->head.x[0], o->head.x[1] };
+    for (int s = 0; s < c->n_substeps; ++s) octo_substep(o);
+    octo_epilogue(o, before, individual, shared, reward, terminated, truncated);
+}
+
+/* The epilogue alone, on whatever state the arms / head / clock hold now, with the
+ * pre-loop head position given: replays the fixtures recorded from the reference's own
+ * FlatEnv.step (tests/golden/ref_octoflat.npz). */
+void oracle_octo_epilogue_probe(oracle_octo* o, const float* action, const double before[2],
+                                float* individual, float* shared, double* reward, uint8_t* terminated,
+                                uint8_t* truncated)
+{
+    for (int i = 0; i < o->n_arm * o->cfg.n_knots; ++i) o->prev_action[i] = action[i];
+    octo_epilogue(o, before, individual, shared, reward, terminated, truncated);
+}
+void oracle_octo_set_target(oracle_octo* o, const double t[2]) { o->target[0] = t[0]; o->target[1] = t[1]; }
 
 void oracle_octo_substeps(oracle_octo* o, int n) { for (int s = 0; s < n; ++s) octo_substep(o); }
 double oracle_octo_time(const oracle_octo* o) { return o->time; }

@@ -77,6 +77,11 @@ def _load(omp: bool) -> C.CDLL:
     lib.oracle_octo_joint_probe.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
     lib.oracle_octo_head_constrain_probe.argtypes = [C.c_void_p]
     lib.oracle_octo_set_time.argtypes = [C.c_void_p, C.c_double]
+    lib.oracle_octo_set_target.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_octo_epilogue_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    lib.oracle_constrain_probe.argtypes = [C.c_void_p]
+    lib.oracle_set_run_substeps.argtypes = [C.c_void_p, C.c_int]
+    lib.oracle_forcing_probe.argtypes = [C.c_void_p, C.c_double]
     lib.oracle_get.restype = C.c_int
     lib.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.oracle_set.restype = C.c_int
@@ -96,6 +101,10 @@ _SHAPES = {
     "mass": lambda n: (n + 1,), "lengths": lambda n: (n,), "dilatation": lambda n: (n,),
     "rest_lengths": lambda n: (n,), "damp_t": lambda n: (1,), "rest_kappa": lambda n: (3, n - 1),
     "control": lambda n: (4,), "radius": lambda n: (n,),
+    "f_ext": lambda n: (3, n + 1), "t_ext": lambda n: (3, n), "time": lambda n: (1,),
+    "prev_kappa": lambda n: (n - 1,), "prev_com": lambda n: (2,), "prev_action7": lambda n: (7,),
+    "prev_action2": lambda n: (2,), "prev_action": lambda n: (1,), "fixed_pos": lambda n: (3,),
+    "fixed_dir": lambda n: (3, 3),
 }
 
 
@@ -133,6 +142,19 @@ class OracleRod:
 
     def refresh_strains(self) -> None:
         self._lib.oracle_refresh_strains(self._h)
+
+    def set_run_substeps(self, n: int) -> None:
+        """env_step* run n substeps instead of cfg.n_substeps (0: prologue + epilogue only, on the
+        state as it is); every constant that depends on step_skip keeps its configured value."""
+        self._lib.oracle_set_run_substeps(self._h, int(n))
+
+    def constrain_probe(self) -> None:
+        """One application of constrain_values then constrain_rates on the current state."""
+        self._lib.oracle_constrain_probe(self._h)
+
+    def forcing_probe(self, point_force: float) -> None:
+        """The forcing group (gravity adds, the point force assigns) on the current f_ext."""
+        self._lib.oracle_forcing_probe(self._h, float(point_force))
 
     def set_prev_action(self, a: float) -> None:
         self._lib.oracle_set_prev_action(self._h, float(a))
@@ -333,6 +355,26 @@ class OracleOcto:
 
     def substeps(self, n: int) -> None:
         self._lib.oracle_octo_substeps(self._h, int(n))
+
+    def set_target(self, target) -> None:
+        t = np.ascontiguousarray(target, np.float64).reshape(2)
+        self._lib.oracle_octo_set_target(self._h, t.ctypes.data)
+
+    def set_time(self, t: float) -> None:
+        self._lib.oracle_octo_set_time(self._h, float(t))
+
+    def epilogue_probe(self, action, xposbefore):
+        """FlatEnv.step after the substep loop on the CURRENT state, given the pre-loop head position."""
+        nk = int(self.cfg.n_knots)
+        a = np.ascontiguousarray(action, dtype=np.float32).reshape(self.n_arm * nk)
+        b = np.ascontiguousarray(xposbefore, np.float64).reshape(2)
+        ind, sh = self._obs()
+        rew = np.empty(1, np.float64)
+        term = np.empty(1, np.uint8)
+        trunc = np.empty(1, np.uint8)
+        self._lib.oracle_octo_epilogue_probe(self._h, a.ctypes.data, b.ctypes.data, ind.ctypes.data,
+                                             sh.ctypes.data, rew.ctypes.data, term.ctypes.data, trunc.ctypes.data)
+        return {"individual": ind, "shared": sh}, float(rew[0]), bool(term[0]), bool(trunc[0])
 
     @property
     def time(self) -> float:

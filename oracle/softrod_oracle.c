@@ -23,6 +23,12 @@
  * tests/test_oracle_golden.py; the physics is pinned by known-answer tests
  * (tests/test_oracle_physics.py).
  *
+ * Round-2 corrections of the recollection (each moves results far below 1e-5; regression pins
+ * regenerated): (1) _get_rotation_matrix normalises the axis with the UNSCALED |omega| + 1e-14
+ * and scales the angle afterwards; (2) anisotropic_friction distributes the kinetic friction with
+ * the unit vector of the total SLIP velocity (rolling slip incl. the contact point's spin + axial
+ * velocity), the 1e-14 added component-wise before the norm — not with the element velocity.
+ *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: Numba does not
  * contract a*b+c either).
  */
@@ -78,6 +84,8 @@ typedef struct oracle_rod {
     double torque_mag[2][NMAX];
     double spline_breaks[SOFTROD_MAX_SPLINE_PIECES + 1];
     double spline_coef[SOFTROD_MAX_SPLINE_PIECES][SOFTROD_MAX_CTRL][4];
+    int run_substeps;      /* >= 0: substeps the env_step functions really run (fixture replay: the
+                              epilogue alone on an injected state); < 0: cfg.n_substeps */
     long tick;             /* soft_arm_tracking.py:222 */
     double arm_target[3];  /* wsol[tick] */
 } oracle_rod;
@@ -330,11 +338,14 @@ static void kinematic_step(oracle_rod* r, double prefac)
     for (int i = 0; i < 3; ++i)
         for (int k = 0; k <= n; ++k) r->x[i][k] += prefac * r->v[i][k];
     for (int k = 0; k < n; ++k) {
-        double v0 = prefac * r->w[0][k], v1 = prefac * r->w[1][k], v2 = prefac * r->w[2][k];
+        /* _get_rotation_matrix(scale = prefac, axis_collection = omega): the axis is normalised
+         * with the UNSCALED |omega| + 1e-14, the angle is scaled afterwards (theta *= scale) */
+        double v0 = r->w[0][k], v1 = r->w[1][k], v2 = r->w[2][k];
         double theta = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
         v0 /= theta + r->cfg.eps_rot_axis;
         v1 /= theta + r->cfg.eps_rot_axis;
         v2 /= theta + r->cfg.eps_rot_axis;
+        theta *= prefac;
         const double up = sin(theta), usq = 1.0 - cos(theta);
         double R[3][3];
         R[0][0] = 1.0 - usq * (v1 * v1 + v2 * v2);
@@ -521,8 +532,16 @@ static void plane_contact(oracle_rod* r)
         const double sroll = vroll + vrot;
         double sroll_vec[3] = { sroll * roll[0][k], sroll * roll[1][k], sroll * roll[2][k] };
         slip_roll[k] = slip_function(sroll_vec, c->slip_velocity_tol);
-        const double vm = sqrt(ve[0] * ve[0] + ve[1] * ve[1] + ve[2] * ve[2]) + 1e-14;
-        double u[3] = { ve[0] / vm, ve[1] / vm, ve[2] / vm };
+        /* unitized_total_velocity = slip_velocity_along_rolling_direction + velocity_along_axial_direction;
+         * unitized_total_velocity /= _batch_norm(unitized_total_velocity + 1e-14): the total SLIP
+         * velocity in the plane (the rolling part includes the contact point's spin velocity), and
+         * the 1e-14 is added to every component of the vector before its norm is taken */
+        double u[3] = { sroll_vec[0] + vax_vec[0], sroll_vec[1] + vax_vec[1], sroll_vec[2] + vax_vec[2] };
+        {
+            const double t0 = u[0] + 1e-14, t1 = u[1] + 1e-14, t2 = u[2] + 1e-14;
+            const double vm = sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+            u[0] /= vm; u[1] /= vm; u[2] /= vm;
+        }
         const double uax = u[0] * axial[0][k] + u[1] * axial[1][k] + u[2] * axial[2][k];
         const double uro = u[0] * roll[0][k] + u[1] * roll[1][k] + u[2] * roll[2][k];
         double fk_ax[3], fk_ro[3];
@@ -730,6 +749,12 @@ static void position_verlet_step(oracle_rod* r)
     }
 }
 
+static int substeps_to_run(const oracle_rod* r)
+{
+    return r->run_substeps >= 0 ? r->run_substeps : r->cfg.n_substeps;
+}
+void oracle_set_run_substeps(oracle_rod* r, int n) { r->run_substeps = n; }
+
 /* ------------------------------------------------------------------------- */
 /* env epilogue: soft_pendulum.py:149-161 (get_state) and :196-251             */
 /* ------------------------------------------------------------------------- */
@@ -769,6 +794,7 @@ oracle_rod* oracle_create(const softrod_config* cfg)
     if (!r) return NULL;
     r->cfg = *cfg;
     r->n = cfg->n_elem;
+    r->run_substeps = -1;
     return r;
 }
 
@@ -818,7 +844,7 @@ void oracle_env_step(oracle_rod* r, float action, float obs[4], double* reward,
     const int n = r->n;
     r->prev_action = action;          /* :165 */
     r->point_force = (double)action;  /* :166 (float32 value held in float64) */
-    for (int s = 0; s < r->cfg.n_substeps; ++s) position_verlet_step(r);
+    for (int s = 0; s < substeps_to_run(r); ++s) position_verlet_step(r);
     int invalid = 0;
     for (int i = 0; i < 3; ++i)
         for (int k = 0; k <= n; ++k)
@@ -894,7 +920,7 @@ void oracle_env_step3d(oracle_rod* r, const float action[2], float obs[9], doubl
     }
     r->prev_action2[0] = action[0];
     r->prev_action2[1] = action[1];
-    for (int s = 0; s < r->cfg.n_substeps; ++s) position_verlet_step(r);
+    for (int s = 0; s < substeps_to_run(r); ++s) position_verlet_step(r);
     int invalid = 0;
     for (int i = 0; i < 3; ++i)
         for (int k = 0; k <= n; ++k)
@@ -982,7 +1008,7 @@ void oracle_env_step_arm(oracle_rod* r, const float action[7], const double* res
     const int n = r->n;
     for (int i = 0; i < 7; ++i) r->prev_action7[i] = action[i];
     for (int k = 0; k < n - 1; ++k) r->rest_kappa[0][k] = rest_kappa0[k];
-    for (int s = 0; s < c->n_substeps; ++s) position_verlet_step(r);
+    for (int s = 0; s < substeps_to_run(r); ++s) position_verlet_step(r);
     /* control penalty: float32 arithmetic (np.square/mean on the float32 action, and
      * python-float * np.float32 stays float32 under NumPy 2 promotion) */
     float sq = 0.0f;
@@ -1009,6 +1035,10 @@ void oracle_env_step_arm(oracle_rod* r, const float action[7], const double* res
     }
     *truncated = (r->time > c->final_time) ? 1 : 0;
     *reward = forward - (double)pen + survive;
+    /* invalid branch: forward_reward is still the Python float 0.0, so `0.0 - np.float32 + (-1.0)`
+     * stays float32 under NumPy 2 promotion (:255-259,274-276,296); every other branch has a
+     * float64 forward_reward */
+    if (invalid) *reward = (double)((0.0f - pen) + (-1.0f));
     get_state_arm(r, obs);
 }
 
@@ -1064,6 +1094,14 @@ int oracle_get(const oracle_rod* r, const char* name, double* out)
         out[2] = r->ctrl_vel[0]; out[3] = r->ctrl_vel[1];
         return 4;
     }
+    if (!strcmp(name, "time")) { out[0] = r->time; return 1; }
+    if (!strcmp(name, "prev_kappa")) { for (int k = 0; k < n - 1; ++k) out[k] = r->prev_kappa[k]; return n - 1; }
+    if (!strcmp(name, "prev_com")) { out[0] = r->prev_com[0]; out[1] = r->prev_com[1]; return 2; }
+    if (!strcmp(name, "prev_action7")) { for (int i = 0; i < 7; ++i) out[i] = (double)r->prev_action7[i]; return 7; }
+    if (!strcmp(name, "prev_action2")) { out[0] = r->prev_action2[0]; out[1] = r->prev_action2[1]; return 2; }
+    if (!strcmp(name, "prev_action")) { out[0] = r->prev_action; return 1; }
+    if (!strcmp(name, "fixed_pos")) { for (int i = 0; i < 3; ++i) out[i] = r->fixed_pos[i]; return 3; }
+    if (!strcmp(name, "fixed_dir")) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out[3 * i + j] = r->fixed_dir[i][j]; return 9; }
     return -1;
 }
 
@@ -1077,13 +1115,41 @@ int oracle_set(oracle_rod* r, const char* name, const double* in)
     if (!strcmp(name, "v")) SET3(v, n + 1);
     if (!strcmp(name, "w")) SET3(w, n);
     if (!strcmp(name, "rest_kappa")) SET3(rest_kappa, n - 1);
+    /* caches and env memory: lets a test put the oracle into exactly the state a recorded
+     * reference epilogue saw (tests/golden/ref_*.npz) */
+    if (!strcmp(name, "tangents")) SET3(tang, n);
+    if (!strcmp(name, "kappa")) SET3(kappa, n - 1);
+    if (!strcmp(name, "f_ext")) SET3(f_ext, n + 1);
 #undef SET3
+    if (!strcmp(name, "time")) { r->time = in[0]; return 0; }
+    if (!strcmp(name, "prev_kappa")) { for (int k = 0; k < n - 1; ++k) r->prev_kappa[k] = in[k]; return 0; }
+    if (!strcmp(name, "prev_com")) { r->prev_com[0] = in[0]; r->prev_com[1] = in[1]; return 0; }
+    if (!strcmp(name, "prev_action7")) { for (int i = 0; i < 7; ++i) r->prev_action7[i] = (float)in[i]; return 0; }
+    if (!strcmp(name, "prev_action2")) { r->prev_action2[0] = (float)in[0]; r->prev_action2[1] = (float)in[1]; return 0; }
+    if (!strcmp(name, "prev_action")) { r->prev_action = (float)in[0]; return 0; }
+    if (!strcmp(name, "control")) {
+        r->ctrl_pos[0] = in[0]; r->ctrl_pos[1] = in[1]; r->ctrl_vel[0] = in[2]; r->ctrl_vel[1] = in[3];
+        return 0;
+    }
+    if (!strcmp(name, "fixed_pos")) { for (int i = 0; i < 3; ++i) r->fixed_pos[i] = in[i]; return 0; }
+    if (!strcmp(name, "fixed_dir")) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r->fixed_dir[i][j] = in[3 * i + j]; return 0; }
     if (!strcmp(name, "Q")) {
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < n; ++k)
             r->Q[i][j][k] = in[(i * 3 + j) * n + k];
         return 0;
     }
     return -1;
+}
+
+/* Operator probes for the fixtures recorded from the reference's own classes
+ * (tests/golden/ref_*.npz): one application of constrain_values + constrain_rates
+ * (build.py:71-79, soft_pendulum_3d/build.py:31-39), or of the forcing group on a
+ * prefilled external_forces (build.py:88-105: gravity adds, the point force assigns). */
+void oracle_constrain_probe(oracle_rod* r) { constrain_values(r); constrain_rates(r); }
+void oracle_forcing_probe(oracle_rod* r, double point_force)
+{
+    r->point_force = point_force;
+    apply_forcing(r);
 }
 
 /* ------------------------------------------------------------------------- */

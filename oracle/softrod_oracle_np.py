@@ -155,9 +155,10 @@ class NumpyRod:
     def _kinematic(self, prefac):
         c = self.cfg
         self.x = self.x + prefac * self.v
-        ax = prefac * self.w
+        ax = self.w                    # _get_rotation_matrix(prefac, omega): unscaled axis norm,
         theta = np.sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2])
         u = ax / (theta + c.eps_rot_axis)
+        theta = theta * prefac         # then the angle is scaled
         up, usq = np.sin(theta), 1.0 - np.cos(theta)
         R = np.empty((3, 3, self.n))
         R[0, 0] = 1.0 - usq * (u[1] * u[1] + u[2] * u[2])
