@@ -25,15 +25,23 @@ def build(force: bool = False) -> None:
     subprocess.run(args, check=True, capture_output=True)
 
 
-def _load(omp: bool) -> C.CDLL:
-    key = "omp" if omp else "st"
+def build_fma() -> None:
+    """The same source with FMA contraction allowed (-ffp-contract=fast -mfma): a second correct
+    evaluation of the same algorithm that differs only in rounding — the control of the
+    episode-length parity measurements (tools/episode_parity.py)."""
+    subprocess.run(["make", "-C", str(_DIR), "fma"], check=True, capture_output=True)
+
+
+def _load(omp) -> C.CDLL:
+    key = omp if isinstance(omp, str) else ("omp" if omp else "st")
     if key in _libs:
         return _libs[key]
-    path = _DIR / ("libsoftrod_oracle_omp.so" if omp else "libsoftrod_oracle.so")
-    if not omp and os.environ.get("SOFTROD_ORACLE_LIB"):      # e.g. the ASan/UBSan build (oracle/Makefile: asan)
+    path = _DIR / {"omp": "libsoftrod_oracle_omp.so", "st": "libsoftrod_oracle.so",
+                   "fma": "libsoftrod_oracle_fma.so"}[key]
+    if key == "st" and os.environ.get("SOFTROD_ORACLE_LIB"):      # e.g. the ASan/UBSan build (oracle/Makefile: asan)
         path = Path(os.environ["SOFTROD_ORACLE_LIB"])
     if not path.exists():
-        build()
+        build_fma() if key == "fma" else build()
     lib = C.CDLL(str(path))
     lib.oracle_create.restype = C.c_void_p
     lib.oracle_create.argtypes = [C.POINTER(SoftrodConfig)]
@@ -120,7 +128,8 @@ def filter_rate(rate, order: int) -> np.ndarray:
 class OracleRod:
     """One rod stepped by the C oracle."""
 
-    def __init__(self, cfg: SoftrodConfig, omp: bool = False):
+    def __init__(self, cfg: SoftrodConfig, omp=False):
+        """omp: False (default build), True (OpenMP build), or "fma" (the rounding control)."""
         self._lib = _load(omp)
         self.cfg = cfg.copy()
         self.n = int(cfg.n_elem)
@@ -299,8 +308,8 @@ class _ArmView:
 class OracleOcto:
     """OctoFlat-v0 (8 arms + rigid head) stepped by the C oracle (octoflat_oracle.inc.c)."""
 
-    def __init__(self, cfg: SoftrodConfig):
-        self._lib = _load(False)
+    def __init__(self, cfg: SoftrodConfig, variant=False):
+        self._lib = _load(variant)
         self.cfg = cfg.copy()
         self.n_arm = int(cfg.n_arm)
         self.n = int(cfg.n_elem)

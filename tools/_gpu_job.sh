@@ -1,4 +1,10 @@
 set -x
-python -m pytest tests/test_gpu_reference_fixtures.py -m gpu -q 2>&1 | tail -40 > gpurun_out/r2b_reffix.log
-python -m pytest tests -m gpu -q -x --deselect tests/test_gpu_reference_fixtures.py 2>&1 | tail -25 > gpurun_out/r2b_gputests.log
-cat gpurun_out/r2b_reffix.log gpurun_out/r2b_gputests.log
+make -C oracle fma >/dev/null 2>&1
+timeout 1500 python tools/episode_parity.py > gpurun_out/parity_episode.json 2> gpurun_out/parity_episode.err
+tail -5 gpurun_out/parity_episode.err
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/parity_episode.json'))
+for k,v in d['scenarios'].items():
+    print(k, v['steps_within_1e-5'], {a: '%.1e'%b for a,b in v['max'].items()}, v['flags_equal_all_steps'])
+PY

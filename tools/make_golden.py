@@ -1,15 +1,9 @@
 """Generate tests/golden/*.  Two kinds of fixture, kept apart on purpose:
 
-1. softpendulum_reset.json — REFERENCE-DERIVED golden vectors.  The only outputs of
-   SoftPendulum-v0 that depend on gym-softrobot's own code + NumPy alone (PyElastica
-   is not importable here): the observation returned by `reset(seed=s)`.  The
-   expressions below are the reference's, evaluated with NumPy:
-     theta0, direction                gym_softrobot/envs/soft_pendulum/build.py:47-51
-     rng = Generator(PCG64(SeedSequence(seed)))   gymnasium.utils.seeding.np_random,
-                                      reached via soft_pendulum.py:114
-     obs = [x0, vx0, prev_action, wrap(arctan(mean tx / mean ty))]
-                                      soft_pendulum.py:149-161
-   with tangents of a straight rod = direction (CosseratRod.straight_rod).
+1. softpendulum_reset.json, other_envs_reset.json — REFERENCE-DERIVED golden vectors: the
+   reset observations, re-exported from the fixtures that tools/make_env_golden.py records by
+   EXECUTING the reference's own reset() / build_* / get_state (tests/golden/ref_*.npz; run that
+   tool first).  No expression of the reference is re-typed here.
 2. softpendulum_oracle_rollout.npz — REGRESSION pins produced by this repo's own fp64
    C oracle (oracle/softrod_oracle.c).  They are NOT reference outputs ("parity
    unpinned", see the oracle header); they freeze the oracle so that an accidental edit
@@ -26,18 +20,19 @@ sys.path.insert(0, str(ROOT))
 
 
 def reset_vectors():
+    """From tests/golden/ref_softpendulum.npz: the reset observations and rod frames the
+    reference's own SoftPendulumEnv.reset / build_soft_pendulum produced (tools/make_env_golden.py
+    executes them); u is the RNG draw behind the recorded direction, theta0 its angle."""
+    z = np.load(ROOT / "tests" / "golden" / "ref_softpendulum.npz")
     out = []
-    for seed in (0, 1, 2, 3, 42, 123, 2024):
-        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+    for i, seed in enumerate(z["reset_seed"]):
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(seed))))
         u = rng.random()
+        d = z["reset_direction"][i]
         theta = np.deg2rad(90 + (u - 0.5) * 10)
-        direction = np.array([1.0 * np.cos(theta), 1.0 * np.sin(theta), 0.0])
-        tangents = np.repeat(direction[:, None], 50, axis=1)
-        tm = np.mean(tangents, axis=1)
-        th = np.arctan(tm[0] / tm[1])
-        th = ((th + np.pi) % (2 * np.pi)) - np.pi
-        obs = np.hstack([0.0, 0.0, np.zeros(1, np.float32), th]).astype(np.float32)
-        out.append({"seed": seed, "u": float(u), "theta0": float(theta), "obs": [float(v) for v in obs]})
+        assert d[0] == 1.0 * np.cos(theta) and d[1] == 1.0 * np.sin(theta)     # build.py:47-50 as executed
+        out.append({"seed": int(seed), "u": float(u), "theta0": float(theta),
+                    "obs": [float(v) for v in z["reset_obs"][i]]})
     return out
 
 
@@ -64,49 +59,27 @@ def oracle_rollout():
 
 
 def reset_vectors_other_envs():
-    """REFERENCE-DERIVED reset observations of the other envs (gym-softrobot's code + NumPy/SciPy
-    only; straight rods at rest, so no PyElastica arithmetic is involved)."""
-    from scipy.spatial.transform import Rotation as Rot
-
+    """Reset observations of the other envs, from the fixtures recorded by executing the
+    reference's own reset() (tests/golden/ref_softpendulum3d.npz, ref_armsingle.npz,
+    ref_octoflat.npz; tools/make_env_golden.py)."""
+    g = ROOT / "tests" / "golden"
     out = {}
-    # SoftPendulum3D-v0: soft_pendulum_3d/build.py:51-53, soft_pendulum_3d.py:60-98
+    z = np.load(g / "ref_softpendulum3d.npz")
     v3 = []
-    for seed in (0, 1, 42, 123):
-        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
-        tilt = np.deg2rad(rng.uniform(-1.0, 1.0))
-        direction = np.array([np.sin(tilt), 0.0, np.cos(tilt)])
-        tangent = np.mean(np.repeat(direction[:, None], 50, axis=1), axis=1)
-        tangent /= np.linalg.norm(tangent)
-        ang = float(np.arccos(np.clip(tangent[2], -1.0, 1.0)))
-        obs = np.concatenate([np.zeros(3), np.zeros(3), np.zeros(2), [ang]]).astype(np.float32)
-        v3.append({"seed": seed, "tilt": float(tilt), "obs": [float(x) for x in obs]})
+    for i, s in enumerate(z["reset_seed"]):
+        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(int(s))))
+        tilt = np.deg2rad(rng.uniform(-1.0, 1.0))          # the draw behind the recorded direction
+        d = z["reset_direction"][i]
+        assert d[0] == np.sin(tilt) and d[2] == np.cos(tilt)   # soft_pendulum_3d/build.py:51-52 as executed
+        v3.append({"seed": int(s), "tilt": float(tilt), "obs": [float(x) for x in z["reset_obs"][i]]})
     out["SoftPendulum3D-v0"] = v3
-    # OctoArmSingle-v0: arm_single_env.py:160-219 on a straight arm at rest (kappa = 0, rates = 0,
-    # com rate = 0, _prev_action = 0, target (1, 0)); do_normalization = (x - lo) / (hi - lo)
-    kr, krr = (-49.33508476187419, 49.33545827754751), (-21.063520620377012, 24.664591289161944)
-    obs = np.hstack([np.full(7, (0.0 - kr[0]) / (kr[1] - kr[0])), np.full(7, (0.0 - krr[0]) / (krr[1] - krr[0])),
-                     np.zeros(2), np.zeros(7), [1.0, 0.0]]).astype(np.float32)
-    out["OctoArmSingle-v0"] = [{"seed": 0, "obs": [float(x) for x in obs]}]
-    # OctoFlat-v0: flat_env.py:171-286, octopus/build.py:73-105 (8 arms of 10 elements, L0 = 0.35)
-    vo = []
-    n_arm, n_el, L0, head_r = 8, 10, 0.35, 0.04
-    for seed in (0, 1, 42):
-        rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
-        target = (2 - 0.5) * rng.random(2) + 0.5
-        rows = []
-        for arm_i in range(n_arm):
-            rot = Rot.from_euler("z", 360 / n_arm * arm_i, degrees=True)
-            start, direction = rot.apply([head_r, 0.0, 0.0]), rot.apply([1.0, 0.0, 0.0])
-            end = start + direction * L0
-            pos = np.stack([np.linspace(start[i], end[i], n_el + 1) for i in range(3)])   # straight_rod
-            rows.append(np.hstack([np.zeros(n_el - 1), pos[0] - 0.0, pos[1] - 0.0, np.zeros(n_el + 1),
-                                   np.zeros(n_el + 1), np.zeros(3)]))
-        shared = np.concatenate([target - np.zeros(2), np.zeros(2),
-                                 np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]).ravel()])
-        vo.append({"seed": seed, "target": [float(x) for x in target],
-                   "individual": np.vstack(rows).astype(np.float32).tolist(),
-                   "shared": shared.astype(np.float32).tolist()})
-    out["OctoFlat-v0"] = vo
+    z = np.load(g / "ref_armsingle.npz")
+    out["OctoArmSingle-v0"] = [{"seed": 0, "obs": [float(x) for x in z["reset_obs"]]}]
+    z = np.load(g / "ref_octoflat.npz")
+    out["OctoFlat-v0"] = [
+        {"seed": int(s), "target": [float(x) for x in z["reset_target"][i]],
+         "individual": z["reset_individual"][i].tolist(), "shared": z["reset_shared"][i].tolist()}
+        for i, s in enumerate(z["reset_seed"])]
     return out
 
 
