@@ -35,6 +35,7 @@ struct softrod_handle {
     double* d_spline = nullptr;   // breaks[MAX_PIECES + 1], coef[pieces][n_ctrl][4] (softrod_set_spline_table)
     bool spline_set = false;
     RodParams* d_params = nullptr;  // device copy of P
+    StatePtrs* d_state = nullptr;   // device copy of S (re-uploaded whenever S changes)
     bool basis_set = false;
     double* h_init = nullptr;     // pinned
     uint8_t* h_mask = nullptr;    // pinned
@@ -580,6 +581,8 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     if (rc == SOFTROD_OK && hipMemcpy(h->d_params, &h->P, sizeof(RodParams), hipMemcpyHostToDevice) != hipSuccess)
         rc = SOFTROD_EHIP;
     h->S.params = h->d_params;
+    alloc((void**)&h->d_state, sizeof(StatePtrs));
+    h->S.self = h->d_state;
     alloc((void**)&h->d_basis, (size_t)2 * kLanes * 7 * sizeof(double));
     h->S.basis = h->d_basis;
     alloc((void**)&h->d_init, N * h->init_stride * sizeof(double));
@@ -587,6 +590,8 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     if (rc == SOFTROD_OK && hipHostMalloc((void**)&h->h_init, N * h->init_stride * sizeof(double)) != hipSuccess) rc = SOFTROD_ENOMEM;
     if (rc == SOFTROD_OK && hipHostMalloc((void**)&h->h_mask, N) != hipSuccess) rc = SOFTROD_ENOMEM;
     if (rc == SOFTROD_OK && hipEventCreateWithFlags(&h->ev_reset, hipEventDisableTiming) != hipSuccess)
+        rc = SOFTROD_EHIP;
+    if (rc == SOFTROD_OK && hipMemcpy(h->d_state, &h->S, sizeof(StatePtrs), hipMemcpyHostToDevice) != hipSuccess)
         rc = SOFTROD_EHIP;
     if (rc != SOFTROD_OK) {
         softrod_destroy(h);
@@ -650,6 +655,7 @@ int softrod_autoreset_enable(softrod_handle* h, int depth) {
     h->S.q_underflow = h->d_underflow;
     h->S.q_depth = depth;
     h->S.q_record = (int)h->init_stride;
+    SR_HIP(h, hipMemcpy(h->d_state, &h->S, sizeof(StatePtrs), hipMemcpyHostToDevice));
     return SOFTROD_OK;
 }
 
@@ -961,7 +967,7 @@ int softrod_destroy(softrod_handle* h) {
     if (h->h_produced) (void)hipHostFree(h->h_produced);
     if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_basis, h->d_spline, h->d_init, h->d_mask};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_basis, h->d_spline, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

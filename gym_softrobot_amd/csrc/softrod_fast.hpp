@@ -408,16 +408,37 @@ __device__ __forceinline__ void general_substeps(const RodParams& P, const RodPa
         if (!last && P.time_two_half_adds) time += P.half_dt;
     }
 }
-// The cold path reads the parameters from their device-memory copy (StatePtrs.params) instead of
-// having the caller copy 1.6 KB of kernel arguments to the stack.
-template <unsigned F, int EPL>
-__device__ __attribute__((noinline)) void general_substeps_cold(const RodParams* __restrict__ params,
-                                                                const ConstN<EPL>& C, const BcTargets& B, int lane,
-                                                                LaneN<EPL>& L, double& time, int n_sub) {
+// The SoftPendulum kernel's fallback for a state that is NOT planar (written through the state
+// view, or reset with an out-of-plane frame): the general 3-D substeps as an out-of-line call that
+// shares NOTHING with its caller but scalars — it reads the parameters and the array pointers
+// from their device-memory copies (StatePtrs.params / .self), loads the rod from its HBM rows,
+// establishes the constraint invariants, steps, and stores the rod and its clock back; the
+// caller reloads.  Nothing of the caller's lane state is address-taken that way, so the planar
+// path keeps every value in registers and the kernel writes no scratch (r1k: a by-reference
+// call parked 692 B per lane in scratch on EVERY launch, 164 MB of the 240 MB HBM traffic).
+template <unsigned F, int E, int EPL>
+__device__ __attribute__((noinline)) void general_step_cold(const RodParams* __restrict__ params,
+                                                            const StatePtrs* __restrict__ sp, int rod, int lane,
+                                                            const float* __restrict__ actions, int n_sub) {
     const RodParams P = *params;
+    const StatePtrs S = *sp;
+    const size_t N = (size_t)P.n_envs;
+    LaneN<EPL> L;
+    load_lane<EPL, F>(S, N, rod, lane, L);
+    BcTargets B;
+    load_bc(S, N, rod, B);
+    EnvAction A;
+    set_action_n<F, E, EPL>(P, S, N, rod, lane, actions, A, B, L);
+    constrain_rates_n<F, EPL>(P, B, lane, L);
+    constrain_values_n<F, EPL>(P, B, lane, L);
+    double time = S.time[rod];
+    ConstN<EPL> C;
+    build_const<F, EPL>(P, lane, A, C);
     RodParams Pk = P;
     if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
     general_substeps<F, EPL>(P, Pk, C, B, lane, L, time, n_sub);
+    store_lane<EPL, F>(S, N, rod, lane, L);
+    if (lane == 0) S.time[rod] = time;
 }
 
 // SOFTROD_FAST_WAVES: minimum waves per SIMD the register allocator must leave room for
@@ -508,9 +529,12 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
         }
     }
     if (n_sub > 0 && !stepped) {
-        if constexpr (F == SOFTROD_FEATURES_SOFTPENDULUM)
-            general_substeps_cold<F, EPL>(S.params, C, B, lane, L, time, n_sub);
-        else
+        if constexpr (F == SOFTROD_FEATURES_SOFTPENDULUM) {
+            general_step_cold<F, E, EPL>(S.params, S.self, rod, lane, actions, n_sub);   // HBM -> HBM
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            load_lane<EPL, F>(S, N, rod, lane, L);
+            time = S.time[rod];
+        } else
             general_substeps<F, EPL>(P, Pk, C, B, lane, L, time, n_sub);
     }
     store_lane<EPL, F>(S, N, rod, lane, L);

@@ -119,6 +119,7 @@ struct StatePtrs {
     int* q_underflow;       // [1] envs that needed a record when none was staged
     int q_depth, q_record;
     const struct RodParams* params;   // device copy of the kernel's RodParams (cold paths read it)
+    const struct StatePtrs* self;     // device copy of this struct (cold paths read it)
 };
 
 // ---------------------------------------------------------------------------------

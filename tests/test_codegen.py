@@ -64,3 +64,13 @@ def test_planar_hot_loop_has_no_scratch_traffic(tmp_path):
     assert len(valu) <= 102, f"planar substep grew to {len(valu)} VALU instructions"
     assert not [x for x in path if x.startswith(("scratch", "global", "buffer", "flat"))]
     assert not [x for x in valu if x.startswith("v_mov_b64")], "register copies inside the planar substep"
+    # the whole kernel: its only scratch traffic brackets the out-of-line 3-D fallback call (live
+    # values saved around s_swappc in the block a non-planar rod takes); a planar rod never
+    # executes a scratch instruction (r1k: 692 B per lane were written on every launch)
+    calls = [i for i, x in enumerate(ins) if "s_swappc" in x]
+    assert len(calls) == 1
+    bounds = sorted(set(labels.values()))
+    lo = max(b for b in bounds if b <= calls[0])
+    hi = min([b for b in bounds if b > calls[0]] + [len(ins)])
+    stray = [i for i, x in enumerate(ins) if x.startswith("scratch") and not lo <= i < hi]
+    assert not stray, f"{len(stray)} scratch instructions outside the fallback-call block"
