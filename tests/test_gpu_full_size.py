@@ -1,0 +1,108 @@
+"""BASELINE.json configs[2] and the per-GPU share of configs[4] at their FULL sizes (config[1] at
+4096 envs is tests/test_gpu_parity.py::test_full_size_batch_properties): size-independent
+properties of the whole batch — finite, bitwise repeatable, independent of the batch an env sits
+in — plus spot parity of a few envs against the oracle.  The oracle cannot step thousands of
+envs in a test; a handful spread over the batch (first, last, across wave / workgroup / XCD
+boundaries) is what it checks."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch
+
+
+def test_config3_4096_arms_of_100_elements(torch_gpu, hip_lib, oracle_built):
+    """OctoArmSingle-style reach, 4096 envs x 100 elements, 714 substeps per env.step: the
+    two-window kernel + the epilogue launch (softrod_window.hpp)."""
+    import gym_softrobot_amd as gsa
+
+    n, T = 4096, 2
+    acts = np.random.default_rng(2).uniform(-6, 6, (T, n, 7)).astype(np.float32)
+
+    def rollout(idx):
+        env = gsa.make_vec("OctoArmSingle-v0", len(idx), n_elems=100)
+        assert env.backend.cfg.n_elem == 100
+        env.reset(seed=0)
+        out = []
+        for t in range(T):
+            o, r, te, tr, _ = env.step(acts[t, idx])
+            out.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), te.cpu().numpy().copy(), tr.cpu().numpy().copy()))
+        st = env.backend.state_numpy()
+        env.close()
+        return out, st
+
+    full, st = rollout(np.arange(n))
+    again, _ = rollout(np.arange(n))
+    for a, b in zip(full, again):                                    # bitwise run-to-run (K7)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    obs, rew, term, trunc = full[-1]
+    assert np.isfinite(obs).all() and np.isfinite(rew).all() and not trunc.any()
+    # a few arms may end their episode early (|omega|_F > 250 is `invalid`, arm_single_env.py:270;
+    # 100 elements whip harder than 50): that is the env, and the oracle must agree on which
+    assert term.mean() < 0.05
+    np.testing.assert_array_equal(obs[:, 16:23], acts[-1])            # _prev_action = the action just taken
+    np.testing.assert_array_equal(obs[:, 23:25], np.broadcast_to(np.float32([1.0, 0.0]), (n, 2)))
+    Q = st["Q"]
+    QQt = np.einsum("eimk,ejmk->eijk", Q, Q)
+    assert np.abs(QQt - np.eye(3)[None, :, :, None]).max() < 1e-11  # directors stay orthonormal
+    spots = np.array([0, 1, 63, 64, 2047, 4095])
+    few, _ = rollout(spots)                                           # batch independence (K8)
+    for t in range(T):
+        for x, y in zip(full[t], few[t]):
+            np.testing.assert_array_equal(x[spots], y)
+    ended = [int(i) for i in np.nonzero(full[0][2] | full[1][2])[0][:2]]
+    for i in [0, 2047, 4095] + ended:                                 # spot parity vs the oracle
+        r = oracle_built.OracleRod(gsa._capi.arm_single_config(1, n_elems=100))
+        r.reset_arm()
+        for t in range(T):
+            o, rw, te, tr = r.env_step_arm(acts[t, i])
+            assert te == bool(full[t][2][i]) and tr == bool(full[t][3][i])
+        np.testing.assert_allclose(obs[i], o, rtol=RTOL, atol=2e-6)
+        np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-8)
+
+
+def test_config5_share_1024_octoflat_envs(torch_gpu, hip_lib, oracle_built):
+    """Octopus multi-arm, the per-GPU share of configs[4]: 1024 envs x 8 arms x 10 elements + head,
+    2857 substeps per env.step, one workgroup of two wavefronts per env."""
+    import gym_softrobot_amd as gsa
+
+    n = 1024
+    acts = np.random.default_rng(3).uniform(-22, 22, (n, 24)).astype(np.float32)
+
+    def one_step(idx):
+        env = gsa.make_vec("OctoFlat-v0", len(idx), numpy_output=True)
+        env.reset(seed=[int(i) for i in idx])
+        o, r, te, tr, _ = env.step(acts[idx])
+        res = (o.copy(), r.copy(), te.copy(), tr.copy())
+        tg = env.targets.copy()
+        env.close()
+        return res, tg
+
+    full, targets = one_step(np.arange(n))
+    again, _ = one_step(np.arange(n))
+    for x, y in zip(full, again):
+        np.testing.assert_array_equal(x, y)
+    obs, rew, term, trunc = full
+    assert obs.shape == (n, 461) and np.isfinite(obs).all() and np.isfinite(rew).all() and not trunc.any()
+    spots = np.array([0, 1, 255, 256, 1023])
+    few, _ = one_step(spots)
+    for x, y in zip(full, few):
+        np.testing.assert_array_equal(x[spots], y)
+    for i in (0, 256, 1023):
+        o = oracle_built.OracleOcto(gsa._capi.octo_flat_config(1))
+        o.reset(targets[i])
+        ob, rw, te, tr = o.env_step(acts[i])
+        flat = np.concatenate([ob["individual"].ravel(), ob["shared"]])
+        np.testing.assert_allclose(obs[i], flat, rtol=RTOL, atol=2e-6)
+        np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-6)
+        assert bool(term[i]) == te and bool(trunc[i]) == tr

@@ -1,4 +1,1 @@
-set -x
-python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > gpurun_out/r2c_gputests.log
-bash tools/profile_gpu.sh r2c > gpurun_out/r2c_profile.log 2>&1
-cat gpurun_out/r2c_gputests.log; tail -60 gpurun_out/r2c_profile.log
+python -m pytest tests/test_gpu_full_size.py tests/test_gpu_episode_parity.py -m gpu -q -x 2>&1 | tail -15
