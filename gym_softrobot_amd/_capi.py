@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -25,6 +25,9 @@ FEAT_PLANE_CONTACT_ANISO = 1 << 8
 FEAT_REST_KAPPA_ACTION = 1 << 9
 FEAT_OCTO_HEAD = 1 << 10
 FEAT_SPLINE_MUSCLE_TORQUES = 1 << 11
+FEAT_SUCKER_CONSTRAINT = 1 << 12
+MAX_SUCKERS = 4
+MATERIAL_ROWS = 16
 FEATURES_SOFTPENDULUM = (
     FEAT_GRAVITY | FEAT_POINT_FORCE_NODE0_X | FEAT_PENDULUM_BC | FEAT_ANALYTICAL_DAMPER
 )
@@ -127,6 +130,10 @@ class SoftrodConfig(C.Structure):
         ("muscle_torque_scale", C.c_double),
         ("max_activation_rate", C.c_double),
         ("arm_target", C.c_double * 3),
+        ("n_suckers", C.c_int32),
+        ("sucker_index", C.c_int32 * 4),
+        ("reserved2", C.c_int32),
+        ("sucker_reduction_ratio", C.c_double),
     ]
 
     def copy(self) -> "SoftrodConfig":
@@ -156,6 +163,8 @@ class SoftrodStateView(C.Structure):
         ("prev_action", C.c_void_p),
         ("head", C.c_void_p),
         ("bc_targets", C.c_void_p),
+        ("sucker_ratio", C.c_void_p),
+        ("material", C.c_void_p),
     ]
 
 
@@ -438,6 +447,7 @@ _EXPORTS = {
     "softrod_queue_status": (C.c_int, [_VP, _VP, _VP, _VP]),
     "softrod_queue_advance": (C.c_int, [_VP, _VP, _VP]),
     "softrod_set_action_basis": (C.c_int, [_VP, _VP]),
+    "softrod_set_radius_profile": (C.c_int, [_VP, _VP]),
     "softrod_create": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "softrod_reset": (C.c_int, [_VP, _VP, _VP, _VP]),
     "softrod_reset_straight": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),

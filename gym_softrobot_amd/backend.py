@@ -91,6 +91,12 @@ class HipRodBackend:
         return a.contiguous()
 
     # -- C-ABI calls ----------------------------------------------------------------
+    def set_radius_profile(self, radius) -> None:
+        """CosseratRod.straight_rod(base_radius=<array>): a tapered rod (octopus/arm_push_env.py:
+        160-179).  Before the first reset."""
+        r = np.ascontiguousarray(radius, dtype=np.float64).reshape(int(self.cfg.n_elem))
+        check(self._lib.softrod_set_radius_profile(self._h, r.ctypes.data), self._h)
+
     def reset(self, theta0: np.ndarray, mask: Optional[np.ndarray] = None) -> None:
         th = np.ascontiguousarray(theta0, dtype=np.float64).reshape(self.n_envs)
         m = None
@@ -286,11 +292,13 @@ class HipRodBackend:
                                            device=self.device),
             "head": torch.as_tensor(_DevArray(v.head, (20, n), "<f8", self), device=self.device),
             "bc_targets": torch.as_tensor(_DevArray(v.bc_targets, (12, n), "<f8", self), device=self.device),
+            "sucker_ratio": torch.as_tensor(_DevArray(v.sucker_ratio, (_capi.MAX_SUCKERS, n), "<f8", self),
+                                            device=self.device),
             "arm_stride": int(v.arm_stride),
         }
 
     _SNAPSHOT_KEYS = ("position", "velocity", "director", "omega", "tangents", "time", "control", "kappa",
-                      "rest_kappa", "env_memory", "prev_action", "head", "bc_targets")
+                      "rest_kappa", "env_memory", "prev_action", "head", "bc_targets", "sucker_ratio")
 
     def config_fingerprint(self) -> bytes:
         """What a snapshot is only valid for: the ABI and every field of softrod_config except the

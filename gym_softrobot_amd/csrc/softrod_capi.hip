@@ -36,6 +36,10 @@ struct softrod_handle {
     bool spline_set = false;
     RodParams* d_params = nullptr;  // device copy of P
     StatePtrs* d_state = nullptr;   // device copy of S (re-uploaded whenever S changes)
+    double* d_mat = nullptr;        // [kMatRows][64] material table of a tapered rod
+    double* d_sucker = nullptr;     // [SOFTROD_MAX_SUCKERS][N]
+    bool tapered = false;
+    bool was_reset = false;
     bool basis_set = false;
     double* h_init = nullptr;     // pinned
     uint8_t* h_mask = nullptr;    // pinned
@@ -200,6 +204,8 @@ void fill_params(const softrod_config& c, RodParams& P) {
     P.max_rate = c.max_activation_rate;
     P.base_length = c.base_length;
     for (int i = 0; i < 3; ++i) P.arm_target[i] = c.arm_target[i];
+    P.n_suckers = c.n_suckers;
+    for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) P.sucker_index[j] = c.sucker_index[j];
 }
 
 bool is_octo(const softrod_handle* h) { return (h->cfg.features & SOFTROD_FEAT_OCTO_HEAD) != 0; }
@@ -262,7 +268,10 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
             else                                                                                    \
                 SR_LAUNCH(kRuntimeFeatures, kRuntimeEnv, EPL);                                      \
         } while (0)
-        if (h->epl == 2) SR_DISPATCH(2); else SR_DISPATCH(1);
+        if (h->tapered)      // per-lane material constants: the general instantiation only
+            hipLaunchKernelGGL((softrod_step_fast_kernel<kRuntimeFeatures, kRuntimeEnv, 1, true>), grid, block, 0, st,
+                               h->P, h->S, actions, obs, reward, term, trunc, aux, n_sub, epilogue, pack);
+        else if (h->epl == 2) SR_DISPATCH(2); else SR_DISPATCH(1);
 #undef SR_DISPATCH
 #undef SR_LAUNCH
     } else
@@ -291,6 +300,7 @@ int upload_and_reset(softrod_handle* h, hipStream_t st, bool use_mask) {
         hipLaunchKernelGGL(softrod_reset_kernel<1>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
     SR_HIP(h, hipGetLastError());
     SR_HIP(h, hipEventRecord(h->ev_reset, st));
+    h->was_reset = true;
     return SOFTROD_OK;
 }
 
@@ -518,6 +528,13 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         if (!(cfg->head_radius > 0.0) || !(cfg->head_density > 0.0))
             return fail(nullptr, SOFTROD_EINVAL, "OctoFlat needs head_radius > 0 and head_density > 0");
     }
+    if (cfg->features & SOFTROD_FEAT_SUCKER_CONSTRAINT) {
+        if (octo || cfg->n_suckers < 1 || cfg->n_suckers > SOFTROD_MAX_SUCKERS)
+            return fail(nullptr, SOFTROD_EINVAL, "ControllableFixConstraint: 1 <= n_suckers <= 4, not with OctoFlat");
+        for (int j = 0; j < cfg->n_suckers; ++j)
+            if (cfg->sucker_index[j] < 0 || cfg->sucker_index[j] >= cfg->n_elem)
+                return fail(nullptr, SOFTROD_EINVAL, "ControllableFixConstraint: 0 <= sucker_index < n_elem");
+    }
     if ((cfg->features & SOFTROD_FEAT_LAPLACE_FILTER) && (cfg->filter_order < 1 || cfg->n_elem < 3))
         return fail(nullptr, SOFTROD_EINVAL, "LaplaceDissipationFilter needs filter_order >= 1");
     {
@@ -583,6 +600,16 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     h->S.params = h->d_params;
     alloc((void**)&h->d_state, sizeof(StatePtrs));
     h->S.self = h->d_state;
+    alloc((void**)&h->d_sucker, (size_t)SOFTROD_MAX_SUCKERS * N * sizeof(double));
+    h->S.sucker = h->d_sucker;
+    if (rc == SOFTROD_OK && (cfg->features & SOFTROD_FEAT_SUCKER_CONSTRAINT)) {
+        // the controllers are switched on after finalize (arm_push_env.py:222): effective ratio = the configured one
+        std::vector<double> init((size_t)SOFTROD_MAX_SUCKERS * N, 0.0);
+        for (int j = 0; j < cfg->n_suckers; ++j)
+            for (size_t e = 0; e < N; ++e) init[(size_t)j * N + e] = cfg->sucker_reduction_ratio;
+        if (hipMemcpy(h->d_sucker, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+            rc = SOFTROD_EHIP;
+    }
     alloc((void**)&h->d_basis, (size_t)2 * kLanes * 7 * sizeof(double));
     h->S.basis = h->d_basis;
     alloc((void**)&h->d_init, N * h->init_stride * sizeof(double));
@@ -829,6 +856,71 @@ int softrod_set_spline_table(softrod_handle* h, const double* breaks, const doub
     return SOFTROD_OK;
 }
 
+// CosseratRod.straight_rod's allocation (elastica/rod/factory_function.py allocate(), recalled)
+// with base_radius an ARRAY of n_elements radii (octopus/arm_push_env.py:160-179): the rows of
+// kernels' per-lane material table.  Mirrors straight_rod() of oracle/softrod_oracle.c.
+int softrod_set_radius_profile(softrod_handle* h, const double* radius) {
+    if (!h || !radius) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (is_octo(h) || h->epl != 1 || h->window_refresh > 0)
+        return fail(h, SOFTROD_EINVAL, "tapered rods: one rod of up to 63 elements per env");
+    if (h->was_reset) return fail(h, SOFTROD_EINVAL, "softrod_set_radius_profile must precede the first reset");
+    const softrod_config& c = h->cfg;
+    const int n = c.n_elem;
+    for (int k = 0; k < n; ++k)
+        if (!(radius[k] > 0.0)) return fail(h, SOFTROD_EINVAL, "radii must be positive");
+    SR_ON_DEVICE(h);
+    constexpr int W = kLanes;
+    std::vector<double> T((size_t)kMatRows * W, 0.0);
+    const double rest_len = c.base_length / (double)n;
+    std::vector<double> mass((size_t)n + 1, 0.0), bend01((size_t)n), bend2((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        const double r = radius[k];
+        const double A0 = M_PI * r * r;
+        const double I1 = A0 * A0 / (4.0 * M_PI), I3 = 2.0 * I1;
+        const double J0 = I1 * (c.density * rest_len), J2 = I3 * (c.density * rest_len);
+        T[(size_t)kMatJ0 * W + k] = J0; T[(size_t)kMatJ2 * W + k] = J2;
+        T[(size_t)kMatInvJ0 * W + k] = 1.0 / J0; T[(size_t)kMatInvJ2 * W + k] = 1.0 / J2;
+        T[(size_t)kMatShear01 * W + k] = c.alpha_c * c.shear_modulus * A0;
+        T[(size_t)kMatShear2 * W + k] = c.youngs_modulus * A0;
+        bend01[(size_t)k] = c.youngs_modulus * I1;
+        bend2[(size_t)k] = c.shear_modulus * I3;
+        const double volume = M_PI * (r * r) * rest_len;
+        mass[(size_t)k] += 0.5 * c.density * volume;
+        mass[(size_t)k + 1] += 0.5 * c.density * volume;
+        T[(size_t)kMatR0s * W + k] = r * std::sqrt(rest_len);
+        T[(size_t)kMatInvR0s * W + k] = 1.0 / (r * std::sqrt(rest_len));
+    }
+    for (int k = 0; k < n - 1; ++k) {      // rest-length-weighted average onto the Voronoi vertices
+        T[(size_t)kMatBend01 * W + k] = (bend01[(size_t)k + 1] * rest_len + bend01[(size_t)k] * rest_len) / (rest_len + rest_len);
+        T[(size_t)kMatBend2 * W + k] = (bend2[(size_t)k + 1] * rest_len + bend2[(size_t)k] * rest_len) / (rest_len + rest_len);
+    }
+    double ms = 0.0;
+    for (int k = 0; k <= n; ++k) { T[(size_t)kMatMass * W + k] = mass[(size_t)k]; ms += mass[(size_t)k]; }
+    for (int k = n + 1; k < W; ++k) T[(size_t)kMatMass * W + k] = 1.0;     // finite filler past the rod
+    for (int k = 0; k < n; ++k) {          // AnalyticalLinearDamper's per-element coefficients
+        double me = 0.5 * (mass[(size_t)k + 1] + mass[(size_t)k]);
+        if (k == 0) me += 0.5 * mass[0];
+        if (k == n - 1) me += 0.5 * mass[(size_t)n];
+        const double l0 = -c.damping_constant * c.dt * me * T[(size_t)kMatInvJ0 * W + k];
+        const double l2 = -c.damping_constant * c.dt * me * T[(size_t)kMatInvJ2 * W + k];
+        T[(size_t)kMatDampLog0 * W + k] = l0; T[(size_t)kMatDampLog2 * W + k] = l2;
+        T[(size_t)kMatDampR0 * W + k] = std::exp(l0); T[(size_t)kMatDampR2 * W + k] = std::exp(l2);
+    }
+    for (int k = n; k < W; ++k) {           // slots past the last element: harmless finite values
+        T[(size_t)kMatInvJ0 * W + k] = 0.0; T[(size_t)kMatInvJ2 * W + k] = 0.0;
+        T[(size_t)kMatDampR0 * W + k] = 1.0; T[(size_t)kMatDampR2 * W + k] = 1.0;
+        T[(size_t)kMatR0s * W + k] = 1.0; T[(size_t)kMatInvR0s * W + k] = 1.0;
+    }
+    if (!h->d_mat) SR_HIP(h, hipMalloc((void**)&h->d_mat, T.size() * sizeof(double)));
+    SR_HIP(h, hipMemcpy(h->d_mat, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->S.mat = h->d_mat;
+    h->P.mass_total = ms;
+    h->tapered = true;
+    SR_HIP(h, hipMemcpy(h->d_params, &h->P, sizeof(RodParams), hipMemcpyHostToDevice));
+    SR_HIP(h, hipMemcpy(h->d_state, &h->S, sizeof(StatePtrs), hipMemcpyHostToDevice));
+    return SOFTROD_OK;
+}
+
 int softrod_set_action_basis(softrod_handle* h, const double* basis) {
     if (!h || !basis) return fail(h, SOFTROD_EINVAL, "null argument");
     SR_ON_DEVICE(h);
@@ -911,6 +1003,8 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->prev_action = h->S.prev_action;
     out->head = h->S.head;
     out->bc_targets = h->S.bc;
+    out->sucker_ratio = h->S.sucker;
+    out->material = h->d_mat;
     return SOFTROD_OK;
 }
 
@@ -967,7 +1061,7 @@ int softrod_destroy(softrod_handle* h) {
     if (h->h_produced) (void)hipHostFree(h->h_produced);
     if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_basis, h->d_spline, h->d_init, h->d_mask};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_mat, h->d_sucker, h->d_basis, h->d_spline, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

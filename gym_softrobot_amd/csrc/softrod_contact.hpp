@@ -54,7 +54,7 @@ __device__ __forceinline__ double slip_function(double a, double thr, double inv
 // In:  F[s][3]   nodal internal + external force of node EPL*lane+s (so far)
 //      tq[s][3]  element internal + external torque (local frame) (so far)
 // Out: fc[s][3]  contact force added to that node;  tq += contact torques.
-template <int EPL, bool ZUP, bool FM>
+template <int EPL, bool ZUP, bool FM, bool TAPER = false>
 __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const RodParams& P, int lane,
                                                 const ConstN<EPL>& K, const LaneN<EPL>& L,
                                                 const double (&xn)[EPL][3], const double (&vn)[EPL][3],
@@ -89,12 +89,12 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
         double fel[3];
         if constexpr (FM) {
             const double rsl = fast_rsqrt(len[s]);
-            radius[s] = C.r0_sqrt_rest_len * rsl;
-            inv_radius[s] = (len[s] * rsl) * C.inv_r0_sqrt_rest_len;      // sqrt(len) / (r0 sqrt(l_rest))
+            radius[s] = (TAPER ? K.r0s[s] : C.r0_sqrt_rest_len) * rsl;
+            inv_radius[s] = (len[s] * rsl) * (TAPER ? K.ir0s[s] : C.inv_r0_sqrt_rest_len);   // sqrt(len) / (r0 sqrt(l_rest))
 #pragma unroll
             for (int i = 0; i < 3; ++i) fel[i] = fma(wb[s], Fn[s][i], wa[s] * F[s][i]);
         } else {
-            radius[s] = C.r0_sqrt_rest_len / sqrt(len[s]);
+            radius[s] = (TAPER ? K.r0s[s] : C.r0_sqrt_rest_len) / sqrt(len[s]);
             inv_radius[s] = 1.0 / radius[s];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {

@@ -160,7 +160,7 @@ struct NoConnections {
 };
 
 // ---- forces, torques, rate update, dampers, constrain_rates -------------------------------------
-template <unsigned F, int EPL, class Connections = NoConnections>
+template <unsigned F, int EPL, bool TAPER = false, class Connections = NoConnections>
 __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>& C, const BcTargets& B,
                                           int lane, LaneN<EPL>& L, Connections&& connect = Connections()) {
     const int n = P.n_elem;
@@ -290,7 +290,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         const double num = fma(d[s][2], vn[s][2] - L.v[s][2],
                                fma(d[s][1], vn[s][1] - L.v[s][1], d[s][0] * (vn[s][0] - L.v[s][0])));
         const double sdil = num * il[s] * il[s];
-        const double j01 = P.J[0] * ie[s], j2 = P.J[2] * ie[s];
+        const double j01 = (TAPER ? C.j01[s] : P.J[0]) * ie[s], j2 = (TAPER ? C.j2[s] : P.J[2]) * ie[s];
         const double z = w[2] * (j01 - j2);
         tq[s][0] = fma(w[1], z, tq[s][0]);
         tq[s][1] = fma(-w[0], z, tq[s][1]);
@@ -321,9 +321,9 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
             }
         }
         if (has<F>(P, kFeatPlaneZup))
-            plane_contact_n<EPL, true, true>(contact_params(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);
+            plane_contact_n<EPL, true, true, TAPER>(contact_params(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);
         else
-            plane_contact_n<EPL, false, true>(contact_params(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);
+            plane_contact_n<EPL, false, true, TAPER>(contact_params(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);
 #pragma unroll
         for (int s = 0; s < EPL; ++s)
 #pragma unroll
@@ -343,8 +343,9 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
             // c_r^e = c_r * c_r^(e-1): the strain e-1 is small, so the exponent stays in the
             // polynomial's range also where log c_r is not (octopus arms: log c_r = -0.057)
             const double em1 = e[s] - 1.0;
-            exp_pair(em1 * P.damp_logr[0], em1 * P.damp_logr[2], elem_valid, ex0, ex2);
-            ex0 *= P.damp_r[0]; ex2 *= P.damp_r[2];
+            exp_pair(em1 * (TAPER ? C.dlog0[s] : P.damp_logr[0]), em1 * (TAPER ? C.dlog2[s] : P.damp_logr[2]),
+                     elem_valid, ex0, ex2);
+            ex0 *= TAPER ? C.dr0[s] : P.damp_r[0]; ex2 *= TAPER ? C.dr2[s] : P.damp_r[2];
             w0 *= ex0; w1 *= ex0; w2 *= ex2;
         }
         L.w[s][0] = w0; L.w[s][1] = w1; L.w[s][2] = w2;
@@ -352,10 +353,12 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
     if (P.damp_before_constrain) {
         if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) laplace_filter_rates_fast<EPL>(P, lane, L);
         constrain_rates_n<F, EPL>(P, B, lane, L);
+        sucker_rates_n<F, EPL>(P, B, lane, L);
     } else {
         BcTargets Bs = B;
         Bs.vel[0] *= P.damp_t; Bs.vel[1] *= P.damp_t; Bs.vel[2] *= P.damp_t;
         constrain_rates_n<F, EPL>(P, Bs, lane, L);
+        sucker_rates_n<F, EPL>(P, B, lane, L);
         if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) laplace_filter_rates_fast<EPL>(P, lane, L);
     }
 }
@@ -394,14 +397,14 @@ __device__ __forceinline__ void poison_rod(LaneN<EPL>& L) {
 // The substeps of one launch on the general 3-D state.  `always_inline` for every kernel whose
 // only path it is; the SoftPendulum kernel keeps it OUT of line (cold fallback for non-planar
 // states) so that its register demand cannot leak spills into the planar hot loop.
-template <unsigned F, int EPL>
+template <unsigned F, int EPL, bool TAPER = false>
 __device__ __forceinline__ void general_substeps(const RodParams& P, const RodParams& Pk, const ConstN<EPL>& C,
                                                  const BcTargets& B, int lane, LaneN<EPL>& L, double& time,
                                                  int n_sub) {
     kinematic_n<EPL>(P.half_dt, C, L);
     if (P.time_two_half_adds) time += P.half_dt;
     for (int s = 0; s < n_sub; ++s) {
-        dynamic_n<F, EPL>(Pk, C, B, lane, L);
+        dynamic_n<F, EPL, TAPER>(Pk, C, B, lane, L);
         const bool last = (s == n_sub - 1);
         kinematic_n<EPL>(last ? P.half_dt : P.dt, C, L);
         time += P.time_two_half_adds ? P.half_dt : P.dt;
@@ -451,7 +454,9 @@ __device__ __attribute__((noinline)) void general_step_cold(const RodParams* __r
 #endif
 // Two slots per lane need the whole 512-entry register file (1 wave per SIMD); the contact
 // and Laplace-filter instantiations trade a wave of occupancy for not spilling in the loop.
-template <unsigned F, int E, int EPL>
+// TAPER: the rod's radius varies along its length (softrod_set_radius_profile): material constants
+// come from the per-lane table S.mat instead of the kernel arguments.
+template <unsigned F, int E, int EPL, bool TAPER = false>
 __global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))) ? SOFTROD_CONTACT_WAVES : SOFTROD_FAST_WAVES)))
 softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
@@ -469,6 +474,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     load_lane<EPL, F>(S, N, rod, lane, L);
     BcTargets B;
     load_bc(S, N, rod, B);
+    load_suckers<F>(P, S, N, rod, B);
     EnvAction A;
     set_action_n<F, E, EPL>(P, S, N, rod, lane, actions, A, B, L);
     if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)) muscle_load<EPL>(P, S, rod, actions != nullptr, A, L);
@@ -482,7 +488,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     }
     double time = S.time[rod];
     ConstN<EPL> C;
-    build_const<F, EPL>(P, lane, A, C);
+    build_const<F, EPL, TAPER>(P, lane, A, C, S.mat);
     RodParams Pk = P;
     if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
 
@@ -535,7 +541,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             load_lane<EPL, F>(S, N, rod, lane, L);
             time = S.time[rod];
         } else
-            general_substeps<F, EPL>(P, Pk, C, B, lane, L, time, n_sub);
+            general_substeps<F, EPL, TAPER>(P, Pk, C, B, lane, L, time, n_sub);
     }
     store_lane<EPL, F>(S, N, rod, lane, L);
     if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)) muscle_store<EPL>(P, S, rod, lane, L);

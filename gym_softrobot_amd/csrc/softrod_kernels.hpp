@@ -92,7 +92,14 @@ struct RodParams {
     double muscle_scale, max_rate, base_length, arm_target[3];
     const double* spline;   // device: breaks[SOFTROD_MAX_SPLINE_PIECES + 1], then coef[p][j][4] (j < n_ctrl)
     double joint_k, joint_nu, joint_kt;
+    // ControllableFixConstraint (octopus/controllable_constraint.py:24-69)
+    int n_suckers, sucker_index[SOFTROD_MAX_SUCKERS], pad2;
 };
+
+// Rows of the per-lane material table of a TAPERED rod (softrod_set_radius_profile): what
+// CosseratRod.straight_rod derives from a per-element radius.  [row][slot], shared by all envs.
+enum MatRow { kMatMass = 0, kMatShear01, kMatShear2, kMatBend01, kMatBend2, kMatJ0, kMatJ2, kMatInvJ0, kMatInvJ2,
+              kMatDampLog0, kMatDampLog2, kMatDampR0, kMatDampR2, kMatR0s, kMatInvR0s, kMatRows = SOFTROD_MATERIAL_ROWS };
 
 struct StatePtrs {
     double* pos;   // [3][N][64]
@@ -120,6 +127,8 @@ struct StatePtrs {
     int q_depth, q_record;
     const struct RodParams* params;   // device copy of the kernel's RodParams (cold paths read it)
     const struct StatePtrs* self;     // device copy of this struct (cold paths read it)
+    const double* mat;      // [kMatRows][64*EPL] material table of a tapered rod, or nullptr (uniform)
+    double* sucker;         // [SOFTROD_MAX_SUCKERS][N] effective reduction ratio of each sucker
 };
 
 // ---------------------------------------------------------------------------------
@@ -208,6 +217,9 @@ struct ConstN {
     double s01[EPL], s2[EPL];
     double b01[EPL], bd[EPL];
     double mass[EPL], mass_next[EPL], inv_mass_pair[EPL];   // 1 / (m_k + m_{k+1}): element velocity
+    // tapered rods only (TAPER instantiations; dead otherwise): the constants a uniform rod
+    // keeps in scalar registers (RodParams), per element
+    double j01[EPL], j2[EPL], dlog0[EPL], dlog2[EPL], dr0[EPL], dr2[EPL], r0s[EPL], ir0s[EPL];
 };
 
 // value of index+1 / index-1 for a per-slot array
@@ -274,6 +286,7 @@ struct BcTargets {
     double pos[3];
     double Q[9];
     double vel[3];      // imposed base velocity (moving base), else 0
+    double keep[SOFTROD_MAX_SUCKERS];   // 1 - effective reduction ratio of each sucker (this env)
 };
 
 // Per-env action handling done once per env.step before the substeps.
@@ -288,6 +301,37 @@ __device__ __forceinline__ void load_bc(const StatePtrs& S, size_t N, int rod, B
 #pragma unroll
     for (int i = 0; i < 9; ++i) B.Q[i] = S.bc[(size_t)(3 + i) * N + rod];
     B.vel[0] = B.vel[1] = B.vel[2] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) B.keep[j] = 1.0;
+}
+
+// ControllableFixConstraint.constrain_rates (octopus/controllable_constraint.py:45-69):
+//   velocity_collection[..., index] *= 1.0 - reduction_ratio ; omega_collection[..., index] *= ...
+// NOT idempotent (unless the ratio is 1), so unlike the other constraints it is applied once per
+// substep only and never at kernel entry.
+template <unsigned F>
+__device__ __forceinline__ void load_suckers(const RodParams& P, const StatePtrs& S, size_t N, int rod, BcTargets& B) {
+    if (has<F>(P, SOFTROD_FEAT_SUCKER_CONSTRAINT)) {
+#pragma unroll
+        for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j)
+            B.keep[j] = (j < P.n_suckers) ? 1.0 - S.sucker[(size_t)j * N + rod] : 1.0;
+    }
+}
+template <unsigned F, int EPL>
+__device__ __forceinline__ void sucker_rates_n(const RodParams& P, const BcTargets& B, int lane, LaneN<EPL>& L) {
+    if (has<F>(P, SOFTROD_FEAT_SUCKER_CONSTRAINT)) {
+#pragma unroll
+        for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) {
+            if (j >= P.n_suckers) continue;
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) {
+                const bool here = (lane * EPL + s) == P.sucker_index[j];
+                const double k = here ? B.keep[j] : 1.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { L.v[s][c] *= k; L.w[s][c] *= k; }
+            }
+        }
+    }
 }
 
 // ---- boundary conditions act on node 0 / element 0 = lane 0, slot 0 -------------------------
@@ -829,23 +873,45 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
     }
 }
 
-template <unsigned F, int EPL>
+template <unsigned F, int EPL, bool TAPER = false>
 __device__ __forceinline__ void build_const(const RodParams& P, int lane, const EnvAction& A,
-                                            ConstN<EPL>& C) {
+                                            ConstN<EPL>& C, const double* __restrict__ mat = nullptr) {
     const int n = P.n_elem;
     const bool damp = has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER);
     const double ct = damp ? P.damp_t : 1.0;
+    constexpr int W = kLanes * EPL;
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
-        const int idx = slot_local<F>(P, lane * EPL + s);
+        const int raw = lane * EPL + s;
+        const int idx = slot_local<F>(P, raw);
         const bool first = (idx == 0);
         const bool held_q = first && has<F>(P, SOFTROD_FEAT_PENDULUM_BC | SOFTROD_FEAT_FIXED_BC |
                                                SOFTROD_FEAT_MOVING_BASE_BC);
         const bool held_x = first && has<F>(P, SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_MOVING_BASE_BC);
         const bool node_valid = idx <= n, elem_valid = idx < n, vor_valid = idx < n - 1;
-        const double mass = (idx == 0 || idx == n) ? 0.5 * P.mass_node : P.mass_node;
+        double mass = (idx == 0 || idx == n) ? 0.5 * P.mass_node : P.mass_node;
+        double mass_next = (idx + 1 == n) ? 0.5 * P.mass_node : P.mass_node;
+        double shear01 = P.shear[0], shear2 = P.shear[2], bend01 = P.bend[0], bend2 = P.bend[2];
+        double invJ0 = P.invJ[0], invJ2 = P.invJ[2];
+        if constexpr (TAPER) {      // CosseratRod.straight_rod with an array of radii: per-element constants
+            const int nx = raw + 1 < W ? raw + 1 : raw;
+            mass = node_valid ? mat[kMatMass * W + raw] : 1.0;
+            mass_next = (idx + 1 <= n) ? mat[kMatMass * W + nx] : 1.0;
+            shear01 = mat[kMatShear01 * W + raw]; shear2 = mat[kMatShear2 * W + raw];
+            bend01 = mat[kMatBend01 * W + raw]; bend2 = mat[kMatBend2 * W + raw];
+            invJ0 = mat[kMatInvJ0 * W + raw]; invJ2 = mat[kMatInvJ2 * W + raw];
+            C.j01[s] = mat[kMatJ0 * W + raw]; C.j2[s] = mat[kMatJ2 * W + raw];
+            C.dlog0[s] = mat[kMatDampLog0 * W + raw]; C.dlog2[s] = mat[kMatDampLog2 * W + raw];
+            C.dr0[s] = mat[kMatDampR0 * W + raw]; C.dr2[s] = mat[kMatDampR2 * W + raw];
+            C.r0s[s] = mat[kMatR0s * W + raw]; C.ir0s[s] = mat[kMatInvR0s * W + raw];
+        } else {
+            C.j01[s] = P.J[0]; C.j2[s] = P.J[2];
+            C.dlog0[s] = P.damp_logr[0]; C.dlog2[s] = P.damp_logr[2];
+            C.dr0[s] = P.damp_r[0]; C.dr2[s] = P.damp_r[2];
+            C.r0s[s] = P.r0_sqrt_rest_len; C.ir0s[s] = 1.0 / P.r0_sqrt_rest_len;
+        }
         C.mass[s] = mass;
-        C.mass_next[s] = (idx + 1 == n) ? 0.5 * P.mass_node : P.mass_node;
+        C.mass_next[s] = mass_next;
         C.inv_mass_pair[s] = 1.0 / (C.mass[s] + C.mass_next[s]);
         C.hx[s] = held_x ? 0.0 : 1.0;
         C.hq[s] = held_q ? 0.0 : 1.0;
@@ -860,12 +926,12 @@ __device__ __forceinline__ void build_const(const RodParams& P, int lane, const 
             fe0 += P.tip_force[0]; fe1 += P.tip_force[1]; fe2 += P.tip_force[2];
         }
         C.ca[s][0] = cdm * fe0; C.ca[s][1] = cdm * fe1; C.ca[s][2] = cdm * fe2;
-        C.cw01[s] = elem_valid ? P.dt * P.invJ[0] : 0.0;
-        C.cw2[s] = elem_valid ? P.dt * P.invJ[2] : 0.0;
-        C.s01[s] = elem_valid ? P.shear[0] : 0.0;
-        C.s2[s] = elem_valid ? P.shear[2] : 0.0;
-        C.b01[s] = vor_valid ? P.bend[0] : 0.0;
-        C.bd[s] = vor_valid ? P.bend[2] - P.bend[0] : 0.0;
+        C.cw01[s] = elem_valid ? P.dt * invJ0 : 0.0;
+        C.cw2[s] = elem_valid ? P.dt * invJ2 : 0.0;
+        C.s01[s] = elem_valid ? shear01 : 0.0;
+        C.s2[s] = elem_valid ? shear2 : 0.0;
+        C.b01[s] = vor_valid ? bend01 : 0.0;
+        C.bd[s] = vor_valid ? bend2 - bend01 : 0.0;
     }
 }
 
@@ -1066,9 +1132,36 @@ __device__ __forceinline__ void libm_kinematic_step(const RodParams& P, double h
     for (int i = 0; i < 9; ++i) L.Q[0][i] = Qn[i];
 }
 
+// The material constants of this lane's element / Voronoi vertex: RodParams for a uniform rod,
+// the per-lane table for a tapered one (softrod_set_radius_profile).
+struct LibmMat {
+    double shear[3], bend[3], J[3], invJ[3], damp_r[3], mass_next, r0s;
+};
+__device__ __forceinline__ void libm_material(const RodParams& P, const double* __restrict__ mat, int lane,
+                                              LibmMat& M) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M.shear[i] = P.shear[i]; M.bend[i] = P.bend[i]; M.J[i] = P.J[i]; M.invJ[i] = P.invJ[i];
+        M.damp_r[i] = P.damp_r[i];
+    }
+    M.mass_next = (lane + 1 == P.n_elem) ? 0.5 * P.mass_node : P.mass_node;
+    M.r0s = P.r0_sqrt_rest_len;
+    if (mat) {
+        constexpr int W = kLanes;
+        const int nx = lane + 1 < W ? lane + 1 : lane;
+        M.shear[0] = M.shear[1] = mat[kMatShear01 * W + lane]; M.shear[2] = mat[kMatShear2 * W + lane];
+        M.bend[0] = M.bend[1] = mat[kMatBend01 * W + lane]; M.bend[2] = mat[kMatBend2 * W + lane];
+        M.J[0] = M.J[1] = mat[kMatJ0 * W + lane]; M.J[2] = mat[kMatJ2 * W + lane];
+        M.invJ[0] = M.invJ[1] = mat[kMatInvJ0 * W + lane]; M.invJ[2] = mat[kMatInvJ2 * W + lane];
+        M.damp_r[0] = M.damp_r[1] = mat[kMatDampR0 * W + lane]; M.damp_r[2] = mat[kMatDampR2 * W + lane];
+        M.mass_next = mat[kMatMass * W + nx];
+        M.r0s = mat[kMatR0s * W + lane];
+    }
+}
+
 // Internal forces/torques + forcing + dynamic update + dampers + rate constraints:
 // steps (3)-(6) of the substep (DESIGN.md "substep order").
-__device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTargets& B, int lane,
+__device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const LibmMat& M, const BcTargets& B, int lane,
                                                   double action, double mass, LaneN<1>& L) {
     const int n = P.n_elem;
     const bool node_valid = lane <= n;
@@ -1086,9 +1179,9 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     const double qt0 = L.Q[0][0] * L.t[0][0] + L.Q[0][1] * L.t[0][1] + L.Q[0][2] * L.t[0][2];
     const double qt1 = L.Q[0][3] * L.t[0][0] + L.Q[0][4] * L.t[0][1] + L.Q[0][5] * L.t[0][2];
     const double qt2 = L.Q[0][6] * L.t[0][0] + L.Q[0][7] * L.t[0][1] + L.Q[0][8] * L.t[0][2];
-    const double n0 = P.shear[0] * (e * qt0);
-    const double n1 = P.shear[1] * (e * qt1);
-    const double n2 = P.shear[2] * (e * qt2 - 1.0);
+    const double n0 = M.shear[0] * (e * qt0);
+    const double n1 = M.shear[1] * (e * qt1);
+    const double n2 = M.shear[2] * (e * qt2 - 1.0);
 
     // ---- internal force: difference of Q^T n / e ----
     double cs0 = (L.Q[0][0] * n0 + L.Q[0][3] * n1 + L.Q[0][6] * n2) / e;
@@ -1117,8 +1210,8 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     const double fk = (-0.5 * theta / sin(theta + P.eps_sin)) / P.rest_vor;
     const double k0 = vec0 * fk, k1 = vec1 * fk, k2 = vec2 * fk;
     L.kap[0][0] = k0; L.kap[0][1] = k1; L.kap[0][2] = k2;
-    const double m0 = P.bend[0] * (k0 - L.rk[0][0]), m1 = P.bend[1] * (k1 - L.rk[0][1]),
-                 m2 = P.bend[2] * (k2 - L.rk[0][2]);
+    const double m0 = M.bend[0] * (k0 - L.rk[0][0]), m1 = M.bend[1] * (k1 - L.rk[0][1]),
+                 m2 = M.bend[2] * (k2 - L.rk[0][2]);
     const double vd = 0.5 * (len_n + len) / P.rest_vor;
     const double e3 = 1.0 / (vd * vd * vd);
     double c20 = m0 * e3, c21 = m1 * e3, c22 = m2 * e3;
@@ -1145,7 +1238,7 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     const double rp1v = (xn0 * L.v[0][0] + xn1 * L.v[0][1]) + xn2 * L.v[0][2];
     const double rvp1 = (L.x[0][0] * vn0 + L.x[0][1] * vn1) + L.x[0][2] * vn2;
     const double dil_rate = (rv + rvn - rvp1 - rp1v) / len / P.rest_len;
-    const double jw0 = P.J[0] * L.w[0][0] / e, jw1 = P.J[1] * L.w[0][1] / e, jw2 = P.J[2] * L.w[0][2] / e;
+    const double jw0 = M.J[0] * L.w[0][0] / e, jw1 = M.J[1] * L.w[0][1] / e, jw2 = M.J[2] * L.w[0][2] / e;
     tq0 += jw1 * L.w[0][2] - jw2 * L.w[0][1];
     tq1 += jw2 * L.w[0][0] - jw0 * L.w[0][2];
     tq2 += jw0 * L.w[0][1] - jw1 * L.w[0][0];
@@ -1156,9 +1249,12 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     // contact_before_forcing. ----
     double fe0 = 0.0, fe1 = 0.0, fe2 = 0.0;
     const bool has_contact = (P.features & SOFTROD_FEAT_PLANE_CONTACT_ANISO) != 0;
-    const double mass_next = (lane + 1 == n) ? 0.5 * P.mass_node : P.mass_node;
+    const double mass_next = M.mass_next;
     const double xn[1][3] = {{xn0, xn1, xn2}}, vn[1][3] = {{vn0, vn1, vn2}};
     ConstN<1> CK;
+    ContactParams CP = contact_params(P);
+    CP.r0_sqrt_rest_len = M.r0s;
+    CP.inv_r0_sqrt_rest_len = 1.0 / M.r0s;
     CK.mass[0] = mass;
     CK.mass_next[0] = mass_next;
     CK.inv_mass_pair[0] = 1.0 / (mass + mass_next);
@@ -1166,7 +1262,7 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     if (has_contact && P.contact_before_forcing) {
         const double F[1][3] = {{f0, f1, f2}};
         double tq[1][3] = {{tq0, tq1, tq2}}, fc[1][3];
-        plane_contact_n<1, false, false>(contact_params(P), P, lane, CK, L, xn, vn, len1, F, tq, fc);
+        plane_contact_n<1, false, false>(CP, P, lane, CK, L, xn, vn, len1, F, tq, fc);
         fe0 = fc[0][0]; fe1 = fc[0][1]; fe2 = fc[0][2];
         tq0 = tq[0][0]; tq1 = tq[0][1]; tq2 = tq[0][2];
     }
@@ -1184,14 +1280,14 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
         const double F[1][3] = {{f0 + (node_valid ? fe0 : 0.0), f1 + (node_valid ? fe1 : 0.0),
                                  f2 + (node_valid ? fe2 : 0.0)}};
         double tq[1][3] = {{tq0, tq1, tq2}}, fc[1][3];
-        plane_contact_n<1, false, false>(contact_params(P), P, lane, CK, L, xn, vn, len1, F, tq, fc);
+        plane_contact_n<1, false, false>(CP, P, lane, CK, L, xn, vn, len1, F, tq, fc);
         fe0 += fc[0][0]; fe1 += fc[0][1]; fe2 += fc[0][2];
         tq0 = tq[0][0]; tq1 = tq[0][1]; tq2 = tq[0][2];
     }
 
     // ---- accelerations and rate update (v += dt a ; w += dt alpha) ----
     const double a0 = (f0 + fe0) / mass, a1 = (f1 + fe1) / mass, a2 = (f2 + fe2) / mass;
-    const double al0 = (P.invJ[0] * tq0) * e, al1 = (P.invJ[1] * tq1) * e, al2 = (P.invJ[2] * tq2) * e;
+    const double al0 = (M.invJ[0] * tq0) * e, al1 = (M.invJ[1] * tq1) * e, al2 = (M.invJ[2] * tq2) * e;
     L.v[0][0] += node_valid ? P.dt * a0 : 0.0;
     L.v[0][1] += node_valid ? P.dt * a1 : 0.0;
     L.v[0][2] += node_valid ? P.dt * a2 : 0.0;
@@ -1200,15 +1296,21 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const BcTa
     L.w[0][2] += elem_valid ? P.dt * al2 : 0.0;
 
     // ---- dampers (registration order) and constrain_rates ----
-    if (!P.damp_before_constrain) constrain_rates_n<kRuntimeFeatures, 1>(P, B, lane, L);
+    if (!P.damp_before_constrain) {
+        constrain_rates_n<kRuntimeFeatures, 1>(P, B, lane, L);
+        sucker_rates_n<kRuntimeFeatures, 1>(P, B, lane, L);
+    }
     if (P.features & SOFTROD_FEAT_ANALYTICAL_DAMPER) {
         L.v[0][0] *= P.damp_t; L.v[0][1] *= P.damp_t; L.v[0][2] *= P.damp_t;
-        L.w[0][0] *= pow(P.damp_r[0], e);
-        L.w[0][1] *= pow(P.damp_r[1], e);
-        L.w[0][2] *= pow(P.damp_r[2], e);
+        L.w[0][0] *= pow(M.damp_r[0], e);
+        L.w[0][1] *= pow(M.damp_r[1], e);
+        L.w[0][2] *= pow(M.damp_r[2], e);
     }
     if (P.features & SOFTROD_FEAT_LAPLACE_FILTER) laplace_filter_rates_n<1>(P, lane, L);
-    if (P.damp_before_constrain) constrain_rates_n<kRuntimeFeatures, 1>(P, B, lane, L);
+    if (P.damp_before_constrain) {
+        constrain_rates_n<kRuntimeFeatures, 1>(P, B, lane, L);
+        sucker_rates_n<kRuntimeFeatures, 1>(P, B, lane, L);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1232,10 +1334,14 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
     load_lane<1, kRuntimeFeatures>(S, N, rod, lane, L);
     BcTargets B;
     load_bc(S, N, rod, B);
+    load_suckers<kRuntimeFeatures>(P, S, N, rod, B);
     EnvAction A;
     set_action_n<kRuntimeFeatures, kRuntimeEnv, 1>(P, S, N, rod, lane, actions, A, B, L);
     ConstN<1> C;
-    build_const<kRuntimeFeatures, 1>(P, lane, A, C);
+    if (S.mat) build_const<kRuntimeFeatures, 1, true>(P, lane, A, C, S.mat);
+    else build_const<kRuntimeFeatures, 1>(P, lane, A, C);
+    LibmMat M;
+    libm_material(P, S.mat, lane, M);
 
     double time = S.time[rod];
     const double mass = C.mass[0];
@@ -1244,7 +1350,7 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
         libm_kinematic_step(P, P.half_dt, L);
         if (P.time_two_half_adds) time += P.half_dt;
         constrain_values_n<kRuntimeFeatures, 1>(P, B, lane, L);
-        libm_dynamic_step(P, B, lane, A.force, mass, L);
+        libm_dynamic_step(P, M, B, lane, A.force, mass, L);
         libm_kinematic_step(P, P.half_dt, L);
         time += P.time_two_half_adds ? P.half_dt : P.dt;
         constrain_values_n<kRuntimeFeatures, 1>(P, B, lane, L);
@@ -1279,7 +1385,8 @@ softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __rest
     for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
     A.force = 0.0;
     ConstN<EPL> C;
-    build_const<kRuntimeFeatures, EPL>(P, lane, A, C);
+    if (S.mat) build_const<kRuntimeFeatures, EPL, true>(P, lane, A, C, S.mat);
+    else build_const<kRuntimeFeatures, EPL>(P, lane, A, C);
     const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2
                    : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 0 : 1;
     float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1339,7 +1446,8 @@ __device__ __forceinline__ void reset_rod(const RodParams& P, const StatePtrs& S
         for (int i = 0; i < 7; ++i) A0.a[i] = 0.0f;
         A0.force = 0.0;
         ConstN<EPL> C;
-        build_const<kRuntimeFeatures, EPL>(P, lane, A0, C);
+        if (S.mat) build_const<kRuntimeFeatures, EPL, true>(P, lane, A0, C, S.mat);
+        else build_const<kRuntimeFeatures, EPL>(P, lane, A0, C);
         com_xy_n<EPL>(P, C, lane, L, com);
     }
     if (lane == 0) {
@@ -1401,7 +1509,8 @@ softrod_autoreset_kernel(const RodParams P, const StatePtrs S, float* __restrict
     for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
     A.force = 0.0;
     ConstN<EPL> C;
-    build_const<kRuntimeFeatures, EPL>(P, lane, A, C);
+    if (S.mat) build_const<kRuntimeFeatures, EPL, true>(P, lane, A, C, S.mat);
+    else build_const<kRuntimeFeatures, EPL>(P, lane, A, C);
     float pa[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) pa[i] = S.prev_action[7 * (size_t)rod + i];

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 9
+#define SOFTROD_ABI_VERSION 10
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -98,6 +98,14 @@ enum softrod_feature {
      *   soft_arm/soft_arm_tracking.py:352-383,
      *   utils/custom_elastica/muscle_torque/muscle_torques_with_bspline.py:128-225       */
     SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES = 1u << 11,
+    /* ControllableFixConstraint ("sucker"): constrain_rates scales the velocity of node `index`
+     * and the angular velocity of element `index` by (1 - reduction_ratio) while the
+     * SuckerController's flag is on; constrain_values is a no-op
+     *   octopus/controllable_constraint.py:24-69; registered at octopus/arm_push_env.py:188-195,
+     *   587-595, arm_two_env.py:137-152 (several per arm, ratio set from the action :228),
+     *   crawl_env.py:148-161.  Up to SOFTROD_MAX_SUCKERS per rod (softrod_config.sucker_index);
+     *   the per-env effective ratio lives in softrod_state_view.sucker_ratio.                */
+    SOFTROD_FEAT_SUCKER_CONSTRAINT = 1u << 12,
 };
 
 #define SOFTROD_FEATURES_SOFTPENDULUM                                             \
@@ -204,8 +212,15 @@ typedef struct softrod_config {
     double muscle_torque_scale; /* alpha = torque_scale * radius * E   :350        */
     double max_activation_rate; /* max_rate_of_change_of_activation: inf  :143     */
     double arm_target[3];     /* target_location (game_mode 1)          :147      */
+    /* ---- ControllableFixConstraint (octopus/controllable_constraint.py:24-69) ---- */
+    int32_t n_suckers;        /* constraints of this kind registered on the rod (0..4)      */
+    int32_t sucker_index[4];  /* SuckerController.index of each (node AND element index)    */
+    int32_t reserved2;
+    double sucker_reduction_ratio; /* initial reduction_ratio of every sucker (1.0, :11); the
+                                 controllers are on after finalize (arm_push_env.py:222)  */
 } softrod_config;
 
+#define SOFTROD_MAX_SUCKERS 4
 #define SOFTROD_MAX_CTRL 8           /* control points per direction             */
 #define SOFTROD_MAX_SPLINE_PIECES 8
 
@@ -272,6 +287,13 @@ typedef struct softrod_state_view {
                          constrained_director_idx=(0,)).  With the rows above it makes the
                          view a complete snapshot: copying every array out and back in
                          restores a batch exactly (checkpoint / resume).            */
+    double* sucker_ratio; /* [SOFTROD_MAX_SUCKERS][n_envs]  effective reduction ratio of each
+                         ControllableFixConstraint: SuckerController.reduction_ratio while its
+                         flag is on, 0 while it is off (x * (1 - 0) is x).  Written by the
+                         caller between steps (arm_two_env.py:228 sets it from the action) */
+    double* material; /* [SOFTROD_MATERIAL_ROWS][lane_stride]  per-node / per-element constants of
+                         a TAPERED rod (softrod_set_radius_profile), shared by all envs; NULL
+                         for a uniform rod.  Read-only for the caller.                     */
 } softrod_state_view;
 
 /* Fill `cfg` with SoftPendulumEnv.__init__ defaults (soft_pendulum.py:59-78)
@@ -302,6 +324,19 @@ int softrod_config_soft_arm(softrod_config* cfg, int n_envs);
  * pieces, as BSpline's default extrapolation does).  Needed before the first softrod_step
  * of a handle with SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES.                          */
 int softrod_set_spline_table(softrod_handle* h, const double* breaks, const double* coef);
+
+/* Replaces: CosseratRod.straight_rod(..., base_radius=<array of n_elements radii>, ...) — a
+ * TAPERED rod, as the muscle-arm envs allocate it
+ *   radius = np.linspace(radius_base, radius_tip, n_elem + 1); radius_mean = (radius[:-1] + radius[1:]) / 2
+ *                                   octopus/arm_push_env.py:160-179, build_muscle_octopus.py
+ * Every per-element constant of the allocation (area, volume, nodal masses, second moments,
+ * shear / bend matrices and their Voronoi average, the damper's per-element coefficients,
+ * the contact radius) then varies along the rod: the library keeps them as per-lane rows
+ * (softrod_state_view.material) instead of kernel-argument scalars and runs its general
+ * instantiation.  radius: host [n_elem] float64.  Call before the first reset; rods of up to
+ * 63 elements; not with SOFTROD_FEAT_OCTO_HEAD.                                            */
+#define SOFTROD_MATERIAL_ROWS 16
+int softrod_set_radius_profile(softrod_handle* h, const double* radius);
 
 /* Replaces the constant part of set_action's
  *   interp1d(linspace(0,1,n_action), action, kind="cubic")(linspace(0,1,n_seg))

@@ -88,6 +88,8 @@ def _load(omp) -> C.CDLL:
     lib.oracle_octo_set_target.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_octo_epilogue_probe.argtypes = [C.c_void_p] + [C.c_void_p] * 7
     lib.oracle_constrain_probe.argtypes = [C.c_void_p]
+    lib.oracle_set_radius_profile.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_set_sucker_ratio.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_set_run_substeps.argtypes = [C.c_void_p, C.c_int]
     lib.oracle_forcing_probe.argtypes = [C.c_void_p, C.c_double]
     lib.oracle_get.restype = C.c_int
@@ -156,6 +158,17 @@ class OracleRod:
         """env_step* run n substeps instead of cfg.n_substeps (0: prologue + epilogue only, on the
         state as it is); every constant that depends on step_skip keeps its configured value."""
         self._lib.oracle_set_run_substeps(self._h, int(n))
+
+    def set_radius_profile(self, radius) -> None:
+        """straight_rod(base_radius=<array of n_elements radii>); before reset_straight."""
+        a = np.ascontiguousarray(radius, np.float64).reshape(self.n)
+        self._lib.oracle_set_radius_profile(self._h, a.ctypes.data)
+
+    def set_sucker_ratio(self, ratio) -> None:
+        """Effective reduction ratio of each ControllableFixConstraint (0 = controller off)."""
+        a = np.zeros(4, np.float64)
+        a[: len(np.atleast_1d(ratio))] = np.atleast_1d(ratio)
+        self._lib.oracle_set_sucker_ratio(self._h, a.ctypes.data)
 
     def constrain_probe(self) -> None:
         """One application of constrain_values then constrain_rates on the current state."""

@@ -84,6 +84,13 @@ typedef struct oracle_rod {
     double torque_mag[2][NMAX];
     double spline_breaks[SOFTROD_MAX_SPLINE_PIECES + 1];
     double spline_coef[SOFTROD_MAX_SPLINE_PIECES][SOFTROD_MAX_CTRL][4];
+    /* CosseratRod.straight_rod(base_radius=<array>): per-element rest radii of a tapered rod
+     * (octopus/arm_push_env.py:160-179); has_profile = 0: the uniform cfg.base_radius */
+    double radius_profile[NMAX];
+    int has_profile;
+    /* ControllableFixConstraint: effective reduction ratio of each sucker (controller.flag ?
+     * controller.reduction_ratio : 0), octopus/controllable_constraint.py:45-69 */
+    double sucker_ratio[SOFTROD_MAX_SUCKERS];
     int run_substeps;      /* >= 0: substeps the env_step functions really run (fixture replay: the
                               epilogue alone on an injected state); < 0: cfg.n_substeps */
     long tick;             /* soft_arm_tracking.py:222 */
@@ -125,11 +132,13 @@ static void straight_rod(oracle_rod* r, const double start[3],
         r->Q[1][2][k] = t[0] * normal[1] - t[1] * normal[0];
         for (int i = 0; i < 3; ++i) r->Q[2][i][k] = t[i];
     }
-    const double radius = c->base_radius;
-    const double A0 = M_PI * radius * radius;
-    const double I1 = A0 * A0 / (4.0 * M_PI);
-    const double I[3] = { I1, I1, 2.0 * I1 };
+    /* radius[:] = base_radius broadcasts a scalar or takes an array of n_elements radii */
+    double be[3][NMAX];
     for (int k = 0; k < n; ++k) {
+        const double radius = r->has_profile ? r->radius_profile[k] : c->base_radius;
+        const double A0 = M_PI * radius * radius;
+        const double I1 = A0 * A0 / (4.0 * M_PI);
+        const double I[3] = { I1, I1, 2.0 * I1 };
         for (int i = 0; i < 3; ++i) {
             r->J[i][k] = I[i] * (c->density * r->rest_len[k]);
             r->invJ[i][k] = 1.0 / r->J[i][k];
@@ -138,10 +147,7 @@ static void straight_rod(oracle_rod* r, const double start[3],
         r->shear[1][k] = c->alpha_c * c->shear_modulus * A0;
         r->shear[2][k] = c->youngs_modulus * A0;
         r->volume[k] = M_PI * (radius * radius) * r->rest_len[k];
-    }
-    /* element bend matrix, then rest-length-weighted average onto Voronoi */
-    double be[3][NMAX];
-    for (int k = 0; k < n; ++k) {
+        /* element bend matrix, then rest-length-weighted average onto Voronoi */
         be[0][k] = c->youngs_modulus * I[0];
         be[1][k] = c->youngs_modulus * I[1];
         be[2][k] = c->shear_modulus * I[2];
@@ -183,6 +189,9 @@ static void straight_rod(oracle_rod* r, const double start[3],
     r->time = 0.0;
     r->point_force = 0.0;
     for (int i = 0; i < 3; ++i) { r->ctrl_pos[i] = 0.0; r->ctrl_vel[i] = 0.0; }
+    /* SuckerController: reduction_ratio as configured, switched on after finalize (arm_push_env.py:188,222) */
+    for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j)
+        r->sucker_ratio[j] = (j < c->n_suckers) ? c->sucker_reduction_ratio : 0.0;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -411,6 +420,14 @@ static void constrain_rates(oracle_rod* r)
         r->v[2][0] = 0.0;
         for (int i = 0; i < 3; ++i) r->w[i][0] = 0.0;
     }
+    /* ControllableFixConstraint.nb_compute_constrain_rates, octopus/controllable_constraint.py:63-69
+     * (a controller that is off is an effective ratio of 0: x * (1 - 0) = x) */
+    if (r->cfg.features & SOFTROD_FEAT_SUCKER_CONSTRAINT)
+        for (int j = 0; j < r->cfg.n_suckers; ++j) {
+            const int idx = r->cfg.sucker_index[j];
+            const double keep = 1.0 - r->sucker_ratio[j];
+            for (int i = 0; i < 3; ++i) { r->v[i][idx] *= keep; r->w[i][idx] *= keep; }
+        }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1146,6 +1163,15 @@ int oracle_set(oracle_rod* r, const char* name, const double* in)
  * (build.py:71-79, soft_pendulum_3d/build.py:31-39), or of the forcing group on a
  * prefilled external_forces (build.py:88-105: gravity adds, the point force assigns). */
 void oracle_constrain_probe(oracle_rod* r) { constrain_values(r); constrain_rates(r); }
+void oracle_set_radius_profile(oracle_rod* r, const double* radius)
+{
+    for (int k = 0; k < r->n; ++k) r->radius_profile[k] = radius[k];
+    r->has_profile = 1;
+}
+void oracle_set_sucker_ratio(oracle_rod* r, const double* ratio)
+{
+    for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) r->sucker_ratio[j] = ratio[j];
+}
 void oracle_forcing_probe(oracle_rod* r, double point_force)
 {
     r->point_force = point_force;

@@ -1,0 +1,127 @@
+"""HIP path vs the oracle for the on-disk part of SURVEY.md §8(f) N3: a TAPERED rod
+(softrod_set_radius_profile: CosseratRod.straight_rod(base_radius=<array>), arm_push_env.py:160-179)
+and ControllableFixConstraint suckers (controllable_constraint.py:24-69) whose ratios the caller
+changes between steps (arm_two_env.py:228).  Both math modes; through the C-ABI.  The reference
+class itself pins the oracle's constraint in tests/test_taper_and_suckers.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch
+
+
+def _radii(n, base=0.012, tip=0.001):
+    r = np.linspace(base, tip, n + 1)                  # arm_push_env.py:163-165
+    return (r[:-1] + r[1:]) / 2
+
+
+def _cfg(n_envs, n, math_mode, features, **kw):
+    from gym_softrobot_amd import _capi
+
+    cfg = _capi.softpendulum_config(n_envs, n_elems=n, math_mode=math_mode)
+    cfg.env_kind = _capi.ENV_NONE
+    cfg.features = features
+    cfg.base_length, cfg.density, cfg.youngs_modulus, cfg.shear_modulus = 0.2, 700.0, 1e4, 1e4 / 1.5
+    cfg.damping_constant = 0.05 * 2 * 1e2               # arm_push_env.py:166,183
+    cfg.dt = 1e-4
+    cfg.gravity[0], cfg.gravity[1], cfg.gravity[2] = 0.0, 0.0, -9.81
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _compare(be, rods, atol=1e-9):
+    st = be.state_numpy()
+    for i, r in enumerate(rods):
+        for name in ("x", "v", "w", "Q"):
+            np.testing.assert_allclose(st[name][i], r.get(name), rtol=RTOL, atol=atol, err_msg=f"{name} env {i}")
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+def test_tapered_arm_with_suckers_matches_oracle(torch_gpu, hip_lib, oracle_built, math_mode):
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    n, N = 40, 3
+    feats = _capi.FEAT_GRAVITY | _capi.FEAT_ANALYTICAL_DAMPER | _capi.FEAT_SUCKER_CONSTRAINT
+    cfg = _cfg(N, n, math_mode, feats, n_suckers=2, sucker_reduction_ratio=1.0)
+    cfg.sucker_index[0], cfg.sucker_index[1] = 0, 25
+    be = HipRodBackend(cfg, 0)
+    be.set_radius_profile(_radii(n))
+    start, direction, normal = np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.0, 1.0, 0.0])
+    be.reset_straight(start, direction, normal)
+    with pytest.raises(_capi.SoftrodError):
+        be.set_radius_profile(_radii(n))                # only before the first reset
+    rods = []
+    for i in range(N):
+        c1 = cfg.copy()
+        c1.n_envs = 1
+        r = oracle_built.OracleRod(c1)
+        r.set_radius_profile(_radii(n))
+        r.reset_straight(start, direction, normal)
+        rods.append(r)
+    st = be.state()
+    # phase 1: both suckers hold fully in env 0; env 1 has the second one at 0.3; env 2 has none
+    ratios = np.array([[1.0, 1.0, 0.0], [1.0, 0.3, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]])     # [sucker][env]
+    st["sucker_ratio"][:] = torch_gpu.from_numpy(ratios).to(st["sucker_ratio"].device)
+    for i, r in enumerate(rods):
+        r.set_sucker_ratio(ratios[:2, i])
+    be.substeps(None, 250)
+    for r in rods:
+        r.substeps(0.0, 250)
+    torch_gpu.cuda.synchronize()
+    _compare(be, rods)
+    x = be.state_numpy()["x"]
+    assert abs(x[0, :, 0]).max() < 1e-12 and x[2, 2, 0] < -1e-4      # node 0 held in env 0, falling in env 2
+    # phase 2: the base sucker lets go in env 0, the other weakens (arm_two_env.py:228)
+    ratios[:, 0] = [0.0, 0.9, 0.0, 0.0]
+    st["sucker_ratio"][:] = torch_gpu.from_numpy(ratios).to(st["sucker_ratio"].device)
+    rods[0].set_sucker_ratio(ratios[:2, 0])
+    be.substeps(None, 250)
+    for r in rods:
+        r.substeps(0.0, 250)
+    torch_gpu.cuda.synchronize()
+    _compare(be, rods)
+    be.close()
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+def test_tapered_arm_on_the_plane_matches_oracle(torch_gpu, hip_lib, oracle_built, math_mode):
+    """Per-element contact radius: the thick base of a tapered arm lies a hair above the plane,
+    its thin tip well above it; 60 ms of falling, landing and sliding."""
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    n = 40
+    feats = _capi.FEAT_GRAVITY | _capi.FEAT_ANALYTICAL_DAMPER | _capi.FEAT_PLANE_CONTACT_ANISO
+    arm = _capi.arm_single_config(1)
+    cfg = _cfg(2, n, math_mode, feats, contact_k=arm.contact_k, contact_nu=arm.contact_nu,
+               slip_velocity_tol=arm.slip_velocity_tol, surface_tol=arm.surface_tol)
+    for i in range(3):
+        cfg.kinetic_mu[i], cfg.static_mu[i] = arm.kinetic_mu[i], arm.static_mu[i]
+        cfg.plane_normal[i] = [0.0, 0.0, 1.0][i]
+        cfg.plane_origin[i] = [0.0, 0.0, -0.012][i]
+    be = HipRodBackend(cfg, 0)
+    be.set_radius_profile(_radii(n))
+    start, direction, normal = np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0])
+    be.reset_straight(start, direction, normal)
+    c1 = cfg.copy()
+    c1.n_envs = 1
+    rod = oracle_built.OracleRod(c1)
+    rod.set_radius_profile(_radii(n))
+    rod.reset_straight(start, direction, normal)
+    be.substeps(None, 600)
+    rod.substeps(0.0, 600)
+    torch_gpu.cuda.synchronize()
+    _compare(be, [rod, rod], atol=1e-8)
+    z = be.state_numpy()["x"][0, 2]
+    assert abs(z[0]) < 2e-3          # the plane holds the base (free fall would be at -0.0177 by now)
+    be.close()

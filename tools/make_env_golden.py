@@ -594,6 +594,40 @@ def octoflat(records):
     np.savez_compressed(GOLD / "ref_octoflat.npz", **out)
 
 
+# =============================================================================================
+# ControllableFixConstraint ("sucker"), octopus/controllable_constraint.py:24-69
+# =============================================================================================
+def sucker(records):
+    mod = refshim.load("gym_softrobot.envs.octopus.controllable_constraint")
+    rng = np.random.default_rng(41)
+    B = Stack()
+    n = 20
+    for case in range(12):
+        index = int(rng.integers(0, n))
+        ratio = [1.0, 0.9, 0.3, 0.0][case % 4]
+        ctrl = mod.SuckerController(index=index, reduction_ratio=ratio)
+        bc = mod.ControllableFixConstraint(index=index, controller=ctrl)
+        if case % 5 == 4:
+            ctrl.turn_off()
+        sysm = refshim.FakeRod(n)
+        sysm.position_collection[:] = rng.normal(0, 0.3, (3, n + 1))
+        sysm.velocity_collection[:] = rng.normal(0, 1.0, (3, n + 1))
+        sysm.director_collection[:] = rng.normal(0, 1.0, (3, 3, n))
+        sysm.omega_collection[:] = rng.normal(0, 2.0, (3, n))
+        pin = {k: getattr(sysm, k).copy() for k in ("position_collection", "velocity_collection",
+                                                   "director_collection", "omega_collection")}
+        bc.constrain_values(sysm, 0.0)
+        bc.constrain_rates(sysm, 0.0)
+        B.add(index=index, ratio=np.float64(ratio), flag=bool(ctrl), x_in=pin["position_collection"],
+              v_in=pin["velocity_collection"], Q_in=pin["director_collection"], w_in=pin["omega_collection"],
+              x_out=sysm.position_collection, v_out=sysm.velocity_collection, Q_out=sysm.director_collection,
+              w_out=sysm.omega_collection)
+    default = mod.SuckerController(index=0)
+    records["ControllableFixConstraint"] = {"default_reduction_ratio": default.reduction_ratio,
+                                            "default_flag": bool(default)}
+    np.savez_compressed(GOLD / "ref_sucker.npz", **B.arrays("op_"))
+
+
 def main():
     refshim.install()
     # straight_rod calls back into the generator so that the fake rod holds a real allocation
@@ -614,6 +648,7 @@ def main():
     softpendulum3d(records)
     armsingle(records)
     octoflat(records)
+    sucker(records)
     (GOLD / "ref_build_records.json").write_text(json.dumps(jsonable(records), indent=1) + "\n")
     for f in sorted(GOLD.glob("ref_*")):
         print(f.name, f.stat().st_size)

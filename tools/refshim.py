@@ -197,6 +197,10 @@ class ConstraintBase:
         self.constrained_director_idx = np.array(kwargs.get("constrained_director_idx", []), dtype=int)
 
 
+class FreeBC(ConstraintBase):
+    pass
+
+
 class NoForces:
     def __init__(self):
         pass
@@ -323,7 +327,7 @@ def _isnan_check(array):          # elastica/_calculus.py (RECALLED): njit np.is
 def _install_elastica():
     el = types.ModuleType("elastica")
     for cls in (BaseSystemCollection, Constraints, Forcing, Damping, Connections, Contact, CallBacks,
-                PositionVerlet, ConstraintBase, NoForces, FreeJoint, CosseratRod, Cylinder, Plane):
+                PositionVerlet, ConstraintBase, FreeBC, NoForces, FreeJoint, CosseratRod, Cylinder, Plane):
         setattr(el, cls.__name__, cls)
     for name in ("GravityForces", "AnalyticalLinearDamper", "LaplaceDissipationFilter",
                  "RodPlaneContactWithAnisotropicFriction", "OneEndFixedBC", "Sphere", "MuscleTorques"):
