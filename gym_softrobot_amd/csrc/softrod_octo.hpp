@@ -60,6 +60,10 @@ __device__ __forceinline__ void store_head(const StatePtrs& S, size_t N, int env
 // v_z = 0 and omega = (0, 0, w_z) — established at kernel entry and after every rate update —
 // so the step is a planar one: x, y advance, z stays, and the transposed Rodrigues matrix
 // R(h w) reduces to a rotation about e_z acting on the x, y components of d1 and d2.
+// d1 and d2 enter every step normalised to rounding (head_normalize at kernel entry) and a
+// rotation keeps |d|^2 = 1 + O(1e-16), where 1/sqrt(n2) and its first Newton iterate
+// (3 - n2)/2 agree to O(1e-32): one FMA instead of the quarter-rate v_rsq_f64 and its
+// refinement, on the head's serial critical path.
 __device__ __forceinline__ void head_kinematic(double h, HeadState& H) {
     H.x[0] = fma(h, H.v[0], H.x[0]);
     H.x[1] = fma(h, H.v[1], H.x[1]);
@@ -70,9 +74,17 @@ __device__ __forceinline__ void head_kinematic(double h, HeadState& H) {
     const double sn = sc * a, cs = fma(-cc, t, 1.0);
     const double q00 = fma(sn, H.Q[3], cs * H.Q[0]), q01 = fma(sn, H.Q[4], cs * H.Q[1]);
     const double q10 = fma(-sn, H.Q[0], cs * H.Q[3]), q11 = fma(-sn, H.Q[1], cs * H.Q[4]);
-    const double i0 = fast_rsqrt(fma(q00, q00, q01 * q01)), i1 = fast_rsqrt(fma(q10, q10, q11 * q11));
+    const double i0 = fma(-0.5, fma(q00, q00, q01 * q01), 1.5), i1 = fma(-0.5, fma(q10, q10, q11 * q11), 1.5);
     H.Q[0] = q00 * i0; H.Q[1] = q01 * i0; H.Q[2] = 0.0;
     H.Q[3] = q10 * i1; H.Q[4] = q11 * i1; H.Q[5] = 0.0;
+    H.Q[6] = 0.0; H.Q[7] = 0.0; H.Q[8] = 1.0;
+}
+// BodyBoundaryCondition.compute_contrain_values on whatever the state rows hold (kernel entry)
+__device__ __forceinline__ void head_normalize(HeadState& H) {
+    const double i0 = fast_rsqrt(fma(H.Q[0], H.Q[0], H.Q[1] * H.Q[1]));
+    const double i1 = fast_rsqrt(fma(H.Q[3], H.Q[3], H.Q[4] * H.Q[4]));
+    H.Q[0] *= i0; H.Q[1] *= i0; H.Q[2] = 0.0;
+    H.Q[3] *= i1; H.Q[4] *= i1; H.Q[5] = 0.0;
     H.Q[6] = 0.0; H.Q[7] = 0.0; H.Q[8] = 1.0;
 }
 
@@ -168,7 +180,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                          const int n_sub, const int epilogue, const int pack) {
-    __shared__ double xch[2][MAXW * 4][3];   // [buffer][arm][Fx, Fy, Tz]
+    __shared__ double xch[2][MAXW][4];       // [buffer][wave][Fx, Fy, Tz of the wave's arms, pad]
     __shared__ double sxy[kLanes * MAXW][2];
     __shared__ int scount;
 
@@ -180,6 +192,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     const int n = P.n_elem, nk = P.n_action;
     const int r = tid & (P.seg - 1), arm = tid >> P.seg_shift;
     const bool arm_ok = arm < P.n_arm;
+    if (tid < 2 * MAXW * 4) (&xch[0][0][0])[tid] = 0.0;   // rows of absent waves read as zero loads
     if (epilogue && S.skip && S.skip[env]) {   // reset by the auto-reset pass of this env.step
         __syncthreads();                       // every thread has read the flag
         if (tid == 0) S.skip[env] = 0;
@@ -229,7 +242,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     double time = S.time[env];
     int parity = 0;
 
-    auto connect = [&](double (&f)[1][3], double (&tq)[1][3], const LaneN<1>& Lc, const double (&xn)[1][3]) {
+    auto joints = [&](double (&f)[1][3], double (&tq)[1][3], const LaneN<1>& Lc, const double (&xn)[1][3]) {
         // FixedJoint2Rigid.apply_forces (joint.py:48-123): spring + normal damping between the
         // arm's node 0 and the point head_radius along the arm's direction from the head axis.
         // The head's d2 lies in the plane (constrain_values), so the direction has no z part.
@@ -264,33 +277,79 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             tq[0][i] += base ? fma(Q[3 * i + 2], tj[2], fma(Q[3 * i + 1], tj[1], Q[3 * i] * tj[0])) : 0.0;
         }
         // Net load on the head.  Its rates are held to (vx, vy, 0), (0, 0, wz) and its d3 to e_z,
-        // so only Fx, Fy and the lab-frame torque about z (= torque along d3) reach it.  Every
-        // arm posts its three numbers in LDS; they are consumed after the arms' contact and
-        // rate update (head_update below), which hides the LDS round trip and lets the waves
-        // of the env reach the barrier together.
-        if (base) {
-            xch[parity][arm][0] = fj[0];
-            xch[parity][arm][1] = fj[1];
-            xch[parity][arm][2] = tj[2];
+        // so only Fx, Fy and the lab-frame torque about z (= torque along d3) reach it.  The arms
+        // of a wave are summed IN the wave: a xor-butterfly over the arm stride (ds_bpermute: the
+        // LDS crossbar, no memory, no VALU) leaves the sum of the wave's base lanes in every base
+        // lane, in a fixed order; lane 0 posts the wave's three numbers in LDS.  They are consumed
+        // after the arms' contact and rate update (head_update below), which hides the round trip
+        // and lets the waves of the env reach the barrier together.
+        double part[3] = {base ? fj[0] : 0.0, base ? fj[1] : 0.0, base ? tj[2] : 0.0};
+#pragma unroll
+        for (int off = 16; off < kLanes; off <<= 1) {
+            if (off >= P.seg) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) part[i] += __shfl_xor(part[i], off);
+            }
+        }
+        if (lane == 0) {
+            xch[parity][wave][0] = part[0];
+            xch[parity][wave][1] = part[1];
+            xch[parity][wave][2] = part[2];
         }
     };
     // RigidBodyBase.update_accelerations + the rate update under
     // BodyBoundaryCondition.compute_constrain_rates (constraint.py:60-85): with
-    // w = (0, 0, wz) the gyroscopic term J w x w vanishes identically.  Every lane sums the
-    // arms in the same order (arm 0 first, as the reference's loop over connections), so the
-    // head replicas stay bit-identical.  LDS is double-buffered: ONE barrier per substep.
-    auto head_update = [&]() {
-        __syncthreads();
-        double tot[3] = {0.0, 0.0, 0.0};
-        for (int a = 0; a < P.n_arm; ++a) {
+    // w = (0, 0, wz) the gyroscopic term J w x w vanishes identically.  Every lane adds the
+    // waves' partial sums in the same order (wave 0 first), so the head replicas stay
+    // bit-identical; the order differs from the reference's loop over connections (arm by arm)
+    // by the rounding of a sum of eight numbers.  LDS is double-buffered: ONE barrier per substep.
+    // The head's step between two force evaluations: RigidBodyBase.update_accelerations + the rate
+    // update under BodyBoundaryCondition.compute_constrain_rates (constraint.py:60-85) — with
+    // w = (0, 0, wz) the gyroscopic term J w x w vanishes identically — then its kinematic step.
+    // `pend` holds the waves' partial sums read from LDS right after the barrier, `hk` the step
+    // the head takes with them (the first half step at entry, with zero loads).  (Running this
+    // chain at the top of the next dynamic_n instead, to interleave it with the arms' geometry,
+    // was measured and loses: 13.1 against 12.0 ms, profiles/README.md.)  Every lane adds
+    // the partials in the same order (wave 0 first), so the head replicas stay bit-identical;
+    // the order differs from the reference's loop over connections (arm by arm) by the rounding
+    // of a sum of eight numbers.  LDS is double-buffered: ONE barrier per substep.
+    double pend[MAXW == 2 ? 2 : 1][3] = {};
+    double hk = P.half_dt;
+    auto head_step = [&]() {
+        double tot[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) tot[i] += xch[parity][a][i];
-        }
-        parity ^= 1;
+        for (int i = 0; i < 3; ++i) tot[i] = (MAXW == 2) ? pend[0][i] + pend[MAXW == 2 ? 1 : 0][i] : pend[0][i];
         H.v[0] = fma(P.dt, tot[0] * head_inv_mass, H.v[0]);
         H.v[1] = fma(P.dt, tot[1] * head_inv_mass, H.v[1]);
         H.w[2] = fma(P.dt, P.head_invJ[2] * (-tot[2]), H.w[2]);
+        head_kinematic(hk, H);
     };
+    auto exchange = [&]() {       // after the arms' kinematic step: everyone has posted
+        __syncthreads();
+        if constexpr (MAXW == 2) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                pend[0][i] = xch[parity][0][i];
+                pend[MAXW == 2 ? 1 : 0][i] = xch[parity][MAXW == 2 ? 1 : 0][i];   // zero if nw == 1 (cleared at entry)
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pend[0][i] = 0.0;
+            for (int w = 0; w < nw; ++w) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pend[0][i] += xch[parity][w][i];
+            }
+        }
+        parity ^= 1;
+    };
+    struct Hooks {
+        decltype(head_step)& hs;
+        decltype(joints)& jt;
+        __device__ __forceinline__ void begin() {}
+        __device__ __forceinline__ void operator()(double (&f)[1][3], double (&tq)[1][3], const LaneN<1>& Lc,
+                                                   const double (&xn)[1][3]) { jt(f, tq, Lc, xn); }
+    };
+    Hooks connect{head_step, joints};
 
     // an env that already holds a NaN is not integrated (see softrod_step_fast_kernel)
     bool dead = false;
@@ -314,15 +373,17 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     }
     if (n_sub > 0 && !dead) {
         kinematic_n<1>(P.half_dt, C, L);
-        head_kinematic(P.half_dt, H);
+        head_normalize(H);                       // hk = dt/2 and zero loads: the head's first half step
+        head_step();
         if (P.time_two_half_adds) time += P.half_dt;
         for (int s = 0; s < n_sub; ++s) {
             dynamic_n<F, 1>(Pk, C, B, tid, L, connect);
             const bool last = (s == n_sub - 1);
             const double h = last ? P.half_dt : P.dt;
             kinematic_n<1>(h, C, L);
-            head_update();
-            head_kinematic(h, H);
+            exchange();
+            hk = h;
+            head_step();
             time += P.time_two_half_adds ? P.half_dt : P.dt;
             if (!last && P.time_two_half_adds) time += P.half_dt;
         }
