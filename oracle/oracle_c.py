@@ -91,6 +91,7 @@ def _load(omp) -> C.CDLL:
     lib.oracle_set_radius_profile.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_set_sucker_ratio.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_set_run_substeps.argtypes = [C.c_void_p, C.c_int]
+    lib.oracle_set_round_state_f32.argtypes = [C.c_void_p, C.c_int]
     lib.oracle_forcing_probe.argtypes = [C.c_void_p, C.c_double]
     lib.oracle_get.restype = C.c_int
     lib.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
@@ -169,6 +170,11 @@ class OracleRod:
         a = np.zeros(4, np.float64)
         a[: len(np.atleast_1d(ratio))] = np.atleast_1d(ratio)
         self._lib.oracle_set_sucker_ratio(self._h, a.ctypes.data)
+
+    def set_round_state_f32(self, on: bool = True) -> None:
+        """Diagnostic: round x, v, Q, omega to float32 after every substep (float32 storage,
+        float64 arithmetic) — the fp32 divergence proxy of tools/episode_parity.py."""
+        self._lib.oracle_set_round_state_f32(self._h, int(bool(on)))
 
     def constrain_probe(self) -> None:
         """One application of constrain_values then constrain_rates on the current state."""

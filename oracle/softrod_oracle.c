@@ -91,6 +91,9 @@ typedef struct oracle_rod {
     /* ControllableFixConstraint: effective reduction ratio of each sucker (controller.flag ?
      * controller.reduction_ratio : 0), octopus/controllable_constraint.py:45-69 */
     double sucker_ratio[SOFTROD_MAX_SUCKERS];
+    int round_state_f32;   /* diagnostic (tools/episode_parity.py --fp32-proxy): the dynamic state is
+                              rounded to float32 after every substep — float32 STORAGE with float64
+                              arithmetic, a lower bound on what a float32 stepper loses */
     int run_substeps;      /* >= 0: substeps the env_step functions really run (fixture replay: the
                               epilogue alone on an injected state); < 0: cfg.n_substeps */
     long tick;             /* soft_arm_tracking.py:222 */
@@ -764,6 +767,15 @@ static void position_verlet_step(oracle_rod* r)
         for (int k = 0; k <= n; ++k) r->f_ext[i][k] = 0.0;
         for (int k = 0; k < n; ++k) r->t_ext[i][k] = 0.0;
     }
+    if (r->round_state_f32) {
+        for (int i = 0; i < 3; ++i) {
+            for (int k = 0; k <= n; ++k) { r->x[i][k] = (double)(float)r->x[i][k]; r->v[i][k] = (double)(float)r->v[i][k]; }
+            for (int k = 0; k < n; ++k) {
+                r->w[i][k] = (double)(float)r->w[i][k];
+                for (int j = 0; j < 3; ++j) r->Q[i][j][k] = (double)(float)r->Q[i][j][k];
+            }
+        }
+    }
 }
 
 static int substeps_to_run(const oracle_rod* r)
@@ -771,6 +783,7 @@ static int substeps_to_run(const oracle_rod* r)
     return r->run_substeps >= 0 ? r->run_substeps : r->cfg.n_substeps;
 }
 void oracle_set_run_substeps(oracle_rod* r, int n) { r->run_substeps = n; }
+void oracle_set_round_state_f32(oracle_rod* r, int on) { r->round_state_f32 = on; }
 
 /* ------------------------------------------------------------------------- */
 /* env epilogue: soft_pendulum.py:149-161 (get_state) and :196-251             */

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""the fp32-vs-fp64 divergence report, measured on the CPU oracle.
+
+This repo ships no float32 stepper (a wave64 fp32 VALU op issues at the fp64 rate on CDNA4, and
+the reference computes in float64).  What float32 would cost the REFERENCE'S formulation — state
+= absolute node positions, velocities, directors, angular velocities — is measured here with a
+float64 stepper whose state is rounded to float32 after every substep (float32 storage, float64
+arithmetic).  The stretch strain is a difference of neighbouring positions (|x| ~ 1, spacing
+0.02, EA = 7854 N): one float32 ulp of position is a 3e-6 strain and a 0.02 N force on a 0.16 kg
+node, every substep.  For each SoftPendulum-v0 action script of
+tools/episode_parity.py this prints the env.steps for which that run stays within north_star's
+1e-5 of the plain float64 run, and the error after 1, 3, 10 and 126 steps.
+
+    python tools/fp32_proxy.py > profiles/fp32_proxy.json        (CPU only)
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from gym_softrobot_amd import _capi  # noqa: E402
+from gym_softrobot_amd.seeding import initial_angle, np_random  # noqa: E402
+from oracle import oracle_c  # noqa: E402
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-3)))
+
+
+def run(script, n=8, steps=126):
+    cfg = _capi.softpendulum_config(1)
+    ref = [oracle_c.OracleRod(cfg) for _ in range(n)]
+    f32 = [oracle_c.OracleRod(cfg) for _ in range(n)]
+    for i in range(n):
+        th = initial_angle(np_random(i)[0])
+        ref[i].reset_pendulum(th)
+        f32[i].reset_pendulum(th)
+        f32[i].set_round_state_f32(True)
+    obs = np.stack([r.observe() for r in ref])
+    curve = []
+    for t in range(steps):
+        a = script(t, obs)
+        e = 0.0
+        for i in range(n):
+            o, rw, _, _ = ref[i].env_step(a[i, 0])
+            o2, rw2, _, _ = f32[i].env_step(a[i, 0])
+            obs[i] = o
+            e = max(e, rel(o2, o), rel(rw2, rw))
+        curve.append(e)
+    bad = [t for t, v in enumerate(curve) if not v <= 1e-5]
+    return {"steps_within_1e-5": len(curve) if not bad else bad[0],
+            "error_after": {str(t): curve[t - 1] for t in (1, 3, 10, 30, 126)},
+            "curve": [float(f"{v:.3e}") for v in curve]}
+
+
+def main():
+    n = 8
+    rng = np.random.default_rng(1)
+    rnd = rng.uniform(-22, 22, (126, n, 1)).astype(np.float32)
+    prev = {"th": None}
+
+    def pd(t, obs):
+        x, v, th = (obs[:, k].astype(np.float64) for k in (0, 1, 3))
+        dth = np.zeros_like(th) if t == 0 else (th - prev["th"]) / 0.04
+        prev["th"] = th.copy()
+        return np.clip(100.0 * th + 20.0 * dth + 10.0 * x + 8.0 * v, -22, 22).astype(np.float32)[:, None]
+
+    doc = {"what": "float64 oracle whose state (absolute x, v, Q, omega) is rounded to float32 after every substep "
+                   "(float32 storage, float64 arithmetic) against the plain float64 oracle; "
+                   "SoftPendulum-v0, 8 envs, 126 env.steps; metric as profiles/parity_episode.json",
+           "zero action": run(lambda t, o: np.zeros((n, 1), np.float32)),
+           "random +-22 N": run(lambda t, o: rnd[t]),
+           "stabilising PD script": run(pd)}
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()
