@@ -154,7 +154,6 @@ __device__ __forceinline__ void kinematic_n(double h, const ConstN<EPL>& C, Lane
 // Connections (joints) plug in between the internal loads and the contact operator, in
 // the registration order of build_octopus (octopus/build.py:117-200).
 struct NoConnections {
-    __device__ __forceinline__ void begin() const {}
     template <int EPL>
     __device__ __forceinline__ void operator()(double (&)[EPL][3], double (&)[EPL][3], const LaneN<EPL>&,
                                                const double (&)[EPL][3]) const {}
@@ -168,7 +167,6 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
     double xn[EPL][3], vn[EPL][3], d[EPL][3];
     double len[EPL], il[EPL], e[EPL], ie[EPL];
     double qt[EPL][3], np[EPL][3], cs[EPL][3], f[EPL][3], tq[EPL][3];
-    connect.begin();     // hook for work of the connected bodies that may overlap the rod's geometry (unused)
 
     // next-node position / velocity per slot
 #pragma unroll

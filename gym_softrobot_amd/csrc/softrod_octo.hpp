@@ -342,14 +342,6 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         }
         parity ^= 1;
     };
-    struct Hooks {
-        decltype(head_step)& hs;
-        decltype(joints)& jt;
-        __device__ __forceinline__ void begin() {}
-        __device__ __forceinline__ void operator()(double (&f)[1][3], double (&tq)[1][3], const LaneN<1>& Lc,
-                                                   const double (&xn)[1][3]) { jt(f, tq, Lc, xn); }
-    };
-    Hooks connect{head_step, joints};
 
     // an env that already holds a NaN is not integrated (see softrod_step_fast_kernel)
     bool dead = false;
@@ -377,7 +369,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         head_step();
         if (P.time_two_half_adds) time += P.half_dt;
         for (int s = 0; s < n_sub; ++s) {
-            dynamic_n<F, 1>(Pk, C, B, tid, L, connect);
+            dynamic_n<F, 1>(Pk, C, B, tid, L, joints);
             const bool last = (s == n_sub - 1);
             const double h = last ? P.half_dt : P.dt;
             kinematic_n<1>(h, C, L);
