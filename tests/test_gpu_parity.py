@@ -1057,3 +1057,50 @@ def test_capi_calls_leave_the_current_device_alone(torch_gpu, hip_lib):
     env.backend.observe(None)
     env.close()
     assert torch_gpu.cuda.current_device() == before
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+@pytest.mark.parametrize("mode", ["twist", "stretch", "twist+bend"])
+def test_torsional_and_axial_modes_match_oracle(torch_gpu, hip_lib, oracle_built, mode, math_mode):
+    """The channels no planar env excites: twist (G I3, J3, rotation about d3), stretch and their
+    coupling with bending through the transport term — the rods of tests/test_oracle_physics.py
+    k14 / k15 (exact discrete-chain frequencies), stepped by both kernels and compared with the
+    oracle; `twist+bend` adds a transverse rate so that (J w) x w and kappa x B kappa are non-zero."""
+    from gym_softrobot_amd import _capi
+
+    n = 50
+    cfg = _capi.softpendulum_config(2, n_elems=n, math_mode=math_mode)
+    cfg.env_kind = _capi.ENV_NONE
+    cfg.features = _capi.FEAT_FIXED_BC
+    cfg.damping_constant = 0.0
+    be = _backend(cfg)
+    be.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    c1 = cfg.copy()
+    c1.n_envs = 1
+    rod = oracle_built.OracleRod(c1)
+    rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    s_el = (np.arange(n) + 0.5) / n
+    s_nd = np.arange(n + 1) / n
+    w, v = np.zeros((3, n)), np.zeros((3, n + 1))
+    if mode in ("twist", "twist+bend"):
+        w[2] = 5.0 * np.sin(np.pi * s_el / 2)
+    if mode == "stretch":
+        v[0] = 0.05 * np.sin(np.pi * s_nd / 2)
+    if mode == "twist+bend":
+        w[0] = 2.0 * np.sin(np.pi * s_el)
+        v[1] = 0.3 * s_nd ** 2
+    w[:, 0] = 0.0
+    v[:, 0] = 0.0
+    rod.set("w", w)
+    rod.set("v", v)
+    _inject(be, "omega", w)
+    _inject(be, "velocity", v)
+    be.substeps(None, 600)
+    rod.substeps(0.0, 600)
+    torch_gpu.cuda.synchronize()
+    st = be.state_numpy()
+    for name in ("x", "v", "w", "Q"):
+        np.testing.assert_allclose(st[name][0], rod.get(name), rtol=RTOL, atol=1e-9, err_msg=name)
+        np.testing.assert_array_equal(st[name][0], st[name][1])
+    assert np.abs(st["w"][0][2]).max() > 1e-2 or mode == "stretch"
+    be.close()

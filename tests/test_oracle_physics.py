@@ -341,3 +341,66 @@ def test_k13_spline_muscle_static_curvature(oracle_built):
     kappa = o.get("kappa")
     np.testing.assert_allclose(kappa[0][:-1], (couple / EI)[:-1], rtol=1e-4)
     assert np.abs(kappa[1]).max() < 1e-12 and np.abs(kappa[2]).max() < 1e-12
+
+
+def _period_from_zero_crossings(t, y):
+    s = np.sign(y)
+    idx = np.nonzero(s[1:] * s[:-1] < 0)[0]
+    tz = t[idx] - y[idx] * (t[idx + 1] - t[idx]) / (y[idx + 1] - y[idx])     # linear interpolation
+    return 2.0 * np.mean(np.diff(tz))
+
+
+def test_k14_torsional_wave_first_mode(oracle_built):
+    """Twist: a rod clamped at one end and free at the other, released with a small twist-rate
+    profile sin(pi s / 2L) about d3, rings at the first torsional frequency of a fixed-free
+    bar, f1 = sqrt(G / rho) / (4 L) — which involves exactly the pieces the planar tests never
+    touch: the twist stiffness G I3 on the Voronoi vertices, the polar inertia J3 = 2 J1 and
+    the director update about d3.  The rod is a chain of n - 1 free elements (element 0 is held)
+    with inertia rho I3 l coupled by springs G I3 / l, whose first fixed-free mode is exactly
+    omega1 = (2 / l) sqrt(G / rho) sin(pi / (2 (2n - 1)))  (-> the continuum value with L - l/2)."""
+    n, L = 50, 1.0
+    cfg = _free_cfg(n_elem=n, dt=1e-4, features=_capi.FEAT_FIXED_BC)
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    s = (np.arange(n) + 0.5) * (L / n)
+    w = np.zeros((3, n))
+    w[2] = 1e-3 * np.sin(np.pi * s / (2 * L))
+    rod.set("w", w)
+    G, rho = cfg.shear_modulus, cfg.density
+    ell = L / n
+    f1 = (2.0 / ell) * np.sqrt(G / rho) * np.sin(np.pi / (2 * (2 * n - 1))) / (2 * np.pi)
+    assert f1 == pytest.approx(np.sqrt(G / rho) / (4 * (L - ell / 2)), rel=1e-4)      # = 4.610 Hz
+    steps_per_sample, samples = 10, 700                      # 0.7 s = 3.2 periods
+    t, y = [], []
+    for k in range(samples):
+        rod.substeps(0.0, steps_per_sample)
+        t.append((k + 1) * steps_per_sample * cfg.dt)
+        y.append(rod.get("w")[2, -1])
+    period = _period_from_zero_crossings(np.array(t), np.array(y))
+    assert 1.0 / period == pytest.approx(f1, rel=5e-4)
+    assert np.abs(rod.get("w")[:2]).max() < 1e-12 and np.abs(rod.get("v")).max() < 1e-12   # pure twist
+
+
+def test_k15_axial_wave_first_mode(oracle_built):
+    """Stretch: the same bar released with an axial velocity profile rings at
+    f1 = sqrt(E / rho) / (4 L) (stretch stiffness E A, nodal masses with the half end mass, the
+    force difference): exactly omega1 = (2 / l) sqrt(E / rho) sin(pi / (4 n)) for the chain."""
+    n, L = 50, 1.0
+    cfg = _free_cfg(n_elem=n, dt=5e-5, features=_capi.FEAT_FIXED_BC)
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    s = np.arange(n + 1) * (L / n)
+    v = np.zeros((3, n + 1))
+    v[0] = 1e-4 * np.sin(np.pi * s / (2 * L))
+    rod.set("v", v)
+    f1 = (2.0 * n / L) * np.sqrt(cfg.youngs_modulus / cfg.density) * np.sin(np.pi / (4 * n)) / (2 * np.pi)
+    assert f1 == pytest.approx(np.sqrt(cfg.youngs_modulus / cfg.density) / (4 * L), rel=1e-4)   # = 7.906 Hz
+    steps_per_sample, samples = 10, 900                      # 0.45 s = 3.6 periods
+    t, y = [], []
+    for k in range(samples):
+        rod.substeps(0.0, steps_per_sample)
+        t.append((k + 1) * steps_per_sample * cfg.dt)
+        y.append(rod.get("v")[0, -1])
+    period = _period_from_zero_crossings(np.array(t), np.array(y))
+    assert 1.0 / period == pytest.approx(f1, rel=5e-4)
+    assert np.abs(rod.get("v")[1:]).max() < 1e-12 and np.abs(rod.get("w")).max() < 1e-12    # pure stretch
