@@ -233,6 +233,13 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
 #define SR_OCTO(FEATS, MAXW)                                                                        \
         hipLaunchKernelGGL((softrod_octo_step_kernel<FEATS, MAXW>), grid, block, 0, st, h->P, h->S,     \
                            actions, obs, reward, term, trunc, n_sub, epilogue, pack)
+        // the reference shape (two waves per env): four envs per workgroup, partner waves on one SIMD
+        const char* one = std::getenv("SOFTROD_OCTO_ONE_ENV_PER_BLOCK");     // A/B switch for profiling and tests
+        if (zup && h->nw == 2 && !(one && one[0] == '1')) {
+            hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_OCTO_FLAT | kFeatPlaneZup, 2, 4>),
+                               dim3((unsigned)((h->cfg.n_envs + 3) / 4)), dim3(kLanes * 8), 0, st, h->P, h->S,
+                               actions, obs, reward, term, trunc, n_sub, epilogue, pack);
+        } else
         if (zup) { if (h->nw <= 2) SR_OCTO(SOFTROD_FEATURES_OCTO_FLAT | kFeatPlaneZup, 2);
                    else SR_OCTO(SOFTROD_FEATURES_OCTO_FLAT | kFeatPlaneZup, 8); }
         else     { if (h->nw <= 2) SR_OCTO(SOFTROD_FEATURES_OCTO_FLAT, 2);

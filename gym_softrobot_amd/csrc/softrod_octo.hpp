@@ -174,29 +174,71 @@ __device__ __forceinline__ int octo_obs_dim(const RodParams& P) {
 #ifndef SOFTROD_OCTO_WAVES
 #define SOFTROD_OCTO_WAVES 2
 #endif
-template <unsigned F, int MAXW>
-__global__ void __launch_bounds__(kLanes * MAXW, SOFTROD_OCTO_WAVES)
+// EPB = envs per workgroup.  EPB = 1: one env per workgroup of nw waves, the waves meet at
+// s_barrier once per substep.  EPB = 4 (the reference shape, nw = 2): FOUR envs per workgroup of
+// eight waves, env e on waves e and e + 4.  The hardware places waves w and w + 4 of a workgroup
+// on the SAME SIMD (probed with s_getreg HW_ID on gfx950: 4096 of 4096 pairs; partners of a
+// two-wave workgroup always sit on different SIMDs), and a workgroup of 8 x 256 VGPRs is exactly
+// one CU.  The two waves of an env then share one SIMD's issue slots: while one waits for the
+// other's joint loads the other is the one running, so the wait costs no SIMD time, and the
+// rendezvous becomes a flag in LDS (release / acquire at workgroup scope) instead of a
+// workgroup-wide s_barrier that would couple four unrelated envs.
+template <unsigned F, int MAXW, int EPB = 1>
+__global__ void __launch_bounds__(kLanes * MAXW * EPB, SOFTROD_OCTO_WAVES)
 softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
                          const int n_sub, const int epilogue, const int pack) {
-    __shared__ double xch[2][MAXW][4];       // [buffer][wave][Fx, Fy, Tz of the wave's arms, pad]
-    __shared__ double sxy[kLanes * MAXW][2];
-    __shared__ int scount;
+    static_assert(EPB == 1 || MAXW == 2, "several envs per workgroup: the two-wave shape only");
+    __shared__ double xch_[EPB][2][MAXW][4];  // [env][buffer][wave][Fx, Fy, Tz of the wave's arms, pad]
+    __shared__ double sxy_[EPB][kLanes * MAXW][2];
+    __shared__ int scount_[EPB];
+    __shared__ int flag_[EPB][2][MAXW];       // EPB > 1: substeps posted by each wave, per buffer
+    __shared__ int sany_[2][EPB];             // EPB > 1: per-env "any" of the two collectives
 
-    const int env = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nw = blockDim.x >> 6;
+    const int wib = threadIdx.x >> 6;         // wave in the block
+    const int es = (EPB == 1) ? 0 : (wib & (EPB - 1));           // env slot in the block
+    const int wave = (EPB == 1) ? wib : (wib / EPB);             // wave of the env
+    const int lane = threadIdx.x & 63;
+    const int tid = wave * kLanes + lane;     // thread of the env
+    const int nw = (EPB == 1) ? (int)(blockDim.x >> 6) : MAXW;
+    const int nthr = nw * kLanes;
+    const bool active = (EPB == 1) || ((int)blockIdx.x * EPB + es < P.n_envs);
+    const int env = active ? (int)blockIdx.x * EPB + es : P.n_envs - 1;   // idle slots shadow a real env, read-only
+    auto& xch = xch_[es];
+    auto& sxy = sxy_[es];
+    int& scount = scount_[es];
     const size_t N = (size_t)P.n_envs, NR = N * (size_t)nw;
     const int row = env * nw + wave;
     const int n = P.n_elem, nk = P.n_action;
     const int r = tid & (P.seg - 1), arm = tid >> P.seg_shift;
     const bool arm_ok = arm < P.n_arm;
     if (tid < 2 * MAXW * 4) (&xch[0][0][0])[tid] = 0.0;   // rows of absent waves read as zero loads
-    if (epilogue && S.skip && S.skip[env]) {   // reset by the auto-reset pass of this env.step
-        __syncthreads();                       // every thread has read the flag
-        if (tid == 0) S.skip[env] = 0;
-        return;
+    if (EPB > 1 && tid < 2 * MAXW) (&flag_[es][0][0])[tid] = 0;
+    // per-env "any thread of the env": the workgroup barrier when the env IS the workgroup; with
+    // several envs per workgroup every wave takes the same barriers and the answer is per slot
+    auto env_any = [&](bool pred, int which) -> bool {
+        if constexpr (EPB == 1) return __syncthreads_or(pred ? 1 : 0) != 0;
+        else {
+            if (tid == 0) sany_[which][es] = 0;
+            __syncthreads();
+            if (__any(pred) && lane == 0) atomicOr(&sany_[which][es], 1);
+            __syncthreads();
+            return sany_[which][es] != 0;
+        }
+    };
+    bool live = active;
+    if (epilogue && S.skip && S.skip[env] && active) {   // reset by the auto-reset pass of this env.step
+        if constexpr (EPB == 1) {
+            __syncthreads();                   // every thread has read the flag
+            if (tid == 0) S.skip[env] = 0;
+            return;
+        }
+        live = false;
+    }
+    if constexpr (EPB > 1) {
+        __syncthreads();                       // flags cleared; every thread has read its skip flag
+        if (!live && active && tid == 0) S.skip[env] = 0;
     }
 
     LaneN<1> L;
@@ -209,7 +251,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
 
     // set_action (flat_env.py:288-311): rest_kappa[0,:] = zero-padded cubic interp1d of the
     // arm's knots = basis @ knots
-    if (actions) {
+    if (actions && live) {
         double rk0 = 0.0;
         if (arm_ok && r < n - 1) {
             const float* a = actions + (size_t)env * (P.n_arm * nk) + arm * nk;
@@ -241,6 +283,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
 
     double time = S.time[env];
     int parity = 0;
+    int posted = 0;          // EPB > 1: substeps whose joint loads this wave has posted per buffer pair
 
     auto joints = [&](double (&f)[1][3], double (&tq)[1][3], const LaneN<1>& Lc, const double (&xn)[1][3]) {
         // FixedJoint2Rigid.apply_forces (joint.py:48-123): spring + normal damping between the
@@ -295,6 +338,8 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             xch[parity][wave][0] = part[0];
             xch[parity][wave][1] = part[1];
             xch[parity][wave][2] = part[2];
+            if constexpr (EPB > 1)
+                __hip_atomic_store(&flag_[es][parity][wave], posted + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
     // RigidBodyBase.update_accelerations + the rate update under
@@ -325,7 +370,12 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         head_kinematic(hk, H);
     };
     auto exchange = [&]() {       // after the arms' kinematic step: everyone has posted
-        __syncthreads();
+        if constexpr (EPB == 1) __syncthreads();
+        else {                    // the partner wave runs on this SIMD: wait for its flag, not for a barrier
+            while (__hip_atomic_load(&flag_[es][parity][wave ^ 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= posted)
+                __builtin_amdgcn_s_sleep(1);
+            posted += parity;     // both buffers of this pair used: the next pair carries the next count
+        }
         if constexpr (MAXW == 2) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -354,7 +404,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
                   (arm_ok && r < n && isnan(L.w[0][c]));
 #pragma unroll
         for (int c = 0; c < 9; ++c) bad = bad || (arm_ok && r < n && isnan(L.Q[0][c]));
-        dead = __syncthreads_or(bad ? 1 : 0) != 0;
+        dead = env_any(bad, 0);
         if (dead) {
             poison_rod<1>(L);
             for (int s = 0; s < n_sub; ++s) {
@@ -363,7 +413,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             }
         }
     }
-    if (n_sub > 0 && !dead) {
+    if (n_sub > 0 && !dead && live) {
         kinematic_n<1>(P.half_dt, C, L);
         head_normalize(H);                       // hk = dt/2 and zero loads: the head's first half step
         head_step();
@@ -380,16 +430,18 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             if (!last && P.time_two_half_adds) time += P.half_dt;
         }
     }
-    store_lane<1, F>(S, NR, row, lane, L);
-    if (tid == 0) {
-        S.time[env] = time;
-        store_head(S, N, env, H);
+    if (live) {
+        store_lane<1, F>(S, NR, row, lane, L);
+        if (tid == 0) {
+            S.time[env] = time;
+            store_head(S, N, env, H);
+        }
     }
     if (!epilogue) return;
 
     // ---- FlatEnv.step epilogue, flat_env.py:330-408 ----
     const int adim = P.n_arm * nk;
-    if (tid < adim) S.prev_action[(size_t)env * adim + tid] = actions[(size_t)env * adim + tid];
+    if (tid < adim && live) S.prev_action[(size_t)env * adim + tid] = actions[(size_t)env * adim + tid];
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) bad = bad || isnan(L.x[0][c]) || isnan(L.v[0][c]);
@@ -397,11 +449,11 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     sxy[tid][0] = L.x[0][0];
     sxy[tid][1] = L.x[0][1];
     if (tid == 0) scount = 0;
-    const int invalid = __syncthreads_or(bad ? 1 : 0);
+    const bool invalid = env_any(bad, 1);
     // arm crossings: pairs (i-1, i) for i = 0..n_arm-2, index -1 wrapping to the last arm
     int cnt = 0;
     const int per = n * n, total = (P.n_arm - 1) * per;
-    for (int q = tid; q < total; q += blockDim.x) {
+    for (int q = tid; q < total; q += nthr) {
         const int i = q / per, rem = q - i * per;
         const int ii = rem / n, jj = rem - ii * n;
         const int a1 = (i - 1 + P.n_arm) % P.n_arm, a2 = i;
@@ -424,6 +476,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     __syncthreads();
     const int od = octo_obs_dim(P);
     float* o = out_row(obs, env, od, pack);
+    if (!live) return;                         // (no barrier below)
     if (tid == 0) {
         const double tx = tgt[0] - H.x[0], ty = tgt[1] - H.x[1];
         const double dist = sqrt(tx * tx + ty * ty);
