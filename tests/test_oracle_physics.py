@@ -224,6 +224,44 @@ def test_k9_axial_sliding_decelerates_with_kinetic_coulomb_friction(oracle_built
     assert np.abs(rod.get("x")[2]).max() < 1e-6                 # stays on the plane
 
 
+def test_k9b_sideways_sliding_and_pure_rolling(oracle_built):
+    """Rolling direction of the anisotropic friction.  (a) A rod sliding SIDEWAYS without spinning
+    is slowed by mu_sideways g at first (kinetic friction acts on the SLIP velocity of the contact
+    point) while the friction couple spins it up.  (b) A rod that ROLLS without slipping — contact
+    point velocity v + omega x (-n r) = 0 — feels no kinetic friction at all and keeps rolling:
+    the friction is distributed by the unit vector of the total slip velocity (rolling slip incl.
+    the spin + axial velocity), not by the element's own velocity."""
+    cfg = _arm_cfg()
+    cfg.damping_constant = 0.0
+    n, r0, dt = cfg.n_elem, cfg.base_radius, cfg.dt
+    # (a) sideways slide: first 100 substeps, before the spin-up matters
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    v = np.zeros((3, n + 1))
+    v[1] = 0.2
+    rod.set("v", v)
+    rod.substeps(0.0, 100)
+    vy = rod.get("v")[1]
+    assert vy.mean() == pytest.approx(0.2 - cfg.kinetic_mu[2] * 9.81 * 100 * dt, rel=5e-3)
+    spin = rod.get("w")[2]                       # about d3 = the rod's axis
+    assert np.all(np.abs(spin[1:-1]) > 1.0) and np.all(np.sign(spin[1:-1]) == np.sign(spin[1]))
+    # (b) pure rolling towards +y: omega about the axis (+x) with v_y = -omega r ... the contact
+    # point sits at -r e_z, its velocity is v + omega x (-r e_z) = (0, v_y + omega_x r, 0)
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    rod.substeps(0.0, 4000)                      # settle onto the plane first
+    v_roll = 0.05
+    v = rod.get("v") * 0.0
+    v[1] = v_roll
+    w = np.zeros((3, n))
+    w[2] = -v_roll / r0                          # local d3 = +x: omega_x = -v_y / r gives zero slip
+    rod.set("v", v)
+    rod.set("w", w)
+    rod.substeps(0.0, 2000)                      # 0.14 s: sliding would have lost mu_s g t = 0.24 m/s
+    assert rod.get("v")[1].mean() == pytest.approx(v_roll, rel=2e-2)
+    assert rod.get("w")[2].mean() == pytest.approx(-v_roll / r0, rel=2e-2)
+
+
 # ---- LaplaceDissipationFilter (SoftPendulum3D-v0) -------------------------------------------
 def test_k10_laplace_filter_is_a_high_frequency_low_pass(oracle_built):
     # f_k <- (2 f_k - f_{k-1} - f_{k+1})/4 has the interior eigenfunctions sin(k theta) with
