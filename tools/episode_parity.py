@@ -141,6 +141,68 @@ def run(kind, n, steps, script, window=0, with_control=True, **kw):
     return out
 
 
+def inject_octo(env, oracles):
+    """GPU state <- the oracle envs' (arms, head, clock), through softrod_state_view."""
+    st = env.backend.state()
+    seg = st["arm_stride"]
+    dev = st["position"].device
+    T = torch.from_numpy
+    for i, o in enumerate(oracles):
+        for a in range(o.n_arm):
+            arm = o.arm(a)
+            lo = a * seg
+            for name, key, comps in (("position", "x", 3), ("velocity", "v", 3), ("omega", "w", 3), ("director", "Q", 9),
+                                     ("kappa", "kappa", 3), ("rest_kappa", "rest_kappa", 3)):
+                v = np.ascontiguousarray(arm.get(key).reshape(comps, -1))
+                st[name][:, i, lo : lo + v.shape[1]] = T(v).to(dev)
+        h = o.head()
+        st["head"][0:18, i] = T(np.concatenate([h["x"], h["v"], h["Q"].ravel(), h["w"]])).to(dev)
+        st["time"][i] = o.time
+
+
+def run_octo(n, steps, amax, window):
+    """OctoFlat-v0 over a whole 5 s episode (35 env.steps of 2857 substeps).  Whole rollouts are
+    chaotic at rounding level (the friction's stick-slip switches), so the curve of interest is the
+    re-synchronised one: before every `window`-th step the HIP state and the control's are
+    overwritten with the oracle's, i.e. the error of ONE env.step along the oracle's trajectory."""
+    env = gsa.make_vec("OctoFlat-v0", n, device=0, numpy_output=True)
+    env.reset(seed=0)
+    orc = [oracle_c.OracleOcto(env.cfg) for _ in range(n)]
+    ctl = [oracle_c.OracleOcto(env.cfg, "fma") for _ in range(n)]
+    for i in range(n):
+        orc[i].reset(env.targets[i])
+        ctl[i].reset(env.targets[i])
+    acts = np.random.default_rng(7).uniform(-amax, amax, (steps, n, 24)).astype(np.float32)
+    flat = lambda ob: np.concatenate([ob["individual"].ravel(), ob["shared"]])   # noqa: E731
+    curves = {k: [] for k in ("gpu_obs", "gpu_reward", "ctl_obs", "ctl_reward", "flags_equal", "crossings_equal")}
+    for t in range(steps):
+        if window and t % window == 0 and t > 0:
+            inject_octo(env, orc)
+            for i in range(n):
+                ctl[i].copy_state_from(orc[i])
+        g_obs, g_rew, g_te, g_tr, _ = env.step(acts[t])
+        eo = er = co = cr = 0.0
+        same = True
+        for i in range(n):
+            ob, rw, te, tr = orc[i].env_step(acts[t, i])
+            ob2, rw2, _, _ = ctl[i].env_step(acts[t, i])
+            eo, er = max(eo, rel(g_obs[i], flat(ob))), max(er, rel(g_rew[i], rw))
+            co, cr = max(co, rel(flat(ob2), flat(ob))), max(cr, rel(rw2, rw))
+            same = same and bool(g_te[i]) == te and bool(g_tr[i]) == tr
+        for k, v in (("gpu_obs", eo), ("gpu_reward", er), ("ctl_obs", co), ("ctl_reward", cr), ("flags_equal", same)):
+            curves[k].append(v)
+    env.close()
+    within = lambda c: int(np.sum(np.asarray(c) <= 1e-5))   # noqa: E731
+    return {"envs": n, "steps": steps, "window": window, "action_amplitude": amax,
+            "steps_within_1e-5_of": steps,
+            "steps_within_1e-5": {"gpu": within(np.maximum(curves["gpu_obs"], curves["gpu_reward"])),
+                                  "ctl": within(np.maximum(curves["ctl_obs"], curves["ctl_reward"]))},
+            "max": {k: float(np.max(curves[k])) for k in ("gpu_obs", "gpu_reward", "ctl_obs", "ctl_reward")},
+            "median": {k: float(np.median(curves[k])) for k in ("gpu_obs", "gpu_reward", "ctl_obs", "ctl_reward")},
+            "flags_equal_all_steps": bool(all(curves["flags_equal"])),
+            "curves": {k: [float(f"{v:.3e}") for v in curves[k]] for k in ("gpu_obs", "gpu_reward", "ctl_obs", "ctl_reward")}}
+
+
 def main():
     doc = {"metric": "max over envs and entries of |a - oracle| / (|oracle| + 1e-3); gpu = HIP path, ctl = the same "
                      "oracle source built with FMA contraction (rounding control); tests assert 1e-5 (north_star)",
@@ -173,6 +235,9 @@ def main():
     S["OctoArmSingle-v0, 201 steps (to truncation), random +-6"] = run("OctoArmSingle-v0", m, 201, lambda t, o: rnd6[t])
     S["OctoArmSingle-v0, 201 steps, random +-6, re-synchronised every 5 steps"] = run(
         "OctoArmSingle-v0", m, 201, lambda t, o: rnd6[t], window=5)
+    S["OctoFlat-v0, 36 steps of 2857 substeps (to truncation), random +-22, re-synchronised before every step"] = run_octo(4, 36, 22.0, 1)
+    S["OctoFlat-v0, 36 steps, random +-5 (gentle), re-synchronised before every step"] = run_octo(4, 36, 5.0, 1)
+    S["OctoFlat-v0, 8 steps, random +-22, free-running"] = run_octo(4, 8, 22.0, 0)
     print(json.dumps(doc, indent=1))
 
 
