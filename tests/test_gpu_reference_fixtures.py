@@ -322,3 +322,44 @@ def test_octoflat_step_from_the_recorded_pre_state(torch_gpu, hip_lib):
     rk = be.octo_state_numpy()["rest_kappa"]
     np.testing.assert_allclose(rk, z["step_rest_kappa"][keep], rtol=1e-12, atol=1e-12)
     env.close()
+
+
+def test_octoflatlite_step_from_the_recorded_pre_state(torch_gpu, hip_lib):
+    """OctoFlatLite-v0 (n_arm = 1, n_action = 8): reset observation, then the reference's step()
+    outputs from the recorded pre-loop states through the real 40 substeps."""
+    import gym_softrobot_amd as gsa
+
+    z = np.load(GOLD / "ref_octoflatlite.npz")
+    seeds = [int(s) for s in z["reset_seed"]]
+    env = gsa.make_vec("OctoFlat-v0", len(seeds), numpy_output=True, n_arm=1, n_action=8)
+    obs, _ = env.reset(seed=seeds)
+    d = env.split_obs(obs)
+    np.testing.assert_allclose(d["individual"], z["reset_individual"], **OBS_TOL)
+    np.testing.assert_allclose(d["shared"], z["reset_shared"], **OBS_TOL)
+    env.close()
+    n = len(z["step_label"])
+    env = gsa.make_vec("OctoFlat-v0", n, numpy_output=True, recording_fps=FLAT_FPS, n_arm=1, n_action=8)
+    env.reset(seed=0)
+    st = env.backend.state()
+    dev = st["position"].device
+    T = torch_gpu.from_numpy
+    for i in range(n):
+        st["position"][:, i, :11] = T(z["step_pre_x"][i][0].copy()).to(dev)
+        st["velocity"][:, i, :11] = T(z["step_pre_v"][i][0].copy()).to(dev)
+        st["omega"][:, i, :10] = T(z["step_pre_w"][i][0].copy()).to(dev)
+        st["director"][:, i, :10] = T(np.ascontiguousarray(z["step_pre_Q"][i][0].reshape(9, 10))).to(dev)
+        st["kappa"][:, i, :9] = T(z["step_pre_kappa"][i][0].copy()).to(dev)
+        st["rest_kappa"][:, i, :9] = T(z["step_pre_rest_kappa"][i][0].copy()).to(dev)
+        head = np.concatenate([z["step_pre_head_x"][i], z["step_pre_head_v"][i], z["step_pre_head_Q"][i].ravel(),
+                               z["step_pre_head_w"][i], z["step_target"][i]])
+        st["head"][0:20, i] = T(head).to(dev)
+        st["time"][i] = float(z["step_time"][i]) - 40 * float(env.cfg.dt)
+        st["prev_action"][i, :8] = T(z["step_prev_action_before"][i].copy()).to(dev)
+    obs, rew, term, trunc, _ = env.step(z["step_action"])
+    d = env.split_obs(obs)
+    np.testing.assert_allclose(d["individual"], z["step_individual"], rtol=RTOL, atol=2e-6)
+    np.testing.assert_allclose(d["shared"], z["step_shared"], rtol=RTOL, atol=2e-6)
+    np.testing.assert_allclose(rew, z["step_reward"], rtol=RTOL, atol=1e-6)
+    np.testing.assert_array_equal(term, z["step_terminated"])
+    np.testing.assert_array_equal(trunc, z["step_truncated"])
+    env.close()

@@ -461,9 +461,9 @@ def armsingle(records):
 FLAT_FPS = 357          # int(1 / (357 * 7e-5)) = 40 substeps per env.step: short, not yet chaotic
 
 
-def octoflat(records):
+def octoflat(records, n_arm=8, n_action=3, name="OctoFlat-v0", fname="ref_octoflat.npz", specials=True):
     mod = refshim.load("gym_softrobot.envs.octopus.flat_env")
-    cfg = _capi.octo_flat_config(1, recording_fps=FLAT_FPS)
+    cfg = _capi.octo_flat_config(1, recording_fps=FLAT_FPS, n_arm=n_arm, n_action=n_action)
     assert int(cfg.n_substeps) == 40
     out = {}
     refshim.CosseratRod._on_create = None
@@ -479,7 +479,7 @@ def octoflat(records):
         hd.omega_collection[:, 0] = h["w"]
 
     def snapshot(orc):
-        arms = {k: np.stack([orc.arm(a).get(k) for a in range(8)]) for k in ("x", "v", "Q", "w", "kappa", "rest_kappa")}
+        arms = {k: np.stack([orc.arm(a).get(k) for a in range(n_arm)]) for k in ("x", "v", "Q", "w", "kappa", "rest_kappa")}
         h = orc.head()
         arms.update(head_x=h["x"].copy(), head_v=h["v"].copy(), head_Q=h["Q"].copy(), head_w=h["w"].copy())
         return arms
@@ -492,22 +492,22 @@ def octoflat(records):
     def finalize_and_fill(sim):
         orig_finalize(sim)
         env = state_holder["env"]
-        env.shearable_rods = sim._systems[:8]
-        env.rigid_rod = sim._systems[8]
+        env.shearable_rods = sim._systems[:n_arm]
+        env.rigid_rod = sim._systems[n_arm]
         orc.reset([1.0, 1.0])                           # geometry only; the target is the env's draw
         fill_all(env, orc)
     refshim.BaseSystemCollection.finalize = finalize_and_fill
     R = Stack()
     for seed in (0, 1, 42):
-        env = mod.FlatEnv(recording_fps=FLAT_FPS)
+        env = mod.FlatEnv(recording_fps=FLAT_FPS, n_arm=n_arm, n_action=n_action)
         state_holder["env"] = env
         obs, info = env.reset(seed=seed)
         R.add(seed=seed, target=env._target.copy(), individual=obs["individual"], shared=obs["shared"])
         if seed == 0:
-            records["OctoFlat-v0"] = {
+            records[name] = {
                 "init": {"step_skip": env.step_skip, "final_time": env.final_time, "time_step": env.time_step,
                          "n_elems": env.n_elems, "n_arm": env.n_arm, "n_action": env.n_action,
-                         "default_step_skip": mod.FlatEnv().step_skip,
+                         "default_step_skip": mod.FlatEnv(n_arm=n_arm, n_action=n_action).step_skip,
                          "action_low": env.action_space.low, "action_high": env.action_space.high},
                 "order": env.simulator.order(), "ops": op_records(env.simulator)}
             out["arm_start"] = np.stack([r.recorded["start"] for r in env.shearable_rods])
@@ -517,13 +517,13 @@ def octoflat(records):
 
     # step: the reference's FlatEnv.step over an oracle rollout of 40-substep steps
     S = Stack()
-    env = mod.FlatEnv(recording_fps=FLAT_FPS)
+    env = mod.FlatEnv(recording_fps=FLAT_FPS, n_arm=n_arm, n_action=n_action)
     state_holder["env"] = env
     env.reset(seed=7)
     orc.reset(env._target)
     fill_all(env, orc)
     rng = np.random.default_rng(31)
-    acts = rng.uniform(-22, 22, (8, 24)).astype(np.float32)
+    acts = rng.uniform(-22, 22, (8, n_arm * n_action)).astype(np.float32)
 
     def ref_step(action, pre, post, time, label, target=None):
         if target is not None:
@@ -563,35 +563,36 @@ def octoflat(records):
         post = snapshot(orc)
         ref_step(a, pre, post, orc.time, f"rollout{t}")
         pre = post
-    base_pre, base_post, t_end = S.rows[-1], post, orc.time
-    pre_last = {k[4:]: v for k, v in base_pre.items() if k.startswith("pre_")}
-    for label, key, idx in (("nan_x", "x", (3, 0, 5)), ("nan_v", "v", (7, 1, 0))):
+    if specials:
+        base_pre, base_post, t_end = S.rows[-1], post, orc.time
+        pre_last = {k[4:]: v for k, v in base_pre.items() if k.startswith("pre_")}
+        for label, key, idx in (("nan_x", "x", (3, 0, 5)), ("nan_v", "v", (7, 1, 0))):
+            st = {k: v.copy() for k, v in base_post.items()}
+            st[key][idx] = np.nan
+            ref_step(acts[1], pre_last, st, t_end, label)
+        # head within 0.1 of the target: +100, terminated, reward -= dist - 0.1
+        tgt = base_post["head_x"][:2] + np.array([0.05, -0.03])
+        ref_step(acts[2], pre_last, base_post, t_end, "at_target", target=tgt)
+        ref_step(acts[2], pre_last, base_post, 5.0, "time_eq_final", target=[1.2, 0.9])
+        ref_step(acts[2], pre_last, base_post, np.nextafter(5.0, 10.0), "time_just_past", target=[1.2, 0.9])
+        # crossing arms (radial arms never cross, so three arms are laid across others as straight
+        # polylines): arm 1 across arm 0 and arm 7 across arm 0 are counted — pairs (0, 1) and (7, 0) —
+        # arm 6 across the displaced arm 7 is not: the loop never tests the pair (6, 7) (flat_env.py:347-357)
         st = {k: v.copy() for k, v in base_post.items()}
-        st[key][idx] = np.nan
-        ref_step(acts[1], pre_last, st, t_end, label)
-    # head within 0.1 of the target: +100, terminated, reward -= dist - 0.1
-    tgt = base_post["head_x"][:2] + np.array([0.05, -0.03])
-    ref_step(acts[2], pre_last, base_post, t_end, "at_target", target=tgt)
-    ref_step(acts[2], pre_last, base_post, 5.0, "time_eq_final", target=[1.2, 0.9])
-    ref_step(acts[2], pre_last, base_post, np.nextafter(5.0, 10.0), "time_just_past", target=[1.2, 0.9])
-    # crossing arms (radial arms never cross, so three arms are laid across others as straight
-    # polylines): arm 1 across arm 0 and arm 7 across arm 0 are counted — pairs (0, 1) and (7, 0) —
-    # arm 6 across the displaced arm 7 is not: the loop never tests the pair (6, 7) (flat_env.py:347-357)
-    st = {k: v.copy() for k, v in base_post.items()}
-    x0 = st["x"][0]
+        x0 = st["x"][0]
 
-    def lay(arm, p, q):
-        for c in range(2):
-            st["x"][arm, c] = np.linspace(p[c], q[c], 11)
-    up = np.array([0.0, 1.0])
-    lay(1, 0.5 * (x0[:2, 2] + x0[:2, 3]) + 0.04 * up, 0.5 * (x0[:2, 6] + x0[:2, 7]) - 0.04 * up)
-    lay(7, 0.5 * (x0[:2, 8] + x0[:2, 9]) + 0.03 * up, 0.5 * (x0[:2, 9] + x0[:2, 10]) - 0.03 * up)
-    x7 = st["x"][7]
-    lay(6, x7[:2, 2] + np.array([0.02, 0.001]), x7[:2, 3] - np.array([0.02, 0.0]))
-    ref_step(acts[3], pre_last, st, t_end, "crossing", target=[1.2, 0.9])
+        def lay(arm, p, q):
+            for c in range(2):
+                st["x"][arm, c] = np.linspace(p[c], q[c], 11)
+        up = np.array([0.0, 1.0])
+        lay(1, 0.5 * (x0[:2, 2] + x0[:2, 3]) + 0.04 * up, 0.5 * (x0[:2, 6] + x0[:2, 7]) - 0.04 * up)
+        lay(7, 0.5 * (x0[:2, 8] + x0[:2, 9]) + 0.03 * up, 0.5 * (x0[:2, 9] + x0[:2, 10]) - 0.03 * up)
+        x7 = st["x"][7]
+        lay(6, x7[:2, 2] + np.array([0.02, 0.001]), x7[:2, 3] - np.array([0.02, 0.0]))
+        ref_step(acts[3], pre_last, st, t_end, "crossing", target=[1.2, 0.9])
     out.update(S.arrays("step_"))
     refshim.BaseSystemCollection.finalize = orig_finalize
-    np.savez_compressed(GOLD / "ref_octoflat.npz", **out)
+    np.savez_compressed(GOLD / fname, **out)
 
 
 # =============================================================================================
@@ -648,6 +649,8 @@ def main():
     softpendulum3d(records)
     armsingle(records)
     octoflat(records)
+    # OctoFlatLite-v0: the same class registered with n_arm = 1, n_action = 8 (gym_softrobot/__init__.py:11-15)
+    octoflat(records, n_arm=1, n_action=8, name="OctoFlatLite-v0", fname="ref_octoflatlite.npz", specials=False)
     sucker(records)
     (GOLD / "ref_build_records.json").write_text(json.dumps(jsonable(records), indent=1) + "\n")
     for f in sorted(GOLD.glob("ref_*")):
