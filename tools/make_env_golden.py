@@ -629,6 +629,31 @@ def sucker(records):
     np.savez_compressed(GOLD / "ref_sucker.npz", **B.arrays("op_"))
 
 
+# =============================================================================================
+# diagnostic callbacks, utils/custom_elastica/callback_func.py:4-41
+# =============================================================================================
+def callbacks(records):
+    mod = refshim.load("gym_softrobot.utils.custom_elastica.callback_func")
+    from collections import defaultdict
+    out = {}
+    rod = refshim.FakeRod(6)
+    rod.dilatation = np.ones(6)
+    rod.voronoi_dilatation = np.ones(5)
+    body = refshim.FakeRigidBody()
+    for cls, system in ((mod.RodCallBack, rod), (mod.RigidCylinderCallBack, body)):
+        d = defaultdict(list)
+        cb = cls(step_skip=4, callback_params=d)
+        fired = []
+        for step in range(0, 13):
+            before = len(d["time"])
+            cb.make_callback(system, 0.1 * step, step)
+            if len(d["time"]) > before:
+                fired.append(step)
+        out[cls.__name__] = {"fields": list(d.keys()), "fires_at_steps_with_step_skip_4": fired,
+                             "shapes": {k: list(np.shape(v[0])) for k, v in d.items()}}
+    records["callbacks"] = out
+
+
 def main():
     refshim.install()
     # straight_rod calls back into the generator so that the fake rod holds a real allocation
@@ -652,6 +677,7 @@ def main():
     # OctoFlatLite-v0: the same class registered with n_arm = 1, n_action = 8 (gym_softrobot/__init__.py:11-15)
     octoflat(records, n_arm=1, n_action=8, name="OctoFlatLite-v0", fname="ref_octoflatlite.npz", specials=False)
     sucker(records)
+    callbacks(records)
     (GOLD / "ref_build_records.json").write_text(json.dumps(jsonable(records), indent=1) + "\n")
     for f in sorted(GOLD.glob("ref_*")):
         print(f.name, f.stat().st_size)
