@@ -36,6 +36,7 @@ struct softrod_handle {
     bool spline_set = false;
     RodParams* d_params = nullptr;  // device copy of P
     StatePtrs* d_state = nullptr;   // device copy of S (re-uploaded whenever S changes)
+    double* d_time_tab = nullptr;   // clock after k env.steps from a reset (SoftPendulum's planar loop)
     double* d_mat = nullptr;        // [kMatRows][64] material table of a tapered rod
     double* d_sucker = nullptr;     // [SOFTROD_MAX_SUCKERS][N]
     bool tapered = false;
@@ -607,6 +608,30 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     h->S.params = h->d_params;
     alloc((void**)&h->d_state, sizeof(StatePtrs));
     h->S.self = h->d_state;
+    if (rc == SOFTROD_OK && cfg->features == SOFTROD_FEATURES_SOFTPENDULUM && cfg->n_substeps > 0) {
+        // the clock as `self.time = self.do_step(self.simulator, self.time, self.time_step)` accumulates it
+        // (soft_pendulum.py:183-184): same additions, same order, IEEE doubles -> bit-identical
+        constexpr int kTab = 1024;
+        std::vector<double> tab((size_t)kTab);
+        double t = 0.0;
+        const double half = 0.5 * cfg->dt;
+        for (int k = 0; k < kTab; ++k) {
+            tab[(size_t)k] = t;
+            for (int s = 0; s < cfg->n_substeps; ++s) {
+                if (cfg->time_two_half_adds) { t = t + half; t = t + half; }
+                else t = t + cfg->dt;
+            }
+        }
+        alloc((void**)&h->d_time_tab, tab.size() * sizeof(double));
+        if (rc == SOFTROD_OK && hipMemcpy(h->d_time_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+            rc = SOFTROD_EHIP;
+        h->S.time_tab = h->d_time_tab;
+        h->P.tab_len = kTab;
+        h->P.tab_n_sub = cfg->n_substeps;
+        h->P.inv_step_time = 1.0 / ((double)cfg->n_substeps * cfg->dt);
+        if (rc == SOFTROD_OK && hipMemcpy(h->d_params, &h->P, sizeof(RodParams), hipMemcpyHostToDevice) != hipSuccess)
+            rc = SOFTROD_EHIP;
+    }
     alloc((void**)&h->d_sucker, (size_t)SOFTROD_MAX_SUCKERS * N * sizeof(double));
     h->S.sucker = h->d_sucker;
     if (rc == SOFTROD_OK && (cfg->features & SOFTROD_FEAT_SUCKER_CONSTRAINT)) {
@@ -1068,7 +1093,7 @@ int softrod_destroy(softrod_handle* h) {
     if (h->h_produced) (void)hipHostFree(h->h_produced);
     if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_mat, h->d_sucker, h->d_basis, h->d_spline, h->d_init, h->d_mask};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_time_tab, h->d_mat, h->d_sucker, h->d_basis, h->d_spline, h->d_init, h->d_mask};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

@@ -513,10 +513,21 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
         if (n_sub > 0 && !stepped && planar_from_lane<EPL>(P, B, lane, L, Z)) {
             PlanarC<EPL> K;
             planar_build_const<EPL>(Pk, C, lane, K);
-            // the clock takes the reference's additions in the reference's order: 2 n_sub times
-            // +dt/2, or n_sub times +dt (then tb = 0 and x + 0 = x)
+            // The clock takes the reference's additions in the reference's order: 2 n_sub times
+            // +dt/2, or n_sub times +dt.  They are 2 of the loop's ~100 VALU instructions, and the
+            // result does not depend on the rod: the host has accumulated the same sequence of
+            // float64 additions from a reset into a table (StatePtrs.time_tab).  If this rod's clock
+            // IS the table's k-th entry — it is, unless somebody wrote the time row — the new clock
+            // is entry k + 1 and the loop carries no clock; otherwise the additions run after the
+            // loop (bit-identical either way).
             const double ta = P.time_two_half_adds ? P.half_dt : P.dt;
             const double tb = P.time_two_half_adds ? P.half_dt : 0.0;
+            int tk = -1;
+            if (S.time_tab && n_sub == P.tab_n_sub) {
+                const double kf = rint(time * P.inv_step_time);
+                const int k = (kf >= 0.0 && kf < (double)(P.tab_len - 1)) ? (int)kf : -1;
+                tk = (k >= 0 && S.time_tab[k] == time) ? k : -1;
+            }
             // two half kinematic steps between force evaluations are one whole step; the last
             // substep (half a step) is peeled so that the loop's step length is a constant
             // (the step length as a vector register where scalar ones are short: uniform_k)
@@ -525,11 +536,12 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             for (int s = 0; s + 1 < n_sub; ++s) {
                 planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
                 planar_kinematic_n<EPL>(step_dt, K.hq_dt, C, K, Z);
-                time = (time + ta) + tb;
             }
             planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
             planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
-            time = (time + ta) + tb;
+            if (__builtin_amdgcn_readfirstlane(tk) >= 0) time = S.time_tab[tk + 1];
+            else
+                for (int s = 0; s < n_sub; ++s) time = (time + ta) + tb;
             planar_to_lane<EPL>(Z, L);
             stepped = true;
         }

@@ -94,6 +94,9 @@ struct RodParams {
     double joint_k, joint_nu, joint_kt;
     // ControllableFixConstraint (octopus/controllable_constraint.py:24-69)
     int n_suckers, sucker_index[SOFTROD_MAX_SUCKERS], pad2;
+    // clock table (StatePtrs.time_tab): entries, and 1 / (n_substeps dt) to find an env's entry
+    int tab_len, tab_n_sub;
+    double inv_step_time;
 };
 
 // Rows of the per-lane material table of a TAPERED rod (softrod_set_radius_profile): what
@@ -127,6 +130,9 @@ struct StatePtrs {
     int q_depth, q_record;
     const struct RodParams* params;   // device copy of the kernel's RodParams (cold paths read it)
     const struct StatePtrs* self;     // device copy of this struct (cold paths read it)
+    const double* time_tab; // [tab_len] the float64 clock after k env.steps from a reset, accumulated on the
+                            // host exactly as PositionVerlet.step advances it (2 n_substeps additions of
+                            // dt/2 per env.step, soft_pendulum.py:183-184); nullptr: none
     const double* mat;      // [kMatRows][64*EPL] material table of a tapered rod, or nullptr (uniform)
     double* sucker;         // [SOFTROD_MAX_SUCKERS][N] effective reduction ratio of each sucker
 };

@@ -117,7 +117,7 @@ __device__ __forceinline__ void planar_build_const(const RodParams& P, const Con
 // exp(x) for the damper (see exp_pair)
 template <int EPL>
 __device__ __forceinline__ double exp_one(const PlanarC<EPL>& K, double x) {
-    if (!wave_any(!(fabs(x) < 1.0e-3)))
+    if (__builtin_expect(!wave_any(!(fabs(x) < 1.0e-3)), 1))      // (the hint keeps the in-range path the fall-through)
         return fma(x, fma(x, fma(x, fma(x, K.e4, K.e3), 0.5), 1.0), 1.0);
     int k = 0;
     while (wave_any(!(fabs(x) < 1.0e-3)) && k < 24) { x *= 0.5; ++k; }
@@ -210,7 +210,7 @@ __device__ __forceinline__ void planar_kinematic_n(double h, const double (&hq_h
         ra[s] = a;
         const double t = a * a;
         double sc, cs;
-        if (!wave_any(t >= 1.0e-3)) {      // sinc_cosc's range, on the opaque coefficients; the
+        if (__builtin_expect(!wave_any(t >= 1.0e-3), 1)) {      // sinc_cosc's range, on the opaque coefficients; the
             sc = fma(t, fma(t, fma(t, K.s3, K.s2), K.s1), 1.0);       // cosine directly (t^4/8! < 3e-17)
             cs = fma(t, fma(t, fma(t, K.c3, K.c2), -0.5), 1.0);
         } else {

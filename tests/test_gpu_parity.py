@@ -1104,3 +1104,36 @@ def test_torsional_and_axial_modes_match_oracle(torch_gpu, hip_lib, oracle_built
         np.testing.assert_array_equal(st[name][0], st[name][1])
     assert np.abs(st["w"][0][2]).max() > 1e-2 or mode == "stretch"
     be.close()
+
+
+def test_clock_table_and_its_fallback_are_bit_identical_to_the_accumulation(torch_gpu, hip_lib, oracle_built):
+    """The planar loop carries no clock: a rod whose time IS the k-th entry of the host-accumulated
+    table takes entry k + 1, any other clock (written through the state view, or beyond the table)
+    is advanced by the 2 n_substeps additions after the loop.  Both must equal the oracle's
+    `time += dt/2` chain bit for bit (the truncation flag is a strict comparison on it)."""
+    import gym_softrobot_amd as gsa
+
+    n = 6
+    env = gsa.make_vec("SoftPendulum-v0", n)
+    env.reset(seed=0)
+    st = env.backend.state()
+    start = np.array([0.0, 0.0, 0.12345678901234567, 40.96 + 1e-13, 3.9999999999, 1e6])
+    acts = np.zeros((3, n, 1), np.float32)
+    env.step(acts[0])                                     # everybody at table entry 1
+    t1 = st["time"].cpu().numpy().copy()
+    st["time"][2:] = torch_gpu.from_numpy(start[2:]).to(st["time"].device)      # off the table / beyond it
+    rods = []
+    for i in range(n):
+        r = oracle_built.OracleRod(env.cfg)
+        r.reset_pendulum(_theta(i))
+        r.env_step(0.0)
+        if i >= 2:
+            r.set("time", [start[i]])
+        rods.append(r)
+    assert t1[0] == rods[0].time
+    for t in (1, 2):
+        env.step(acts[t])
+        for r in rods:
+            r.env_step(0.0)
+        np.testing.assert_array_equal(st["time"].cpu().numpy(), np.array([r.time for r in rods]))
+    env.close()
