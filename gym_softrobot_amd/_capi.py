@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -445,6 +445,8 @@ _EXPORTS = {
     "softrod_queue_push_straight": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
     "softrod_queue_push_octo": (C.c_int, [_VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
     "softrod_queue_status": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "softrod_queue_status_begin": (C.c_int, [_VP, _VP]),
+    "softrod_queue_status_poll": (C.c_int, [_VP, C.c_int, _VP, _VP]),
     "softrod_queue_advance": (C.c_int, [_VP, _VP, _VP]),
     "softrod_set_action_basis": (C.c_int, [_VP, _VP]),
     "softrod_set_radius_profile": (C.c_int, [_VP, _VP]),

@@ -185,6 +185,20 @@ class HipRodBackend:
         check(self._lib.softrod_queue_status(self._h, cons.ctypes.data, C.byref(uf), self._stream()), self._h)
         return cons, int(uf.value)
 
+    def queue_status_begin(self) -> None:
+        """Start a non-blocking read of the queue counters (softrod_queue_status_begin)."""
+        check(self._lib.softrod_queue_status_begin(self._h, self._stream()), self._h)
+
+    def queue_status_poll(self, wait: bool = False):
+        """None while the read is in flight, else (consumed[n_envs], underflow) as of when it was
+        started; `wait` blocks until that read (not the whole stream) has arrived."""
+        cons = np.zeros(self.n_envs, np.int32)
+        uf = C.c_int32(0)
+        rc = self._lib.softrod_queue_status_poll(self._h, int(bool(wait)), cons.ctypes.data, C.byref(uf))
+        if rc < 0:
+            check(rc, self._h)
+        return None if rc == 0 else (cons, int(uf.value))
+
     def queue_advance(self, by) -> None:
         """Mark by[e] staged records of env e as used (by[e] < 0: all of them)."""
         b = np.ascontiguousarray(by, dtype=np.int32).reshape(self.n_envs)

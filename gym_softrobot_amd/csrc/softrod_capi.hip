@@ -57,6 +57,15 @@ struct softrod_handle {
     uint8_t* d_flags = nullptr;     // [2][N]: needs_reset, skip
     int* h_produced = nullptr;      // pinned [N]
     std::vector<int> seen_consumed; // as of the last softrod_queue_status
+    std::vector<int2> pending;      // (env, slot) written into h_queue since the last commit
+    double* h_stage = nullptr;      // pinned: the pending records, compacted
+    int2* h_where = nullptr;        // pinned
+    double* d_stage = nullptr;
+    int2* d_where = nullptr;
+    size_t stage_cap = 0;           // records the staging buffers hold
+    int* h_status = nullptr;        // pinned [N + 1]: consumed, underflow (softrod_queue_status_begin)
+    hipEvent_t ev_status = nullptr;
+    bool status_pending = false;
     hipEvent_t ev_queue = nullptr;  // guards reuse of h_queue / h_produced
     std::string err;
 };
@@ -704,6 +713,13 @@ int softrod_autoreset_enable(softrod_handle* h, int depth) {
     SR_HIP(h, hipHostMalloc((void**)&h->h_produced, N * sizeof(int)));
     std::memset(h->h_produced, 0, N * sizeof(int));
     SR_HIP(h, hipEventCreateWithFlags(&h->ev_queue, hipEventDisableTiming));
+    h->stage_cap = 2 * N;     // pushes of more records than this upload the whole ring instead
+    SR_HIP(h, hipHostMalloc((void**)&h->h_stage, h->stage_cap * h->init_stride * sizeof(double)));
+    SR_HIP(h, hipHostMalloc((void**)&h->h_where, h->stage_cap * sizeof(int2)));
+    SR_HIP(h, hipMalloc((void**)&h->d_stage, h->stage_cap * h->init_stride * sizeof(double)));
+    SR_HIP(h, hipMalloc((void**)&h->d_where, h->stage_cap * sizeof(int2)));
+    SR_HIP(h, hipHostMalloc((void**)&h->h_status, (N + 1) * sizeof(int)));
+    SR_HIP(h, hipEventCreateWithFlags(&h->ev_status, hipEventDisableTiming));
     h->seen_consumed.assign(N, 0);
     h->q_depth = depth;
     h->S.needs_reset = h->d_flags;
@@ -734,12 +750,29 @@ int queue_begin(softrod_handle* h, const int32_t* counts, int max_count) {
     return SOFTROD_OK;
 }
 double* queue_slot(softrod_handle* h, int e, int k) {
+    h->pending.push_back(make_int2(e, k % h->q_depth));
     return h->h_queue + ((size_t)(k % h->q_depth) * (size_t)h->cfg.n_envs + (size_t)e) * h->init_stride;
 }
 int queue_commit(softrod_handle* h, hipStream_t st) {
     const size_t N = (size_t)h->cfg.n_envs;
-    SR_HIP(h, hipMemcpyAsync(h->d_queue, h->h_queue, (size_t)h->q_depth * N * h->init_stride * sizeof(double),
-                             hipMemcpyHostToDevice, st));
+    const size_t M = h->pending.size(), R = h->init_stride;
+    if (M > 0 && M <= h->stage_cap) {
+        // only the records of this push cross PCIe: compacted copy + a scatter kernel
+        for (size_t m = 0; m < M; ++m) {
+            const int2 w = h->pending[m];
+            std::memcpy(h->h_stage + m * R, h->h_queue + ((size_t)w.y * N + (size_t)w.x) * R, R * sizeof(double));
+            h->h_where[m] = w;
+        }
+        SR_HIP(h, hipMemcpyAsync(h->d_stage, h->h_stage, M * R * sizeof(double), hipMemcpyHostToDevice, st));
+        SR_HIP(h, hipMemcpyAsync(h->d_where, h->h_where, M * sizeof(int2), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(softrod_queue_scatter_kernel, dim3((unsigned)M), dim3(kLanes), 0, st, h->d_queue, h->d_stage,
+                           h->d_where, (int)N, (int)R);
+        SR_HIP(h, hipGetLastError());
+    } else if (M > 0) {
+        SR_HIP(h, hipMemcpyAsync(h->d_queue, h->h_queue, (size_t)h->q_depth * N * R * sizeof(double),
+                                 hipMemcpyHostToDevice, st));
+    }
+    h->pending.clear();
     SR_HIP(h, hipMemcpyAsync(h->d_produced, h->h_produced, N * sizeof(int), hipMemcpyHostToDevice, st));
     SR_HIP(h, hipEventRecord(h->ev_queue, st));
     return SOFTROD_OK;
@@ -813,6 +846,32 @@ int softrod_queue_status(softrod_handle* h, int32_t* consumed, int32_t* underflo
     for (size_t e = 0; e < N; ++e) h->seen_consumed[e] = consumed[e];
     if (underflow) *underflow = uf;
     return SOFTROD_OK;
+}
+
+int softrod_queue_status_begin(softrod_handle* h, void* stream) {
+    if (!h) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (!h->q_depth) return fail(h, SOFTROD_EINVAL, "call softrod_autoreset_enable first");
+    SR_ON_DEVICE(h);
+    const size_t N = (size_t)h->cfg.n_envs;
+    SR_HIP(h, hipMemcpyAsync(h->h_status, h->d_consumed, N * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    SR_HIP(h, hipMemcpyAsync(h->h_status + N, h->d_underflow, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    SR_HIP(h, hipEventRecord(h->ev_status, (hipStream_t)stream));
+    h->status_pending = true;
+    return SOFTROD_OK;
+}
+
+int softrod_queue_status_poll(softrod_handle* h, int wait, int32_t* consumed, int32_t* underflow) {
+    if (!h || !consumed) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (!h->status_pending) return fail(h, SOFTROD_EINVAL, "no softrod_queue_status_begin outstanding");
+    SR_ON_DEVICE(h);
+    const hipError_t q = wait ? hipEventSynchronize(h->ev_status) : hipEventQuery(h->ev_status);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) return fail(h, SOFTROD_EHIP, std::string("queue status event: ") + hipGetErrorString(q));
+    const size_t N = (size_t)h->cfg.n_envs;
+    for (size_t e = 0; e < N; ++e) { consumed[e] = h->h_status[e]; h->seen_consumed[e] = h->h_status[e]; }
+    if (underflow) *underflow = h->h_status[N];
+    h->status_pending = false;
+    return 1;
 }
 
 int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream) {
@@ -1090,6 +1149,12 @@ int softrod_destroy(softrod_handle* h) {
     void* qbufs[] = {h->d_queue, h->d_consumed, h->d_produced, h->d_underflow, h->d_flags};
     for (void* p : qbufs) (void)hipFree(p);
     if (h->h_queue) (void)hipHostFree(h->h_queue);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_where) (void)hipHostFree(h->h_where);
+    if (h->h_status) (void)hipHostFree(h->h_status);
+    (void)hipFree(h->d_stage);
+    (void)hipFree(h->d_where);
+    if (h->ev_status) (void)hipEventDestroy(h->ev_status);
     if (h->h_produced) (void)hipHostFree(h->h_produced);
     if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,

@@ -13,7 +13,7 @@ SURVEY.md §8(f) N2:
                        env's own NumPy stream (so the streams are the ones `autoreset=True`
                        would consume, draw for draw) and staged on the device
                        (softrod_queue_push*); the step applies them itself.  The host tops
-                       the queue up every `queue_depth` steps (one small read).  `infos`
+                       the queue up within every `queue_depth` steps (one small non-blocking read).  `infos`
                        then carry device tensors.
 """
 from __future__ import annotations
@@ -100,8 +100,8 @@ class VecRodEnvBase:
             raise ValueError("autoreset must be False, True/'host' or 'device'")
         self.device_autoreset = autoreset == "device"
         self.autoreset = bool(autoreset) and not self.device_autoreset
-        self.queue_depth = 16
-        self.top_up_every = self.queue_depth   # an env uses at most one record per two steps
+        self.queue_depth = 32
+        self.top_up_every = self.queue_depth - 2   # deadline in steps; see _top_up_tick
         self.action_dim = _capi.config_action_dim(cfg)
         self.obs_dim = _capi.config_obs_dim(cfg)
         self.n_action = self.action_dim
@@ -123,6 +123,7 @@ class VecRodEnvBase:
         self._staged = [deque() for _ in range(self.num_envs)]   # their draws, oldest first
         self._popped = np.zeros(self.num_envs, np.int64)     # draws removed from _staged so far
         self._since_top_up = 0
+        self._status_in_flight = False
         if self.device_autoreset:
             self.backend.autoreset_enable(self.queue_depth)
         # soft_pendulum.py:117-126: RodCallBack -> rod_parameters_dict, one sample per env.step.
@@ -149,25 +150,57 @@ class VecRodEnvBase:
         """backend.queue_push*(...) from draws[i] = list of counts[i] draws."""
         raise NotImplementedError
 
-    def _top_up(self) -> None:
-        """Stage resets until every env has `queue_depth` unconsumed records (device mode)."""
-        from .. import _capi as capi
+    def _top_up(self, status=None) -> None:
+        """Stage resets until every env has `queue_depth` unconsumed records (device mode).
 
-        consumed = self._sync_staged()
+        `status` = (consumed, underflow) from a finished non-blocking read; without it the
+        counters are read now, which waits for the stream."""
+        consumed = self._sync_staged(status)
         counts = (self.queue_depth - (self._produced - consumed)).astype(np.int32)
-        if counts.max(initial=0) > 0:
-            draws = [[self._draw_reset(i) for _ in range(int(counts[i]))] for i in range(self.num_envs)]
+        need = np.nonzero(counts > 0)[0]
+        if need.size:
+            draws = [()] * self.num_envs
+            for i in need:
+                d = [self._draw_reset(i) for _ in range(int(counts[i]))]
+                draws[i] = d
+                self._staged[i].extend(d)
             self._queue_from_draws(draws, counts)
             self._produced += counts
-            for i, d in enumerate(draws):
-                self._staged[i].extend(d)
         self._since_top_up = 0
+        self._status_in_flight = False
 
-    def _sync_staged(self) -> np.ndarray:
+    def _top_up_tick(self) -> None:
+        """Called once per step in device mode.  Right after a top-up the queue counters start
+        their way to the host without stalling the stream (softrod_queue_status_begin); from
+        half way to the deadline (`top_up_every` steps since the last top-up) each step looks
+        whether they have arrived and tops up if so; at the deadline it waits for that read
+        only — the steps enqueued after it keep the GPU busy while the host draws and stages
+        (a host that runs ahead of the GPU, as a rollout loop without a policy does, always ends
+        up there; one that reads every step's outputs tops up at the half-way mark).
+
+        Why an old reading is enough: the counters only grow, so records computed from it always
+        fit; which draw an env's k-th reset uses does not depend on when it was staged; and an
+        env uses at most one record per two steps (the step that resets does not also end an
+        episode), so between a reading and the end of the NEXT top-up — fewer than
+        2 * top_up_every steps — it uses at most top_up_every < queue_depth records."""
+        self._since_top_up += 1
+        due = self._since_top_up >= self.top_up_every
+        if self._status_in_flight:
+            if 2 * self._since_top_up >= self.top_up_every:
+                st = self.backend.queue_status_poll(due)
+                if st is not None:
+                    self._top_up(st)
+        elif due:
+            self._top_up()
+        elif hasattr(self.backend, "queue_status_begin"):
+            self.backend.queue_status_begin()
+            self._status_in_flight = True
+
+    def _sync_staged(self, status=None) -> np.ndarray:
         """Read how many staged records the device has used and forget their draws."""
         from .. import _capi as capi
 
-        consumed, underflow = self.backend.queue_status()
+        consumed, underflow = self.backend.queue_status() if status is None else status
         if underflow:
             raise capi.SoftrodError(
                 f"{underflow} auto-resets found no staged record: top up more often or raise queue_depth")
@@ -280,9 +313,7 @@ class VecRodEnvBase:
         import torch
 
         obs, reward, term, trunc = self.backend.step(a)    # auto-reset pass + step kernel
-        self._since_top_up += 1
-        if self._since_top_up >= self.top_up_every:
-            self._top_up()
+        self._top_up_tick()
         if getattr(self, "_dev_time", None) is None:
             self._dev_time = self.backend.state()["time"]
         infos = {"time": self._out(self._dev_time), "TimeLimit.truncated": self._out(trunc.view(torch.bool))}
@@ -345,9 +376,7 @@ class VecRodEnvBase:
         a = a.reshape(self.num_envs, self.action_dim)
         packed = self.backend.step_packed(a) if out is None else self.backend.step_packed(a, out)
         if self.device_autoreset:
-            self._since_top_up += 1
-            if self._since_top_up >= self.top_up_every:
-                self._top_up()
+            self._top_up_tick()
             return packed, {}
         self._steps += 1
         return packed, self._infos(self._times())

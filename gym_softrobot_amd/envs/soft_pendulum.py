@@ -76,8 +76,8 @@ class VecSoftPendulumEnv(VecRodEnvBase):
 
     def _queue_from_draws(self, draws, counts):
         th = np.zeros((self.num_envs, max(1, int(counts.max()))))
-        for i, d in enumerate(draws):
-            th[i, : len(d)] = d
+        for i in np.nonzero(counts > 0)[0]:
+            th[i, : counts[i]] = draws[i]
         self.backend.queue_push(th, counts)
 
 

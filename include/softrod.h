@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 10
+#define SOFTROD_ABI_VERSION 11
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -421,6 +421,14 @@ int softrod_step_packed(softrod_handle* h, const float* actions, float* packed,
  *                              Fails if staged-but-unconsumed + new records would exceed
  *                              depth (as of the last softrod_queue_status).
  *   softrod_queue_status       synchronises; consumed: host [n_envs] records used so far
+ *   softrod_queue_status_begin / _poll   the same read without stalling the stream: _begin
+ *                              enqueues the copy of the counters (pinned host memory) and an
+ *                              event; _poll returns 1 and fills consumed / underflow once the
+ *                              event has passed, 0 before; with wait != 0 it waits for that
+ *                              event only (work enqueued after _begin keeps the GPU busy
+ *                              meanwhile).  The values are as of _begin, which is safe:
+ *                              consumed only grows, so a top-up computed from them stages
+ *                              at most what fits
  *   softrod_queue_advance      mark by[e] staged records of env e as used (a manual reset
  *                              took the env's next draw), or all of them if by[e] < 0
  *                              (the env's stream was re-seeded); synchronises
@@ -436,6 +444,8 @@ int softrod_queue_push_octo(softrod_handle* h, const double* arm_start,
                             const int32_t* counts, int max_count, void* stream);
 int softrod_queue_status(softrod_handle* h, int32_t* consumed, int32_t* underflow,
                          void* stream);
+int softrod_queue_status_begin(softrod_handle* h, void* stream);
+int softrod_queue_status_poll(softrod_handle* h, int wait, int32_t* consumed, int32_t* underflow);
 int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream);
 
 /* Replaces: get_state() at reset (soft_pendulum.py:145-161,

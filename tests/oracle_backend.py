@@ -100,6 +100,16 @@ class OracleBackend:
     def queue_status(self):
         return self._consumed.copy(), self._underflow
 
+    def queue_status_begin(self):
+        # the counters as of now; delivered one poll late, like a copy still in flight
+        self._status = [self._consumed.copy(), self._underflow, 1]
+
+    def queue_status_poll(self, wait=False):
+        if self._status[2] > 0 and not wait:
+            self._status[2] -= 1
+            return None
+        return self._status[0], self._status[1]
+
     def queue_advance(self, by):
         for i, b in enumerate(np.asarray(by)):
             k = len(self._queue[i]) if b < 0 else min(int(b), len(self._queue[i]))

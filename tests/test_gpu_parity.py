@@ -821,7 +821,7 @@ def test_device_autoreset_underflow_is_reported(torch_gpu, hip_lib):
     env.reset(seed=0)
     a = np.zeros(3, np.float32)
     with pytest.raises(SoftrodError, match="no staged record"):
-        for _ in range(80):
+        for _ in range(4 * env.queue_depth):     # an episode here is 2 steps + the resetting one
             env.step(a)
         env._top_up()
     env.close()
