@@ -1170,3 +1170,10 @@ int softrod_destroy(softrod_handle* h) {
 }
 
 }  // extern "C"
+
+#ifdef SOFTROD_PHASE_CLOCKS
+// diagnostic build only: the phase stamps of the last step launch (tools/phase_clocks.py)
+extern "C" int softrod_debug_phase_clocks(unsigned long long* out, int n_rods) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(softrod::g_phase_clock), (size_t)n_rods * 8 * sizeof(unsigned long long));
+}
+#endif

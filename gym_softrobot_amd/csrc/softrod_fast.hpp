@@ -394,6 +394,31 @@ __device__ __forceinline__ void poison_rod(LaneN<EPL>& L) {
     }
 }
 
+// Wave priority by progress.  The SIMD's instruction arbiter serves the OLDEST of its waves first
+// (at equal s_setprio level): of the rods sharing a SIMD the first runs at the pace of a lone wave
+// (71 % of the issue slots for the planar loop: dependent fp64 operations), the others fill the gaps,
+// and the last one ends up running alone — measured with tools/phase_clocks.py: 4096 rods x 400
+// substeps finish at 105 / 180 / 250 / 317 us on every SIMD, the last 70 us at lone-wave pace.
+// Lowering a wave's priority as it advances (four levels: the quarters below, in 64ths of the
+// loop) makes the arbiter favour whoever is behind, so that the waves of a SIMD leapfrog and end
+// together: the same launch takes 303 us (-5 %).  Two scalar instructions per substep.
+struct ProgressPriority {
+    int next, q, n;
+    __device__ __forceinline__ static int bound(int n, int q) {
+        return (int)(((long long)n * (q == 0 ? 32 : q == 1 ? 48 : q == 2 ? 60 : 64)) / 64);
+    }
+    __device__ __forceinline__ explicit ProgressPriority(int n_) : next(bound(n_, 0)), q(0), n(n_) {}
+    __device__ __forceinline__ void tick(int s) {
+        if (s + 1 == next) {
+            ++q;
+            next = q < 4 ? bound(n, q) : -1;
+            if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+    }
+};
+
 // The substeps of one launch on the general 3-D state.  `always_inline` for every kernel whose
 // only path it is; the SoftPendulum kernel keeps it OUT of line (cold fallback for non-planar
 // states) so that its register demand cannot leak spills into the planar hot loop.
@@ -403,12 +428,14 @@ __device__ __forceinline__ void general_substeps(const RodParams& P, const RodPa
                                                  int n_sub) {
     kinematic_n<EPL>(P.half_dt, C, L);
     if (P.time_two_half_adds) time += P.half_dt;
+    ProgressPriority prio(n_sub);
     for (int s = 0; s < n_sub; ++s) {
         dynamic_n<F, EPL, TAPER>(Pk, C, B, lane, L);
         const bool last = (s == n_sub - 1);
         kinematic_n<EPL>(last ? P.half_dt : P.dt, C, L);
         time += P.time_two_half_adds ? P.half_dt : P.dt;
         if (!last && P.time_two_half_adds) time += P.half_dt;
+        prio.tick(s);
     }
 }
 // The SoftPendulum kernel's fallback for a state that is NOT planar (written through the state
@@ -449,6 +476,9 @@ __device__ __attribute__((noinline)) void general_step_cold(const RodParams* __r
 #ifndef SOFTROD_FAST_WAVES
 #define SOFTROD_FAST_WAVES 3
 #endif
+#ifndef SOFTROD_PLANAR_WAVES      // the SoftPendulum instantiation: all four rods of a SIMD resident (4096 envs)
+#define SOFTROD_PLANAR_WAVES 4
+#endif
 #ifndef SOFTROD_CONTACT_WAVES
 #define SOFTROD_CONTACT_WAVES 2
 #endif
@@ -456,8 +486,18 @@ __device__ __attribute__((noinline)) void general_step_cold(const RodParams* __r
 // and Laplace-filter instantiations trade a wave of occupancy for not spilling in the loop.
 // TAPER: the rod's radius varies along its length (softrod_set_radius_profile): material constants
 // come from the per-lane table S.mat instead of the kernel arguments.
+// Diagnostic build only (-DSOFTROD_PHASE_CLOCKS, tools/phase_clocks.py): where inside a launch the
+// time goes.  Lane 0 of every wave stamps the 100 MHz wall clock at the phase boundaries.
+#ifdef SOFTROD_PHASE_CLOCKS
+__device__ unsigned long long g_phase_clock[16384][8];
+#define SR_PHASE(i) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0 && blockIdx.x < 16384) \
+        g_phase_clock[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define SR_PHASE(i) do {} while (0)
+#endif
+
 template <unsigned F, int E, int EPL, bool TAPER = false>
-__global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))) ? SOFTROD_CONTACT_WAVES : SOFTROD_FAST_WAVES)))
+__global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))) ? SOFTROD_CONTACT_WAVES : (F == SOFTROD_FEATURES_SOFTPENDULUM ? SOFTROD_PLANAR_WAVES : SOFTROD_FAST_WAVES))))
 softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
@@ -470,8 +510,11 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
         return;
     }
 
+    __builtin_amdgcn_s_setprio(3);     // ProgressPriority lowers it as the substeps advance
+    SR_PHASE(0);
     LaneN<EPL> L;
     load_lane<EPL, F>(S, N, rod, lane, L);
+    SR_PHASE(1);
     BcTargets B;
     load_bc(S, N, rod, B);
     load_suckers<F>(P, S, N, rod, B);
@@ -492,7 +535,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     RodParams Pk = P;
     if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
 
-    bool stepped = false;
+    bool stepped = false, stored = false;
     // A rod whose state already holds a NaN (an env that blew up and was not reset — the
     // reference reports terminated and -50 for it on every further step, soft_pendulum.py:
     // 196-208) would only smear that NaN over all of its nodes while dragging every
@@ -532,18 +575,44 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             // substep (half a step) is peeled so that the loop's step length is a constant
             // (the step length as a vector register where scalar ones are short: uniform_k)
             const double step_dt = EPL > 1 ? opaque_v(P.dt) : P.dt;
+            SR_PHASE(2);
             planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
-            for (int s = 0; s + 1 < n_sub; ++s) {
-                planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
-                planar_kinematic_n<EPL>(step_dt, K.hq_dt, C, K, Z);
+            {   // four copies of the loop, one per priority level (ProgressPriority explains; here
+                // without its two scalar instructions and the branch in every trip)
+                int s = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q == 1) __builtin_amdgcn_s_setprio(2);
+                    if (q == 2) __builtin_amdgcn_s_setprio(1);
+                    if (q == 3) __builtin_amdgcn_s_setprio(0);
+                    const int end = ProgressPriority::bound(n_sub - 1, q);
+                    for (; s < end; ++s) {
+                        planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
+                        planar_kinematic_n<EPL>(step_dt, K.hq_dt, C, K, Z);
+                    }
+                }
             }
             planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
             planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
             if (__builtin_amdgcn_readfirstlane(tk) >= 0) time = S.time_tab[tk + 1];
             else
                 for (int s = 0; s < n_sub; ++s) time = (time + ta) + tb;
+            SR_PHASE(3);
+            // Only the rows the step changed go back (12 of 21).  The epilogue reads positions,
+            // velocities and tangents; everything else of the 3-D lane state is dead from here on
+            // the planar path — said explicitly, so that none of it stays in registers (at 128:
+            // in scratch) across the loop for the sake of the other path's merge.
+            planar_store<EPL>(S, N, rod, lane, Z);
+#pragma unroll
+            for (int s = 0; s < EPL; ++s) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { L.x[s][c] = 0.0; L.v[s][c] = 0.0; L.w[s][c] = 0.0; L.t[s][c] = 0.0; }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) L.Q[s][c] = 0.0;
+            }
             planar_to_lane<EPL>(Z, L);
             stepped = true;
+            stored = true;
         }
     }
     if (n_sub > 0 && !stepped) {
@@ -552,16 +621,19 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             load_lane<EPL, F>(S, N, rod, lane, L);
             time = S.time[rod];
+            stored = true;
         } else
             general_substeps<F, EPL, TAPER>(P, Pk, C, B, lane, L, time, n_sub);
     }
-    store_lane<EPL, F>(S, N, rod, lane, L);
+    if (!stored) store_lane<EPL, F>(S, N, rod, lane, L);
     if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)) muscle_store<EPL>(P, S, rod, lane, L);
     if (env_of<E>(P) == SOFTROD_ENV_SOFT_ARM && lane == 0)   // self.tick += 1 per substep, soft_arm_tracking.py:222
         S.ctrl[(size_t)0 * N + rod] += (double)n_sub;
     if (lane == 0) S.time[rod] = time;
+    SR_PHASE(4);
     if (epilogue)
         env_epilogue_n<E, EPL>(P, S, N, rod, lane, C, L, time, A, obs, reward, terminated, truncated, aux, pack);
+    SR_PHASE(5);
 }
 
 

@@ -190,6 +190,30 @@ __device__ __forceinline__ void planar_to_lane(const PlanarN<EPL>& Z, LaneN<EPL>
     }
 }
 
+// What a planar step changes, written to the resident rows: x, y, v_x, v_y, d1 = (-s2 s, s2 c), d3 = (c, s),
+// omega_2 and the tangents — 12 of the rod's 21 rows.  The other nine (z components, d2, the
+// out-of-plane directors and rates) hold the exact values planar_from_lane has just checked.
+template <int EPL>
+__device__ __forceinline__ void planar_store(const StatePtrs& S, size_t N, int rod, int lane, const PlanarN<EPL>& Z) {
+    constexpr size_t W = (size_t)kLanes * EPL;
+    const size_t base = (size_t)rod * W + (size_t)lane * EPL;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            S.pos[c * N * W + base + s] = Z.x[s][c];
+            S.vel[c * N * W + base + s] = Z.v[s][c];
+            S.tan[c * N * W + base + s] = Z.t[s][c];
+        }
+        S.tan[2 * N * W + base + s] = 0.0;
+        S.dir[0 * N * W + base + s] = -Z.s2 * Z.s[s];
+        S.dir[1 * N * W + base + s] = Z.s2 * Z.c[s];
+        S.dir[6 * N * W + base + s] = Z.c[s];
+        S.dir[7 * N * W + base + s] = Z.s[s];
+        S.omg[1 * N * W + base + s] = Z.s2 * Z.wz[s];
+    }
+}
+
 // kinematic_n with a = (0, h w, 0): R0 = R8 = cos, R6 = -R2 = sin, R4 = 1, the rest 0, so
 // the new d3 = sin * d1 + cos * d3 — the rotation of (c, s) about z by h wz.
 template <int EPL>

@@ -32,22 +32,38 @@ def function_body(asm: str, name: str):
 
 
 def hot_path(ins, labels):
-    # the substep loop: the first backward branch that spans more than 100 instructions
-    head = None
+    # the substep loop: the first of the innermost backward branches whose span holds the substep's
+    # v_rsq_f64 (the kernel has other loops: the clock fallback, epilogue reductions)
+    head, best = None, None
     for i, t in enumerate(ins):
         m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", t)
-        if m and labels.get(m.group(1), i) < i - 100:
-            head = labels[m.group(1)]
-            break
+        if m and labels.get(m.group(1), i) < i - 60:
+            lo = labels[m.group(1)]
+            if any(x.startswith("v_rsq_f64") for x in ins[lo:i]) and (best is None or i - lo < best):
+                head, best = lo, i - lo
     if head is None:
         raise SystemExit("no loop found")
     path, pc, seen = [], head, 0
+    const, vcc = {}, None        # s[a:b] pairs holding a known 0 / -1; vcc known zero / non-zero (exec != 0)
     while True:
         t = ins[pc]
         m = re.match(r"(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", t)
+        mm = re.match(r"s_mov_b64\s+(s\[\d+:\d+\]),\s*(-1|0)$", t)
+        ma = re.match(r"(s_and_b64|s_andn2_b64)\s+vcc,\s*exec,\s*(s\[\d+:\d+\])", t)
+        if mm:
+            const[mm.group(1)] = mm.group(2) == "-1"
+        elif re.match(r"s_\w+\s+(s\[\d+:\d+\])", t) and not ma:
+            const.pop(re.match(r"s_\w+\s+(s\[\d+:\d+\])", t).group(1), None)
+        if ma and ma.group(2) in const:       # a flag the compiler carries instead of branching twice
+            vcc = const[ma.group(2)] if ma.group(1) == "s_and_b64" else not const[ma.group(2)]
+        elif t.startswith("v_cmp") or (t.startswith("s_") and " vcc" in t.split(",")[0]):
+            vcc = None
         if m:
             kind, tgt = m.group(1), labels[m.group(2)]
-            taken = kind in ("s_branch", "s_cbranch_vccz", "s_cbranch_execnz")
+            if kind in ("s_cbranch_vccz", "s_cbranch_vccnz") and vcc is not None:
+                taken = (kind == "s_cbranch_vccnz") == vcc
+            else:
+                taken = kind in ("s_branch", "s_cbranch_vccz", "s_cbranch_execnz")
             path.append(t)
             pc = tgt if taken else pc + 1
         else:

@@ -14,7 +14,11 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 amax = float(sys.argv[4]) if len(sys.argv) > 4 else 22.0
 n_elems = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-env = gsa.make_vec(env_id, n, device=0, **({"n_elems": n_elems} if n_elems else {}))
+fps = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0     # SoftPendulum: substeps per step = 1e4 / fps
+kw = {"n_elems": n_elems} if n_elems else {}
+if fps:
+    kw.update(recording_fps=fps, final_time=1e9)
+env = gsa.make_vec(env_id, n, device=0, **kw)
 env.reset(seed=0)
 adim = env.action_dim
 acts = torch.from_numpy(np.random.default_rng(1).uniform(-amax, amax, (T, n, adim)).astype(np.float32)).cuda()
