@@ -183,6 +183,13 @@ __device__ __forceinline__ int octo_obs_dim(const RodParams& P) {
 // other's joint loads the other is the one running, so the wait costs no SIMD time, and the
 // rendezvous becomes a flag in LDS (release / acquire at workgroup scope) instead of a
 // workgroup-wide s_barrier that would couple four unrelated envs.
+// SOFTROD_OCTO_PRIO: a wave's issue priority until it has posted its joint loads of the substep; 0
+// after.  The partner that has NOT posted is the one the SIMD serves first, so the wave that runs
+// ahead (the arbiter favours the older wave) finds the partner's flag set when it gets to the
+// rendezvous instead of sleeping on it: 11.72 -> 11.57 ms (profiles/README.md, r2k).
+#ifndef SOFTROD_OCTO_PRIO
+#define SOFTROD_OCTO_PRIO 1
+#endif
 template <unsigned F, int MAXW, int EPB = 1>
 __global__ void __launch_bounds__(kLanes * MAXW * EPB, SOFTROD_OCTO_WAVES)
 softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
@@ -341,6 +348,9 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             if constexpr (EPB > 1)
                 __hip_atomic_store(&flag_[es][parity][wave], posted + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+#if SOFTROD_OCTO_PRIO
+        if constexpr (EPB > 1) __builtin_amdgcn_s_setprio(0);     // posted: yield to the partner that has not
+#endif
     };
     // RigidBodyBase.update_accelerations + the rate update under
     // BodyBoundaryCondition.compute_constrain_rates (constraint.py:60-85): with
@@ -419,6 +429,9 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         head_step();
         if (P.time_two_half_adds) time += P.half_dt;
         for (int s = 0; s < n_sub; ++s) {
+#if SOFTROD_OCTO_PRIO
+            if constexpr (EPB > 1) __builtin_amdgcn_s_setprio(SOFTROD_OCTO_PRIO);
+#endif
             dynamic_n<F, 1>(Pk, C, B, tid, L, joints);
             const bool last = (s == n_sub - 1);
             const double h = last ? P.half_dt : P.dt;
