@@ -811,6 +811,44 @@ def test_device_autoreset_equals_host_autoreset(torch_gpu, hip_lib, env_id, kw, 
     devp.close()
 
 
+def test_queue_status_without_stalling_the_stream(torch_gpu, hip_lib):
+    """softrod_queue_status_begin / _poll (C-ABI v11): the same counters as the blocking read, as of
+    the begin; poll without a begin is refused; a compact push lands where the whole-ring upload did."""
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd._capi import SoftrodError
+
+    kw = dict(final_time=2e-4, time_step=1e-4, recording_fps=10000, n_elems=10)   # an episode is 3 steps + the resetting one
+    env = gsa.make_vec("SoftPendulum-v0", 5, device=0, autoreset="device", **kw)
+    env.top_up_every = 10**9                      # no top-up on the way: the counters are ours to read
+    env.reset(seed=3)
+    b = env.backend
+    with pytest.raises(SoftrodError, match="no softrod_queue_status_begin"):
+        b.queue_status_poll()
+    a = np.zeros(5, np.float32)
+    for _ in range(9):
+        env.step(a)
+    b.queue_status_begin()
+    for _ in range(4):                             # work enqueued after the begin does not change what it reports
+        env.step(a)
+    st = b.queue_status_poll(wait=True)
+    assert st is not None
+    cons_at_begin, uf = st
+    assert uf == 0 and (cons_at_begin == cons_at_begin[0]).all() and 1 <= cons_at_begin[0] <= 3
+    cons_now, _ = b.queue_status()
+    assert (cons_now >= cons_at_begin).all() and cons_now.sum() > cons_at_begin.sum()
+    # a push of two records for env 1 only (compact path): consumed later, in order, by env 1's resets
+    env._top_up()
+    twin = gsa.make_vec("SoftPendulum-v0", 5, device=0, autoreset=True, **kw)
+    twin.reset(seed=3)
+    for _ in range(13):
+        twin.step(a)
+    for _ in range(12):
+        o1 = env.step(a)[0].cpu().numpy()
+        o2 = twin.step(a)[0].cpu().numpy()
+        np.testing.assert_array_equal(o1, o2)
+    env.close(); twin.close()
+
+
 def test_device_autoreset_underflow_is_reported(torch_gpu, hip_lib):
     import gym_softrobot_amd as gsa
     from gym_softrobot_amd._capi import SoftrodError
