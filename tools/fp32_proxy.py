@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """the fp32-vs-fp64 divergence report, measured on the CPU oracle.
 
-This repo ships no float32 stepper (a wave64 fp32 VALU op issues at the fp64 rate on CDNA4, and
-the reference computes in float64).  What float32 would cost the REFERENCE'S formulation — state
+This repo ships no float32 stepper (the reference computes in float64, and float32 does not hold
+the stated tolerance: that is what this script measures).  What float32 would cost the REFERENCE'S formulation — state
 = absolute node positions, velocities, directors, angular velocities — is measured here with a
 float64 stepper whose state is rounded to float32 after every substep (float32 storage, float64
 arithmetic).  The stretch strain is a difference of neighbouring positions (|x| ~ 1, spacing
