@@ -51,6 +51,12 @@ __device__ __forceinline__ double slip_function(double a, double thr, double inv
     return (fabs(a) > thr) ? fabs(1.0 - m) : 1.0;
 }
 
+// 1 - slip_function for a >= 0 as one clamp: min(max(a / thr - 1, 0), 1)  (a NaN gives 0 here and 1
+// there, like the comparison in slip_function)
+__device__ __forceinline__ double slip_excess(double a, double inv_thr) {
+    return fmin(fmax(fma(a, inv_thr, -1.0), 0.0), 1.0);
+}
+
 // In:  F[s][3]   nodal internal + external force of node EPL*lane+s (so far)
 //      tq[s][3]  element internal + external torque (local frame) (so far)
 // Out: fc[s][3]  contact force added to that node;  tq += contact torques.
@@ -127,8 +133,8 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
         }
         const double pen = fmin(dist - radius[s], 0.0);
         contact[s] = (idx < n) && !((dist - radius[s]) > C.surface_tol);
-        const double resp = (fn > 0.0) ? 0.0 : -fn;
-        nmag[s] = contact[s] ? fabs(resp) : 0.0;
+        const double resp = FM ? fmax(-fn, 0.0) : ((fn > 0.0) ? 0.0 : -fn);
+        nmag[s] = contact[s] ? (FM ? resp : fabs(resp)) : 0.0;
         const double ntot = contact[s] ? resp + (-C.k * pen) + (-C.nu * vnrm) : 0.0;
         // kinetic friction: axial direction = tangent projected on the plane, rolling = ax x n
         if constexpr (ZUP) {
@@ -162,9 +168,14 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
         // |ax| after the normalisation = |ax_raw| / (|ax_raw| + 1e-14)
         const double axn = FM ? sqrt_of<true>(a2) * itp : sqrt(axn2);
         const double ron = ZUP ? axn : sqrt_of<FM>(ron2);   // |ax x e_z| = |ax| term by term
-        const double sgn = sign_of(vax);
-        const double kmu = 0.5 * (C.kin_mu[0] * (1 + sgn) + C.kin_mu[1] * (1 - sgn));
-        slip_ax[s] = slip_function<FM>(fabs(vax) * axn, C.slip_tol, inv_slip);
+        // mu_forward for vax > 0, mu_backward for vax < 0, their mean at exactly 0 — where the
+        // slip function below is 1 and the kinetic force vanishes whatever kmu is (FM: skip the mean)
+        const double sgn = FM ? 0.0 : sign_of(vax);
+        const double kmu = FM ? (vax > 0.0 ? C.kin_mu[0] : C.kin_mu[1])
+                              : 0.5 * (C.kin_mu[0] * (1 + sgn) + C.kin_mu[1] * (1 - sgn));
+        double ex_ax = 0.0, ex_ro = 0.0;      // FM: 1 - slip, computed first
+        if constexpr (FM) { ex_ax = slip_excess(fabs(vax) * axn, inv_slip); slip_ax[s] = 1.0 - ex_ax; }
+        else slip_ax[s] = slip_function<FM>(fabs(vax) * axn, C.slip_tol, inv_slip);
         // velocity of the contact point from the element's spin: Q^T (w x Q arm), arm = -n radius
         const double* Q = L.Q[s];
         const double* w = L.w[s];
@@ -183,7 +194,8 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
             vrot += rot[i] * ro[s][i];
         }
         const double sroll = vroll + vrot;
-        slip_ro[s] = slip_function<FM>(fabs(sroll) * ron, C.slip_tol, inv_slip);
+        if constexpr (FM) { ex_ro = slip_excess(fabs(sroll) * ron, inv_slip); slip_ro[s] = 1.0 - ex_ro; }
+        else slip_ro[s] = slip_function<FM>(fabs(sroll) * ron, C.slip_tol, inv_slip);
         // unit vector of the total slip velocity in the plane, sroll ro + vax ax, with PyElastica's
         // 1e-14 added to every component before the norm (all three: a zero component adds 1e-28)
         double tot[3] = {0.0, 0.0, 0.0}, m2 = 0.0;
@@ -199,8 +211,11 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
             uax += u * ax[s][i];
             uro += u * ro[s][i];
         }
-        const double ka = contact[s] ? -((1.0 - slip_ax[s]) * kmu * nmag[s] * uax) : 0.0;
-        const double kr = contact[s] ? -((1.0 - slip_ro[s]) * C.kin_mu[2] * nmag[s] * uro) : 0.0;
+        // nmag is 0 off the plane, so the products vanish there by themselves (FM: no second select)
+        const double ka = FM ? -(ex_ax * kmu * nmag[s] * uax)
+                             : (contact[s] ? -((1.0 - slip_ax[s]) * kmu * nmag[s] * uax) : 0.0);
+        const double kr = FM ? -(ex_ro * C.kin_mu[2] * nmag[s] * uro)
+                             : (contact[s] ? -((1.0 - slip_ro[s]) * C.kin_mu[2] * nmag[s] * uro) : 0.0);
         double fr[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < D; ++i) fr[i] = kr * ro[s][i];
@@ -272,13 +287,17 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
             const double tt = Q[i] * tq[s][0] + Q[3 + i] * tq[s][1] + Q[6 + i] * tq[s][2];
             tax += tt * ax[s][i];
         }
-        const double sg = sign_of(fax);
-        const double smu = 0.5 * (C.stat_mu[0] * (1 + sg) + C.stat_mu[1] * (1 - sg));
-        const double sa = contact[s] ? -(fmin(fabs(fax), slip_ax[s] * smu * nmag[s]) * sg) : 0.0;
+        // FM: -min(|fax|, cap) sign(fax) = copysign(min(|fax|, cap), -fax); fax = 0 gives 0 either way,
+        // and cap = 0 off the plane
+        const double sg = FM ? 0.0 : sign_of(fax);
+        const double smu = FM ? (fax > 0.0 ? C.stat_mu[0] : C.stat_mu[1])
+                              : 0.5 * (C.stat_mu[0] * (1 + sg) + C.stat_mu[1] * (1 - sg));
+        const double sa = FM ? copysign(fmin(fabs(fax), slip_ax[s] * smu * nmag[s]), -fax)
+                             : (contact[s] ? -(fmin(fabs(fax), slip_ax[s] * smu * nmag[s]) * sg) : 0.0);
         const double noslip = FM ? -((radius[s] * fro - 2.0 * tax) * (1.0 / 3.0) * inv_radius[s])
                                  : -((radius[s] * fro - 2.0 * tax) / 3.0 / radius[s]);
-        const double sr = contact[s]
-            ? fmin(fabs(noslip), slip_ro[s] * C.stat_mu[2] * nmag[s]) * sign_of(noslip) : 0.0;
+        const double sr = FM ? copysign(fmin(fabs(noslip), slip_ro[s] * C.stat_mu[2] * nmag[s]), noslip)
+                             : (contact[s] ? fmin(fabs(noslip), slip_ro[s] * C.stat_mu[2] * nmag[s]) * sign_of(noslip) : 0.0);
         double fr[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < D; ++i) {
