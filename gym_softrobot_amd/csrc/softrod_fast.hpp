@@ -33,14 +33,44 @@
 
 namespace softrod {
 
+// The loops are bound by VALU issue, and the compiler spends instructions on register copies that
+// a three-address v_fma_f64 does not need: it prefers the two-address v_fmac_f64 (result over the
+// ADDEND) and then copies — a Horner step with its coefficient in a register becomes v_mov_b64 +
+// v_fmac, an update x <- m x + a lands over a and is copied back to x at the loop's end.  These
+// wrappers pin the form (same operation, same rounding).
+//   horner(g, y, c)        g y + c with the coefficient in a vector register (as a literal in scalar
+//                          registers it cost the SoftPendulum kernel its scalar budget: 32
+//                          v_readlane per substep of spilled loop constants)
+//   fma_over(d, a, b, c)   d <- a b + c, where d's old value is dead (its register is reused)
+//   fma_inplace_u(x, m, a) x <- m x + a with a wave-uniform m
+__device__ __forceinline__ double horner(double g, double y, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(g), "v"(y), "v"(c));
+    return d;
+}
+__device__ __forceinline__ void fma_over(double& d, double a, double b, double c) {
+    asm("v_fma_f64 %0, %1, %2, %3" : "+v"(d) : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void fma_inplace_u(double& x, double m, double a) {
+    asm("v_fma_f64 %0, %1, %0, %2" : "+v"(x) : "s"(m), "v"(a));
+}
+
 // sin(th)/th and (1-cos(th))/th^2 from t = th^2.  t < 1e-3: degree-3 Taylor in t
 // (remainders t^4/9! < 3e-18, t^4/10! < 3e-19).  Otherwise (|omega| dt > 0.03 rad: only
 // when a simulation is blowing up) the angle is halved k times and rebuilt with
 //   sinc(2p) = sinc(p) cos(p),  cosc(2p) = sinc(p)^2 / 2,  cos(p) = 1 - cosc(p) p^2.
+// (LEAN = false: plain fma, for the one place — the planar loop's out-of-range tier — where the
+// scalar registers of the literals are not to spare)
+template <bool LEAN = true>
 __device__ __forceinline__ void sinc_cosc(double t, double& sc, double& cc) {
     if (!__any(t >= 1.0e-3)) {     // the whole wave is in range: straight-line, one s_cbranch
-        sc = fma(t, fma(t, fma(t, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
-        cc = fma(t, fma(t, fma(t, -1.0 / 40320.0, 1.0 / 720.0), -1.0 / 24.0), 0.5);
+        if constexpr (LEAN) {
+            sc = fma(t, horner(horner(-1.0 / 5040.0, t, 1.0 / 120.0), t, -1.0 / 6.0), 1.0);
+            cc = fma(t, horner(horner(-1.0 / 40320.0, t, 1.0 / 720.0), t, -1.0 / 24.0), 0.5);
+        } else {
+            sc = fma(t, fma(t, fma(t, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+            cc = fma(t, fma(t, fma(t, -1.0 / 40320.0, 1.0 / 720.0), -1.0 / 24.0), 0.5);
+        }
         return;
     }
     // up to 4^16 * 1e-3: more than 250 rad per (sub)step — beyond that the state is garbage on
@@ -75,8 +105,8 @@ __device__ __forceinline__ double theta_over_sin_series(double y) {
     for (int k = 1; k < K; ++k) c[k] = c[k - 1] * (double)(2 * k) / (double)(2 * k + 1);
     double g = c[K - 1];
 #pragma unroll
-    for (int k = K - 2; k >= 0; --k) g = fma(g, y, c[k]);
-    return g;
+    for (int k = K - 2; k >= 1; --k) g = horner(g, y, c[k]);
+    return fma(g, y, 1.0);       // c[0] = 1 is an inline constant
 }
 
 __device__ __forceinline__ double theta_over_sin(double y, bool valid) {
@@ -103,8 +133,8 @@ __device__ __forceinline__ double theta_over_sin(double y, bool valid) {
 // larger |x| (strong damping constants) are halved k times and squared back.
 __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid, double& e0, double& e2) {
     if (!__any(valid && !(fmax(fabs(x0), fabs(x2)) < 1.0e-3))) {
-        e0 = fma(x0, fma(x0, fma(x0, fma(x0, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
-        e2 = fma(x2, fma(x2, fma(x2, fma(x2, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
+        e0 = fma(x0, fma(x0, fma(x0, horner(1.0 / 24.0, x0, 1.0 / 6.0), 0.5), 1.0), 1.0);
+        e2 = fma(x2, fma(x2, fma(x2, horner(1.0 / 24.0, x2, 1.0 / 6.0), 0.5), 1.0), 1.0);
         return;
     }
     int k = 0;   // 2^24 * 1e-3 > 16000: exp underflows long before
@@ -143,10 +173,13 @@ __device__ __forceinline__ void kinematic_n(double h, const ConstN<EPL>& C, Lane
         const double R5 = c12 + s0, R7 = c12 - s0;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double b0 = L.Q[s][j], b1 = L.Q[s][3 + j], b2 = L.Q[s][6 + j];
-            L.Q[s][j] = fma(R2, b2, fma(R1, b1, R0 * b0));
-            L.Q[s][3 + j] = fma(R5, b2, fma(R4, b1, R3 * b0));
-            L.Q[s][6 + j] = fma(R8, b2, fma(R7, b1, R6 * b0));
+            // each new entry's last product lands in the register of the entry it replaces (row 2
+            // last: its own old value is a factor), so Q needs no copy at the loop's end
+            const double b0 = L.Q[s][j], b1 = L.Q[s][3 + j];
+            const double p0 = fma(R1, b1, R0 * b0), p1 = fma(R4, b1, R3 * b0), p2 = fma(R7, b1, R6 * b0);
+            fma_over(L.Q[s][j], R2, L.Q[s][6 + j], p0);
+            fma_over(L.Q[s][3 + j], R5, L.Q[s][6 + j], p1);
+            fma_inplace(L.Q[s][6 + j], R8, p2);
         }
     }
 }
@@ -334,7 +367,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
     for (int s = 0; s < EPL; ++s) {
         const bool elem_valid = slot_local<F>(P, lane * EPL + s) < n;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) L.v[s][c] = fma(P.damp_t, L.v[s][c], fma(C.cf[s], f[s][c], C.ca[s][c]));
+        for (int c = 0; c < 3; ++c) fma_inplace_u(L.v[s][c], P.damp_t, fma(C.cf[s], f[s][c], C.ca[s][c]));
         const double ce01 = C.cw01[s] * e[s], ce2 = C.cw2[s] * e[s];
         double w0 = fma(ce01, tq[s][0], L.w[s][0]), w1 = fma(ce01, tq[s][1], L.w[s][1]),
                w2 = fma(ce2, tq[s][2], L.w[s][2]);

@@ -239,7 +239,7 @@ __device__ __forceinline__ void planar_kinematic_n(double h, const double (&hq_h
             cs = fma(t, fma(t, fma(t, K.c3, K.c2), -0.5), 1.0);
         } else {
             double cc;
-            sinc_cosc(t, sc, cc);
+            sinc_cosc<false>(t, sc, cc);
             cs = fma(-cc, t, 1.0);
         }
         const double sn = sc * a;
