@@ -548,6 +548,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     LaneN<EPL> L;
     load_lane<EPL, F>(S, N, rod, lane, L);
     SR_PHASE(1);
+    if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) sanitize_unused_rates<EPL>(P, lane, L);
     BcTargets B;
     load_bc(S, N, rod, B);
     load_suckers<F>(P, S, N, rod, B);

@@ -449,17 +449,24 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
     // c_j for j = 0..6: C(12, 6+j) / 4096 with alternating sign
     constexpr double c[M + 1] = {924.0 / 4096.0, -792.0 / 4096.0, 495.0 / 4096.0, -220.0 / 4096.0,
                                  66.0 / 4096.0, -12.0 / 4096.0, 1.0 / 4096.0};
-    double r[6][EPL], f1[6][EPL];
+    // The masks of the first pass are factors (0.25 inside, 0 on the boundary entries and beyond),
+    // not selects: the rates of the slots past the rod's end are exact zeros (sanitize_unused_rates
+    // at kernel entry; nothing in a substep moves them), so a product with them is a zero, not a
+    // NaN.  (Dropping the selects of the write-back as well — an entry whose correction is zero
+    // keeps its value by subtracting that zero — is 24 instructions fewer and measured SLOWER,
+    // 1.99 against 1.74 ms: profiles/README.md r2k.)
+    double r[6][EPL], f1[6][EPL], q[2][EPL];
     bool inner[2][EPL];        // [0]: nodes 1..n-1, [1]: elements 1..n-2
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         const int idx = slot_local(P, lane * EPL + s);
         inner[0][s] = (idx >= 1 && idx <= n - 1);
         inner[1][s] = (idx >= 1 && idx <= n - 2);
+        q[0][s] = inner[0][s] ? 0.25 : 0.0;
+        q[1][s] = inner[1][s] ? 0.25 : 0.0;
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) {
-            r[c3][s] = (idx <= n) ? L.v[s][c3] : 0.0;
-            r[3 + c3][s] = (idx < n) ? L.w[s][c3] : 0.0;
+            r[c3][s] = L.v[s][c3]; r[3 + c3][s] = L.w[s][c3];
         }
     }
     // pass 1 in registers
@@ -470,12 +477,12 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
         shift_prev<EPL>(r[fld], pv);
 #pragma unroll
         for (int s = 0; s < EPL; ++s)
-            f1[fld][s] = inner[fld / 3][s] ? ((-nx[s] - pv[s]) + 2.0 * r[fld][s]) * 0.25 : 0.0;
+            f1[fld][s] = ((-nx[s] - pv[s]) + 2.0 * r[fld][s]) * q[fld / 3][s];
     }
     // stage f_1 and its odd reflections
 #pragma unroll
     for (int fld = 3; fld < 6; ++fld) {
-        const int N = (fld < 3) ? n : n - 1;
+        const int N = n - 1;
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
             const int idx = slot_local(P, lane * EPL + s);
@@ -485,26 +492,22 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
         }
     }
     __syncthreads();
-    {   // v: the remaining six passes in registers while the LDS writes settle
-        double qn[EPL];
+    // v: the remaining six passes in registers while the LDS writes settle
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) qn[s] = inner[0][s] ? 0.25 : 0.0;
+    for (int fld = 0; fld < 3; ++fld) {
+        double f[EPL], nx[EPL], pv[EPL];
 #pragma unroll
-        for (int fld = 0; fld < 3; ++fld) {
-            double f[EPL], nx[EPL], pv[EPL];
+        for (int s = 0; s < EPL; ++s) f[s] = f1[fld][s];
+        for (int i = 0; i < 6; ++i) {
+            shift_next<EPL>(f, nx);
+            shift_prev<EPL>(f, pv);
 #pragma unroll
-            for (int s = 0; s < EPL; ++s) f[s] = f1[fld][s];
-            for (int i = 0; i < 6; ++i) {
-                shift_next<EPL>(f, nx);
-                shift_prev<EPL>(f, pv);
+            for (int s = 0; s < EPL; ++s) f[s] = ((-nx[s] - pv[s]) + 2.0 * f[s]) * q[0][s];
+        }
 #pragma unroll
-                for (int s = 0; s < EPL; ++s) f[s] = ((-nx[s] - pv[s]) + 2.0 * f[s]) * qn[s];
-            }
-#pragma unroll
-            for (int s = 0; s < EPL; ++s) {
-                const int idx = slot_local(P, lane * EPL + s);
-                L.v[s][fld] = (idx <= n) ? r[fld][s] - f[s] : L.v[s][fld];
-            }
+        for (int s = 0; s < EPL; ++s) {
+            const int idx = slot_local(P, lane * EPL + s);
+            L.v[s][fld] = (idx <= n) ? r[fld][s] - f[s] : L.v[s][fld];
         }
     }
 #pragma unroll
@@ -516,13 +519,29 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
             double acc = c[0] * row[M];
 #pragma unroll
             for (int j = 1; j <= M; ++j) acc = fma(c[j], row[M + j] + row[M - j], acc);
-            const double out = r[fld][s] - (inner[fld / 3][s] ? acc : 0.0);
+            // (a select here: outside the interior the taps read LDS words nobody wrote)
+            const double out = r[fld][s] - (inner[1][s] ? acc : 0.0);
             const int idx = slot_local(P, base);
-            if (fld < 3) L.v[s][fld] = (idx <= n) ? out : L.v[s][fld];
-            else L.w[s][fld - 3] = (idx < n) ? out : L.w[s][fld - 3];
+            L.w[s][fld - 3] = (idx < n) ? out : L.w[s][fld - 3];
         }
     }
     __syncthreads();     // the next substep overwrites the staging rows
+}
+
+// Kernel entry, SOFTROD_FEAT_LAPLACE_FILTER: the rates in the slots past the rod's end are made
+// the exact zeros the filter's mask-as-factor form relies on (they are zeros after any reset; this
+// covers a state written through the state view).
+template <int EPL>
+__device__ __forceinline__ void sanitize_unused_rates(const RodParams& P, int lane, LaneN<EPL>& L) {
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = slot_local(P, lane * EPL + s);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            L.v[s][c] = (idx <= P.n_elem) ? L.v[s][c] : 0.0;
+            L.w[s][c] = (idx < P.n_elem) ? L.w[s][c] : 0.0;
+        }
+    }
 }
 
 template <int EPL>
