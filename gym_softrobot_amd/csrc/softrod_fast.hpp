@@ -353,7 +353,9 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
                     Fg[s][c] += node_valid ? P.gravity[c] * C.mass[s] : 0.0;
             }
         }
-        if (has<F>(P, kFeatPlaneZup))
+        if constexpr (SOFTROD_OCTO_CONTACT_LDS && F != kRuntimeFeatures && (F & SOFTROD_FEAT_OCTO_HEAD) != 0 && (F & kFeatPlaneZup) != 0)
+            plane_contact_n<EPL, true, true, TAPER>(contact_params_lds(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);
+        else if (has<F>(P, kFeatPlaneZup))
             plane_contact_n<EPL, true, true, TAPER>(contact_params(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);
         else
             plane_contact_n<EPL, false, true, TAPER>(contact_params(P), P, lane, C, L, xn, vn, len, Fg, tq, fc);

@@ -570,6 +570,43 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 #include "softrod_contact.hpp"
 namespace softrod {
 
+// The OctoFlat kernel runs out of scalar registers (some 40 wave-uniform doubles live in its loop
+// next to a dozen lane masks: 32 spilled words were reloaded with v_readlane every substep).  Its
+// contact constants therefore live in LDS and are read where they are used — LDS reads issue
+// beside the VALU, v_readlane issues ON it.  stage: once per workgroup before the first substep
+// (a barrier follows in the caller); fetch: per substep.
+#ifndef SOFTROD_OCTO_CONTACT_LDS
+#define SOFTROD_OCTO_CONTACT_LDS 1
+#endif
+// (one function owns the array, so that every access keeps its LDS address space: handed out as a
+// pointer it became a generic one, flat loads with a vector address per constant)
+// (and ONE function, not two instantiations of a template: each would own an array of its own)
+__device__ __forceinline__ ContactParams contact_params_lds_impl(const RodParams& P, const bool stage) {
+    __shared__ double c[16];
+    ContactParams C;
+    if (stage) {
+        if (threadIdx.x == 0) {
+            c[0] = P.contact_k; c[1] = P.contact_nu; c[2] = P.slip_tol; c[3] = P.surface_tol;
+            c[4] = P.kin_mu[0]; c[5] = P.kin_mu[1]; c[6] = P.kin_mu[2];
+            c[7] = P.stat_mu[0]; c[8] = P.stat_mu[1]; c[9] = P.stat_mu[2];
+            c[10] = P.r0_sqrt_rest_len; c[11] = 1.0 / P.r0_sqrt_rest_len; c[12] = P.plane_origin[2];
+        }
+        return C;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        C.origin[i] = P.plane_origin[i]; C.normal[i] = P.plane_normal[i];
+        C.kin_mu[i] = c[4 + i]; C.stat_mu[i] = c[7 + i];
+    }
+    C.origin[2] = c[12];
+    C.k = c[0]; C.nu = c[1]; C.slip_tol = c[2]; C.surface_tol = c[3];
+    C.r0_sqrt_rest_len = c[10];
+    C.inv_r0_sqrt_rest_len = c[11];
+    return C;
+}
+__device__ __forceinline__ void stage_contact_params(const RodParams& P) { (void)contact_params_lds_impl(P, true); }
+__device__ __forceinline__ ContactParams contact_params_lds(const RodParams& P) { return contact_params_lds_impl(P, false); }
+
 __device__ __forceinline__ ContactParams contact_params(const RodParams& P) {
     ContactParams C;
 #pragma unroll

@@ -220,6 +220,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     const int n = P.n_elem, nk = P.n_action;
     const int r = tid & (P.seg - 1), arm = tid >> P.seg_shift;
     const bool arm_ok = arm < P.n_arm;
+    if constexpr (SOFTROD_OCTO_CONTACT_LDS && (F & kFeatPlaneZup) != 0) stage_contact_params(P);   // (barriers follow)
     if (tid < 2 * MAXW * 4) (&xch[0][0][0])[tid] = 0.0;   // rows of absent waves read as zero loads
     if (EPB > 1 && tid < 2 * MAXW) (&flag_[es][0][0])[tid] = 0;
     // per-env "any thread of the env": the workgroup barrier when the env IS the workgroup; with

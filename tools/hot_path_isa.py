@@ -43,7 +43,7 @@ def hot_path(ins, labels):
                 head, best = lo, i - lo
     if head is None:
         raise SystemExit("no loop found")
-    path, pc, seen = [], head, 0
+    path, pc, seen, first = [], head, 0, {}
     const, vcc = {}, None        # s[a:b] pairs holding a known 0 / -1; vcc known zero / non-zero (exec != 0)
     while True:
         t = ins[pc]
@@ -58,10 +58,15 @@ def hot_path(ins, labels):
             vcc = const[ma.group(2)] if ma.group(1) == "s_and_b64" else not const[ma.group(2)]
         elif t.startswith("v_cmp") or (t.startswith("s_") and " vcc" in t.split(",")[0]):
             vcc = None
+        if pc in first:          # back where the walk has been: the cycle from there on is the substep
+            return path[first[pc]:]
+        first[pc] = len(path)
         if m:
             kind, tgt = m.group(1), labels[m.group(2)]
             if kind in ("s_cbranch_vccz", "s_cbranch_vccnz") and vcc is not None:
                 taken = (kind == "s_cbranch_vccnz") == vcc
+            elif kind == "s_cbranch_execnz" and pc - 30 < tgt <= pc:
+                taken = False      # a spin-wait (the flag rendezvous of the OctoFlat kernel): met at once
             else:
                 taken = kind in ("s_branch", "s_cbranch_vccz", "s_cbranch_execnz")
             path.append(t)
@@ -69,8 +74,6 @@ def hot_path(ins, labels):
         else:
             path.append(t)
             pc += 1
-        if pc == head:
-            return path
         seen += 1
         if seen > 5000:
             raise SystemExit("did not return to the loop header")
