@@ -39,7 +39,7 @@ __device__ __forceinline__ double inv_of(double x) {
 }
 template <bool FM>
 __device__ __forceinline__ double sqrt_of(double x) {   // x >= 0
-    if constexpr (FM) return x > 0.0 ? x * fast_rsqrt(x) : 0.0;
+    if constexpr (FM) return x * fast_rsqrt(fmax(x, 1.0e-300));      // 0 at 0 without a branch around the seed
     else return sqrt(x);
 }
 
