@@ -36,7 +36,7 @@ struct softrod_handle {
     bool spline_set = false;
     RodParams* d_params = nullptr;  // device copy of P
     StatePtrs* d_state = nullptr;   // device copy of S (re-uploaded whenever S changes)
-    double* d_time_tab = nullptr;   // clock after k env.steps from a reset (SoftPendulum's planar loop)
+    double* d_time_tab = nullptr;   // clock after k env.steps from a reset (clock_after, softrod_fast.hpp)
     double* d_mat = nullptr;        // [kMatRows][64] material table of a tapered rod
     double* d_sucker = nullptr;     // [SOFTROD_MAX_SUCKERS][N]
     bool tapered = false;
@@ -617,7 +617,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     h->S.params = h->d_params;
     alloc((void**)&h->d_state, sizeof(StatePtrs));
     h->S.self = h->d_state;
-    if (rc == SOFTROD_OK && cfg->features == SOFTROD_FEATURES_SOFTPENDULUM && cfg->n_substeps > 0) {
+    if (rc == SOFTROD_OK && cfg->n_substeps > 0) {
         // the clock as `self.time = self.do_step(self.simulator, self.time, self.time_step)` accumulates it
         // (soft_pendulum.py:183-184): same additions, same order, IEEE doubles -> bit-identical
         constexpr int kTab = 1024;

@@ -454,22 +454,38 @@ struct ProgressPriority {
     }
 };
 
+// The clock after n_sub substeps, as the reference accumulates it (2 n_sub additions of dt/2, or
+// n_sub of dt: `self.time = self.do_step(self.simulator, self.time, self.time_step)`).  The result
+// does not depend on the rod, so the host has accumulated the same float64 additions from a reset
+// into a table (StatePtrs.time_tab, one entry per env.step); a clock that IS an entry — always,
+// unless somebody wrote the time row — advances to the next entry, any other takes the additions
+// here.  Bit-identical either way; the substep loops carry no clock (4 VALU instructions per
+// substep with their selects in the general loop).
+__device__ __forceinline__ double clock_after(const RodParams& P, const StatePtrs& S, double time, int n_sub) {
+    if (n_sub <= 0) return time;
+    if (S.time_tab && n_sub == P.tab_n_sub) {
+        const double kf = rint(time * P.inv_step_time);
+        const int k = (kf >= 0.0 && kf < (double)(P.tab_len - 1)) ? (int)kf : -1;
+        if (__builtin_amdgcn_readfirstlane(k) >= 0 && S.time_tab[k] == time) return S.time_tab[k + 1];
+    }
+    const double ta = P.time_two_half_adds ? P.half_dt : P.dt;
+    const double tb = P.time_two_half_adds ? P.half_dt : 0.0;
+    for (int s = 0; s < n_sub; ++s) time = (time + ta) + tb;
+    return time;
+}
+
 // The substeps of one launch on the general 3-D state.  `always_inline` for every kernel whose
 // only path it is; the SoftPendulum kernel keeps it OUT of line (cold fallback for non-planar
 // states) so that its register demand cannot leak spills into the planar hot loop.
 template <unsigned F, int EPL, bool TAPER = false>
 __device__ __forceinline__ void general_substeps(const RodParams& P, const RodParams& Pk, const ConstN<EPL>& C,
-                                                 const BcTargets& B, int lane, LaneN<EPL>& L, double& time,
-                                                 int n_sub) {
+                                                 const BcTargets& B, int lane, LaneN<EPL>& L, int n_sub) {
     kinematic_n<EPL>(P.half_dt, C, L);
-    if (P.time_two_half_adds) time += P.half_dt;
     ProgressPriority prio(n_sub);
     for (int s = 0; s < n_sub; ++s) {
         dynamic_n<F, EPL, TAPER>(Pk, C, B, lane, L);
         const bool last = (s == n_sub - 1);
         kinematic_n<EPL>(last ? P.half_dt : P.dt, C, L);
-        time += P.time_two_half_adds ? P.half_dt : P.dt;
-        if (!last && P.time_two_half_adds) time += P.half_dt;
         prio.tick(s);
     }
 }
@@ -501,7 +517,8 @@ __device__ __attribute__((noinline)) void general_step_cold(const RodParams* __r
     build_const<F, EPL>(P, lane, A, C);
     RodParams Pk = P;
     if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
-    general_substeps<F, EPL>(P, Pk, C, B, lane, L, time, n_sub);
+    general_substeps<F, EPL>(P, Pk, C, B, lane, L, n_sub);
+    time = clock_after(P, S, time, n_sub);
     store_lane<EPL, F>(S, N, rod, lane, L);
     if (lane == 0) S.time[rod] = time;
 }
@@ -579,10 +596,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     // throughout (where the reference's would end up after a few substeps), its clock advances.
     if (n_sub > 0 && epilogue && rod_has_nan<EPL>(P, lane, L)) {
         poison_rod<EPL>(L);
-        for (int s = 0; s < n_sub; ++s) {
-            if (P.time_two_half_adds) { time += P.half_dt; time += P.half_dt; }
-            else time += P.dt;
-        }
+        time = clock_after(P, S, time, n_sub);
         stepped = true;
     }
     if constexpr (F == SOFTROD_FEATURES_SOFTPENDULUM) {
@@ -659,7 +673,10 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             time = S.time[rod];
             stored = true;
         } else
-            general_substeps<F, EPL, TAPER>(P, Pk, C, B, lane, L, time, n_sub);
+        {
+            general_substeps<F, EPL, TAPER>(P, Pk, C, B, lane, L, n_sub);
+            time = clock_after(P, S, time, n_sub);
+        }
     }
     if (!stored) store_lane<EPL, F>(S, N, rod, lane, L);
     if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)) muscle_store<EPL>(P, S, rod, lane, L);

@@ -424,17 +424,13 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         dead = env_any(bad, 0);
         if (dead) {
             poison_rod<1>(L);
-            for (int s = 0; s < n_sub; ++s) {
-                if (P.time_two_half_adds) { time += P.half_dt; time += P.half_dt; }
-                else time += P.dt;
-            }
+            time = clock_after(P, S, time, n_sub);
         }
     }
     if (n_sub > 0 && !dead && live) {
         kinematic_n<1>(P.half_dt, C, L);
         head_normalize(H);                       // hk = dt/2 and zero loads: the head's first half step
         head_step();
-        if (P.time_two_half_adds) time += P.half_dt;
         for (int s = 0; s < n_sub; ++s) {
 #if SOFTROD_OCTO_PRIO
             if constexpr (EPB > 1) __builtin_amdgcn_s_setprio(SOFTROD_OCTO_PRIO);
@@ -446,9 +442,8 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             exchange();
             hk = h;
             head_step();
-            time += P.time_two_half_adds ? P.half_dt : P.dt;
-            if (!last && P.time_two_half_adds) time += P.half_dt;
         }
+        time = clock_after(P, S, time, n_sub);
     }
     if (live) {
         store_lane<1, F>(S, NR, row, lane, L);

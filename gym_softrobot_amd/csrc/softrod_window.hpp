@@ -158,23 +158,17 @@ softrod_step_window_kernel(const RodParams P, const StatePtrs S, const float* __
     }
     if (dead) {
         poison_rod<1>(L);
-        for (int s = 0; s < n_sub; ++s) {
-            if (P.time_two_half_adds) { time += P.half_dt; time += P.half_dt; }
-            else time += P.dt;
-        }
     } else if (n_sub > 0) {
         kinematic_n<1>(P.half_dt, C, L);
-        if (P.time_two_half_adds) time += P.half_dt;
         int since = 0;
         for (int s = 0; s < n_sub; ++s) {
             dynamic_n<F, 1>(Pk, C, B, gi, L);
             const bool last = (s == n_sub - 1);
             kinematic_n<1>(last ? P.half_dt : P.dt, C, L);
-            time += P.time_two_half_adds ? P.half_dt : P.dt;
-            if (!last && P.time_two_half_adds) time += P.half_dt;
             if (++since == refresh) { exchange(); since = 0; }
         }
     }
+    time = clock_after(P, S, time, n_sub);
     if (owned) {
         window_store(S, N, rod, g, L);
         constexpr size_t W = 2 * kLanes;
