@@ -469,16 +469,17 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
             r[c3][s] = L.v[s][c3]; r[3 + c3][s] = L.w[s][c3];
         }
     }
-    // pass 1 in registers
-#pragma unroll
-    for (int fld = 0; fld < 6; ++fld) {
+    // pass 1 in registers: the omega fields first — they go to LDS, and the v fields' pass runs
+    // while those writes are on their way (no measurable difference to "all six, then the writes")
+    auto pass1 = [&](int fld) {
         double nx[EPL], pv[EPL];
         shift_next<EPL>(r[fld], nx);
         shift_prev<EPL>(r[fld], pv);
 #pragma unroll
-        for (int s = 0; s < EPL; ++s)
-            f1[fld][s] = ((-nx[s] - pv[s]) + 2.0 * r[fld][s]) * q[fld / 3][s];
-    }
+        for (int s = 0; s < EPL; ++s) f1[fld][s] = ((-nx[s] - pv[s]) + 2.0 * r[fld][s]) * q[fld / 3][s];
+    };
+#pragma unroll
+    for (int fld = 3; fld < 6; ++fld) pass1(fld);
     // stage f_1 and its odd reflections
 #pragma unroll
     for (int fld = 3; fld < 6; ++fld) {
@@ -491,10 +492,22 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
             if (idx >= N - M && idx <= N - 1) lds[fld - 3][M + 2 * N - idx] = -f1[fld][s];
         }
     }
+#pragma unroll
+    for (int fld = 0; fld < 3; ++fld) pass1(fld);
     __syncthreads();
-    // v: the remaining six passes in registers while the LDS writes settle
+    // v: the remaining six passes in registers; omega: the 13 taps out of LDS.  Interleaved field
+    // by field — the taps of an omega field are requested before the DPP passes of a v field and
+    // summed after them, so that the LDS round trip runs under VALU work of the same wave.
+    double tap[M + 1][EPL], tpm[M + 1][EPL];
 #pragma unroll
     for (int fld = 0; fld < 3; ++fld) {
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const double* row = &lds[fld][lane * EPL + s];
+            tap[0][s] = row[M];
+#pragma unroll
+            for (int j = 1; j <= M; ++j) { tap[j][s] = row[M + j]; tpm[j][s] = row[M - j]; }
+        }
         double f[EPL], nx[EPL], pv[EPL];
 #pragma unroll
         for (int s = 0; s < EPL; ++s) f[s] = f1[fld][s];
@@ -509,20 +522,14 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
             const int idx = slot_local(P, lane * EPL + s);
             L.v[s][fld] = (idx <= n) ? r[fld][s] - f[s] : L.v[s][fld];
         }
-    }
-#pragma unroll
-    for (int fld = 3; fld < 6; ++fld) {
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
-            const int base = lane * EPL + s;        // tap j of entry idx sits at M + idx + j
-            const double* row = &lds[fld - 3][base];
-            double acc = c[0] * row[M];
+            double acc = c[0] * tap[0][s];
 #pragma unroll
-            for (int j = 1; j <= M; ++j) acc = fma(c[j], row[M + j] + row[M - j], acc);
-            // (a select here: outside the interior the taps read LDS words nobody wrote)
-            const double out = r[fld][s] - (inner[1][s] ? acc : 0.0);
-            const int idx = slot_local(P, base);
-            L.w[s][fld - 3] = (idx < n) ? out : L.w[s][fld - 3];
+            for (int j = 1; j <= M; ++j) acc = fma(c[j], tap[j][s] + tpm[j][s], acc);
+            const double out = r[3 + fld][s] - (inner[1][s] ? acc : 0.0);
+            const int idx = slot_local(P, lane * EPL + s);
+            L.w[s][fld] = (idx < n) ? out : L.w[s][fld];
         }
     }
     __syncthreads();     // the next substep overwrites the staging rows
