@@ -79,3 +79,33 @@ def test_planar_hot_loop_has_no_scratch_traffic(tmp_path):
     assert len(stores) <= 20, f"{len(stores)} scratch stores outside the fallback-call block"
     # (the hot-path walk above already holds the loop itself to zero memory instructions; the
     # out-of-range tiers inside the loop's address range may spill)
+
+
+def test_3d_loops_keep_their_instruction_budget(tmp_path):
+    """The 3-D substep loops (OctoArmSingle, SoftPendulum3D, OctoFlat) are VALU-issue bound too; what
+    round 2 took out of them — register copies behind two-address FMAs, selects on operands that
+    already vanish, spilled scalar registers reloaded with v_readlane — comes back silently with an
+    unrelated edit.  Budgets are the walked in-range paths at the end of round 2 plus a few per cent."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    asm = tmp_path / "capi.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    "-o", str(asm), str(CSRC / "softrod_capi.hip")], check=True, timeout=900,
+                   stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    sys.path.insert(0, str(ROOT / "tools"))
+    import hot_path_isa
+    budgets = {   # kernel: (VALU, register copies, v_readlane)
+        "fast_kernelILj1073742601ELi3ELi1ELb0E": (535, 8, 4),     # OctoArmSingle: 517 / 3 / 2
+        "fast_kernelILj201ELi2ELi1ELb0E": (550, 10, 4),           # SoftPendulum3D: 533 / 6
+        "octo_step_kernelILj1073743625ELi2ELi4E": (685, 16, 10),  # OctoFlat, four envs per workgroup: 662 / 12 / 6
+    }
+    for key, (valu_max, copies_max, readlane_max) in budgets.items():
+        ins, labels = hot_path_isa.function_body(text, key)
+        path = hot_path_isa.hot_path(ins, labels)
+        valu = [x for x in path if x.startswith("v_")]
+        assert len(valu) <= valu_max, f"{key}: {len(valu)} VALU instructions per substep"
+        assert sum(x.startswith("v_mov_b64") for x in valu) <= copies_max, key
+        assert sum(x.startswith("v_readlane") for x in valu) <= readlane_max, key
+        assert not [x for x in path if x.startswith(("scratch", "global", "buffer", "flat"))], f"{key}: memory traffic in the loop"
