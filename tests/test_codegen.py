@@ -39,15 +39,21 @@ def _loops(asm: str, mangled_substr: str):
     return out
 
 
-def test_planar_hot_loop_has_no_scratch_traffic(tmp_path):
+@pytest.fixture(scope="module")
+def isa_text(tmp_path_factory):
+    """The gfx950 ISA of the whole library (one hipcc -S run for the module)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(hipcc).exists():
         pytest.skip("hipcc not available")
-    asm = tmp_path / "capi.s"
+    asm = tmp_path_factory.mktemp("isa") / "capi.s"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                     "-o", str(asm), str(CSRC / "softrod_capi.hip")], check=True, timeout=900,
                    stderr=subprocess.DEVNULL)
-    text = asm.read_text()
+    return asm.read_text()
+
+
+def test_planar_hot_loop_has_no_scratch_traffic(isa_text):
+    text = isa_text
     loops = _loops(text, "fast_kernelILj15ELi1ELi1E")   # <SOFTPENDULUM, SOFTPENDULUM, EPL = 1>
     assert loops, "no loop found in the SoftPendulum step kernel"
     hot = loops[0]                                                   # the planar substep loop comes first
@@ -81,19 +87,12 @@ def test_planar_hot_loop_has_no_scratch_traffic(tmp_path):
     # out-of-range tiers inside the loop's address range may spill)
 
 
-def test_3d_loops_keep_their_instruction_budget(tmp_path):
+def test_3d_loops_keep_their_instruction_budget(isa_text):
     """The 3-D substep loops (OctoArmSingle, SoftPendulum3D, OctoFlat) are VALU-issue bound too; what
     round 2 took out of them — register copies behind two-address FMAs, selects on operands that
     already vanish, spilled scalar registers reloaded with v_readlane — comes back silently with an
     unrelated edit.  Budgets are the walked in-range paths at the end of round 2 plus a few per cent."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not Path(hipcc).exists():
-        pytest.skip("hipcc not available")
-    asm = tmp_path / "capi.s"
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                    "-o", str(asm), str(CSRC / "softrod_capi.hip")], check=True, timeout=900,
-                   stderr=subprocess.DEVNULL)
-    text = asm.read_text()
+    text = isa_text
     sys.path.insert(0, str(ROOT / "tools"))
     import hot_path_isa
     budgets = {   # kernel: (VALU, register copies, v_readlane)
