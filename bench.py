@@ -379,6 +379,11 @@ def main() -> int:
                 "kernel_ms_avg": kernel_ms,
                 "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz / {CYCLES_PER_FP64_WAVE_INSTR:g} cycles per "
                                    "wave64 fp64 instruction (= 78.6 TFLOP/s of FMAs, MI355X_MICROARCH.md)",
+                # what a stream of independent v_fma_f64 reaches on this chip (tools/microbench/valu_issue.hip,
+                # four waves per SIMD: 4.2-4.6 cycles per instruction at the 1.9-2.0 GHz the clock settles
+                # at under that load) -- context for `frac`, which is priced against the nominal peak
+                "measured_fma_stream_peak": {"value": 466.0, "unit": "G wave64-VALU-instr/s",
+                                             "source": "profiles/r2j_valu_issue_microbench.txt"},
                 "valu_instr_per_rod_substep": valu_per,
                 "valu_instr_source": (valu_rec or {}).get("source"),
                 "rod_substeps_per_launch": rod_substeps,
