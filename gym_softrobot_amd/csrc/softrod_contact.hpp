@@ -26,6 +26,7 @@ struct ContactParams {
     double origin[3], normal[3];
     double k, nu, slip_tol, surface_tol;
     double kin_mu[3], stat_mu[3];   // forward, backward, sideways
+    double kin_am[2], stat_am[2];   // (forward + backward) / 2, (forward - backward) / 2
     double r0_sqrt_rest_len;        // r0 * sqrt(l_rest): radius = this / sqrt(len)
     double inv_r0_sqrt_rest_len;
 };
@@ -171,7 +172,10 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
         // mu_forward for vax > 0, mu_backward for vax < 0, their mean at exactly 0 — where the
         // slip function below is 1 and the kinetic force vanishes whatever kmu is (FM: skip the mean)
         const double sgn = FM ? 0.0 : sign_of(vax);
-        const double kmu = FM ? (vax > 0.0 ? C.kin_mu[0] : C.kin_mu[1])
+        // (FM: mean + sign(vax) * half difference — the half difference is negative for the octopus,
+        // whose backward friction is the larger — one v_bfi and one fma where a select between two
+        // wave-uniform doubles costs four moves and two v_cndmask; mu_f / mu_b to an ulp)
+        const double kmu = FM ? fma(copysign(1.0, vax), C.kin_am[1], C.kin_am[0])
                               : 0.5 * (C.kin_mu[0] * (1 + sgn) + C.kin_mu[1] * (1 - sgn));
         double ex_ax = 0.0, ex_ro = 0.0;      // FM: 1 - slip, computed first
         if constexpr (FM) { ex_ax = slip_excess(fabs(vax) * axn, inv_slip); slip_ax[s] = 1.0 - ex_ax; }
@@ -290,7 +294,7 @@ __device__ __forceinline__ void plane_contact_n(const ContactParams& C, const Ro
         // FM: -min(|fax|, cap) sign(fax) = copysign(min(|fax|, cap), -fax); fax = 0 gives 0 either way,
         // and cap = 0 off the plane
         const double sg = FM ? 0.0 : sign_of(fax);
-        const double smu = FM ? (fax > 0.0 ? C.stat_mu[0] : C.stat_mu[1])
+        const double smu = FM ? fma(copysign(1.0, fax), C.stat_am[1], C.stat_am[0])
                               : 0.5 * (C.stat_mu[0] * (1 + sg) + C.stat_mu[1] * (1 - sg));
         const double sa = FM ? copysign(fmin(fabs(fax), slip_ax[s] * smu * nmag[s]), -fax)
                              : (contact[s] ? -(fmin(fabs(fax), slip_ax[s] * smu * nmag[s]) * sg) : 0.0);

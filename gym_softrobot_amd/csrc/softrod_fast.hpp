@@ -345,12 +345,11 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         double Fg[EPL][3], fc[EPL][3];
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
-            const bool node_valid = slot_local<F>(P, lane * EPL + s) <= n;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 Fg[s][c] = f[s][c];
                 if (has<F>(P, SOFTROD_FEAT_GRAVITY) && !P.contact_before_forcing)
-                    Fg[s][c] += node_valid ? P.gravity[c] * C.mass[s] : 0.0;
+                    Fg[s][c] = f[s][c] + C.gm[s][c];     // (a per-lane constant, 0 past the rod's end: no select, no scalar operand)
             }
         }
         if constexpr (SOFTROD_OCTO_CONTACT_LDS && F != kRuntimeFeatures && (F & SOFTROD_FEAT_OCTO_HEAD) != 0 && (F & kFeatPlaneZup) != 0)

@@ -223,6 +223,7 @@ struct ConstN {
     double s01[EPL], s2[EPL];
     double b01[EPL], bd[EPL];
     double mass[EPL], mass_next[EPL], inv_mass_pair[EPL];   // 1 / (m_k + m_{k+1}): element velocity
+    double gm[EPL][3];                                      // gravity * mass (the weight the contact law sees; 0 past the end)
     // tapered rods only (TAPER instantiations; dead otherwise): the constants a uniform rod
     // keeps in scalar registers (RodParams), per element
     double j01[EPL], j2[EPL], dlog0[EPL], dlog2[EPL], dr0[EPL], dr2[EPL], r0s[EPL], ir0s[EPL];
@@ -597,14 +598,17 @@ __device__ __forceinline__ ContactParams contact_params_lds_impl(const RodParams
             c[4] = P.kin_mu[0]; c[5] = P.kin_mu[1]; c[6] = P.kin_mu[2];
             c[7] = P.stat_mu[0]; c[8] = P.stat_mu[1]; c[9] = P.stat_mu[2];
             c[10] = P.r0_sqrt_rest_len; c[11] = 1.0 / P.r0_sqrt_rest_len; c[12] = P.plane_origin[2];
+            c[4] = 0.5 * (P.kin_mu[0] + P.kin_mu[1]); c[5] = 0.5 * (P.kin_mu[0] - P.kin_mu[1]);      // mean, half difference
+            c[7] = 0.5 * (P.stat_mu[0] + P.stat_mu[1]); c[8] = 0.5 * (P.stat_mu[0] - P.stat_mu[1]);
         }
         return C;
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         C.origin[i] = P.plane_origin[i]; C.normal[i] = P.plane_normal[i];
-        C.kin_mu[i] = c[4 + i]; C.stat_mu[i] = c[7 + i];
+        C.kin_mu[i] = c[4 + i]; C.stat_mu[i] = c[7 + i];     // ([0], [1]: see kin_am / stat_am; only [2] is read)
     }
+    C.kin_am[0] = c[4]; C.kin_am[1] = c[5]; C.stat_am[0] = c[7]; C.stat_am[1] = c[8];
     C.origin[2] = c[12];
     C.k = c[0]; C.nu = c[1]; C.slip_tol = c[2]; C.surface_tol = c[3];
     C.r0_sqrt_rest_len = c[10];
@@ -624,6 +628,8 @@ __device__ __forceinline__ ContactParams contact_params(const RodParams& P) {
     C.k = P.contact_k; C.nu = P.contact_nu; C.slip_tol = P.slip_tol; C.surface_tol = P.surface_tol;
     C.r0_sqrt_rest_len = P.r0_sqrt_rest_len;
     C.inv_r0_sqrt_rest_len = 1.0 / P.r0_sqrt_rest_len;
+    C.kin_am[0] = 0.5 * (P.kin_mu[0] + P.kin_mu[1]); C.kin_am[1] = 0.5 * (P.kin_mu[0] - P.kin_mu[1]);
+    C.stat_am[0] = 0.5 * (P.stat_mu[0] + P.stat_mu[1]); C.stat_am[1] = 0.5 * (P.stat_mu[0] - P.stat_mu[1]);
     return C;
 }
 
@@ -979,9 +985,13 @@ __device__ __forceinline__ void build_const(const RodParams& P, int lane, const 
             C.dr0[s] = P.damp_r[0]; C.dr2[s] = P.damp_r[2];
             C.r0s[s] = P.r0_sqrt_rest_len; C.ir0s[s] = 1.0 / P.r0_sqrt_rest_len;
         }
-        C.mass[s] = mass;
-        C.mass_next[s] = mass_next;
-        C.inv_mass_pair[s] = 1.0 / (C.mass[s] + C.mass_next[s]);
+        // masses of slots past the rod's end are zeros (so that a product with them needs no select);
+        // 1 / (m_k + m_{k+1}) stays finite there
+        C.mass[s] = node_valid ? mass : 0.0;
+        C.mass_next[s] = (idx + 1 <= n) ? mass_next : 0.0;
+        C.inv_mass_pair[s] = 1.0 / (mass + mass_next);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C.gm[s][c] = has<F>(P, SOFTROD_FEAT_GRAVITY) ? P.gravity[c] * C.mass[s] : 0.0;
         C.hx[s] = held_x ? 0.0 : 1.0;
         C.hq[s] = held_q ? 0.0 : 1.0;
         const double cdm = node_valid ? ct * P.dt / mass : 0.0;
