@@ -43,6 +43,15 @@ namespace softrod {
 //                          v_readlane per substep of spilled loop constants)
 //   fma_over(d, a, b, c)   d <- a b + c, where d's old value is dead (its register is reused)
 //   fma_inplace_u(x, m, a) x <- m x + a with a wave-uniform m
+// "does any lane …": the ballot itself.  (__any goes through an integer — v_cndmask 0/1, v_cmp_ne —
+// before it branches: two more VALU instructions per range check.)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// "... any VALID lane": the validity as a lane mask ANDed on the scalar side.  (`valid && cond` as one
+// predicate makes the compiler rebuild it through v_cndmask 0/1 + v_cmp_ne before the ballot.)
+__device__ __forceinline__ bool wave_any_of(unsigned long long lanes, bool p) {
+    return (__builtin_amdgcn_ballot_w64(p) & lanes) != 0ull;
+}
+
 __device__ __forceinline__ double horner(double g, double y, double c) {
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(g), "v"(y), "v"(c));
@@ -63,7 +72,7 @@ __device__ __forceinline__ void fma_inplace_u(double& x, double m, double a) {
 // scalar registers of the literals are not to spare)
 template <bool LEAN = true>
 __device__ __forceinline__ void sinc_cosc(double t, double& sc, double& cc) {
-    if (!__any(t >= 1.0e-3)) {     // the whole wave is in range: straight-line, one s_cbranch
+    if (!wave_any(t >= 1.0e-3)) {     // the whole wave is in range: straight-line, one s_cbranch
         if constexpr (LEAN) {
             sc = fma(t, horner(horner(-1.0 / 5040.0, t, 1.0 / 120.0), t, -1.0 / 6.0), 1.0);
             cc = fma(t, horner(horner(-1.0 / 40320.0, t, 1.0 / 720.0), t, -1.0 / 24.0), 0.5);
@@ -76,7 +85,7 @@ __device__ __forceinline__ void sinc_cosc(double t, double& sc, double& cc) {
     // up to 4^16 * 1e-3: more than 250 rad per (sub)step — beyond that the state is garbage on
     // its way to NaN and only the cost of getting there matters
     int k = 0;
-    while (__any(t >= 1.0e-3) && k < 16) { t *= 0.25; ++k; }   // wave-uniform trip count
+    while (wave_any(t >= 1.0e-3) && k < 16) { t *= 0.25; ++k; }   // wave-uniform trip count
     sc = fma(t, fma(t, fma(t, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
     cc = fma(t, fma(t, fma(t, -1.0 / 40320.0, 1.0 / 720.0), -1.0 / 24.0), 0.5);
     for (; k > 0; --k) {
@@ -109,12 +118,13 @@ __device__ __forceinline__ double theta_over_sin_series(double y) {
     return fma(g, y, 1.0);       // c[0] = 1 is an inline constant
 }
 
-__device__ __forceinline__ double theta_over_sin(double y, bool valid) {
-    if (!__any(valid && !(y < 2.5e-3))) return theta_over_sin_series<6>(y);
-    if (!__any(valid && !(y < 0.04))) return theta_over_sin_series<12>(y);
+__device__ __forceinline__ double theta_over_sin(double y, bool valid_lane) {
+    const unsigned long long valid = __builtin_amdgcn_ballot_w64(valid_lane);     // (loop-invariant: two scalar registers)
+    if (!wave_any_of(valid, !(y < 2.5e-3))) return theta_over_sin_series<6>(y);
+    if (!wave_any_of(valid, !(y < 0.04))) return theta_over_sin_series<12>(y);
     const double y0 = y;
     int k = 0;
-    while (__any(valid && !(y < 0.15)) && k < 12) {
+    while (wave_any_of(valid, !(y < 0.15)) && k < 12) {
         const double om = fmax(1.0 - y, 1.0e-300);
         y = 0.5 * y * fast_rcp(1.0 + om * fast_rsqrt(om));
         ++k;
@@ -131,14 +141,15 @@ __device__ __forceinline__ double theta_over_sin(double y, bool valid) {
 
 // exp(x) for the damper: |x| < 1e-3 -> degree-4 Taylor (remainder x^5/120 < 1e-17);
 // larger |x| (strong damping constants) are halved k times and squared back.
-__device__ __forceinline__ void exp_pair(double x0, double x2, bool valid, double& e0, double& e2) {
-    if (!__any(valid && !(fmax(fabs(x0), fabs(x2)) < 1.0e-3))) {
+__device__ __forceinline__ void exp_pair(double x0, double x2, bool valid_lane, double& e0, double& e2) {
+    const unsigned long long valid = __builtin_amdgcn_ballot_w64(valid_lane);
+    if (!wave_any_of(valid, !(fmax(fabs(x0), fabs(x2)) < 1.0e-3))) {
         e0 = fma(x0, fma(x0, fma(x0, horner(1.0 / 24.0, x0, 1.0 / 6.0), 0.5), 1.0), 1.0);
         e2 = fma(x2, fma(x2, fma(x2, horner(1.0 / 24.0, x2, 1.0 / 6.0), 0.5), 1.0), 1.0);
         return;
     }
     int k = 0;   // 2^24 * 1e-3 > 16000: exp underflows long before
-    while (__any(valid && !(fmax(fabs(x0), fabs(x2)) < 1.0e-3)) && k < 24) {
+    while (wave_any_of(valid, !(fmax(fabs(x0), fabs(x2)) < 1.0e-3)) && k < 24) {
         x0 *= 0.5; x2 *= 0.5; ++k;
     }
     e0 = fma(x0, fma(x0, fma(x0, fma(x0, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
@@ -347,9 +358,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         for (int s = 0; s < EPL; ++s) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                Fg[s][c] = f[s][c];
-                if (has<F>(P, SOFTROD_FEAT_GRAVITY) && !P.contact_before_forcing)
-                    Fg[s][c] = f[s][c] + C.gm[s][c];     // (a per-lane constant, 0 past the rod's end: no select, no scalar operand)
+                Fg[s][c] = f[s][c] + C.gm[s][c];     // (a per-lane constant: no select, no scalar operand)
             }
         }
         if constexpr (SOFTROD_OCTO_CONTACT_LDS && F != kRuntimeFeatures && (F & SOFTROD_FEAT_OCTO_HEAD) != 0 && (F & kFeatPlaneZup) != 0)

@@ -223,7 +223,7 @@ struct ConstN {
     double s01[EPL], s2[EPL];
     double b01[EPL], bd[EPL];
     double mass[EPL], mass_next[EPL], inv_mass_pair[EPL];   // 1 / (m_k + m_{k+1}): element velocity
-    double gm[EPL][3];                                      // gravity * mass (the weight the contact law sees; 0 past the end)
+    double gm[EPL][3];                                      // gravity * mass: the weight the contact law sees (0 past the end, 0 if contact precedes forcing)
     // tapered rods only (TAPER instantiations; dead otherwise): the constants a uniform rod
     // keeps in scalar registers (RodParams), per element
     double j01[EPL], j2[EPL], dlog0[EPL], dlog2[EPL], dr0[EPL], dr2[EPL], r0s[EPL], ir0s[EPL];
@@ -991,7 +991,8 @@ __device__ __forceinline__ void build_const(const RodParams& P, int lane, const 
         C.mass_next[s] = (idx + 1 <= n) ? mass_next : 0.0;
         C.inv_mass_pair[s] = 1.0 / (mass + mass_next);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) C.gm[s][c] = has<F>(P, SOFTROD_FEAT_GRAVITY) ? P.gravity[c] * C.mass[s] : 0.0;
+        for (int c = 0; c < 3; ++c)      // (zero when the contact operator runs BEFORE the forcing: it then sees no weight)
+            C.gm[s][c] = (has<F>(P, SOFTROD_FEAT_GRAVITY) && !P.contact_before_forcing) ? P.gravity[c] * C.mass[s] : 0.0;
         C.hx[s] = held_x ? 0.0 : 1.0;
         C.hq[s] = held_q ? 0.0 : 1.0;
         const double cdm = node_valid ? ct * P.dt / mass : 0.0;

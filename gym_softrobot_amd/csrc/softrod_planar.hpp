@@ -83,7 +83,6 @@ __device__ __forceinline__ double uniform_k(double k) { return EPL > 1 ? opaque_
 __device__ __forceinline__ void fma_inplace(double& x, double m, double a) {
     asm("v_fma_f64 %0, %1, %0, %2" : "+v"(x) : "v"(m), "v"(a));
 }
-__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 __device__ __forceinline__ double rcp3(double x) { return fast_rcp(x); }       // (third order, softrod_kernels.hpp)
 __device__ __forceinline__ double rsqrt3(double x) { return fast_rsqrt(x); }

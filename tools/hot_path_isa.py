@@ -44,7 +44,7 @@ def hot_path(ins, labels):
     if head is None:
         raise SystemExit("no loop found")
     path, pc, seen, first = [], head, 0, {}
-    const, vcc = {}, None        # s[a:b] pairs holding a known 0 / -1; vcc known zero / non-zero (exec != 0)
+    const, vcc, scc = {}, None, None    # s[a:b] pairs holding a known 0 / -1; vcc known zero / non-zero (exec != 0); scc
     while True:
         t = ins[pc]
         m = re.match(r"(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", t)
@@ -61,8 +61,23 @@ def hot_path(ins, labels):
         if pc in first:          # back where the walk has been: the cycle from there on is the substep
             return path[first[pc]:]
         first[pc] = len(path)
+        # a range check ANDed with a validity mask on the scalar side: `s_cmp_eq_u64 x, 0` / `s_cmp_lg_u64
+        # x, 0` on the lanes out of range -- none, on this path
+        mz = re.match(r"s_cmp_(eq|lg)_u64\s+\S+,\s*0$", t)
+        if mz:
+            scc = mz.group(1) == "eq"
+        elif t.startswith("s_cmp") or t.startswith("s_add") or t.startswith("s_sub"):
+            scc = None
         if m:
             kind, tgt = m.group(1), labels[m.group(2)]
+            if kind in ("s_cbranch_scc0", "s_cbranch_scc1") and scc is not None:
+                taken = (kind == "s_cbranch_scc1") == scc
+                path.append(t)
+                pc = tgt if taken else pc + 1
+                seen += 1
+                if seen > 5000:
+                    raise SystemExit("did not return to the loop header")
+                continue
             if kind in ("s_cbranch_vccz", "s_cbranch_vccnz") and vcc is not None:
                 taken = (kind == "s_cbranch_vccnz") == vcc
             elif kind == "s_cbranch_execnz" and pc - 30 < tgt <= pc:
