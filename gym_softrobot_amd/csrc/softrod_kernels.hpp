@@ -442,10 +442,13 @@ __device__ __forceinline__ void laplace_filter_rates_n(const RodParams& P, int l
 // its reflections go to LDS once; each entry then reads its 13 taps.  Per field: 13 FMAs and
 // 13 LDS reads instead of 6 x (4 DPP moves + 3 fp64 ops); the block is one wavefront, so
 // the barrier between the writes and the reads costs nothing.  Needs N >= 6.
+#ifndef SOFTROD_FILTER_V_LDS
+#define SOFTROD_FILTER_V_LDS 0      // how many of the three v fields take the LDS stencil as well (from v_z down)
+#endif
 template <int EPL>
 __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, int lane, LaneN<EPL>& L) {
-    constexpr int M = 6, W = kLanes * EPL;
-    __shared__ double lds[3][W + 2 * M];
+    constexpr int M = 6, W = kLanes * EPL, KV = SOFTROD_FILTER_V_LDS, NL = 3 + KV, ND = 3 - KV;
+    __shared__ double lds[NL][W + 2 * M];
     const int n = P.n_elem;
     // c_j for j = 0..6: C(12, 6+j) / 4096 with alternating sign
     constexpr double c[M + 1] = {924.0 / 4096.0, -792.0 / 4096.0, 495.0 / 4096.0, -220.0 / 4096.0,
@@ -470,8 +473,10 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
             r[c3][s] = L.v[s][c3]; r[3 + c3][s] = L.w[s][c3];
         }
     }
-    // pass 1 in registers: the omega fields first — they go to LDS, and the v fields' pass runs
-    // while those writes are on their way (no measurable difference to "all six, then the writes")
+    // LDS row k holds field lfield(k): the omega fields, then v_z, v_y; the other v fields keep DPP
+    auto lfield = [](int k) { return k < 3 ? 3 + k : 5 - k; };      // 3, 4, 5, 2, 1
+    // pass 1 in registers: the fields that go to LDS first, the others while those writes are on
+    // their way (no measurable difference to "all six, then the writes")
     auto pass1 = [&](int fld) {
         double nx[EPL], pv[EPL];
         shift_next<EPL>(r[fld], nx);
@@ -480,57 +485,65 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
         for (int s = 0; s < EPL; ++s) f1[fld][s] = ((-nx[s] - pv[s]) + 2.0 * r[fld][s]) * q[fld / 3][s];
     };
 #pragma unroll
-    for (int fld = 3; fld < 6; ++fld) pass1(fld);
+    for (int k = 0; k < NL; ++k) pass1(lfield(k));
     // stage f_1 and its odd reflections
 #pragma unroll
-    for (int fld = 3; fld < 6; ++fld) {
-        const int N = n - 1;
+    for (int k = 0; k < NL; ++k) {
+        const int fld = lfield(k);
+        const int N = (fld < 3) ? n : n - 1;
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
             const int idx = slot_local(P, lane * EPL + s);
-            if (idx <= N) lds[fld - 3][M + idx] = f1[fld][s];
-            if (idx >= 1 && idx <= M) lds[fld - 3][M - idx] = -f1[fld][s];
-            if (idx >= N - M && idx <= N - 1) lds[fld - 3][M + 2 * N - idx] = -f1[fld][s];
+            if (idx <= N) lds[k][M + idx] = f1[fld][s];
+            if (idx >= 1 && idx <= M) lds[k][M - idx] = -f1[fld][s];
+            if (idx >= N - M && idx <= N - 1) lds[k][M + 2 * N - idx] = -f1[fld][s];
         }
     }
 #pragma unroll
-    for (int fld = 0; fld < 3; ++fld) pass1(fld);
+    for (int fld = 0; fld < ND; ++fld) pass1(fld);
     __syncthreads();
-    // v: the remaining six passes in registers; omega: the 13 taps out of LDS.  Interleaved field
-    // by field — the taps of an omega field are requested before the DPP passes of a v field and
-    // summed after them, so that the LDS round trip runs under VALU work of the same wave.
+    // The remaining six passes: in registers (DPP) for the first ND v fields, as the 13 taps out of
+    // LDS for the others.  Interleaved — the taps of an LDS field are requested before the DPP
+    // passes of a register field and summed after them, so that the LDS round trip runs under VALU
+    // work of the same wave.
     double tap[M + 1][EPL], tpm[M + 1][EPL];
 #pragma unroll
-    for (int fld = 0; fld < 3; ++fld) {
+    for (int k = 0; k < NL; ++k) {
+        const int lf = lfield(k);
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
-            const double* row = &lds[fld][lane * EPL + s];
+            const double* row = &lds[k][lane * EPL + s];
             tap[0][s] = row[M];
 #pragma unroll
             for (int j = 1; j <= M; ++j) { tap[j][s] = row[M + j]; tpm[j][s] = row[M - j]; }
         }
-        double f[EPL], nx[EPL], pv[EPL];
+        if (k < ND) {
+            const int fld = k;
+            double f[EPL], nx[EPL], pv[EPL];
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) f[s] = f1[fld][s];
-        for (int i = 0; i < 6; ++i) {
-            shift_next<EPL>(f, nx);
-            shift_prev<EPL>(f, pv);
+            for (int s = 0; s < EPL; ++s) f[s] = f1[fld][s];
+            for (int i = 0; i < 6; ++i) {
+                shift_next<EPL>(f, nx);
+                shift_prev<EPL>(f, pv);
 #pragma unroll
-            for (int s = 0; s < EPL; ++s) f[s] = ((-nx[s] - pv[s]) + 2.0 * f[s]) * q[0][s];
-        }
+                for (int s = 0; s < EPL; ++s) f[s] = ((-nx[s] - pv[s]) + 2.0 * f[s]) * q[0][s];
+            }
 #pragma unroll
-        for (int s = 0; s < EPL; ++s) {
-            const int idx = slot_local(P, lane * EPL + s);
-            L.v[s][fld] = (idx <= n) ? r[fld][s] - f[s] : L.v[s][fld];
+            for (int s = 0; s < EPL; ++s) {
+                const int idx = slot_local(P, lane * EPL + s);
+                L.v[s][fld] = (idx <= n) ? r[fld][s] - f[s] : L.v[s][fld];
+            }
         }
 #pragma unroll
         for (int s = 0; s < EPL; ++s) {
             double acc = c[0] * tap[0][s];
 #pragma unroll
             for (int j = 1; j <= M; ++j) acc = fma(c[j], tap[j][s] + tpm[j][s], acc);
-            const double out = r[3 + fld][s] - (inner[1][s] ? acc : 0.0);
+            // (a select: outside the interior the taps read LDS words nobody wrote)
+            const double out = r[lf][s] - (inner[lf / 3][s] ? acc : 0.0);
             const int idx = slot_local(P, lane * EPL + s);
-            L.w[s][fld] = (idx < n) ? out : L.w[s][fld];
+            if (lf < 3) L.v[s][lf] = (idx <= n) ? out : L.v[s][lf];
+            else L.w[s][lf - 3] = (idx < n) ? out : L.w[s][lf - 3];
         }
     }
     __syncthreads();     // the next substep overwrites the staging rows
