@@ -443,7 +443,7 @@ __device__ __forceinline__ void laplace_filter_rates_n(const RodParams& P, int l
 // 13 LDS reads instead of 6 x (4 DPP moves + 3 fp64 ops); the block is one wavefront, so
 // the barrier between the writes and the reads costs nothing.  Needs N >= 6.
 #ifndef SOFTROD_FILTER_V_LDS
-#define SOFTROD_FILTER_V_LDS 0      // how many of the three v fields take the LDS stencil as well (from v_z down)
+#define SOFTROD_FILTER_V_LDS 0      // how many of the three v fields take the LDS stencil as well (from v_z down); -1: omega_3 on DPP too
 #endif
 template <int EPL>
 __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, int lane, LaneN<EPL>& L) {
@@ -499,8 +499,10 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
             if (idx >= N - M && idx <= N - 1) lds[k][M + 2 * N - idx] = -f1[fld][s];
         }
     }
+    // register (DPP) field k: the v fields, then omega_3 (KV = -1: only two omega fields in LDS)
+    auto dfield = [](int k) { return k < 3 ? k : 8 - k; };       // 0, 1, 2, 5
 #pragma unroll
-    for (int fld = 0; fld < ND; ++fld) pass1(fld);
+    for (int k = 0; k < ND; ++k) pass1(dfield(k));
     __syncthreads();
     // The remaining six passes: in registers (DPP) for the first ND v fields, as the 13 taps out of
     // LDS for the others.  Interleaved — the taps of an LDS field are requested before the DPP
@@ -517,8 +519,9 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
 #pragma unroll
             for (int j = 1; j <= M; ++j) { tap[j][s] = row[M + j]; tpm[j][s] = row[M - j]; }
         }
-        if (k < ND) {
-            const int fld = k;
+#pragma unroll
+        for (int kd = k; kd < ND; kd += NL) {       // (more register fields than LDS fields: several per turn)
+            const int fld = dfield(kd);
             double f[EPL], nx[EPL], pv[EPL];
 #pragma unroll
             for (int s = 0; s < EPL; ++s) f[s] = f1[fld][s];
@@ -526,12 +529,13 @@ __device__ __forceinline__ void laplace_filter_rates_lds7(const RodParams& P, in
                 shift_next<EPL>(f, nx);
                 shift_prev<EPL>(f, pv);
 #pragma unroll
-                for (int s = 0; s < EPL; ++s) f[s] = ((-nx[s] - pv[s]) + 2.0 * f[s]) * q[0][s];
+                for (int s = 0; s < EPL; ++s) f[s] = ((-nx[s] - pv[s]) + 2.0 * f[s]) * q[fld / 3][s];
             }
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
                 const int idx = slot_local(P, lane * EPL + s);
-                L.v[s][fld] = (idx <= n) ? r[fld][s] - f[s] : L.v[s][fld];
+                if (fld < 3) L.v[s][fld] = (idx <= n) ? r[fld][s] - f[s] : L.v[s][fld];
+                else L.w[s][fld - 3] = (idx < n) ? r[fld][s] - f[s] : L.w[s][fld - 3];
             }
         }
 #pragma unroll
