@@ -1175,3 +1175,39 @@ def test_clock_table_and_its_fallback_are_bit_identical_to_the_accumulation(torc
             r.env_step(0.0)
         np.testing.assert_array_equal(st["time"].cpu().numpy(), np.array([r.time for r in rods]))
     env.close()
+
+
+def test_clock_outside_the_general_loops_equals_the_accumulation(torch_gpu, hip_lib, oracle_built):
+    """clock_after (general 3-D loop: OctoArmSingle; also with a substep count the table was not built
+    for): table entry and after-the-loop additions both equal the oracle's clock bit for bit."""
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    n = 4
+    cfg = _capi.arm_single_config(n)
+    cfg.n_substeps = 40
+    be = HipRodBackend(cfg, 0)
+    be.reset_straight(np.zeros((n, 3)), np.tile([1.0, 0, 0], (n, 1)), np.tile([0, 0, 1.0], (n, 1)))
+    be.observe(None)
+    rods = [oracle_built.OracleRod(cfg) for _ in range(n)]
+    for r in rods:
+        r.reset_arm()
+    st = be.state()
+    a = np.zeros((n, 7), np.float32)
+    be.step(a)
+    for r in rods:
+        r.env_step_arm(a[0])
+    off = np.array([0.0, 0.0, 0.0123456789, 7.0e-5 * 40 * 2000 + 1e-9])          # on the table, off it, beyond it
+    st["time"][2:] = torch_gpu.from_numpy(off[2:]).to(st["time"].device)
+    for i in (2, 3):
+        rods[i].set("time", [off[i]])
+    for _ in range(3):
+        be.step(a)
+        for r in rods:
+            r.env_step_arm(a[0])
+        np.testing.assert_array_equal(st["time"].cpu().numpy(), np.array([r.time for r in rods]))
+    be.substeps(None, 7)                 # not the substep count of the table: the additions run
+    for r in rods:
+        r.substeps(0.0, 7)
+    np.testing.assert_array_equal(st["time"].cpu().numpy(), np.array([r.time for r in rods]))
+    be.close()
