@@ -28,6 +28,18 @@ passes, profiles/hbm_traffic.json); `roofline.hbm` carries the measured-traffic 
 and, labelled as a model, SURVEY.md §8(d)'s algorithmic-bytes streaming figure (rods x
 substeps x 2*(18n+6)*8 B / kernel time), which a fused kernel exceeds by construction.
 
+Clock: the first launches after an idle period run at a lower shader clock (0.38 -> 0.30 ms over
+~20 launches).  Before the declared warm-up an un-timed PRE-HEAT steps a scratch batch of the same
+shape until the HIP-event kernel time has stopped falling (cap 60 launches); the measured batch is
+untouched by it, so the timed window stays inside one episode.  `steps`/`warmup` echo the
+arguments; when warm-up + 3 windows of K steps fit one episode (120 steps) three consecutive
+windows of K steps are timed, each bracketed like the contract says, and `value` / `ms_per_step`
+are the MEDIAN window's (all windows are listed under `windows`).
+
+Staleness: profiles/valu_counts.json and hbm_traffic.json entries carry the source hash of the
+library they were measured on (softrod_source_hash); when it differs from the loaded library's,
+`roofline.frac` / `traffic` are null and `frac_withheld` says why.
+
 cpu_baseline: the repo's fp64 C oracle (a port/restatement, NOT PyElastica — see
 oracle/softrod_oracle.c) timed on this box's host cores with OpenMP over rods, rank 0,
 N=1 only, on a bounded sample of the same workload.  `cores` = the CPUs the process may
@@ -151,14 +163,23 @@ def parse_args(argv=None):
     ap.add_argument("--actions", choices=["random", "zero"], default="random",
                     help="random (default): uniform in the action box; zero: SURVEY.md §8(d)'s zero-action run")
     ap.add_argument("--n-elems", type=int, default=None, help="elements per rod (env default if omitted)")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="timed windows of --steps steps each (value = the median window); 0 (default): 3 if "
+                         "warmup + 3*steps <= 120 (one SoftPendulum episode), else as many as fit, at least 1")
+    ap.add_argument("--preheat", type=int, default=60,
+                    help="cap of the un-timed pre-heat launches on a scratch batch (0 = none)")
     return ap.parse_args(argv)
 
 
-def self_launch(args) -> int:
+def self_launch(args, script=None, argv=None) -> int:
     """`python bench.py --gpus N` (N > 1, not under torchrun): start the N ranks as a CHILD
     `python -m torch.distributed.run` — this parent has not imported torch or touched the GPU,
-    and it never exec()s — relay rank 0's JSON line on stdout, everything else on stderr, and
-    return the child's exit code."""
+    and it never exec()s — relay rank 0's JSON line on stdout (everything else of the child's
+    stdout goes to stderr) and return the child's exit code.  The child runs in its own process
+    group and is killed as a group when it exceeds SOFTROD_BENCH_LAUNCH_TIMEOUT seconds (default
+    1800) or when this parent is interrupted.  `script` (tests only): the file the ranks run,
+    default this one."""
+    import signal
     import socket
     import subprocess
 
@@ -166,12 +187,25 @@ def self_launch(args) -> int:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(Path(script or __file__).resolve())] + list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=float(os.environ.get("SOFTROD_BENCH_LAUNCH_TIMEOUT", "1800")))
+    except BaseException as exc:           # timeout, KeyboardInterrupt: do not leave ranks behind
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
+        sys.stderr.write(f"bench.py: child launch aborted ({type(exc).__name__})\n")
+        if isinstance(exc, subprocess.TimeoutExpired):
+            return 124
+        raise
     n_json = 0
-    for ln in proc.stdout:
+    for ln in out.splitlines(keepends=True):
         txt = ln.strip()
         is_line = False
         if txt.startswith("{") and '"metric"' in txt:
@@ -185,7 +219,7 @@ def self_launch(args) -> int:
             print(txt, flush=True)
         else:
             sys.stderr.write(ln)
-    rc = proc.wait()
+    rc = proc.returncode
     if rc == 0 and n_json != 1:
         sys.stderr.write(f"bench.py: expected one JSON line from rank 0, saw {n_json}\n")
         return 1
@@ -201,10 +235,63 @@ def load_profile_table(name: str, key: str):
         return None
 
 
-def main() -> int:
-    args = parse_args()
+def fresh_or_none(rec, lib_hash):
+    """A profile-table entry is used only when it was measured on the library that is loaded now
+    (entry["source_hash"] == softrod_source_hash()).  Returns (entry or None, reason or None)."""
+    if rec is None:
+        return None, "no tracked profile entry for this workload"
+    h = rec.get("source_hash")
+    if lib_hash is None:
+        return None, "the stepping backend is not libsoftrod_hip.so"
+    if h != lib_hash:
+        return None, (f"profile entry was measured on source hash {h}, the loaded library is {lib_hash}: "
+                      "re-run tools/profile_all.sh")
+    return rec, None
+
+
+def useful_lane_fraction(cfg, octo: bool, n_waves: int) -> float:
+    """Lanes that carry a node / lanes launched, for one env: 51/64 (SoftPendulum, 50 elements),
+    101/128 (100 elements on two slots per lane or two windows), 88/128 (OctoFlat: 8 arms x 11)."""
+    n_nodes = int(cfg.n_elem) + 1
+    if octo:
+        return int(cfg.n_arm) * n_nodes / (64.0 * n_waves)
+    return n_nodes / (64.0 * (1 if n_nodes <= 64 else 2))
+
+
+def preheat(make_scratch, acts_dev, cap: int):
+    """Un-timed launches on a SCRATCH batch of the measured shape until the step kernel's HIP-event
+    duration has stopped falling: groups of 5 launches, settled when a group's mean is within 1 %
+    of (or above) the previous group's; at least 10, at most `cap` launches.  The scratch batch
+    stays allocated until the end of the run (no hipFree in front of the timed region)."""
+    import numpy as np
+
+    if cap < 5:
+        return None, {"launches": 0}
+    scratch = make_scratch()
+    scratch.reset(seed=10_000_019)
+    be = scratch.backend
+    groups, n = [], 0
+    while n + 5 <= cap:
+        be.set_timing(5)
+        for k in range(5):
+            scratch.step(acts_dev[(n + k) % acts_dev.shape[0]])
+        kt = be.kernel_times_ms()
+        n += 5
+        groups.append([float(x) for x in kt])
+        if len(groups) >= 2 and np.mean(groups[-1]) >= 0.99 * np.mean(groups[-2]):
+            break
+    be.set_timing(0)
+    flat = [x for g in groups for x in g]
+    return scratch, {"launches": n, "first_kernel_ms": flat[0], "settled_kernel_ms": float(np.mean(groups[-1])),
+                     "group_means_ms": [float(np.mean(g)) for g in groups],
+                     "settled": bool(len(groups) >= 2 and np.mean(groups[-1]) >= 0.99 * np.mean(groups[-2])),
+                     "what": "scratch batch of the same env/size, random actions, not the measured batch"}
+
+
+def main(argv=None, script=None) -> int:
+    args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return self_launch(args)
+        return self_launch(args, script=script, argv=argv)
 
     import numpy as np
     import torch
@@ -214,35 +301,26 @@ def main() -> int:
     from gym_softrobot_amd import _capi
     from gym_softrobot_amd.distributed import ShardedVecEnv
 
-    # CPU tests of this file's argument handling / launch / sharding logic swap the device layer
-    # for a module under tests/ (an oracle-backed double over gloo); such a run labels its line
-    # "data": "TEST-SHIM" and is not a measurement.  Nothing under oracle/ is reachable from here
-    # otherwise (cpu_baseline excepted, which only times it).
-    shim = None
-    if os.environ.get("SOFTROD_BENCH_TEST_SHIM"):
-        import importlib
-
-        shim = importlib.import_module(os.environ["SOFTROD_BENCH_TEST_SHIM"])
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    if shim is None:
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs a MI355X: the hot path has no CPU fallback")
-        if os.environ.get("SOFTROD_BENCH_ALL_RANKS_ON_DEVICE0") == "1":
-            local_rank = 0   # smoke-testing the N>1 code path on a 1-GPU box (not a measurement)
-        torch.cuda.set_device(local_rank)
-    device_sync = torch.cuda.synchronize if shim is None else (lambda: None)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the hot path has no CPU fallback")
+    if os.environ.get("SOFTROD_BENCH_ALL_RANKS_ON_DEVICE0") == "1":
+        local_rank = 0   # the N>1 code path on a 1-GPU box (tests/test_gpu_two_ranks.py; not a measurement)
+    torch.cuda.set_device(local_rank)
     force_dist = os.environ.get("SOFTROD_BENCH_FORCE_DIST") == "1"   # RCCL smoke test in a world of one
-    if world > 1 or force_dist:
+    distributed = world > 1 or force_dist
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        backend = os.environ.get("SOFTROD_BENCH_DIST_BACKEND", "nccl" if shim is None else "gloo")
+        # transport of the packed rows: RCCL ("nccl") unless told otherwise (two ranks on ONE device
+        # need gloo: RCCL refuses two ranks per GPU)
+        backend = os.environ.get("SOFTROD_BENCH_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -255,16 +333,18 @@ def main() -> int:
         n_local //= world
     n_total = n_local * world
     K, W = args.steps, args.warmup
+    R = args.windows if args.windows > 0 else max(1, min(3, (120 - W) // max(K, 1)))
     math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
     extra = {} if args.n_elems is None else {"n_elems": args.n_elems}
+    scratch_kw = dict(extra)
+    T = W + R * K
     if args.autoreset == "auto":
-        args.autoreset = "off" if (args.steps + args.warmup <= 120 or args.env != "SoftPendulum-v0") else "device"
+        args.autoreset = "off" if (T <= 120 or args.env != "SoftPendulum-v0") else "device"
     if args.autoreset != "off":
         extra["autoreset"] = True if args.autoreset == "host" else "device"
-    if shim is None:
-        local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode, **extra)
-    else:
-        local = shim.make_vec(args.env, n_local, **extra)
+    local = gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode, **extra)
+    hip = type(local.backend).__name__ == "HipRodBackend"     # a test double labels its line (tests/bench_cpu_launcher.py)
+    lib_hash = _capi.library_source_hash() if hip else None
     # world > 1: kernel-packed rows + one all-gather per step, issued asynchronously so that the
     # next step's kernel does not wait for it (ShardedVecEnv overlap; the final sync is timed)
     env = ShardedVecEnv(local, n_total, overlap=True, force_collective=force_dist)
@@ -277,42 +357,55 @@ def main() -> int:
         amax = 0.0
     # the truncation flag of SoftPendulum first fires on env.step #126; the default window
     # (120 steps) stays inside one episode
-    T = W + K
     acts = np.random.default_rng(1).uniform(-amax, amax, (T, n_total, adim)).astype(np.float32)
     acts_dev = torch.from_numpy(acts[:, lo:hi].copy()).to(local.backend.device)
 
+    timed = hasattr(local.backend, "set_timing")
+    scratch, heat = None, {"launches": 0}
+    if timed and args.preheat > 0:
+        scratch, heat = preheat(lambda: gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode,
+                                                     **scratch_kw), acts_dev, args.preheat)
     for t in range(W):
         env.step(acts_dev[t])
-    timed = hasattr(local.backend, "set_timing")
     if timed:
-        local.backend.set_timing(K)
-    restarts_before = int(local.backend.queue_status()[0].sum()) if args.autoreset == "device" else 0
-    if world > 1 or force_dist:
-        dist.barrier()
-    device_sync()
-    t0 = time.perf_counter()
-    for t in range(W, T):
-        obs, rew, term, trunc, _ = env.step(acts_dev[t])
-    env.sync()
-    device_sync()
-    if world > 1 or force_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1 or force_dist:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=local.backend.device)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+        local.backend.set_timing(R * K)
 
-    kt = local.backend.kernel_times_ms() if timed else np.full(K, elapsed / K * 1e3)
-    assert len(kt) == K or args.autoreset != "off"
-    # env-steps that restarted an episode instead of integrating are not counted as work
-    restarts = 0
-    if args.autoreset == "device":
-        restarts = int(local.backend.queue_status()[0].sum()) - restarts_before
-    if world > 1 or force_dist:
-        rs = torch.tensor([restarts], dtype=torch.int64, device=local.backend.device)
-        dist.all_reduce(rs)
-        restarts = int(rs.item())
+    def restarts_so_far():
+        return int(local.backend.queue_status()[0].sum()) if args.autoreset == "device" else 0
+
+    win_elapsed, win_restarts = [], []
+    r_before = restarts_so_far()
+    for w in range(R):
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(W + w * K, W + (w + 1) * K):
+            obs, rew, term, trunc, _ = env.step(acts_dev[t])
+        env.sync()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        # env-steps that restarted an episode instead of integrating are not counted as work
+        r_now = restarts_so_far()
+        rs = r_now - r_before
+        r_before = r_now
+        if distributed:
+            el = torch.tensor([elapsed], dtype=torch.float64, device=local.backend.device)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            elapsed = float(el.item())
+            rt = torch.tensor([rs], dtype=torch.int64, device=local.backend.device)
+            dist.all_reduce(rt)
+            rs = int(rt.item())
+        win_elapsed.append(elapsed)
+        win_restarts.append(rs)
+
+    kt = local.backend.kernel_times_ms() if timed else np.repeat(np.asarray(win_elapsed) / K * 1e3, K)
+    assert len(kt) == R * K or args.autoreset != "off"
+    win_value = [(n_total * K - win_restarts[w]) / win_elapsed[w] for w in range(R)]
+    m = int(np.argsort(win_value)[R // 2])           # the median window (the lower one of two)
+    elapsed, restarts = win_elapsed[m], win_restarts[m]
     n_bad = int((~torch.isfinite(obs).all(dim=1)).sum().item())
     # what the last step returned, over ALL envs (gathered rows included): lets two runs be compared
     obs_checksum = float(torch.nan_to_num(obs.double()).sum().item()) + float(torch.nan_to_num(rew.double()).sum().item())
@@ -326,18 +419,29 @@ def main() -> int:
         # OctoFlat: n_arm rods + the rigid head (x, v, Q, w = 18 doubles read and written)
         bytes_per_launch = n_local * nsub * (rods_per_env * algorithmic_bytes_per_rod_substep(int(cfg.n_elem))
                                              + (2 * 18 * 8 if octo else 0))
-        kernel_ms = float(np.mean(kt))
+        per_win_kernel = [float(np.mean(kt[w * K:(w + 1) * K])) for w in range(R)] if len(kt) == R * K else []
+        kernel_ms = per_win_kernel[m] if per_win_kernel else float(np.mean(kt))
         kernel_s = kernel_ms * 1e-3
-        # tracked rocprofv3 evidence, keyed by workload: only a measurement of THIS env / size is used
-        traffic_rec = load_profile_table("hbm_traffic.json", f"{args.env}|n_elem={int(cfg.n_elem)}|envs={n_local}")
+        # tracked rocprofv3 evidence, keyed by workload: only a measurement of THIS env / size on THIS
+        # build of the library is used
+        traffic_rec, traffic_why = fresh_or_none(
+            load_profile_table("hbm_traffic.json", f"{args.env}|n_elem={int(cfg.n_elem)}|envs={n_local}"), lib_hash)
         traffic = (traffic_rec or {}).get("hbm_bytes_per_launch")
-        valu_rec = load_profile_table("valu_counts.json", f"{args.env}|n_elem={int(cfg.n_elem)}") \
-            if args.math_mode == "fast" else None
+        valu_rec, valu_why = (None, "valu_counts.json holds the fast-math kernels only")
+        if args.math_mode == "fast":
+            valu_rec, valu_why = fresh_or_none(
+                load_profile_table("valu_counts.json", f"{args.env}|n_elem={int(cfg.n_elem)}"), lib_hash)
         valu_per = (valu_rec or {}).get("valu_instr_per_rod_substep")
         achieved = None if valu_per is None else valu_per * rod_substeps / kernel_s / 1e9
+        frac = None if achieved is None else achieved / VALU_PEAK_GINSTR
+        n_waves = 1
+        if octo:
+            n_waves = -(-int(cfg.n_arm) * int(local.backend.state()["arm_stride"]) // 64) if hip else 2
+        lanes = useful_lane_fraction(cfg, octo, n_waves)
+        busy_raw = (valu_rec or {}).get("valu_busy_frac")
         line = {
             "metric": "env_steps_per_sec",
-            "value": (n_total * K - restarts) / elapsed,
+            "value": win_value[m],
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": K,
@@ -347,7 +451,7 @@ def main() -> int:
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic" if shim is None else "TEST-SHIM",
+            "data": "synthetic" if hip else "TEST-DOUBLE (not a measurement)",
             "config": {
                 "workload": f"{args.env}, {n_local} envs x "
                             + (f"{rods_per_env} arms x " if octo else "") + f"{int(cfg.n_elem)} elements per GPU "
@@ -362,15 +466,32 @@ def main() -> int:
                 "sharding": "contiguous env blocks per rank; one packed all_gather per step" if world > 1 else "single GPU",
                 "rod_substeps_per_sec": (n_total * K - restarts) * rods_per_env * nsub / elapsed,
                 "non_finite_envs_at_end": n_bad, "last_step_checksum": obs_checksum,
+                "library_source_hash": lib_hash,
             },
+            # every timed window of K steps (value / ms_per_step above are the median window's)
+            "windows": {
+                "count": R, "median_index": m,
+                "value": win_value,
+                "ms_per_step": [e / K * 1e3 for e in win_elapsed],
+                "kernel_ms_avg": per_win_kernel,
+                "spread": (max(win_value) - min(win_value)) / win_value[m],
+            },
+            "preheat": heat,
             "roofline": {
                 # what bounds a register-resident kernel: fp64 VALU issue slots
                 "bound": "fp64_valu",
                 "achieved": achieved,
                 "peak": VALU_PEAK_GINSTR,
                 "unit": "G wave64-VALU-instr/s",
-                "frac": None if achieved is None else achieved / VALU_PEAK_GINSTR,
+                "frac": frac,
+                "frac_withheld": valu_why,
                 "traffic": traffic,
+                "traffic_withheld": traffic_why,
+                # lanes that carry a node / lanes launched: `frac` counts every issued wave instruction
+                # as work, idle lanes included; frac x useful_lane_frac is the share of the chip's fp64
+                # LANE-slots that advance a node
+                "useful_lane_frac": lanes,
+                "frac_of_lane_slots": None if frac is None else frac * lanes,
                 "kernel": "softrod_octo_step_kernel" if octo else
                           "softrod_step_window_kernel + softrod_step_fast_kernel (epilogue only)"
                           if (args.env == "OctoArmSingle-v0" and 64 <= int(cfg.n_elem) <= 102
@@ -379,16 +500,22 @@ def main() -> int:
                 "kernel_ms_avg": kernel_ms,
                 "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz / {CYCLES_PER_FP64_WAVE_INSTR:g} cycles per "
                                    "wave64 fp64 instruction (= 78.6 TFLOP/s of FMAs, MI355X_MICROARCH.md)",
-                # what a stream of independent v_fma_f64 reaches on this chip (tools/microbench/valu_issue.hip,
-                # four waves per SIMD: 4.2-4.6 cycles per instruction at the 1.9-2.0 GHz the clock settles
-                # at under that load) -- context for `frac`, which is priced against the nominal peak
-                "measured_fma_stream_peak": {"value": 466.0, "unit": "G wave64-VALU-instr/s",
-                                             "source": "profiles/r2j_valu_issue_microbench.txt"},
+                # ONE measured sample of a pure stream of independent v_fma_f64 (tools/microbench/valu_issue.hip,
+                # four waves per SIMD: 4.2-4.6 cycles per instruction at the 1.9-2.0 GHz the clock settles at
+                # under that load).  Context only, NOT a ceiling: a mixed stream (mul/add/DPP next to the
+                # FMAs) draws less power, clocks at 2.25-2.3 GHz and can exceed it, as `achieved` does
+                "fma_stream_sample": {"value": 466.0, "unit": "G wave64-VALU-instr/s",
+                                      "source": "profiles/r2j_valu_issue_microbench.txt",
+                                      "note": "one sample at ~1.9-2.0 GHz; not a ceiling on `achieved`"},
                 "valu_instr_per_rod_substep": valu_per,
                 "valu_instr_source": (valu_rec or {}).get("source"),
                 "rod_substeps_per_launch": rod_substeps,
-                # the same fraction from the profiler's own cycle counter (clock-independent), if tracked
-                "profiled_valu_busy_frac": (valu_rec or {}).get("valu_busy_frac"),
+                # the same fraction from the profiler's own cycle counter (clock-independent), if tracked:
+                # SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).  The raw quotient can exceed 1
+                # by ~1 % (GRBM_GUI_ACTIVE / 8 is the mean over the XCDs' active cycles and the counter's
+                # 4-cycle granule is nominal); reported clamped, with the raw value beside it
+                "profiled_valu_busy_frac": None if busy_raw is None else min(1.0, busy_raw),
+                "profiled_valu_busy_frac_raw": busy_raw,
                 "hbm": {
                     "measured_traffic_GBs": None if traffic is None else traffic / kernel_s / 1e9,
                     "measured_traffic_frac_of_8TBs": None if traffic is None else traffic / kernel_s / 1e9 / HBM_PEAK_GBS,
@@ -403,14 +530,16 @@ def main() -> int:
                 },
             },
         }
-        if world == 1 and not args.no_cpu_baseline and args.env == "SoftPendulum-v0" and shim is None:
+        if world == 1 and not args.no_cpu_baseline and args.env == "SoftPendulum-v0" and hip:
             line["cpu_baseline"] = cpu_baseline(cfg, usable_cpus())
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
 
     env.close()
-    if world > 1 or force_dist:
+    if scratch is not None:
+        scratch.close()
+    if distributed:
         dist.destroy_process_group()
     return 0
 

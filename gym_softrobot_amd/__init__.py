@@ -33,12 +33,14 @@ register(id="OctoFlatLite-v0", entry_point=FlatEnv, kwargs=dict(n_arm=1, n_actio
 # gym_softrobot/__init__.py:60-63
 register(id="SoftArmTracking-v0", entry_point=SoftArmTrackingEnv)
 
+# the batched form of every id registered above: (class, the registration's kwargs)
 _VEC = {
-    "SoftPendulum-v0": VecSoftPendulumEnv,
-    "SoftPendulum3D-v0": VecSoftPendulum3DEnv,
-    "OctoArmSingle-v0": VecArmSingleEnv,
-    "OctoFlat-v0": VecOctoFlatEnv,
-    "SoftArmTracking-v0": VecSoftArmTrackingEnv,
+    "SoftPendulum-v0": (VecSoftPendulumEnv, {}),
+    "SoftPendulum3D-v0": (VecSoftPendulum3DEnv, {}),
+    "OctoArmSingle-v0": (VecArmSingleEnv, {}),
+    "OctoFlat-v0": (VecOctoFlatEnv, {}),
+    "OctoFlatLite-v0": (VecOctoFlatEnv, dict(n_arm=1, n_action=8)),   # gym_softrobot/__init__.py:11-15
+    "SoftArmTracking-v0": (VecSoftArmTrackingEnv, {}),
 }
 
 
@@ -46,7 +48,8 @@ def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
     """N parallel envs on one GPU (the batched form of `make`)."""
     if id not in _VEC:
         raise KeyError(f"no batched implementation registered for {id!r}; have {sorted(_VEC)}")
-    return _VEC[id](num_envs, **kwargs)
+    cls, kw = _VEC[id]
+    return cls(num_envs, **{**kw, **kwargs})
 
 
 __all__ = [

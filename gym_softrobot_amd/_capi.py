@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -428,6 +428,7 @@ _VP = C.c_void_p
 _EXPORTS = {
     # name: (restype, argtypes)
     "softrod_abi_version": (C.c_int, []),
+    "softrod_source_hash": (C.c_char_p, []),
     "softrod_action_dim": (C.c_int, [C.c_int]),
     "softrod_obs_dim": (C.c_int, [C.c_int]),
     "softrod_aux_dim": (C.c_int, [C.c_int]),
@@ -507,6 +508,25 @@ def load_library() -> C.CDLL:
         raise SoftrodError("libsoftrod_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def library_source_hash() -> str:
+    """The source hash the LOADED library was built from (softrod_source_hash, include/softrod.h)."""
+    return load_library().softrod_source_hash().decode()
+
+
+def source_hash() -> str:
+    """The same hash taken over the sources on disk (csrc/Makefile's SOURCE_HASH): differs from
+    library_source_hash() when the .so is older than the sources."""
+    import hashlib
+
+    csrc = Path(__file__).resolve().parent / "csrc"
+    files = sorted(csrc.glob("*.hpp"), key=lambda f: f.name) + [csrc / "softrod_capi.hip",
+                                                                 csrc.parents[1] / "include" / "softrod.h"]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def check(rc: int, handle=None) -> None:

@@ -46,6 +46,9 @@ class HipRodBackend:
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
         self._h = C.c_void_p()
+        # per-handle physics tables that live outside softrod_config (action basis, spline table,
+        # radius profile): their bytes go into config_fingerprint()
+        self._tables: Dict[str, bytes] = {}
         check(self._lib.softrod_create(C.byref(self.cfg), self.device_index, C.byref(self._h)))
         if self.cfg.features & _capi.FEAT_REST_KAPPA_ACTION:
             if self.is_octo:
@@ -53,11 +56,13 @@ class HipRodBackend:
             else:
                 basis = _capi.action_basis(int(cfg.n_elem), self.action_dim)
             check(self._lib.softrod_set_action_basis(self._h, basis.ctypes.data), self._h)
+            self._tables["action_basis"] = basis.tobytes()
         if self.cfg.features & _capi.FEAT_SPLINE_MUSCLE_TORQUES:
             breaks, coef = _capi.spline_table(float(cfg.base_length), int(cfg.n_ctrl))
             if len(breaks) != int(cfg.n_spline_pieces) + 1:
                 raise _capi.SoftrodError("n_spline_pieces does not match the interpolant")
             check(self._lib.softrod_set_spline_table(self._h, breaks.ctypes.data, coef.ctypes.data), self._h)
+            self._tables["spline_table"] = breaks.tobytes() + coef.tobytes()
         n = self.n_envs
         with torch.cuda.device(self.device):
             self.obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=self.device)
@@ -96,6 +101,7 @@ class HipRodBackend:
         160-179).  Before the first reset."""
         r = np.ascontiguousarray(radius, dtype=np.float64).reshape(int(self.cfg.n_elem))
         check(self._lib.softrod_set_radius_profile(self._h, r.ctypes.data), self._h)
+        self._tables["radius_profile"] = r.tobytes()
 
     def reset(self, theta0: np.ndarray, mask: Optional[np.ndarray] = None) -> None:
         th = np.ascontiguousarray(theta0, dtype=np.float64).reshape(self.n_envs)
@@ -315,12 +321,20 @@ class HipRodBackend:
                       "rest_kappa", "env_memory", "prev_action", "head", "bc_targets", "sucker_ratio")
 
     def config_fingerprint(self) -> bytes:
-        """What a snapshot is only valid for: the ABI and every field of softrod_config except the
-        batch size (checked through the shapes) — a snapshot taken under another dt, substep
-        count, feature set or material continues with the wrong physics otherwise."""
+        """What a snapshot is only valid for: the ABI, every field of softrod_config except the
+        batch size (checked through the shapes), and a digest of the per-handle tables that hold
+        physics outside the config — the radius profile of a tapered rod (masses, stiffnesses,
+        damping per lane), the spline table and the action basis.  A snapshot taken under another
+        dt, substep count, feature set, material or taper continues with the wrong physics
+        otherwise."""
+        import hashlib
+
         c = self.cfg.copy()
         c.n_envs = 0
-        return bytes([_capi.ABI_VERSION]) + bytes(memoryview(c).cast("B"))
+        d = hashlib.sha256()
+        for k in sorted(self._tables):
+            d.update(k.encode() + b"\0" + self._tables[k])
+        return bytes([_capi.ABI_VERSION]) + bytes(memoryview(c).cast("B")) + d.digest()
 
     def snapshot(self) -> Dict[str, torch.Tensor]:
         """Host copy of the whole resident batch (every array of softrod_state_view): what
@@ -341,8 +355,9 @@ class HipRodBackend:
                                      "stale needs_reset / skip flags would reset or skip the wrong envs")
         fp = snap.get("config_fingerprint")
         if fp is None or bytes(fp.numpy().tobytes()) != self.config_fingerprint():
-            raise ValueError("snapshot was taken under a different softrod_config / ABI version "
-                             "(dt, n_substeps, features, env_kind, material ...): refusing to load it")
+            raise ValueError("snapshot was taken under a different softrod_config / ABI version / table set "
+                             "(dt, n_substeps, features, env_kind, material, radius profile, spline table, "
+                             "action basis ...): refusing to load it")
         st = self.state()
         for k in self._SNAPSHOT_KEYS:
             if tuple(snap[k].shape) != tuple(st[k].shape):

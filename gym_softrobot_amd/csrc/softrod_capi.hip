@@ -27,6 +27,7 @@ struct softrod_handle {
     size_t init_stride = 18;  // doubles of reset staging per env
     int window_refresh = 0;   // > 0: the rod runs on two overlapping wave windows (softrod_window.hpp),
                               // halo refreshed every so many substeps
+    bool octo_one_env_per_block = false;  // A/B switch SOFTROD_OCTO_ONE_ENV_PER_BLOCK, read once in softrod_create
     RodParams P{};
     StatePtrs S{};
     double* d_init = nullptr;     // [N][18] staging for reset
@@ -244,8 +245,7 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
         hipLaunchKernelGGL((softrod_octo_step_kernel<FEATS, MAXW>), grid, block, 0, st, h->P, h->S,     \
                            actions, obs, reward, term, trunc, n_sub, epilogue, pack)
         // the reference shape (two waves per env): four envs per workgroup, partner waves on one SIMD
-        const char* one = std::getenv("SOFTROD_OCTO_ONE_ENV_PER_BLOCK");     // A/B switch for profiling and tests
-        if (zup && h->nw == 2 && !(one && one[0] == '1')) {
+        if (zup && h->nw == 2 && !h->octo_one_env_per_block) {
             hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_OCTO_FLAT | kFeatPlaneZup, 2, 4>),
                                dim3((unsigned)((h->cfg.n_envs + 3) / 4)), dim3(kLanes * 8), 0, st, h->P, h->S,
                                actions, obs, reward, term, trunc, n_sub, epilogue, pack);
@@ -368,6 +368,11 @@ void config_common(softrod_config* cfg, int n_envs) {
 extern "C" {
 
 int softrod_abi_version(void) { return SOFTROD_ABI_VERSION; }
+
+#ifndef SOFTROD_SOURCE_HASH
+#define SOFTROD_SOURCE_HASH "unhashed"
+#endif
+const char* softrod_source_hash(void) { return SOFTROD_SOURCE_HASH; }
 
 int softrod_action_dim(int env_kind) {
     return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 2 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 7
@@ -577,6 +582,8 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         h->nw = (cfg->n_arm * h->P.seg + kLanes - 1) / kLanes;
         h->init_stride = (size_t)cfg->n_arm * 18 + 2;
     }
+    if (const char* one = std::getenv("SOFTROD_OCTO_ONE_ENV_PER_BLOCK"))   // A/B switch for profiling and tests
+        h->octo_one_env_per_block = one[0] == '1';
     {   // two-window form: ArmSingle with the e_z contact, 64..102 elements
         const int halo = kLanes - (cfg->n_elem + 2) / 2;     // the narrower of the two halos
         const char* off = std::getenv("SOFTROD_NO_WINDOW");  // A/B switch for profiling and tests

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 11
+#define SOFTROD_ABI_VERSION 12
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -478,6 +478,12 @@ int softrod_last_kernel_ms(softrod_handle* h, float* ms);
 const char* softrod_last_error(softrod_handle* h);
 int softrod_destroy(softrod_handle* h);
 int softrod_abi_version(void);
+/* First 16 hex digits of the SHA-256 over the sources this library was built from (csrc/*.hpp in
+ * name order, softrod_capi.hip, include/softrod.h; the Makefile passes it as SOFTROD_SOURCE_HASH).
+ * Profiles record it, and bench.py refuses to price a kernel against instruction counts / traffic
+ * measured on a different build (profiles/valu_counts.json, hbm_traffic.json).  No reference
+ * counterpart: measurement plumbing.                                                            */
+const char* softrod_source_hash(void);
 
 #ifdef __cplusplus
 }

