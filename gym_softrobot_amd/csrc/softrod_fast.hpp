@@ -646,7 +646,12 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
                     const int end = ProgressPriority::bound(n_sub - 1, q);
                     for (; s < end; ++s) {
                         planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
+#ifdef SOFTROD_DIAG_TWO_HALF_STEPS
+                        planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
+                        planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
+#else
                         planar_kinematic_n<EPL>(step_dt, K.hq_dt, C, K, Z);
+#endif
                     }
                 }
             }

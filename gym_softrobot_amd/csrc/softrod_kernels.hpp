@@ -578,7 +578,14 @@ __device__ __forceinline__ void laplace_filter_rates_fast(const RodParams& P, in
 // ---- SOFTROD_MATH_FAST primitives (softrod_fast.hpp explains where they are used) ----
 // 1/x: v_rcp_f64 seed (2^-23) + one third-order correction r (1 + e + e^2), e = 1 - x r:
 // relative error e^3 ~ 2^-69 before the final rounding.
+//
+// Diagnostic builds (tools/fastmath_cost.sh; never the shipped library): SOFTROD_DIAG_IEEE_DIV
+// replaces both by the correctly rounded IEEE division / square root, to measure what the
+// third-order forms cost in parity horizon ("fast-math cost").
 __device__ __forceinline__ double fast_rcp(double x) {
+#ifdef SOFTROD_DIAG_IEEE_DIV
+    return 1.0 / x;
+#endif
     const double r = __builtin_amdgcn_rcp(x);
     const double e = fma(-x, r, 1.0);
     return fma(r, fma(e, e, e), r);
@@ -586,6 +593,9 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // 1/sqrt(x): v_rsq_f64 seed + one third-order correction: with r = (1 + d)/sqrt(x),
 // e = 1/2 - x r^2/2 = -(d + d^2/2) and 1 + e + 3/2 e^2 = 1/(1 + d) + O(d^3).
 __device__ __forceinline__ double fast_rsqrt(double x) {
+#ifdef SOFTROD_DIAG_IEEE_DIV
+    return 1.0 / sqrt(x);
+#endif
     const double r = __builtin_amdgcn_rsq(x);
     const double e = fma(-(0.5 * x) * r, r, 0.5);
     return fma(r, e * fma(1.5, e, 1.0), r);

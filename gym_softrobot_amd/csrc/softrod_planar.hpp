@@ -42,6 +42,19 @@
 //   * the Taylor coefficients are handed to the compiler as opaque registers: as immediates it
 //     turns every Horner step into v_mov + v_fmac instead of one v_fma;
 //   * 1/x and 1/sqrt(x) take one third-order correction of the 2^-23 hardware seed.
+//
+// Diagnostic builds (tools/fastmath_cost.sh -> variants/, never the shipped library) undo ONE of
+// these reformulations each, so that its share of the parity horizon can be measured on the
+// stabilised inverted pendulum (DESIGN.md §3 "fast-math cost"):
+//   SOFTROD_DIAG_IEEE_DIV          IEEE 1/x and 1/sqrt(x) instead of the refined seeds
+//   SOFTROD_DIAG_LIBM_TRIG         libm sin / cos / exp instead of the range-checked polynomials
+//   SOFTROD_DIAG_RECOMPUTE_EDGES   edge vectors from the node positions every substep (as the
+//                                  reference does) instead of integrating them with v_{k+1} - v_k
+//   SOFTROD_DIAG_RECOMPUTE_ANGLE   bending angle from the directors (atan2) every substep instead
+//                                  of integrating it with the rotation-rate difference
+//   SOFTROD_DIAG_TWO_HALF_STEPS    two kinematic half steps between force evaluations, as
+//                                  PositionVerlet takes them, instead of one merged step
+//   SOFTROD_DIAG_NO_PLANAR         never take this path: the general 3-D fast loop steps the rod
 #pragma once
 
 namespace softrod {
@@ -116,6 +129,9 @@ __device__ __forceinline__ void planar_build_const(const RodParams& P, const Con
 // exp(x) for the damper (see exp_pair)
 template <int EPL>
 __device__ __forceinline__ double exp_one(const PlanarC<EPL>& K, double x) {
+#ifdef SOFTROD_DIAG_LIBM_TRIG
+    return exp(x);
+#endif
     if (__builtin_expect(!wave_any(!(fabs(x) < 1.0e-3)), 1))      // (the hint keeps the in-range path the fall-through)
         return fma(x, fma(x, fma(x, fma(x, K.e4, K.e3), 0.5), 1.0), 1.0);
     int k = 0;
@@ -173,6 +189,9 @@ __device__ __forceinline__ bool planar_from_lane(const RodParams& P, const BcTar
             Z.dl[s] = vor_valid ? atan2(sinD, cosD) : 0.0;
         }
     }
+#ifdef SOFTROD_DIAG_NO_PLANAR
+    return false;
+#endif
     return !__any(!ok);
 }
 
@@ -233,6 +252,12 @@ __device__ __forceinline__ void planar_kinematic_n(double h, const double (&hq_h
         ra[s] = a;
         const double t = a * a;
         double sc, cs;
+#ifdef SOFTROD_DIAG_LIBM_TRIG
+        cs = cos(a);
+        const double sn = sin(a);
+        sc = 0.0;
+        (void)sc;
+#else
         if (__builtin_expect(!wave_any(t >= 1.0e-3), 1)) {      // sinc_cosc's range, on the opaque coefficients; the
             sc = fma(t, fma(t, fma(t, K.s3, K.s2), K.s1), 1.0);       // cosine directly (t^4/8! < 3e-17)
             cs = fma(t, fma(t, fma(t, K.c3, K.c2), -0.5), 1.0);
@@ -242,6 +267,7 @@ __device__ __forceinline__ void planar_kinematic_n(double h, const double (&hq_h
             cs = fma(-cc, t, 1.0);
         }
         const double sn = sc * a;
+#endif
         // both products of the old c first, so that c and s are then updated in place
         const double p = cs * Z.c[s], q = sn * Z.c[s];
         Z.c[s] = fma(-sn, Z.s[s], p);
@@ -252,6 +278,30 @@ __device__ __forceinline__ void planar_kinematic_n(double h, const double (&hq_h
     shift_next<EPL>(ra, ran);
 #pragma unroll
     for (int s = 0; s < EPL; ++s) Z.dl[s] += ran[s] - ra[s];
+#ifdef SOFTROD_DIAG_RECOMPUTE_EDGES
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        double a[EPL], o[EPL];
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) a[s] = Z.x[s][c];
+        shift_next<EPL>(a, o);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) Z.d[s][c] = o[s] - a[s];
+    }
+#endif
+#ifdef SOFTROD_DIAG_RECOMPUTE_ANGLE
+    {
+        double cnx[EPL], snx[EPL];
+        shift_next<EPL>(Z.c, cnx);
+        shift_next<EPL>(Z.s, snx);
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            const double sinD = fma(snx[s], Z.c[s], -cnx[s] * Z.s[s]);
+            const double cosD = fma(cnx[s], Z.c[s], snx[s] * Z.s[s]);
+            Z.dl[s] = atan2(sinD, cosD);      // (finite on invalid slots; their stiffness is zero)
+        }
+    }
+#endif
 }
 
 // dynamic_n for SOFTROD_FEATURES_SOFTPENDULUM (gravity and the point force live in C.ca,

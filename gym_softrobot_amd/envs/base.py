@@ -100,8 +100,7 @@ class VecRodEnvBase:
             raise ValueError("autoreset must be False, True/'host' or 'device'")
         self.device_autoreset = autoreset == "device"
         self.autoreset = bool(autoreset) and not self.device_autoreset
-        self.queue_depth = 32
-        self.top_up_every = self.queue_depth - 2   # deadline in steps; see _top_up_tick
+        self._queue_depth = 32             # fixed once the device queue exists (queue_depth property)
         self.action_dim = _capi.config_action_dim(cfg)
         self.obs_dim = _capi.config_obs_dim(cfg)
         self.n_action = self.action_dim
@@ -131,6 +130,30 @@ class VecRodEnvBase:
         # `record_envs` set before reset).
         self.record_envs = (0,)
         self.recorder = None
+
+    @property
+    def queue_depth(self) -> int:
+        """Staged reset records per env (device auto-reset).  Read-only once the device queue has
+        been allocated: the top-up deadline below is derived from it."""
+        return self._queue_depth
+
+    @queue_depth.setter
+    def queue_depth(self, depth: int) -> None:
+        if self.device_autoreset:
+            raise AttributeError("queue_depth is fixed once device-side auto-reset is enabled")
+        if int(depth) < 4:
+            raise ValueError("queue_depth must be at least 4")
+        self._queue_depth = int(depth)
+
+    @property
+    def top_up_every(self) -> int:
+        """Deadline of the non-blocking top-up in steps (see _top_up_tick).  An env uses at most
+        one record per two steps, so between a reading of the counters and the end of the NEXT
+        top-up (< 2 * top_up_every steps) it uses at most top_up_every records, which must stay
+        below the queue_depth - 1 records that are certainly staged at the reading."""
+        every = self._queue_depth - 2
+        assert 2 * every - 1 <= 2 * (self._queue_depth - 1)
+        return every
 
     # -- hooks ---------------------------------------------------------------------
     def _reset_backend(self, mask: np.ndarray, use_mask: bool, draws: Optional[dict] = None) -> None:

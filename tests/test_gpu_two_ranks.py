@@ -1,0 +1,100 @@
+"""BASELINE configs[3] / configs[4] in their stated form — a batch SHARDED over ranks — on the real HIP
+backend (VERDICT r2 "weak" #3, "next" #1).  The pool's box has ONE GPU and RCCL refuses two ranks on
+one device, so the two ranks share cuda:0 and the packed rows travel over gloo
+(SOFTROD_BENCH_ALL_RANKS_ON_DEVICE0=1, SOFTROD_BENCH_DIST_BACKEND=gloo): self-launch, sharding, the
+kernel-packed rows, the overlapped all-gather buffers, device-side auto-reset across ranks and the
+rank-0 JSON relay all run on real kernels with two real processes.  What stays for an 8-GPU node:
+RCCL's own transport between DIFFERENT devices (xGMI) — tests/test_gpu_rccl.py runs RCCL in a world
+of one."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+TWO_ON_ONE = {"SOFTROD_BENCH_ALL_RANKS_ON_DEVICE0": "1", "SOFTROD_BENCH_DIST_BACKEND": "gloo"}
+
+
+def _bench(extra_env, *args, timeout=900):
+    """`python bench.py ...` exactly as the driver calls it: no torchrun around it, no WORLD_SIZE."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", *args], env=env,
+                         capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_pair(two, one, total, steps):
+    for d, n in ((two, 2), (one, 1)):
+        assert d["n_gpus"] == n and d["steps"] == steps and d["value"] > 0 and d["data"] == "synthetic"
+        assert d["config"]["envs_total"] == total
+    assert two["scaling"] == "weak" and "all_gather" in two["config"]["sharding"]
+    # same envs, same actions, same number of steps: the rows of BOTH ranks reached rank 0 and hold
+    # exactly what one process stepping the whole batch returns
+    assert two["config"]["last_step_checksum"] == one["config"]["last_step_checksum"]
+    assert two["config"]["non_finite_envs_at_end"] == one["config"]["non_finite_envs_at_end"]
+
+
+def test_bench_two_ranks_softpendulum(hip_lib):
+    """configs[3]'s shape at world 2: 2 x 2048 envs against 1 x 4096."""
+    a = ("--steps", "12", "--warmup", "2")
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "2048", *a)
+    one = _bench({}, "--gpus", "1", "--envs-per-gpu", "4096", *a)
+    _check_pair(two, one, 4096, 12)
+    assert two["windows"]["count"] == one["windows"]["count"] == 3
+    assert one["roofline"]["frac"] is None or 0.2 < one["roofline"]["frac"] < 1.0
+
+
+def test_bench_two_ranks_octoflat(hip_lib):
+    """configs[4]'s shape at world 2: 2 x 512 OctoFlat envs (8 arms + head each) against 1 x 1024."""
+    a = ("--env", "OctoFlat-v0", "--steps", "3", "--warmup", "1", "--windows", "1", "--preheat", "5")
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "512", *a)
+    one = _bench({}, "--gpus", "1", "--envs-per-gpu", "1024", *a)
+    _check_pair(two, one, 1024, 3)
+
+
+def test_bench_two_ranks_device_autoreset_across_the_shard_boundary(hip_lib):
+    """140 steps: every env is truncated on step 126 and restarts on 127 from its staged record, on
+    both ranks; the restarted envs' rows are gathered like any other."""
+    a = ("--steps", "140", "--warmup", "2", "--autoreset", "device", "--preheat", "10")
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "1024", *a)
+    one = _bench({}, "--gpus", "1", "--envs-per-gpu", "2048", *a)
+    _check_pair(two, one, 2048, 140)
+    assert two["config"]["autoreset"] == "device"
+    assert two["config"]["episode_restarts_not_counted"] == one["config"]["episode_restarts_not_counted"] >= 2048
+
+
+def _worker(*args, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", str(ROOT / "tests" / "two_rank_hip_worker.py"), *args]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert "TWO-RANK-OK" in out.stdout, out.stdout[-2000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("env_id,per,t1,t2", [("SoftPendulum-v0", 96, 5, 6), ("SoftPendulum3D-v0", 32, 3, 3),
+                                               ("OctoArmSingle-v0", 16, 2, 2), ("OctoFlat-v0", 6, 2, 2)])
+def test_sharded_env_two_hip_ranks_with_a_masked_reset_mid_rollout(hip_lib, env_id, per, t1, t2):
+    """ShardedVecEnv(overlap=True) over two HIP ranks, a masked reset between two stretches of steps
+    (envs on both sides of the shard boundary), every gathered step bit-equal to one process."""
+    _worker(env_id, str(per), str(t1), str(t2))
+
+
+def test_sharded_env_two_hip_ranks_device_autoreset(hip_lib):
+    """Device-side NEXT_STEP auto-reset on both ranks (3-step episodes, so every env restarts several
+    times) against ONE process with host-driven auto-reset: the same draws, the same rows."""
+    out = _worker("SoftPendulum-v0", "64", "7", "8", "device")
+    flagged = int(out.split("flagged=")[1].split()[0])
+    assert flagged >= 128 * 3

@@ -203,9 +203,44 @@ def run_octo(n, steps, amax, window):
             "curves": {k: [float(f"{v:.3e}") for v in curves[k]] for k in ("gpu_obs", "gpu_reward", "ctl_obs", "ctl_reward")}}
 
 
+def pd_script(n):
+    """The stabilising PD law on the ORACLE's observation (all paths get its numbers)."""
+    st = {"prev": None}
+
+    def pd(t, obs):
+        x, v, th = obs[:, 0].astype(np.float64), obs[:, 1].astype(np.float64), obs[:, 3].astype(np.float64)
+        dth = np.zeros_like(th) if st["prev"] is None or t == 0 else (th - st["prev"]) / 0.04
+        st["prev"] = th.copy()
+        return np.clip(100.0 * th + 20.0 * dth + 10.0 * x + 8.0 * v, -22, 22).astype(np.float32)[:, None]
+    return pd
+
+
+def pd_horizons(n=8):
+    """`--pd-horizons`: the stabilised inverted pendulum (126 steps) on the LOADED library
+    (SOFTROD_HIP_LIB selects a diagnostic build of tools/fastmath_cost.sh) in both math modes:
+    env.steps within 1e-5 of the oracle, next to the control's.  One JSON object on stdout."""
+    from gym_softrobot_amd import _capi
+
+    out = {"library": str(_capi.library_path()), "library_source_hash": _capi.library_source_hash(), "envs": n}
+    for name, mode in (("fast", _capi.MATH_FAST), ("libm", _capi.MATH_LIBM)):
+        r = run("SoftPendulum-v0", n, 126, pd_script(n), with_control=(name == "fast"), math_mode=mode)
+        out[name] = {"steps_within_1e-5": r["steps_within_1e-5"]["gpu"], "max": r["max"]["gpu_obs"],
+                     "at_steps": {k: max(v["gpu_obs"], v["gpu_reward"]) for k, v in r["at_steps"].items()}}
+        if name == "fast":
+            out["control"] = {"steps_within_1e-5": r["steps_within_1e-5"]["ctl"], "max": r["max"]["ctl_obs"],
+                              "at_steps": {k: max(v["ctl_obs"], v["ctl_reward"]) for k, v in r["at_steps"].items()}}
+    print(json.dumps(out))
+
+
 def main():
+    if "--pd-horizons" in sys.argv:
+        return pd_horizons()
+    from gym_softrobot_amd import _capi
+
+    LIBM = dict(math_mode=_capi.MATH_LIBM)
     doc = {"metric": "max over envs and entries of |a - oracle| / (|oracle| + 1e-3); gpu = HIP path, ctl = the same "
                      "oracle source built with FMA contraction (rounding control); tests assert 1e-5 (north_star)",
+           "library_source_hash": _capi.library_source_hash(),
            "scenarios": {}}
     S = doc["scenarios"]
     n = 8
@@ -226,15 +261,22 @@ def main():
         S[f"SoftPendulum-v0, 126 steps, {name}"] = run("SoftPendulum-v0", n, 126, script)
         st["prev"] = None
         S[f"SoftPendulum-v0, 126 steps, {name}, re-synchronised every 5 steps"] = run("SoftPendulum-v0", n, 126, script, window=5)
+        # the libm kernel (SOFTROD_MATH_LIBM: the substep as PyElastica writes it) over the same episode
+        st["prev"] = None
+        S[f"SoftPendulum-v0, 126 steps, {name}, libm kernel"] = run("SoftPendulum-v0", n, 126, script, with_control=False, **LIBM)
     rnd1 = rng.uniform(-1, 1, (125, n, 2)).astype(np.float32)
     S["SoftPendulum3D-v0, 125 steps, random +-1"] = run("SoftPendulum3D-v0", n, 125, lambda t, o: rnd1[t])
     S["SoftPendulum3D-v0, 125 steps, random +-1, re-synchronised every 5 steps"] = run(
         "SoftPendulum3D-v0", n, 125, lambda t, o: rnd1[t], window=5)
+    S["SoftPendulum3D-v0, 125 steps, random +-1, libm kernel"] = run(
+        "SoftPendulum3D-v0", n, 125, lambda t, o: rnd1[t], with_control=False, **LIBM)
     m = 4
     rnd6 = rng.uniform(-6, 6, (201, m, 7)).astype(np.float32)
     S["OctoArmSingle-v0, 201 steps (to truncation), random +-6"] = run("OctoArmSingle-v0", m, 201, lambda t, o: rnd6[t])
     S["OctoArmSingle-v0, 201 steps, random +-6, re-synchronised every 5 steps"] = run(
         "OctoArmSingle-v0", m, 201, lambda t, o: rnd6[t], window=5)
+    S["OctoArmSingle-v0, 201 steps (to truncation), random +-6, libm kernel"] = run(
+        "OctoArmSingle-v0", m, 201, lambda t, o: rnd6[t], with_control=False, **LIBM)
     S["OctoFlat-v0, 36 steps of 2857 substeps (to truncation), random +-22, re-synchronised before every step"] = run_octo(4, 36, 22.0, 1)
     S["OctoFlat-v0, 36 steps, random +-5 (gentle), re-synchronised before every step"] = run_octo(4, 36, 5.0, 1)
     S["OctoFlat-v0, 8 steps, random +-22, free-running"] = run_octo(4, 8, 22.0, 0)
