@@ -30,7 +30,7 @@ substeps x 2*(18n+6)*8 B / kernel time), which a fused kernel exceeds by constru
 
 Clock: the first launches after an idle period run at a lower shader clock (0.38 -> 0.30 ms over
 ~20 launches).  Before the declared warm-up an un-timed PRE-HEAT steps a scratch batch of the same
-shape until the HIP-event kernel time has stopped falling (cap 60 launches); the measured batch is
+shape until the HIP-event kernel time has stopped falling (cap 150 launches); the measured batch is
 untouched by it, so the timed window stays inside one episode.  `steps`/`warmup` echo the
 arguments; when warm-up + 3 windows of K steps fit one episode (120 steps) three consecutive
 windows of K steps are timed, each bracketed like the contract says, and `value` / `ms_per_step`
@@ -166,7 +166,7 @@ def parse_args(argv=None):
     ap.add_argument("--windows", type=int, default=0,
                     help="timed windows of --steps steps each (value = the median window); 0 (default): 3 if "
                          "warmup + 3*steps <= 120 (one SoftPendulum episode), else as many as fit, at least 1")
-    ap.add_argument("--preheat", type=int, default=60,
+    ap.add_argument("--preheat", type=int, default=150,
                     help="cap of the un-timed pre-heat launches on a scratch batch (0 = none)")
     return ap.parse_args(argv)
 
@@ -260,31 +260,33 @@ def useful_lane_fraction(cfg, octo: bool, n_waves: int) -> float:
 
 def preheat(make_scratch, acts_dev, cap: int):
     """Un-timed launches on a SCRATCH batch of the measured shape until the step kernel's HIP-event
-    duration has stopped falling: groups of 5 launches, settled when a group's mean is within 1 %
-    of (or above) the previous group's; at least 10, at most `cap` launches.  The scratch batch
-    stays allocated until the end of the run (no hipFree in front of the timed region)."""
+    duration has stopped falling: groups of G = 10 launches, settled when a group's mean is within
+    0.5 % of (or above) the previous group's (the ramp observed on the pool's boxes falls by 1-5 %
+    per ten launches for the first 50-80); at least 20, at most `cap` launches.  The scratch
+    batch stays allocated until the end of the run (no hipFree in front of the timed region)."""
     import numpy as np
 
-    if cap < 5:
+    G = 10
+    if cap < G:
         return None, {"launches": 0}
     scratch = make_scratch()
     scratch.reset(seed=10_000_019)
     be = scratch.backend
     groups, n = [], 0
-    while n + 5 <= cap:
-        be.set_timing(5)
-        for k in range(5):
+    while n + G <= cap:
+        be.set_timing(G)
+        for k in range(G):
             scratch.step(acts_dev[(n + k) % acts_dev.shape[0]])
         kt = be.kernel_times_ms()
-        n += 5
+        n += G
         groups.append([float(x) for x in kt])
-        if len(groups) >= 2 and np.mean(groups[-1]) >= 0.99 * np.mean(groups[-2]):
+        if len(groups) >= 2 and np.mean(groups[-1]) >= 0.995 * np.mean(groups[-2]):
             break
     be.set_timing(0)
     flat = [x for g in groups for x in g]
     return scratch, {"launches": n, "first_kernel_ms": flat[0], "settled_kernel_ms": float(np.mean(groups[-1])),
                      "group_means_ms": [float(np.mean(g)) for g in groups],
-                     "settled": bool(len(groups) >= 2 and np.mean(groups[-1]) >= 0.99 * np.mean(groups[-2])),
+                     "settled": bool(len(groups) >= 2 and np.mean(groups[-1]) >= 0.995 * np.mean(groups[-2])),
                      "what": "scratch batch of the same env/size, random actions, not the measured batch"}
 
 

@@ -157,6 +157,8 @@ void fill_params(const softrod_config& c, RodParams& P) {
     P.eps_rot_axis = c.eps_rot_axis;
     P.acos_shift = c.acos_shift;
     P.eps_sin = c.eps_sin;
+    P.two_acos_shift = 2.0 * c.acos_shift + 1.0e-200;
+    P.neg_eps_sin = -c.eps_sin;
     P.base_limit = c.base_limit;
     P.step_time = (double)c.n_substeps * c.dt;  // step_skip * time_step, soft_pendulum_3d.py:110-112
     P.base_step = (float)c.base_step;

@@ -139,6 +139,22 @@ __device__ __forceinline__ double theta_over_sin(double y, bool valid_lane) {
     return g;
 }
 
+// The reference divides by sin(theta + 1e-14) (PyElastica _inv_rotate; softrod_config.eps_sin):
+//   theta / sin(theta + d) = (theta / sin theta) (1 - d cot theta + O(d^2)),
+//   cot theta = (1 - 2y) / (2 sqrt(y (1 - y))).
+// For a nearly straight joint theta is the 1.4e-5 that the `- 1e-10` inside arccos leaves, so the
+// term is a relative 7e-10 on kappa — a systematic change of the bending stiffness, not a
+// rounding: without it the stabilised inverted pendulum leaves 1e-5 after 89 env.steps instead of
+// the 107 that two roundings of the same algorithm reach (profiles/r3_fastmath_cost.json).  The
+// raw 2^-23 hardware seed of 1/sqrt is enough (the term itself is < 1e-9).
+__device__ __forceinline__ double eps_sin_factor(double y, double eps_sin) {
+#ifdef SOFTROD_DIAG_NO_EPS_SIN
+    return 1.0;
+#endif
+    const double rho = __builtin_amdgcn_rsq(fmax(fma(-y, y, y), 1.0e-300));      // 2 / sin(theta)
+    return fma(fma(y, eps_sin, -0.5 * eps_sin), rho, 1.0);
+}
+
 // exp(x) for the damper: |x| < 1e-3 -> degree-4 Taylor (remainder x^5/120 < 1e-17);
 // larger |x| (strong damping constants) are halved k times and squared back.
 __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid_lane, double& e0, double& e2) {
@@ -289,7 +305,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
 #undef SR_RD
 #undef SR_RD_SUB
         const double y = fma(-0.25, trace, 0.75 + 0.5 * P.acos_shift);
-        const double gk = theta_over_sin(y, vor_valid) * (-0.5 * P.inv_rest_vor);
+        const double gk = theta_over_sin(y, vor_valid) * eps_sin_factor(y, P.eps_sin) * (-0.5 * P.inv_rest_vor);
         const double k0 = vec0 * gk, k1 = vec1 * gk, k2 = vec2 * gk;
         const double vd = (len_n[s] + len[s]) * (0.5 * P.inv_rest_vor);
         const double rvd = fast_rcp(vd);
@@ -576,6 +592,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     load_lane<EPL, F>(S, N, rod, lane, L);
     SR_PHASE(1);
     if (has<F>(P, SOFTROD_FEAT_LAPLACE_FILTER)) sanitize_unused_rates<EPL>(P, lane, L);
+    if (has<F>(P, SOFTROD_FEAT_PLANE_CONTACT_ANISO)) sanitize_unused_slots<EPL>(P, lane, L);
     BcTargets B;
     load_bc(S, N, rod, B);
     load_suckers<F>(P, S, N, rod, B);

@@ -74,6 +74,7 @@ struct RodParams {
     double damp_r[3];                // exp(-nu*dt*m_e/J_i)
     double damp_logr[3];             // -nu*dt*m_e/J_i  (fast path: exp(e*logr))
     double eps_length, eps_rot_axis, acos_shift, eps_sin;
+    double two_acos_shift, neg_eps_sin;   // 2 acos_shift + 1e-200, -eps_sin (host-computed: the planar loop holds them in SGPRs)
     double base_limit, step_time;    // SoftPendulum3D set_action
     float base_step, control_penalty_coeff;
     // OctoArmSingle-v0
@@ -566,6 +567,26 @@ __device__ __forceinline__ void sanitize_unused_rates(const RodParams& P, int la
             L.v[s][c] = (idx <= P.n_elem) ? L.v[s][c] : 0.0;
             L.w[s][c] = (idx < P.n_elem) ? L.w[s][c] : 0.0;
         }
+    }
+}
+
+// Kernel entry, SOFTROD_FEAT_PLANE_CONTACT_ANISO (fast math): the contact law keeps its masks as factors
+// that vanish off the rod (zero normal force -> zero friction) instead of selects, and the slot
+// past the last element feeds the tip node's element -> node average: a non-finite value written
+// into the unused slots through the state view would turn those zero factors into NaN (0 x NaN).
+// Positions, directors past the rod's end that are not finite become 0, the rates there exact zeros.
+template <int EPL>
+__device__ __forceinline__ void sanitize_unused_slots(const RodParams& P, int lane, LaneN<EPL>& L) {
+    sanitize_unused_rates<EPL>(P, lane, L);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = slot_local(P, lane * EPL + s);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            L.x[s][c] = (idx <= P.n_elem || fabs(L.x[s][c]) <= 1.0e300) ? L.x[s][c] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+            L.Q[s][c] = (idx < P.n_elem || fabs(L.Q[s][c]) <= 1.0e300) ? L.Q[s][c] : 0.0;
     }
 }
 

@@ -251,6 +251,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
 
     LaneN<1> L;
     load_lane<1, F>(S, NR, row, lane, L);
+    sanitize_unused_slots<1>(P, tid, L);        // ghost slots between the arms (softrod_kernels.hpp)
     HeadState H;
     double tgt[2];
     load_head(S, N, env, H, tgt);

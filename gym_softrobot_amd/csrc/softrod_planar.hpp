@@ -26,6 +26,12 @@
 // from the directors every substep through sin D, cos D and the theta/sin(theta) series.  The
 // reference's `- 1e-10` inside arccos turns theta^2 into D^2 + 2e-10, i.e. multiplies kappa by
 // (sin D / D)(theta / sin theta) = 1 + 1e-10/3 + O(1e-10 D^2); that constant factor is kept.
+// Its `+ 1e-14` inside the sine (theta / sin(theta + 1e-14), softrod_config.eps_sin) multiplies
+// kappa by 1 - 1e-14 cot(theta) = 1 - 1e-14 / sqrt(D^2 + 2e-10) to 1e-16: up to 7e-10 for a nearly
+// straight joint, a SYSTEMATIC change of the bending stiffness.  It is applied (one raw v_rsq_f64
+// seed and two FMAs per substep: the term is < 1e-9, so 2^-23 of it is nothing) — without it the
+// stabilised inverted pendulum leaves the 1e-5 tolerance after 89 env.steps instead of 107
+// (profiles/r3_fastmath_cost.json; every other reformulation in this file costs no horizon).
 //
 // The step kernel takes this path only if the loaded state IS planar (planar_from_lane:
 // exact zeros where the argument above needs them, d1 consistent with d3 to 1e-12); any
@@ -55,6 +61,7 @@
 //   SOFTROD_DIAG_TWO_HALF_STEPS    two kinematic half steps between force evaluations, as
 //                                  PositionVerlet takes them, instead of one merged step
 //   SOFTROD_DIAG_NO_PLANAR         never take this path: the general 3-D fast loop steps the rod
+//   SOFTROD_DIAG_NO_EPS_SIN        drop the sin(theta + eps_sin) term (what rounds 1 and 2 shipped)
 #pragma once
 
 namespace softrod {
@@ -77,11 +84,13 @@ struct PlanarC {
     double cfy[EPL], cay[EPL];     // C.cf, C.ca[1] with node 0 (v_y pinned) zeroed
     double cwl[EPL];               // C.cw01 / rest_len:   cw01 * e = cwl * len
     double bk[EPL];                // C.b01 * kappa scale * (2 rest_vor)^3:  B kappa / vd^3 = bk D / (l + l+)^3
+    double bke[EPL];               // -eps_sin * bk: the sin(theta + eps_sin) term, bk (1 - eps_sin / theta) = bk + bke / theta
     double xl[EPL];                // damp_logr / rest_len:  e * logr = xl * len  (0 on invalid slots)
     double hq_dt[EPL], hq_hdt[EPL];  // C.hq * dt, C.hq * dt/2
     double jr;                     // J * rest_len:          J / e = jr / len
     double s3, s2, s1, c3, c2, e4, e3;
     double eps_length, rest_len, damp_t;   // RodParams values the loop uses (see uniform_k)
+    double two_shift;                      // 2 acos_shift (+ a denormal guard): theta^2 = D^2 + two_shift
 };
 
 __device__ __forceinline__ double opaque_s(double k) { asm("" : "+s"(k)); return k; }
@@ -111,6 +120,7 @@ __device__ __forceinline__ void planar_build_const(const RodParams& P, const Con
         K.cwl[s] = C.cw01[s] * P.inv_rest_len;
         const double two_vor = 2.0 * P.rest_vor;
         K.bk[s] = C.b01[s] * (P.inv_rest_vor * (1.0 + P.acos_shift * (1.0 / 3.0))) * (two_vor * two_vor * two_vor);
+        K.bke[s] = P.neg_eps_sin * K.bk[s];
         K.xl[s] = (lane * EPL + s) < P.n_elem ? P.damp_logr[0] * P.inv_rest_len : 0.0;
         K.hq_dt[s] = C.hq[s] * P.dt;
         if (EPL > 1) K.hq_dt[s] = opaque_v(K.hq_dt[s]);     // (or it is recomputed in the loop from a spilled dt)
@@ -123,6 +133,7 @@ __device__ __forceinline__ void planar_build_const(const RodParams& P, const Con
     K.eps_length = EPL > 1 ? opaque_v(P.eps_length) : P.eps_length;
     K.rest_len = EPL > 1 ? opaque_v(P.rest_len) : P.rest_len;
     K.damp_t = EPL > 1 ? opaque_v(P.damp_t) : P.damp_t;
+    K.two_shift = EPL > 1 ? opaque_v(P.two_acos_shift) : P.two_acos_shift;
     if (EPL > 1) K.jr = opaque_v(K.jr);
 }
 
@@ -349,7 +360,13 @@ __device__ __forceinline__ void planar_dynamic_n(const RodParams& P, const Const
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         const double rl = rcp3(len_n[s] + len[s]);          // vd = (l + l+) / (2 rest_vor), folded into bk
-        up[s] = (K.bk[s] * Z.dl[s]) * (rl * rl * rl);
+        // 1 - eps_sin / theta with theta^2 = D^2 + 2 acos_shift (see the header)
+#ifdef SOFTROD_DIAG_NO_EPS_SIN
+        const double bg = K.bk[s];
+#else
+        const double bg = fma(K.bke[s], __builtin_amdgcn_rsq(fma(Z.dl[s], Z.dl[s], K.two_shift)), K.bk[s]);
+#endif
+        up[s] = (bg * Z.dl[s]) * (rl * rl * rl);
     }
     {
         double o[EPL];

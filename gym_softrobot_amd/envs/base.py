@@ -100,7 +100,7 @@ class VecRodEnvBase:
             raise ValueError("autoreset must be False, True/'host' or 'device'")
         self.device_autoreset = autoreset == "device"
         self.autoreset = bool(autoreset) and not self.device_autoreset
-        self._queue_depth = 32             # fixed once the device queue exists (queue_depth property)
+        self._queue_depth = self._ring_depth = 32      # (queue_depth / top_up_every properties)
         self.action_dim = _capi.config_action_dim(cfg)
         self.obs_dim = _capi.config_obs_dim(cfg)
         self.n_action = self.action_dim
@@ -123,6 +123,7 @@ class VecRodEnvBase:
         self._popped = np.zeros(self.num_envs, np.int64)     # draws removed from _staged so far
         self._since_top_up = 0
         self._status_in_flight = False
+        self.top_up_paused = False     # True: the caller reads the queue counters and stages records itself (tests)
         if self.device_autoreset:
             self.backend.autoreset_enable(self.queue_depth)
         # soft_pendulum.py:117-126: RodCallBack -> rod_parameters_dict, one sample per env.step.
@@ -133,26 +134,28 @@ class VecRodEnvBase:
 
     @property
     def queue_depth(self) -> int:
-        """Staged reset records per env (device auto-reset).  Read-only once the device queue has
-        been allocated: the top-up deadline below is derived from it."""
+        """Unconsumed reset records the host keeps staged per env (device auto-reset).  May be
+        lowered at any time; it cannot exceed the device ring allocated when the env was built."""
         return self._queue_depth
 
     @queue_depth.setter
     def queue_depth(self, depth: int) -> None:
-        if self.device_autoreset:
-            raise AttributeError("queue_depth is fixed once device-side auto-reset is enabled")
-        if int(depth) < 4:
-            raise ValueError("queue_depth must be at least 4")
-        self._queue_depth = int(depth)
+        depth = int(depth)
+        if depth < 3:
+            raise ValueError("queue_depth must be at least 3")
+        if self.device_autoreset and depth > self._ring_depth:
+            raise ValueError(f"queue_depth {depth} exceeds the device ring ({self._ring_depth} records per env)")
+        self._queue_depth = depth
 
     @property
     def top_up_every(self) -> int:
-        """Deadline of the non-blocking top-up in steps (see _top_up_tick).  An env uses at most
-        one record per two steps, so between a reading of the counters and the end of the NEXT
-        top-up (< 2 * top_up_every steps) it uses at most top_up_every records, which must stay
-        below the queue_depth - 1 records that are certainly staged at the reading."""
-        every = self._queue_depth - 2
-        assert 2 * every - 1 <= 2 * (self._queue_depth - 1)
+        """Deadline of the non-blocking top-up in steps (see _top_up_tick), DERIVED from
+        queue_depth so that the two cannot drift apart: an env uses at most one record per two
+        steps, so between a reading of the counters and the end of the NEXT top-up (fewer than
+        2 * top_up_every steps) it uses at most top_up_every records — fewer than the
+        queue_depth - 1 that are certainly staged at the reading."""
+        every = max(1, self._queue_depth - 2)
+        assert every <= self._queue_depth - 1
         return every
 
     # -- hooks ---------------------------------------------------------------------
@@ -206,6 +209,8 @@ class VecRodEnvBase:
         env uses at most one record per two steps (the step that resets does not also end an
         episode), so between a reading and the end of the NEXT top-up — fewer than
         2 * top_up_every steps — it uses at most top_up_every < queue_depth records."""
+        if self.top_up_paused:
+            return
         self._since_top_up += 1
         due = self._since_top_up >= self.top_up_every
         if self._status_in_flight:

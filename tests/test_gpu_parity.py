@@ -819,7 +819,7 @@ def test_queue_status_without_stalling_the_stream(torch_gpu, hip_lib):
 
     kw = dict(final_time=2e-4, time_step=1e-4, recording_fps=10000, n_elems=10)   # an episode is 3 steps + the resetting one
     env = gsa.make_vec("SoftPendulum-v0", 5, device=0, autoreset="device", **kw)
-    env.top_up_every = 10**9                      # no top-up on the way: the counters are ours to read
+    env.top_up_paused = True                      # no top-up on the way: the counters are ours to read
     env.reset(seed=3)
     b = env.backend
     with pytest.raises(SoftrodError, match="no softrod_queue_status_begin"):
@@ -855,7 +855,7 @@ def test_device_autoreset_underflow_is_reported(torch_gpu, hip_lib):
 
     kw = dict(final_time=1e-4, time_step=1e-4, recording_fps=10000, n_elems=10)   # every step truncates
     env = gsa.make_vec("SoftPendulum-v0", 3, device=0, autoreset="device", **kw)
-    env.top_up_every = 10**9         # never top up on the way
+    env.top_up_paused = True         # never top up on the way
     env.reset(seed=0)
     a = np.zeros(3, np.float32)
     with pytest.raises(SoftrodError, match="no staged record"):
@@ -1211,3 +1211,40 @@ def test_clock_outside_the_general_loops_equals_the_accumulation(torch_gpu, hip_
         r.substeps(0.0, 7)
     np.testing.assert_array_equal(st["time"].cpu().numpy(), np.array([r.time for r in rods]))
     be.close()
+
+
+def test_contact_kernels_ignore_non_finite_padding(torch_gpu, hip_lib):
+    """the fast-math contact law keeps its masks as factors (zero normal force -> zero
+    friction), and the slot past the last element feeds the tip node's average, so NaN / Inf
+    written through the state view into the UNUSED slots of the rows must not reach the rod:
+    OctoArmSingle (one rod per wave) and OctoFlat (ghost slots between the arms) step exactly
+    as they do with clean padding."""
+    import gym_softrobot_amd as gsa
+
+    for env_id, n, amax in (("OctoArmSingle-v0", 3, 6.0), ("OctoFlat-v0", 2, 22.0)):
+        clean = gsa.make_vec(env_id, n, device=0)
+        dirty = gsa.make_vec(env_id, n, device=0)
+        clean.reset(seed=3)
+        dirty.reset(seed=3)
+        st = dirty.backend.state()
+        ne = int(dirty.cfg.n_elem)
+        if env_id == "OctoFlat-v0":
+            seg, na = int(st["arm_stride"]), int(dirty.cfg.n_arm)
+            node_pad = [a * seg + k for a in range(na) for k in range(ne + 1, seg)]
+            elem_pad = [a * seg + k for a in range(na) for k in range(ne, seg)]
+        else:
+            node_pad, elem_pad = list(range(ne + 1, 64)), list(range(ne, 64))
+        bad = torch_gpu.tensor([float("nan"), float("inf"), -float("inf")], dtype=torch_gpu.float64, device=st["position"].device)
+        for name, pad in (("position", node_pad), ("velocity", node_pad), ("omega", elem_pad), ("director", elem_pad)):
+            idx = torch_gpu.tensor(pad, device=st[name].device)
+            st[name][:, :, idx] = bad[torch_gpu.arange(len(pad), device=bad.device) % 3]
+        acts = np.random.default_rng(0).uniform(-amax, amax, (2, n, clean.action_dim)).astype(np.float32)
+        for t in range(2):
+            a = clean.step(acts[t])
+            b = dirty.step(acts[t])
+            torch_gpu.cuda.synchronize()
+            for x, y in zip(a[:4], b[:4]):
+                assert torch_gpu.equal(x, y), (env_id, t)
+            assert bool(torch_gpu.isfinite(a[0]).all())
+        clean.close()
+        dirty.close()

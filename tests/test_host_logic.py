@@ -354,7 +354,10 @@ def test_device_autoreset_host_logic_equals_host_autoreset(oracle_built):
         cfg = _capi.softpendulum_config(n, **kw)
         envs.append(gsa.VecSoftPendulumEnv(n, backend=OracleBackend(cfg), numpy_output=True, autoreset=mode, **kw))
     host, dev = envs
-    dev.queue_depth, dev.top_up_every = 3, 3
+    dev.queue_depth = 3            # top_up_every follows (1): a top-up on every step
+    assert dev.top_up_every == 1
+    with pytest.raises(ValueError):
+        dev.queue_depth = 64       # beyond the device ring
     o1, _ = host.reset(seed=[5, 6, 7])
     o2, _ = dev.reset(seed=[5, 6, 7])
     np.testing.assert_array_equal(o1, o2)

@@ -80,7 +80,8 @@ def main(root):
     fetch, regs = counters(root, "pmc_fetch")
     write, _ = counters(root, "pmc_write")
     sq, _ = counters(root, "pmc_sq")
-    doc["registers"] = regs
+    pmc3, regs3 = counters(root, "pmc3")
+    doc["registers"] = regs or regs3
     if fetch.get("FETCH_SIZE"):
         f = fetch["FETCH_SIZE"]
         doc["FETCH_SIZE_KiB_per_launch_raw"] = sum(f) / len(f)
@@ -94,36 +95,68 @@ def main(root):
         doc["hbm_bytes_per_launch"] = 2.0 * rd + wr  # gfx950 FETCH_SIZE x2 correction
     if sq:
         doc["sq_per_launch"] = {k: sum(v) / len(v) for k, v in sq.items()}
-    for name in ("bench_trace.log", "bench_pmc_fetch.log"):
+    bench = {}
+    for name in ("bench_trace.log", "bench_pmc_fetch.log", "bench_pmc_write.log", "bench_pmc3.log"):
         p = os.path.join(root, name)
         if os.path.exists(p):
             for line in open(p):
                 if line.startswith("{"):
                     try:
                         b = json.loads(line)
+                        bench[name] = b
                         doc.setdefault("bench_lines", {})[name] = {
                             "value": b["value"], "ms_per_step": b["ms_per_step"],
                             "kernel_ms_avg": b["roofline"]["kernel_ms_avg"],
                             "frac": b["roofline"]["frac"],
+                            "library_source_hash": b["config"].get("library_source_hash"),
+                            "preheat_launches": (b.get("preheat") or {}).get("launches"),
+                            "windows": (b.get("windows") or {}).get("count"),
                         }
                     except Exception:  # noqa: BLE001
                         pass
-    # the launches bench.py times are the LAST `steps` ones (the warm-up runs at a lower clock):
-    # their average is the number to hold against roofline.kernel_ms_avg of the same command
+    hashes = {v["config"].get("library_source_hash") for v in bench.values()}
+    doc["library_source_hash"] = hashes.pop() if len(hashes) == 1 else None    # all passes on ONE build, or none
+    any_line = next(iter(bench.values()), None)
+    if any_line:
+        doc["step_kernels_per_env_step"] = 2 if "window" in any_line["roofline"]["kernel"] else 1
+        doc["workload"] = any_line["config"]["workload"]
+        doc["command"] = "rocprofv3 <pass> -- python3 bench.py " + " ".join(sys.argv[2:])
+    # the 3-counter pass (SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE on the same bench.py command): VALU
+    # wave-instructions per rod-substep over ALL step-kernel launches of one env.step (the windowed arm runs
+    # two kernels per step: their sums), and the busy / issue fractions from the profiler's own cycle counter
+    if pmc3.get("SQ_INSTS_VALU") and any_line:
+        units = any_line["roofline"]["rod_substeps_per_launch"]
+        per_step_kernels = 2 if "window" in any_line["roofline"]["kernel"] else 1
+        n = len(pmc3["SQ_INSTS_VALU"]) / per_step_kernels          # env.steps profiled
+        insts = sum(pmc3["SQ_INSTS_VALU"]) / n
+        active = sum(pmc3["SQ_ACTIVE_INST_VALU"]) / n
+        cyc = sum(pmc3["GRBM_GUI_ACTIVE"]) / n / 8.0               # per XCD (the counter sums the 8 XCDs)
+        doc["pmc3"] = {
+            "env_steps_profiled": n, "SQ_INSTS_VALU_per_env_step": insts, "SQ_ACTIVE_INST_VALU_per_env_step": active,
+            "cycles_per_env_step_per_xcd": cyc,
+            "valu_instr_per_rod_substep": insts / units,
+            "valu_busy_frac": active * 4 / (cyc * 1024),
+            "valu_issue_frac_measured_cycles": insts * 4 / (cyc * 1024),
+        }
+    # the launches bench.py times are the LAST windows x steps ones of the trace (pre-heat and warm-up come
+    # first); the window bench.py reports is windows.median_index: its average is the number to hold
+    # against roofline.kernel_ms_avg of the same command
     dur = timed_launches(root)
-    steps = None
-    p = os.path.join(root, "bench_trace.log")
-    if os.path.exists(p):
-        for line in open(p):
-            if line.startswith("{"):
-                try:
-                    steps = int(json.loads(line)["steps"])
-                except Exception:  # noqa: BLE001
-                    pass
-    if dur and steps and len(dur) >= steps:
-        doc["step_kernel_timed_launches"] = steps
-        doc["step_kernel_timed_avg_ms"] = sum(dur[-steps:]) / steps / 1e6
-        doc["step_kernel_warmup_avg_ms"] = (sum(dur[:-steps]) / max(1, len(dur) - steps)) / 1e6
+    b = bench.get("bench_trace.log")
+    if dur and b:
+        per = 2 if "window" in b["roofline"]["kernel"] else 1
+        if per == 2:        # window kernel + epilogue kernel of one env.step: add them up
+            dur = [dur[i] + dur[i + 1] for i in range(0, len(dur) - 1, 2)]
+        steps, R = int(b["steps"]), int((b.get("windows") or {}).get("count", 1))
+        m = int((b.get("windows") or {}).get("median_index", 0))
+        if len(dur) >= steps * R:
+            timed = dur[-steps * R:]
+            wins = [sum(timed[w * steps:(w + 1) * steps]) / steps / 1e6 for w in range(R)]
+            doc["step_kernel_timed_launches"] = steps * R
+            doc["step_kernel_window_avg_ms"] = wins
+            doc["step_kernel_timed_avg_ms"] = wins[m]
+            doc["step_kernel_untimed_avg_ms"] = (sum(dur[:-steps * R]) / max(1, len(dur) - steps * R)) / 1e6
+            doc["bench_kernel_ms_avg_same_run"] = b["roofline"]["kernel_ms_avg"]
     print(json.dumps(doc, indent=1))
 
 
