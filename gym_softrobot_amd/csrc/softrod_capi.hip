@@ -28,6 +28,7 @@ struct softrod_handle {
     int window_refresh = 0;   // > 0: the rod runs on two overlapping wave windows (softrod_window.hpp),
                               // halo refreshed every so many substeps
     bool octo_one_env_per_block = false;  // A/B switch SOFTROD_OCTO_ONE_ENV_PER_BLOCK, read once in softrod_create
+    bool octo_one_wave = false;           // A/B switch SOFTROD_OCTO_ONE_WAVE: softrod_octo1w.hpp (one wave per env, two slots per lane)
     RodParams P{};
     StatePtrs S{};
     double* d_init = nullptr;     // [N][18] staging for reset
@@ -247,6 +248,11 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
         hipLaunchKernelGGL((softrod_octo_step_kernel<FEATS, MAXW>), grid, block, 0, st, h->P, h->S,     \
                            actions, obs, reward, term, trunc, n_sub, epilogue, pack)
         // the reference shape (two waves per env): four envs per workgroup, partner waves on one SIMD
+        if (zup && h->nw == 2 && h->octo_one_wave && h->P.n_arm * h->P.seg == 2 * kLanes && !(h->P.seg & 1)) {
+            hipLaunchKernelGGL((softrod_octo1w_step_kernel<SOFTROD_FEATURES_OCTO_FLAT | kFeatPlaneZup>),
+                               dim3((unsigned)h->cfg.n_envs), dim3(kLanes), 0, st, h->P, h->S,
+                               actions, obs, reward, term, trunc, n_sub, epilogue, pack);
+        } else
         if (zup && h->nw == 2 && !h->octo_one_env_per_block) {
             hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_OCTO_FLAT | kFeatPlaneZup, 2, 4>),
                                dim3((unsigned)((h->cfg.n_envs + 3) / 4)), dim3(kLanes * 8), 0, st, h->P, h->S,
@@ -586,6 +592,8 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     }
     if (const char* one = std::getenv("SOFTROD_OCTO_ONE_ENV_PER_BLOCK"))   // A/B switch for profiling and tests
         h->octo_one_env_per_block = one[0] == '1';
+    if (const char* one = std::getenv("SOFTROD_OCTO_ONE_WAVE"))            // A/B switch (softrod_octo1w.hpp)
+        h->octo_one_wave = one[0] == '1';
     {   // two-window form: ArmSingle with the e_z contact, 64..102 elements
         const int halo = kLanes - (cfg->n_elem + 2) / 2;     // the narrower of the two halos
         const char* off = std::getenv("SOFTROD_NO_WINDOW");  // A/B switch for profiling and tests

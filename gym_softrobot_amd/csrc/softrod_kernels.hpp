@@ -1670,4 +1670,5 @@ softrod_autoreset_kernel(const RodParams P, const StatePtrs S, float* __restrict
 
 #include "softrod_fast.hpp"
 #include "softrod_octo.hpp"
+#include "softrod_octo1w.hpp"
 #include "softrod_window.hpp"

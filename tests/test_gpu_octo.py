@@ -104,6 +104,49 @@ def test_octo_short_steps_match_oracle(torch_gpu, hip_lib, oracle_built, n_sub):
     be.close()
 
 
+def test_octo_one_wave_variant_matches_oracle_and_the_two_wave_kernel(torch_gpu, hip_lib, oracle_built, monkeypatch):
+    """softrod_octo1w.hpp (SOFTROD_OCTO_ONE_WAVE=1 at softrod_create: one wave per env, two slots per
+    lane, no LDS rendezvous) is an A/B variant kept for measurement (profiles/README.md r3c: it loses,
+    11.99 against 9.53 ms).  It must stay CORRECT: 200-substep steps against the oracle at rtol 1e-5,
+    and within rounding of the shipped two-wave kernel (they differ in the order the eight joint
+    loads are summed)."""
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    n, T, n_sub = 4, 3, 200
+    cfg = _capi.octo_flat_config(n)
+    cfg.n_substeps = n_sub
+    two = HipRodBackend(cfg, device=0)
+    monkeypatch.setenv("SOFTROD_OCTO_ONE_WAVE", "1")       # read once, in softrod_create
+    one = HipRodBackend(cfg, device=0)
+    monkeypatch.delenv("SOFTROD_OCTO_ONE_WAVE")
+    tg = _targets(n, 11)
+    oracles = []
+    for be in (one, two):
+        be.reset_octo(tg)
+    for i in range(n):
+        o = oracle_built.OracleOcto(cfg)
+        o.reset(tg[i])
+        oracles.append(o)
+    acts = np.random.default_rng(3).uniform(-22, 22, (T, n, 24)).astype(np.float32)
+    for t in range(T):
+        obs, rew, term, trunc = (x.cpu().numpy().copy() for x in one.step(acts[t]))
+        obs2, rew2, term2, trunc2 = (x.cpu().numpy().copy() for x in two.step(acts[t]))
+        np.testing.assert_allclose(obs, obs2, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(rew, rew2, rtol=1e-6, atol=1e-7)
+        assert (term == term2).all() and (trunc == trunc2).all()
+        for i, o in enumerate(oracles):
+            ob, rw, te, tr = o.env_step(acts[t, i])
+            np.testing.assert_allclose(obs[i], _flat(ob), rtol=RTOL, atol=2e-7)
+            np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-13 / (n_sub * cfg.dt) + 1e-9)
+            assert bool(term[i]) == te and bool(trunc[i]) == tr
+    _compare_state(one, oracles)
+    x1, x2 = one.octo_state_numpy()["x"], two.octo_state_numpy()["x"]
+    np.testing.assert_allclose(x1, x2, rtol=1e-7, atol=1e-9)
+    one.close()
+    two.close()
+
+
 def test_octo_first_full_step_matches_oracle(torch_gpu, hip_lib, oracle_built):
     """Reference configuration: 2857 substeps per env.step from rest, random knots.
 

@@ -15,7 +15,7 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = ("softrod_step_", "softrod_octo_step_")   # softrod_step_window_kernel matches the first
+KERNELS = ("softrod_step_", "softrod_octo_step_", "softrod_octo1w_step_")   # softrod_step_window_kernel matches the first
 
 
 def is_step_kernel(name):
