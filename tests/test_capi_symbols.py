@@ -75,3 +75,36 @@ def test_backend_refuses_to_run_without_gpu():
         gsa.make_vec("SoftPendulum-v0", 2)
     with pytest.raises(_capi.SoftrodError):
         gsa.make("SoftPendulum-v0")
+
+
+def test_library_is_the_build_of_the_sources_on_disk(hip_lib):
+    """softrod_source_hash(): the .so that will travel to the GPU box must be the build of the
+    sources in the tree (a stale binary would be benchmarked against the wrong profile tables and
+    tested against the wrong kernels)."""
+    assert _capi.library_source_hash() == _capi.source_hash(), \
+        "libsoftrod_hip.so is older than csrc/ or include/: run `python __graft_entry__.py build`"
+    assert re.fullmatch(r"[0-9a-f]{16}", _capi.library_source_hash())
+
+
+def test_profile_tables_name_the_build_they_were_measured_on():
+    """Every entry of the tables bench.py prices kernels against carries the source hash of the
+    library it was measured on (tools/update_profile_tables.py); bench.py withholds `frac` when it
+    is not the loaded library's."""
+    import json
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    for name in ("valu_counts.json", "hbm_traffic.json"):
+        doc = json.loads((ROOT / "profiles" / name).read_text())
+        entries = {k: v for k, v in doc.items() if not k.startswith("_")}
+        assert len(entries) == 6, name
+        for k, v in entries.items():
+            assert re.fullmatch(r"[0-9a-f]{16}", v["source_hash"]), (name, k)
+            assert (ROOT / v["source"].split(" ")[0]).exists(), (name, k, v["source"])
+    rec = {"source_hash": "0123456789abcdef", "valu_instr_per_rod_substep": 1.0}
+    assert bench.fresh_or_none(rec, "0123456789abcdef") == (rec, None)
+    stale, why = bench.fresh_or_none(rec, "fedcba9876543210")
+    assert stale is None and "re-run" in why
+    assert bench.fresh_or_none(None, "0123456789abcdef")[0] is None
