@@ -28,6 +28,7 @@ struct softrod_handle {
     int window_refresh = 0;   // > 0: the rod runs on two overlapping wave windows (softrod_window.hpp),
                               // halo refreshed every so many substeps
     bool octo_one_env_per_block = false;  // A/B switch SOFTROD_OCTO_ONE_ENV_PER_BLOCK, read once in softrod_create
+    bool window_paired = true;            // A/B switch SOFTROD_WINDOW_PAIRED=0: one rod per workgroup with s_barrier
     bool octo_one_wave = false;           // A/B switch SOFTROD_OCTO_ONE_WAVE: softrod_octo1w.hpp (one wave per env, two slots per lane)
     RodParams P{};
     StatePtrs S{};
@@ -266,6 +267,11 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     } else if (h->window_refresh > 0 && epilogue) {
         // substeps on two overlapping one-node-per-lane windows, then reward / observation by the
         // two-slot kernel with n_sub = 0 on the same rows (the timing events bracket both)
+        if (h->window_paired)     // four rods per workgroup, a rod's two windows on one SIMD (softrod_window.hpp)
+            hipLaunchKernelGGL((softrod_step_window_kernel<SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup, 4>),
+                               dim3((unsigned)((h->cfg.n_envs + 3) / 4)), dim3(8 * kLanes), 0, st, h->P, h->S, actions,
+                               n_sub, h->window_refresh);
+        else
         hipLaunchKernelGGL((softrod_step_window_kernel<SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup>), grid,
                            dim3(2 * kLanes), 0, st, h->P, h->S, actions, n_sub, h->window_refresh);
         hipLaunchKernelGGL((softrod_step_fast_kernel<SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup,
@@ -592,6 +598,8 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     }
     if (const char* one = std::getenv("SOFTROD_OCTO_ONE_ENV_PER_BLOCK"))   // A/B switch for profiling and tests
         h->octo_one_env_per_block = one[0] == '1';
+    if (const char* one = std::getenv("SOFTROD_WINDOW_PAIRED"))            // A/B switch (softrod_window.hpp)
+        h->window_paired = one[0] != '0';
     if (const char* one = std::getenv("SOFTROD_OCTO_ONE_WAVE"))            // A/B switch (softrod_octo1w.hpp)
         h->octo_one_wave = one[0] == '1';
     {   // two-window form: ArmSingle with the e_z contact, 64..102 elements

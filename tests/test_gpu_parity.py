@@ -960,7 +960,10 @@ def test_arm_single_100_elements_matches_oracle(torch_gpu, hip_lib, oracle_built
 def test_two_window_kernel_for_long_arms(torch_gpu, hip_lib, oracle_built, n_elems, monkeypatch):
     """OctoArmSingle rods of 64..102 elements run on two overlapping one-node-per-lane windows
     (softrod_window.hpp).  Against the oracle, and against the two-slots-per-lane kernel the same
-    rods use when the window form is switched off: the owned halves must not see the halo."""
+    rods use when the window form is switched off: the owned halves must not see the halo.  The
+    shipped form runs FOUR rods per workgroup with a rod's two windows on one SIMD and an LDS counter
+    as the rendezvous; with SOFTROD_WINDOW_PAIRED=0 it is one rod per workgroup with s_barrier —
+    the same arithmetic, so the two must agree bit for bit (3 rods: one slot of the workgroup idles)."""
     from gym_softrobot_amd import _capi
     from gym_softrobot_amd.backend import HipRodBackend
 
@@ -972,7 +975,7 @@ def test_two_window_kernel_for_long_arms(torch_gpu, hip_lib, oracle_built, n_ele
     for r in rods:
         r.reset_arm()
     outs = {}
-    for name, env in (("window", {}), ("two-slot", {"SOFTROD_NO_WINDOW": "1"})):
+    for name, env in (("window", {}), ("barrier", {"SOFTROD_WINDOW_PAIRED": "0"}), ("two-slot", {"SOFTROD_NO_WINDOW": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         be = HipRodBackend(cfg, 0)
@@ -993,6 +996,11 @@ def test_two_window_kernel_for_long_arms(torch_gpu, hip_lib, oracle_built, n_ele
             np.testing.assert_allclose(outs["window"][0][t][1][i], rw, rtol=RTOL, atol=1e-7)
             assert bool(outs["window"][0][t][2][i]) == te and bool(outs["window"][0][t][3][i]) == tr
     sw, ss = outs["window"][1], outs["two-slot"][1]
+    for k in ("x", "v", "w", "Q", "time", "kappa"):
+        np.testing.assert_array_equal(sw[k], outs["barrier"][1][k], err_msg=f"paired vs barrier window form: {k}")
+    for a, b in zip(outs["window"][0], outs["barrier"][0]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
     for i, r in enumerate(rods):
         np.testing.assert_allclose(sw["x"][i], r.get("x"), rtol=RTOL, atol=1e-7)
         np.testing.assert_allclose(sw["Q"][i], r.get("Q"), rtol=RTOL, atol=1e-6)
