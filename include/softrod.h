@@ -428,7 +428,13 @@ int softrod_step_packed(softrod_handle* h, const float* actions, float* packed,
  *                              event only (work enqueued after _begin keeps the GPU busy
  *                              meanwhile).  The values are as of _begin, which is safe:
  *                              consumed only grows, so a top-up computed from them stages
- *                              at most what fits
+ *                              at most what fits.  A second _begin SUPERSEDES a read still in
+ *                              flight (its result is dropped; _poll then reports the newer
+ *                              one); _poll without a _begin is an error.  An env that found no
+ *                              record goes on stepping its finished episode and goes on
+ *                              reporting truncated (its clock only grows) or terminated (a NaN
+ *                              state stays NaN), so a shortage shows in the step outputs at once
+ *                              and in `underflow` at the next status read
  *   softrod_queue_advance      mark by[e] staged records of env e as used (a manual reset
  *                              took the env's next draw), or all of them if by[e] < 0
  *                              (the env's stream was re-seeded); synchronises

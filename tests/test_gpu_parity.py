@@ -75,9 +75,14 @@ def test_rollout_matches_oracle(torch_gpu, hip_lib, oracle_built, math_mode):
     st = env.backend.state_numpy()
     for i, r in enumerate(rods):
         np.testing.assert_allclose(st["x"][i], r.get("x"), rtol=RTOL, atol=1e-8)
-        np.testing.assert_allclose(st["v"][i], r.get("v"), rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(st["v"][i], r.get("v"), rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(st["Q"][i], r.get("Q"), rtol=RTOL, atol=1e-8)
-        np.testing.assert_allclose(st["w"][i], r.get("w"), rtol=RTOL, atol=1e-5)
+        np.testing.assert_allclose(st["w"][i], r.get("w"), rtol=RTOL, atol=1e-8)
+        # north_star's tolerance is RELATIVE: every field against its own scale, no absolute floor
+        # (the entry-wise checks above carry an atol for the entries that pass through zero)
+        for name in ("x", "v", "Q", "w"):
+            ref = r.get(name)
+            assert np.max(np.abs(st[name][i] - ref)) <= RTOL * np.max(np.abs(ref)), name
         assert st["time"][i] == r.time
     env.close()
 
