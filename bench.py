@@ -406,7 +406,7 @@ def main(argv=None, script=None) -> int:
     kt = local.backend.kernel_times_ms() if timed else np.repeat(np.asarray(win_elapsed) / K * 1e3, K)
     assert len(kt) == R * K or args.autoreset != "off"
     win_value = [(n_total * K - win_restarts[w]) / win_elapsed[w] for w in range(R)]
-    m = int(np.argsort(win_value)[R // 2])           # the median window (the lower one of two)
+    m = int(np.argsort(win_value)[(R - 1) // 2])     # the median window (the LOWER one of two)
     elapsed, restarts = win_elapsed[m], win_restarts[m]
     n_bad = int((~torch.isfinite(obs).all(dim=1)).sum().item())
     # what the last step returned, over ALL envs (gathered rows included): lets two runs be compared
