@@ -15,6 +15,16 @@ from pathlib import Path
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 ROOT = Path(__file__).resolve().parents[1]
 TWO_ON_ONE = {"SOFTROD_BENCH_ALL_RANKS_ON_DEVICE0": "1", "SOFTROD_BENCH_DIST_BACKEND": "gloo"}
 
@@ -77,7 +87,7 @@ def _worker(*args, timeout=900):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", str(ROOT / "tests" / "two_rank_hip_worker.py"), *args]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "tests" / "two_rank_hip_worker.py"), *args]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     assert "TWO-RANK-OK" in out.stdout, out.stdout[-2000:]
