@@ -28,10 +28,12 @@ passes, profiles/hbm_traffic.json); `roofline.hbm` carries the measured-traffic 
 and, labelled as a model, SURVEY.md §8(d)'s algorithmic-bytes streaming figure (rods x
 substeps x 2*(18n+6)*8 B / kernel time), which a fused kernel exceeds by construction.
 
-Clock: the first launches after an idle period run at a lower shader clock (0.38 -> 0.30 ms over
-~20 launches).  Before the declared warm-up an un-timed PRE-HEAT steps a scratch batch of the same
-shape until the HIP-event kernel time has stopped falling (cap 150 launches); the measured batch is
-untouched by it, so the timed window stays inside one episode.  `steps`/`warmup` echo the
+Clock: after an idle period the shader clock ramps for ~45 ms under load (0.38 -> 0.297 ms per
+launch over 140 launches) and is often pulled back once more ~50 ms in (a power-controller
+transient: 0.297 -> 0.333 ms, gone 15 ms later).  Before the declared warm-up an un-timed PRE-HEAT
+steps a scratch batch of the same shape with zero actions until the HIP-event kernel time is
+stable (groups of ~6 ms of kernel time, three groups within 0.5 %, after 120 and within 600 ms of
+kernel time); the measured batch is untouched by it, so the timed window stays inside one episode.  `steps`/`warmup` echo the
 arguments; when warm-up + 3 windows of K steps fit one episode (120 steps) three consecutive
 windows of K steps are timed, each bracketed like the contract says, and `value` / `ms_per_step`
 are the MEDIAN window's (all windows are listed under `windows`).
@@ -166,8 +168,9 @@ def parse_args(argv=None):
     ap.add_argument("--windows", type=int, default=0,
                     help="timed windows of --steps steps each (value = the median window); 0 (default): 3 if "
                          "warmup + 3*steps <= 120 (one SoftPendulum episode), else as many as fit, at least 1")
-    ap.add_argument("--preheat", type=int, default=150,
-                    help="cap of the un-timed pre-heat launches on a scratch batch (0 = none)")
+    ap.add_argument("--preheat", type=float, default=600.0,
+                    help="cap of the un-timed pre-heat on a scratch batch, in ms of kernel time (0 = none); it "
+                         "ends earlier once the kernel time has been stable for three groups after 120 ms")
     return ap.parse_args(argv)
 
 
@@ -258,36 +261,54 @@ def useful_lane_fraction(cfg, octo: bool, n_waves: int) -> float:
     return n_nodes / (64.0 * (1 if n_nodes <= 64 else 2))
 
 
-def preheat(make_scratch, acts_dev, cap: int):
+def preheat(make_scratch, acts_dev, cap_ms: float, min_ms: float = 120.0):
     """Un-timed launches on a SCRATCH batch of the measured shape until the step kernel's HIP-event
-    duration has stopped falling: groups of G = 10 launches, settled when a group's mean is within
-    0.5 % of (or above) the previous group's (the ramp observed on the pool's boxes falls by 1-5 %
-    per ten launches for the first 50-80); at least 20, at most `cap` launches.  The scratch
-    batch stays allocated until the end of the run (no hipFree in front of the timed region)."""
+    duration is STABLE.  What the pool's boxes do under this load (4096 SoftPendulum envs, per-launch
+    times of five runs in profiles/README.md "bench.py on the settled clock"): the clock ramps for
+    ~45 ms (0.38 -> 0.297 ms per launch over 140 launches), and ~50 ms after the load began the power
+    controller often pulls it back once (0.297 -> 0.333 ms within 10 launches, recovering over the
+    next 40).  Both are a matter of TIME under load, not of launches, so the pre-heat is too: groups
+    of ~6 ms of kernel time; stable = the last three group means within 0.5 % of each other, after at
+    least `min_ms` and at most `cap_ms` of kernel time.  The scratch batch is stepped with ZERO
+    actions and never reset on the way (driven at random for more than an episode a pendulum blows
+    up and its steps get slower; a reset idles the GPU for ~10 ms of host work, enough for the
+    clock to fall back: 0.297 -> 0.365 ms measured).  It stays allocated until the end of the run;
+    the warm-up of the measured batch follows at once."""
     import numpy as np
 
-    G = 10
-    if cap < G:
+    if cap_ms <= 0:
         return None, {"launches": 0}
     scratch = make_scratch()
     scratch.reset(seed=10_000_019)
     be = scratch.backend
-    groups, n = [], 0
-    while n + G <= cap:
+    zero = acts_dev[0] * 0
+    be.set_timing(2)
+    scratch.step(zero)
+    scratch.step(zero)
+    first = be.kernel_times_ms()
+    G = int(min(20, max(2, round(6.0 / max(float(first[1]), 1e-3)))))
+    groups, n, busy = [], 2, float(first.sum())
+
+    def stable():
+        if len(groups) < 3:
+            return False
+        last = [float(np.mean(g)) for g in groups[-3:]]
+        return max(last) <= 1.005 * min(last)
+
+    while busy < cap_ms and not (busy >= min_ms and stable()):
         be.set_timing(G)
         for k in range(G):
-            scratch.step(acts_dev[(n + k) % acts_dev.shape[0]])
+            scratch.step(zero)
         kt = be.kernel_times_ms()
         n += G
+        busy += float(kt.sum())
         groups.append([float(x) for x in kt])
-        if len(groups) >= 2 and np.mean(groups[-1]) >= 0.995 * np.mean(groups[-2]):
-            break
     be.set_timing(0)
-    flat = [x for g in groups for x in g]
-    return scratch, {"launches": n, "first_kernel_ms": flat[0], "settled_kernel_ms": float(np.mean(groups[-1])),
-                     "group_means_ms": [float(np.mean(g)) for g in groups],
-                     "settled": bool(len(groups) >= 2 and np.mean(groups[-1]) >= 0.995 * np.mean(groups[-2])),
-                     "what": "scratch batch of the same env/size, random actions, not the measured batch"}
+    return scratch, {"launches": n, "kernel_ms_total": busy, "first_kernel_ms": float(first[0]),
+                     "settled_kernel_ms": float(np.mean(groups[-1])) if groups else float(first[1]),
+                     "group_launches": G, "group_means_ms": [round(float(np.mean(g)), 4) for g in groups],
+                     "stable": stable(),
+                     "what": "scratch batch of the same env/size, zero actions, not the measured batch"}
 
 
 def main(argv=None, script=None) -> int:
@@ -363,14 +384,22 @@ def main(argv=None, script=None) -> int:
     acts_dev = torch.from_numpy(acts[:, lo:hi].copy()).to(local.backend.device)
 
     timed = hasattr(local.backend, "set_timing")
+    # Everything that costs host time once — the first call through the stepping path (lazy imports,
+    # allocations of the gather buffers) and the creation of the timing events — happens BEFORE the
+    # pre-heat: an idle GPU loses its clock within ~10 ms, and a cold box has been seen to spend that
+    # between the pre-heat and the first timed window.  The reset puts the batch back (same seeds,
+    # same draws: the state the run starts from is the one it would have started from).
+    env.step(acts_dev[0])
+    env.sync()
+    env.reset(seed=0)
+    if timed:
+        local.backend.set_timing(W + R * K)
     scratch, heat = None, {"launches": 0}
     if timed and args.preheat > 0:
         scratch, heat = preheat(lambda: gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode,
                                                      **scratch_kw), acts_dev, args.preheat)
     for t in range(W):
         env.step(acts_dev[t])
-    if timed:
-        local.backend.set_timing(R * K)
 
     def restarts_so_far():
         return int(local.backend.queue_status()[0].sum()) if args.autoreset == "device" else 0
@@ -403,7 +432,8 @@ def main(argv=None, script=None) -> int:
         win_elapsed.append(elapsed)
         win_restarts.append(rs)
 
-    kt = local.backend.kernel_times_ms() if timed else np.repeat(np.asarray(win_elapsed) / K * 1e3, K)
+    kt_all = local.backend.kernel_times_ms() if timed else np.repeat(np.asarray(win_elapsed) / K * 1e3, K)
+    kt = kt_all[W:] if timed else kt_all
     assert len(kt) == R * K or args.autoreset != "off"
     win_value = [(n_total * K - win_restarts[w]) / win_elapsed[w] for w in range(R)]
     m = int(np.argsort(win_value)[(R - 1) // 2])     # the median window (the LOWER one of two)
@@ -477,6 +507,8 @@ def main(argv=None, script=None) -> int:
                 "ms_per_step": [e / K * 1e3 for e in win_elapsed],
                 "kernel_ms_avg": per_win_kernel,
                 "spread": (max(win_value) - min(win_value)) / win_value[m],
+                # every launch of the measured batch, warm-up first (when there are few enough to print)
+                "kernel_ms_each": [round(float(x), 4) for x in kt_all] if len(kt_all) <= 256 else None,
             },
             "preheat": heat,
             "roofline": {

@@ -65,7 +65,7 @@ def test_bench_two_ranks_softpendulum(hip_lib):
 
 def test_bench_two_ranks_octoflat(hip_lib):
     """configs[4]'s shape at world 2: 2 x 512 OctoFlat envs (8 arms + head each) against 1 x 1024."""
-    a = ("--env", "OctoFlat-v0", "--steps", "3", "--warmup", "1", "--windows", "1", "--preheat", "5")
+    a = ("--env", "OctoFlat-v0", "--steps", "3", "--warmup", "1", "--windows", "1", "--preheat", "40")
     two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "512", *a)
     one = _bench({}, "--gpus", "1", "--envs-per-gpu", "1024", *a)
     _check_pair(two, one, 1024, 3)
@@ -74,7 +74,7 @@ def test_bench_two_ranks_octoflat(hip_lib):
 def test_bench_two_ranks_device_autoreset_across_the_shard_boundary(hip_lib):
     """140 steps: every env is truncated on step 126 and restarts on 127 from its staged record, on
     both ranks; the restarted envs' rows are gathered like any other."""
-    a = ("--steps", "140", "--warmup", "2", "--autoreset", "device", "--preheat", "10")
+    a = ("--steps", "140", "--warmup", "2", "--autoreset", "device", "--preheat", "20")
     two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "1024", *a)
     one = _bench({}, "--gpus", "1", "--envs-per-gpu", "2048", *a)
     _check_pair(two, one, 2048, 140)
