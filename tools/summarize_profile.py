@@ -55,18 +55,42 @@ def timed_launches(root):
     return [d for _, d in rows]
 
 
-def counters(root, sub):
-    """-> {counter_name: [per-dispatch values of the step kernel]} and register info"""
-    vals = defaultdict(list)
+def counters(root, sub, last=None):
+    """-> {counter_name: [per-dispatch values of the step kernel, in dispatch order]} and register info.
+    last = n: only the last n step-kernel dispatches — the MEASURED batch's (warm-up + timed windows);
+    bench.py's pre-heat steps a scratch batch with zero actions before them, and those launches take
+    fewer of the longer series tiers, so they must not dilute the per-launch averages."""
+    rows = defaultdict(list)
     regs = {}
     for p in glob.glob(os.path.join(root, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in read_csv(p):
             if not is_step_kernel(r.get("Kernel_Name", "")):
                 continue
-            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            rows[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
             regs = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
                                           "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
+    vals = {}
+    for k, v in rows.items():
+        v.sort()
+        vals[k] = [x for _, x in (v[-last:] if last else v)]
     return vals, regs
+
+
+def measured_dispatches(root):
+    """Step-kernel dispatches of the measured batch in one bench.py run: (warmup + windows x steps) x
+    kernels per env.step, from the bench line of the trace pass (all passes run the same command)."""
+    for name in ("bench_trace.log", "bench_pmc3.log", "bench_pmc_fetch.log", "bench_pmc_write.log"):
+        p = os.path.join(root, name)
+        if os.path.exists(p):
+            for line in open(p):
+                if line.startswith("{"):
+                    try:
+                        b = json.loads(line)
+                        per = 2 if "window" in b["roofline"]["kernel"] else 1
+                        return (int(b["warmup"]) + int(b["steps"]) * int((b.get("windows") or {}).get("count", 1))) * per
+                    except Exception:  # noqa: BLE001
+                        pass
+    return None
 
 
 def main(root):
@@ -77,10 +101,12 @@ def main(root):
     if step:
         doc["step_kernel_avg_ms"] = step[0]["avg_ns"] / 1e6
         doc["step_kernel_calls"] = step[0]["calls"]
-    fetch, regs = counters(root, "pmc_fetch")
-    write, _ = counters(root, "pmc_write")
-    sq, _ = counters(root, "pmc_sq")
-    pmc3, regs3 = counters(root, "pmc3")
+    last = measured_dispatches(root)
+    doc["counter_dispatches_used"] = last      # the measured batch's launches only (not the pre-heat's)
+    fetch, regs = counters(root, "pmc_fetch", last)
+    write, _ = counters(root, "pmc_write", last)
+    sq, _ = counters(root, "pmc_sq", last)
+    pmc3, regs3 = counters(root, "pmc3", last)
     doc["registers"] = regs or regs3
     if fetch.get("FETCH_SIZE"):
         f = fetch["FETCH_SIZE"]
