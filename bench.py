@@ -29,14 +29,16 @@ and, labelled as a model, SURVEY.md §8(d)'s algorithmic-bytes streaming figure 
 substeps x 2*(18n+6)*8 B / kernel time), which a fused kernel exceeds by construction.
 
 Clock: after an idle period the shader clock ramps for ~45 ms under load (0.38 -> 0.297 ms per
-launch over 140 launches) and is often pulled back once more ~50 ms in (a power-controller
-transient: 0.297 -> 0.333 ms, gone 15 ms later).  Before the declared warm-up an un-timed PRE-HEAT
+launch over 140 launches) and is then pulled back twice, ~55 and ~110 ms after the load began (a
+power-controller transient: 0.30 -> 0.35-0.37 ms, gone 20 ms later), before it holds (0.303 ms).  Before the declared warm-up an un-timed PRE-HEAT
 steps a scratch batch of the same shape with zero actions until the HIP-event kernel time is
 stable (groups of ~6 ms of kernel time, three groups within 0.5 %, after 120 and within 600 ms of
 kernel time); the measured batch is untouched by it, so the timed window stays inside one episode.  `steps`/`warmup` echo the
-arguments; when warm-up + 3 windows of K steps fit one episode (120 steps) three consecutive
-windows of K steps are timed, each bracketed like the contract says, and `value` / `ms_per_step`
-are the MEDIAN window's (all windows are listed under `windows`).
+arguments; as many consecutive windows of K steps as fit one episode together with the warm-up
+(120 steps; at most five) are timed, each bracketed like the contract says, and `value` /
+`ms_per_step` are the MEDIAN window's (all windows are listed under `windows`): on some boxes the
+power controller pulls the clock back for ~20 ms every ~55 ms, and one 6 ms window can fall
+entirely inside or outside such a dip.
 
 Staleness: profiles/valu_counts.json and hbm_traffic.json entries carry the source hash of the
 library they were measured on (softrod_source_hash); when it differs from the loaded library's,
@@ -166,8 +168,8 @@ def parse_args(argv=None):
                     help="random (default): uniform in the action box; zero: SURVEY.md §8(d)'s zero-action run")
     ap.add_argument("--n-elems", type=int, default=None, help="elements per rod (env default if omitted)")
     ap.add_argument("--windows", type=int, default=0,
-                    help="timed windows of --steps steps each (value = the median window); 0 (default): 3 if "
-                         "warmup + 3*steps <= 120 (one SoftPendulum episode), else as many as fit, at least 1")
+                    help="timed windows of --steps steps each (value = the median window); 0 (default): as many as "
+                         "fit one SoftPendulum episode together with the warm-up (120 steps), at most 5, at least 1")
     ap.add_argument("--preheat", type=float, default=600.0,
                     help="cap of the un-timed pre-heat on a scratch batch, in ms of kernel time (0 = none); it "
                          "ends earlier once the kernel time has been stable for three groups after 120 ms")
@@ -265,9 +267,10 @@ def preheat(make_scratch, acts_dev, cap_ms: float, min_ms: float = 120.0):
     """Un-timed launches on a SCRATCH batch of the measured shape until the step kernel's HIP-event
     duration is STABLE.  What the pool's boxes do under this load (4096 SoftPendulum envs, per-launch
     times of five runs in profiles/README.md "bench.py on the settled clock"): the clock ramps for
-    ~45 ms (0.38 -> 0.297 ms per launch over 140 launches), and ~50 ms after the load began the power
-    controller often pulls it back once (0.297 -> 0.333 ms within 10 launches, recovering over the
-    next 40).  Both are a matter of TIME under load, not of launches, so the pre-heat is too: groups
+    ~45 ms (0.38 -> 0.297 ms per launch over 140 launches), and ~55 and ~110 ms after the load began
+    the power controller pulls it back (group means 0.305 0.344 0.348 0.329 0.316 0.309 0.304 ... 0.303
+    0.323 0.371 0.340 0.330 0.317 0.309 0.304 0.303 0.303), after which it holds.  All of this is a
+    matter of TIME under load, not of launches, so the pre-heat is too: groups
     of ~6 ms of kernel time; stable = the last three group means within 0.5 % of each other, after at
     least `min_ms` and at most `cap_ms` of kernel time.  The scratch batch is stepped with ZERO
     actions and never reset on the way (driven at random for more than an episode a pendulum blows
@@ -356,7 +359,7 @@ def main(argv=None, script=None) -> int:
         n_local //= world
     n_total = n_local * world
     K, W = args.steps, args.warmup
-    R = args.windows if args.windows > 0 else max(1, min(3, (120 - W) // max(K, 1)))
+    R = args.windows if args.windows > 0 else max(1, min(5, (120 - W) // max(K, 1)))
     math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
     extra = {} if args.n_elems is None else {"n_elems": args.n_elems}
     scratch_kw = dict(extra)

@@ -39,8 +39,8 @@ def test_single_process_line_has_the_contract_fields(oracle_built):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1
     assert line["data"].startswith("TEST-DOUBLE") and line["config"]["envs_total"] == 4
-    assert line["windows"]["count"] == 3 and len(line["windows"]["value"]) == 3      # 1 + 3*3 steps fit an episode
-    assert line["value"] == sorted(line["windows"]["value"])[1]                       # the median window
+    assert line["windows"]["count"] == 5 and len(line["windows"]["value"]) == 5      # 1 + 5*3 steps fit an episode
+    assert line["value"] == sorted(line["windows"]["value"])[2]                       # the median window
     assert line["roofline"]["frac"] is None and line["roofline"]["frac_withheld"]     # not the HIP library: no pricing
     assert line["roofline"]["bound"] == "fp64_valu" and "frac" in line["roofline"] and "traffic" in line["roofline"]
 
