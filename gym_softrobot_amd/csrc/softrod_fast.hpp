@@ -555,6 +555,9 @@ __device__ __attribute__((noinline)) void general_step_cold(const RodParams* __r
 #ifndef SOFTROD_PLANAR_WAVES      // the SoftPendulum instantiation: all four rods of a SIMD resident (4096 envs)
 #define SOFTROD_PLANAR_WAVES 4
 #endif
+#ifndef SOFTROD_PLANAR_EXEC_MASK
+#define SOFTROD_PLANAR_EXEC_MASK 1
+#endif
 #ifndef SOFTROD_CONTACT_WAVES
 #define SOFTROD_CONTACT_WAVES 2
 #endif
@@ -651,29 +654,43 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             // (the step length as a vector register where scalar ones are short: uniform_k)
             const double step_dt = EPL > 1 ? opaque_v(P.dt) : P.dt;
             SR_PHASE(2);
-            planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
-            {   // four copies of the loop, one per priority level (ProgressPriority explains; here
-                // without its two scalar instructions and the branch in every trip)
-                int s = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q == 1) __builtin_amdgcn_s_setprio(2);
-                    if (q == 2) __builtin_amdgcn_s_setprio(1);
-                    if (q == 3) __builtin_amdgcn_s_setprio(0);
-                    const int end = ProgressPriority::bound(n_sub - 1, q);
-                    for (; s < end; ++s) {
-                        planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
-#ifdef SOFTROD_DIAG_TWO_HALF_STEPS
-                        planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
-                        planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
-#else
-                        planar_kinematic_n<EPL>(step_dt, K.hq_dt, C, K, Z);
+#if SOFTROD_PLANAR_EXEC_MASK
+            // The lanes past the rod's end node (13 of 64 at 50 elements) take no part in the loop:
+            // with EXEC cleared they issue nothing to the fp64 datapath, which under a kernel that
+            // keeps the VALU busy in every cycle is power — and the clock this kernel sustains is
+            // what the power controller leaves it (profiles/README.md r3h: 0.3008 -> 0.2846 ms, bit-
+            // identical).  A DPP shift that would read a disabled lane returns 0 (bound_ctrl), exactly
+            // what it returns past lane 63, and the element after the last node has no stiffness either
+            // way: results are unchanged.  (The same mask on the 3-D loops and on OctoFlat's ghost
+            // slots was measured and changes nothing there: 2.500 / 2.502, 1.685 / 1.684, 9.355 / 9.36 ms.)
+            if (lane * EPL <= P.n_elem + (SOFTROD_PLANAR_EXEC_MASK == 2 ? 64 : 0)) {     // (2: the same code with no lane masked, an A/B control)
 #endif
+                planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
+                {   // four copies of the loop, one per priority level (ProgressPriority explains; here
+                    // without its two scalar instructions and the branch in every trip)
+                    int s = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (q == 1) __builtin_amdgcn_s_setprio(2);
+                        if (q == 2) __builtin_amdgcn_s_setprio(1);
+                        if (q == 3) __builtin_amdgcn_s_setprio(0);
+                        const int end = ProgressPriority::bound(n_sub - 1, q);
+                        for (; s < end; ++s) {
+                            planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
+#ifdef SOFTROD_DIAG_TWO_HALF_STEPS
+                            planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
+                            planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
+#else
+                            planar_kinematic_n<EPL>(step_dt, K.hq_dt, C, K, Z);
+#endif
+                        }
                     }
                 }
+                planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
+                planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
+#if SOFTROD_PLANAR_EXEC_MASK
             }
-            planar_dynamic_n<EPL>(Pk, C, K, lane, Z);
-            planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
+#endif
             if (__builtin_amdgcn_readfirstlane(tk) >= 0) time = S.time_tab[tk + 1];
             else
                 for (int s = 0; s < n_sub; ++s) time = (time + ta) + tb;
