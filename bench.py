@@ -407,15 +407,25 @@ def main(argv=None, script=None) -> int:
     def restarts_so_far():
         return int(local.backend.queue_status()[0].sum()) if args.autoreset == "device" else 0
 
-    win_elapsed, win_restarts = [], []
+    win_elapsed, win_restarts, win_host_worst = [], [], []
+    import gc
+
+    gc.collect()
+    gc.disable()          # no collector pause between two launches of a timed window (re-enabled below)
     r_before = restarts_so_far()
     for w in range(R):
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        tp, worst = t0, (0.0, -1)
         for t in range(W + w * K, W + (w + 1) * K):
             obs, rew, term, trunc, _ = env.step(acts_dev[t])
+            tn = time.perf_counter()
+            if tn - tp > worst[0]:
+                worst = (tn - tp, t)
+            tp = tn
+        win_host_worst.append(worst)
         env.sync()
         torch.cuda.synchronize()
         if distributed:
@@ -435,6 +445,7 @@ def main(argv=None, script=None) -> int:
         win_elapsed.append(elapsed)
         win_restarts.append(rs)
 
+    gc.enable()
     kt_all = local.backend.kernel_times_ms() if timed else np.repeat(np.asarray(win_elapsed) / K * 1e3, K)
     kt = kt_all[W:] if timed else kt_all
     assert len(kt) == R * K or args.autoreset != "off"
@@ -509,6 +520,10 @@ def main(argv=None, script=None) -> int:
                 "value": win_value,
                 "ms_per_step": [e / K * 1e3 for e in win_elapsed],
                 "kernel_ms_avg": per_win_kernel,
+                # the slowest single env.step() call of each window on the HOST (ms, step index): a window
+                # starts from a synchronised stream, so a host hiccup longer than the few steps the host
+                # is ahead by idles the GPU (and an idle GPU loses its clock)
+                "host_call_ms_max": [[round(x * 1e3, 3), t] for x, t in win_host_worst],
                 "spread": (max(win_value) - min(win_value)) / win_value[m],
                 # every launch of the measured batch, warm-up first (when there are few enough to print)
                 "kernel_ms_each": [round(float(x), 4) for x in kt_all] if len(kt_all) <= 256 else None,

@@ -506,3 +506,36 @@ def test_render_rgb_array(oracle_built):
     env.close()
     with pytest.raises(ValueError):
         gsa.SoftPendulumEnv(render_mode="ascii", backend=OracleBackend(_capi.softpendulum_config(1)))
+
+
+def test_time_table_is_the_reference_accumulation_bit_for_bit():
+    """The clock an env reports is accumulated exactly as soft_pendulum.py:183-184 accumulates it
+    (2 x n_substeps additions of dt/2 per env.step).  The table is built with np.add.accumulate,
+    which must reproduce the Python loop's additions in the same order — for every env's dt and
+    substep count, with one or two additions per substep — and growing it must not cost a stall
+    (it used to take 10-20 ms of host time on step 64, 128, ... of a rollout)."""
+    import time
+
+    from gym_softrobot_amd.envs.base import time_table
+
+    def loop(cfg, n):
+        t, half, dt = np.float64(0.0), np.float64(0.5) * np.float64(cfg.dt), np.float64(cfg.dt)
+        out = [t]
+        for _ in range(n):
+            for _ in range(int(cfg.n_substeps)):
+                if cfg.time_two_half_adds:
+                    t = t + half
+                    t = t + half
+                else:
+                    t = t + dt
+            out.append(t)
+        return np.array(out)
+
+    for mk in (_capi.softpendulum_config, _capi.softpendulum3d_config, _capi.arm_single_config, _capi.octo_flat_config):
+        cfg = mk(1)
+        for two in (1, 0):
+            cfg.time_two_half_adds = two
+            np.testing.assert_array_equal(time_table(cfg, 30), loop(cfg, 30))
+    t0 = time.perf_counter()
+    time_table(_capi.softpendulum_config(1), 512)
+    assert time.perf_counter() - t0 < 0.05
