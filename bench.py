@@ -395,6 +395,10 @@ def main(argv=None, script=None) -> int:
     env.step(acts_dev[0])
     env.sync()
     env.reset(seed=0)
+    import gc
+
+    gc.collect()          # (tens of ms with torch loaded: here, not between the pre-heat and the windows)
+    gc.disable()          # no collector pause between two launches of a timed window (re-enabled below)
     if timed:
         local.backend.set_timing(W + R * K)
     scratch, heat = None, {"launches": 0}
@@ -408,10 +412,6 @@ def main(argv=None, script=None) -> int:
         return int(local.backend.queue_status()[0].sum()) if args.autoreset == "device" else 0
 
     win_elapsed, win_restarts, win_host_worst = [], [], []
-    import gc
-
-    gc.collect()
-    gc.disable()          # no collector pause between two launches of a timed window (re-enabled below)
     r_before = restarts_so_far()
     for w in range(R):
         if distributed:
