@@ -177,6 +177,10 @@ __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid_lane, 
 #include "softrod_planar.hpp"
 namespace softrod {
 
+#ifndef SOFTROD_IDLE_LANES_EXEC_MASK     // the 3-D loop's idle lanes sit it out (0: they execute on zeros)
+#define SOFTROD_IDLE_LANES_EXEC_MASK 1
+#endif
+
 // ---- kinematic step, per slot ------------------------------------------------------------------
 template <int EPL>
 __device__ __forceinline__ void kinematic_n(double h, const ConstN<EPL>& C, LaneN<EPL>& L) {
@@ -504,13 +508,24 @@ __device__ __forceinline__ double clock_after(const RodParams& P, const StatePtr
 template <unsigned F, int EPL, bool TAPER = false>
 __device__ __forceinline__ void general_substeps(const RodParams& P, const RodParams& Pk, const ConstN<EPL>& C,
                                                  const BcTargets& B, int lane, LaneN<EPL>& L, int n_sub) {
-    kinematic_n<EPL>(P.half_dt, C, L);
-    ProgressPriority prio(n_sub);
-    for (int s = 0; s < n_sub; ++s) {
-        dynamic_n<F, EPL, TAPER>(Pk, C, B, lane, L);
-        const bool last = (s == n_sub - 1);
-        kinematic_n<EPL>(last ? P.half_dt : P.dt, C, L);
-        prio.tick(s);
+#if SOFTROD_IDLE_LANES_EXEC_MASK
+    // The lanes past the rod's end sit the loop out like in the planar loop (EXEC cleared: a DPP
+    // shift that would read one returns 0, the element behind the last node has no stiffness —
+    // bit-identical).  Worth what the box's power budget makes of it: OctoArmSingle 2.574 -> 2.514 ms
+    // and SoftPendulum3D 1.700 -> 1.687 ms on a box that holds these loops under its clock ceiling,
+    // nothing (2.500 / 2.502, 1.685 / 1.684) on one that does not (profiles/README.md r3h / r3i).
+    // Not with the spline muscles, whose rebuild runs prefix sums over the whole wave.
+    if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) || slot_local<F>(P, lane * EPL) <= P.n_elem)
+#endif
+    {
+        kinematic_n<EPL>(P.half_dt, C, L);
+        ProgressPriority prio(n_sub);
+        for (int s = 0; s < n_sub; ++s) {
+            dynamic_n<F, EPL, TAPER>(Pk, C, B, lane, L);
+            const bool last = (s == n_sub - 1);
+            kinematic_n<EPL>(last ? P.half_dt : P.dt, C, L);
+            prio.tick(s);
+        }
     }
 }
 // The SoftPendulum kernel's fallback for a state that is NOT planar (written through the state
@@ -661,8 +676,8 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             // what the power controller leaves it (profiles/README.md r3h: 0.3008 -> 0.2846 ms, bit-
             // identical).  A DPP shift that would read a disabled lane returns 0 (bound_ctrl), exactly
             // what it returns past lane 63, and the element after the last node has no stiffness either
-            // way: results are unchanged.  (The same mask on the 3-D loops and on OctoFlat's ghost
-            // slots was measured and changes nothing there: 2.500 / 2.502, 1.685 / 1.684, 9.355 / 9.36 ms.)
+            // way: results are unchanged.  (The 3-D loops carry the same mask, general_substeps; on
+            // OctoFlat's ghost slots it was measured and changes nothing: 9.355 / 9.36 ms.)
             if (lane * EPL <= P.n_elem + (SOFTROD_PLANAR_EXEC_MASK == 2 ? 64 : 0)) {     // (2: the same code with no lane masked, an A/B control)
 #endif
                 planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);
