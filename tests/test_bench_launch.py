@@ -111,3 +111,58 @@ def test_usable_cpus_reads_the_cgroup_quota(monkeypatch, tmp_path):
 
     n = bench.usable_cpus()
     assert 1 <= n <= len(os.sched_getaffinity(0))
+
+
+def test_preheat_waits_out_the_ramp_and_the_pull_backs():
+    """bench.preheat on a scripted clock: a 45 ms ramp, pull-backs 55 and 110 ms into the load (what
+    the pool's boxes do, profiles/README.md r3f), then a steady 0.303 ms.  It must not stop on the
+    first plateau (the floor of 120 ms of kernel time), must stop once three groups agree to 0.5 %,
+    and must give up at the cap when the clock never settles."""
+    sys.path.insert(0, str(ROOT))
+    import numpy as np
+    import torch
+
+    import bench
+
+    class FakeBackend:
+        def __init__(self, law):
+            self.law, self.busy, self.n, self.pending = law, 0.0, 0, []
+
+        def set_timing(self, n):
+            self.pending = []
+
+        def launch(self):
+            ms = self.law(self.busy)
+            self.busy += ms
+            self.pending.append(ms)
+
+        def kernel_times_ms(self):
+            out, self.pending = np.asarray(self.pending, np.float32), []
+            return out
+
+    class FakeEnv:
+        def __init__(self, law):
+            self.backend = FakeBackend(law)
+
+        def reset(self, seed=None):
+            pass
+
+        def step(self, a):
+            self.backend.launch()
+
+    def pool_box(busy_ms):
+        if busy_ms < 45:
+            return 0.38 - 0.08 * busy_ms / 45
+        for start in (55.0, 110.0):
+            if start <= busy_ms < start + 20:
+                return 0.30 + 0.06 * (1 - (busy_ms - start) / 20)
+        return 0.303
+
+    acts = torch.zeros((4, 8, 1))
+    env, info = bench.preheat(lambda: FakeEnv(pool_box), acts, cap_ms=600.0)
+    assert info["stable"] and 130.0 <= info["kernel_ms_total"] <= 200.0, info
+    assert abs(info["settled_kernel_ms"] - 0.303) < 1e-3
+    # a clock that never settles: the cap ends it
+    env, info = bench.preheat(lambda: FakeEnv(lambda b: 0.30 + 0.05 * ((int(b / 6) % 2))), acts, cap_ms=300.0)
+    assert not info["stable"] and 300.0 <= info["kernel_ms_total"] < 320.0
+    assert bench.preheat(lambda: FakeEnv(pool_box), acts, cap_ms=0.0) == (None, {"launches": 0})
