@@ -63,6 +63,18 @@ def test_bench_two_ranks_softpendulum(hip_lib):
     assert one["roofline"]["frac"] is None or 0.2 < one["roofline"]["frac"] < 1.0
 
 
+def test_bench_two_ranks_strong_scaling(hip_lib):
+    """SURVEY §8(d) cfg 4 asks for the curve at fixed total N as well: `--scaling strong` splits
+    --envs-per-gpu envs over the ranks (2 x 1024 here) and must return what one rank returns for
+    the same 2048 envs."""
+    a = ("--steps", "10", "--warmup", "2", "--envs-per-gpu", "2048", "--preheat", "30")
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--scaling", "strong", *a)
+    one = _bench({}, "--gpus", "1", *a)
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2 and two["config"]["envs_total"] == 2048
+    assert two["config"]["last_step_checksum"] == one["config"]["last_step_checksum"]
+    assert two["config"]["non_finite_envs_at_end"] == one["config"]["non_finite_envs_at_end"] == 0
+
+
 def test_bench_two_ranks_octoflat(hip_lib):
     """configs[4]'s shape at world 2: 2 x 512 OctoFlat envs (8 arms + head each) against 1 x 1024."""
     a = ("--env", "OctoFlat-v0", "--steps", "3", "--warmup", "1", "--windows", "1", "--preheat", "40")
