@@ -263,7 +263,7 @@ def useful_lane_fraction(cfg, octo: bool, n_waves: int) -> float:
     return n_nodes / (64.0 * (1 if n_nodes <= 64 else 2))
 
 
-def preheat(make_scratch, acts_dev, cap_ms: float, min_ms: float = 120.0):
+def preheat(make_scratch, acts_dev, cap_ms: float, min_ms: float = 120.0, agree=None):
     """Un-timed launches on a SCRATCH batch of the measured shape until the step kernel's HIP-event
     duration is STABLE.  What the pool's boxes do under this load (4096 SoftPendulum envs, per-launch
     times of five runs in profiles/README.md "bench.py on the settled clock"): the clock ramps for
@@ -276,7 +276,10 @@ def preheat(make_scratch, acts_dev, cap_ms: float, min_ms: float = 120.0):
     actions and never reset on the way (driven at random for more than an episode a pendulum blows
     up and its steps get slower; a reset idles the GPU for ~10 ms of host work, enough for the
     clock to fall back: 0.297 -> 0.365 ms measured).  It stays allocated until the end of the run;
-    the warm-up of the measured batch follows at once."""
+    the warm-up of the measured batch follows at once.  With several ranks (`agree`: a reduction
+    over the ranks) everybody heats until EVERY rank is stable or one has reached the cap, so that
+    all of them leave together: a rank that finished early would sit idle in the first collective
+    of the warm-up and lose the clock it had just reached."""
     import numpy as np
 
     if cap_ms <= 0:
@@ -298,7 +301,13 @@ def preheat(make_scratch, acts_dev, cap_ms: float, min_ms: float = 120.0):
         last = [float(np.mean(g)) for g in groups[-3:]]
         return max(last) <= 1.005 * min(last)
 
-    while busy < cap_ms and not (busy >= min_ms and stable()):
+    def go_on():
+        done, capped = (busy >= min_ms and stable()), busy >= cap_ms
+        if agree is not None:
+            done, capped = agree(done, capped)
+        return not (done or capped)
+
+    while go_on():
         be.set_timing(G)
         for k in range(G):
             scratch.step(zero)
@@ -402,9 +411,18 @@ def main(argv=None, script=None) -> int:
     if timed:
         local.backend.set_timing(W + R * K)
     scratch, heat = None, {"launches": 0}
+
+    def agree(done: bool, capped: bool):
+        """all ranks done / any rank capped (one small all-reduce per ~6 ms group of the pre-heat)"""
+        f = torch.tensor([1.0 if done else 0.0, 0.0 if capped else 1.0], device=local.backend.device)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        f = f.cpu()
+        return bool(f[0] > 0), bool(f[1] < 1)
+
     if timed and args.preheat > 0:
         scratch, heat = preheat(lambda: gsa.make_vec(args.env, n_local, device=local_rank, math_mode=math_mode,
-                                                     **scratch_kw), acts_dev, args.preheat)
+                                                     **scratch_kw), acts_dev, args.preheat,
+                                agree=agree if distributed else None)
     for t in range(W):
         env.step(acts_dev[t])
 
