@@ -429,7 +429,7 @@ def main(argv=None, script=None) -> int:
     def restarts_so_far():
         return int(local.backend.queue_status()[0].sum()) if args.autoreset == "device" else 0
 
-    win_elapsed, win_restarts, win_host_worst = [], [], []
+    win_elapsed, win_restarts, win_host_worst, win_host_mean = [], [], [], []
     r_before = restarts_so_far()
     for w in range(R):
         if distributed:
@@ -444,6 +444,7 @@ def main(argv=None, script=None) -> int:
                 worst = (tn - tp, t)
             tp = tn
         win_host_worst.append(worst)
+        win_host_mean.append((tp - t0) / K)
         env.sync()
         torch.cuda.synchronize()
         if distributed:
@@ -542,6 +543,9 @@ def main(argv=None, script=None) -> int:
                 # starts from a synchronised stream, so a host hiccup longer than the few steps the host
                 # is ahead by idles the GPU (and an idle GPU loses its clock)
                 "host_call_ms_max": [[round(x * 1e3, 3), t] for x, t in win_host_worst],
+                # mean host time of one env.step() call (enqueue only): the run is GPU-bound while this
+                # stays below the kernel time
+                "host_call_ms_mean": [round(x * 1e3, 4) for x in win_host_mean],
                 "spread": (max(win_value) - min(win_value)) / win_value[m],
                 # every launch of the measured batch, warm-up first (when there are few enough to print)
                 "kernel_ms_each": [round(float(x), 4) for x in kt_all] if len(kt_all) <= 256 else None,
