@@ -26,6 +26,7 @@ compared with `overlap=False`.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -100,6 +101,14 @@ class ShardedVecEnv:
         w = packed_width(self.obs_dim)
         self._global = torch.empty((self.total_envs, w), dtype=torch.float32, device=dev)
         self.overlap = bool(overlap) and self._collective
+        # The overlapped path launches its step kernels on a stream of its own, created AFTER the
+        # collective backend's stream exists (the gather of reset() creates it): ROCm multiplexes
+        # HIP streams onto a few hardware queues round-robin, and when the step kernels and the
+        # collective share one, the queue executes them strictly in order — kernel, wait, gather,
+        # wait, kernel — with ~20 us of dependency latency on either side of the gather instead of
+        # overlapping it with the next kernel (measured in a world of one: 0.324 ms per step against
+        # 0.287 for the kernel alone).
+        self._compute_stream = None
         if self.overlap:
             n_loc = self.hi - self.lo
             d = max(2, int(overlap_depth))
@@ -127,6 +136,8 @@ class ShardedVecEnv:
         zeros64 = torch.zeros(n, dtype=torch.float64, device=obs.device)
         zeros8 = torch.zeros(n, dtype=torch.uint8, device=obs.device)
         g = self._all_gather(pack_outputs(obs, zeros64, zeros8, zeros8))
+        if self._compute_stream is not None:       # the next steps run after this reset
+            self._compute_stream.wait_stream(torch.cuda.current_stream(obs.device))
         return unpack_outputs(g, self.obs_dim)[0], info
 
     def step(self, actions):
@@ -143,7 +154,27 @@ class ShardedVecEnv:
         o, r, te, tr = unpack_outputs(self._all_gather(packed), self.obs_dim)
         return o, r, te, tr, info
 
+    def _own_stream(self):
+        dev = self.local.backend.device
+        if dev.type != "cuda" or os.environ.get("SOFTROD_SHARDED_OWN_STREAM", "1") == "0":
+            return None
+        if self._compute_stream is None:
+            self._compute_stream = torch.cuda.Stream(device=dev)
+            self._compute_stream.wait_stream(torch.cuda.current_stream(dev))     # reset / earlier steps first
+        return self._compute_stream
+
     def _step_overlapped(self, a):
+        st = self._own_stream()
+        if st is None:
+            return self._step_overlapped_on_current_stream(a)
+        dev = self.local.backend.device
+        a = a.to(dev)
+        st.wait_stream(torch.cuda.current_stream(dev))     # whatever produced the actions
+        a.record_stream(st)
+        with torch.cuda.stream(st):
+            return self._step_overlapped_on_current_stream(a)
+
+    def _step_overlapped_on_current_stream(self, a):
         k = self._k
         if self._works[k] is not None:
             # buffers k were last used two steps ago: their gather has long finished; this only
@@ -158,9 +189,12 @@ class ShardedVecEnv:
     def sync(self) -> None:
         """Make the outputs of the latest step() complete (overlap=True)."""
         if self.overlap:
+            if self._compute_stream is not None:
+                # the caller's stream continues after everything launched on the private one ...
+                torch.cuda.current_stream(self.local.backend.device).wait_stream(self._compute_stream)
             for w in self._works:
                 if w is not None:
-                    w.wait()
+                    w.wait()       # ... and after the gathers
 
     def close(self):
         self.sync()
