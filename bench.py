@@ -167,6 +167,10 @@ def parse_args(argv=None):
     ap.add_argument("--actions", choices=["random", "zero"], default="random",
                     help="random (default): uniform in the action box; zero: SURVEY.md §8(d)'s zero-action run")
     ap.add_argument("--n-elems", type=int, default=None, help="elements per rod (env default if omitted)")
+    ap.add_argument("--transport", choices=["rccl", "p2p"], default="rccl",
+                    help="N > 1: how the packed rows reach the other ranks.  rccl (default, BASELINE's north_star): "
+                         "one all_gather_into_tensor per step; p2p: every rank copies its rows into its block of "
+                         "every peer's buffer (IPC-mapped, xGMI point to point), no collective call per step")
     ap.add_argument("--windows", type=int, default=0,
                     help="timed windows of --steps steps each (value = the median window); 0 (default): as many as "
                          "fit one SoftPendulum episode together with the warm-up (120 steps), at most 5, at least 1")
@@ -382,7 +386,7 @@ def main(argv=None, script=None) -> int:
     lib_hash = _capi.library_source_hash() if hip else None
     # world > 1: kernel-packed rows + one all-gather per step, issued asynchronously so that the
     # next step's kernel does not wait for it (ShardedVecEnv overlap; the final sync is timed)
-    env = ShardedVecEnv(local, n_total, overlap=True, force_collective=force_dist)
+    env = ShardedVecEnv(local, n_total, overlap=True, force_collective=force_dist, transport=args.transport)
     env.reset(seed=0)                      # global env i seeded i
     lo, hi = env.lo, env.hi
     adim = local.backend.action_dim
@@ -528,7 +532,11 @@ def main(argv=None, script=None) -> int:
                 "actions": args.actions,
                 "autoreset": args.autoreset,
                 "episode_restarts_not_counted": restarts,
-                "sharding": "contiguous env blocks per rank; one packed all_gather per step" if world > 1 else "single GPU",
+                "sharding": ("contiguous env blocks per rank; "
+                             + ("one packed all_gather per step" if env.transport == "rccl" else
+                                "peer copies of the packed rows per step (no collective), a barrier at sync")
+                             ) if (world > 1 or force_dist) else "single GPU",
+                "transport": env.transport if (world > 1 or force_dist) else None,
                 "rod_substeps_per_sec": (n_total * K - restarts) * rods_per_env * nsub / elapsed,
                 "non_finite_envs_at_end": n_bad, "last_step_checksum": obs_checksum,
                 "library_source_hash": lib_hash,

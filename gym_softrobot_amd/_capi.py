@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -456,6 +456,7 @@ _EXPORTS = {
     "softrod_reset_straight": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "softrod_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "softrod_step_packed": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "softrod_scatter_rows": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int64, _VP]),
     "softrod_observe": (C.c_int, [_VP, _VP, _VP, _VP]),
     "softrod_substeps": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "softrod_state_view_get": (C.c_int, [_VP, C.POINTER(SoftrodStateView)]),

@@ -254,6 +254,18 @@ class HipRodBackend:
         )
         return out
 
+    def scatter_rows(self, packed: torch.Tensor, peer_ptrs, first_row: int) -> None:
+        """softrod_scatter_rows: this batch's packed rows into rows first_row.. of every buffer in
+        `peer_ptrs` (device pointers: the ranks' output buffers), one small kernel on the current stream."""
+        tab = np.ascontiguousarray(peer_ptrs, dtype=np.uint64)
+        check(
+            self._lib.softrod_scatter_rows(
+                self._h, packed.data_ptr(), tab.ctypes.data, int(tab.size), int(packed.shape[1]), int(first_row),
+                self._stream(),
+            ),
+            self._h,
+        )
+
     def substeps(self, actions, n: int) -> None:
         a = self._actions(actions) if actions is not None else None
         check(

@@ -1074,6 +1074,37 @@ int softrod_step_packed(softrod_handle* h, const float* actions, float* packed, 
                        (hipStream_t)stream);
 }
 
+namespace {
+struct PeerTable { float* p[SOFTROD_MAX_PEERS]; };
+// one thread per 32-bit word of the local rows; every peer's copy of the row block is written from it
+__global__ void __launch_bounds__(256) softrod_scatter_rows_kernel(const float* __restrict__ packed, PeerTable peers,
+                                                                   int n_peers, size_t n_words, size_t offset) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    const float v = packed[i];
+    for (int q = 0; q < n_peers; ++q) peers.p[q][offset + i] = v;
+}
+}  // namespace
+
+int softrod_scatter_rows(softrod_handle* h, const float* packed, const uint64_t* peer_buffers, int n_peers,
+                         int row_words, int64_t first_row, void* stream) {
+    if (!h || !packed || !peer_buffers) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (n_peers < 1 || n_peers > SOFTROD_MAX_PEERS || row_words < 1 || first_row < 0)
+        return fail(h, SOFTROD_EINVAL, "need 1 <= n_peers <= SOFTROD_MAX_PEERS, row_words >= 1, first_row >= 0");
+    SR_ON_DEVICE(h);
+    PeerTable t{};
+    for (int q = 0; q < n_peers; ++q) {
+        if (!peer_buffers[q]) return fail(h, SOFTROD_EINVAL, "null peer buffer");
+        t.p[q] = reinterpret_cast<float*>(static_cast<uintptr_t>(peer_buffers[q]));
+    }
+    const size_t n_words = (size_t)h->cfg.n_envs * (size_t)row_words;
+    const unsigned blocks = (unsigned)((n_words + 255) / 256);
+    hipLaunchKernelGGL(softrod_scatter_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, t,
+                       n_peers, n_words, (size_t)first_row * (size_t)row_words);
+    SR_HIP(h, hipGetLastError());
+    return SOFTROD_OK;
+}
+
 int softrod_substeps(softrod_handle* h, const float* actions, int n, void* stream) {
     if (!h || n < 0) return fail(h, SOFTROD_EINVAL, "bad argument");
     if (actions && h->cfg.env_kind != SOFTROD_ENV_SOFTPENDULUM && h->cfg.env_kind != SOFTROD_ENV_NONE)

@@ -23,6 +23,20 @@ finished) and step t+1's kernel is launched without waiting for it, on alternati
 The tensors returned by `step` are then complete once `sync()` — or the step after next —
 has been called; a policy that needs them immediately calls `sync()` and loses nothing
 compared with `overlap=False`.
+
+`transport="p2p"` (opt-in; `overlap=True` only) replaces the collective by what it amounts to for
+rows this small: right behind its step kernel, ON THE SAME STREAM, every rank launches one small
+kernel (`softrod_scatter_rows`) that stores its packed rows into its block of every rank's output
+buffer (IPC-mapped device memory; between GPUs the stores travel point to point over xGMI) — no
+collective call per step, no second stream, no event.  `sync()` waits for this rank's stream and
+meets the other ranks at a barrier, after which everybody's rows have landed.  Why: 4096 rods are
+exactly four resident waves on every SIMD, so NOTHING overlaps with a step kernel for free — a
+collective (or a copy) on a second stream either waits its turn at ~37 us of cross-queue dependency
+latency per step, or runs alongside and stretches the step kernel by as much (kernel
+traces) — while a 4 us kernel in order behind the step kernel costs its 4 us.
+Ranks are not kept in lockstep by it (a rank may run ahead in an open-loop rollout; a consumer that
+reads every step's rows calls sync() every step and is in lockstep through the barrier).  RCCL
+stays the default, as BASELINE's north_star asks; `bench.py --transport p2p` measures the other.
 """
 from __future__ import annotations
 
@@ -83,7 +97,7 @@ class ShardedVecEnv:
 
     def __init__(self, local_env, total_envs: int, group: Optional[dist.ProcessGroup] = None,
                  gather: bool = True, overlap: bool = False, force_collective: bool = False,
-                 overlap_depth: int = 2):
+                 overlap_depth: Optional[int] = None, transport: str = "rccl"):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -101,21 +115,68 @@ class ShardedVecEnv:
         w = packed_width(self.obs_dim)
         self._global = torch.empty((self.total_envs, w), dtype=torch.float32, device=dev)
         self.overlap = bool(overlap) and self._collective
-        # The overlapped path launches its step kernels on a stream of its own, created AFTER the
-        # collective backend's stream exists (the gather of reset() creates it): ROCm multiplexes
-        # HIP streams onto a few hardware queues round-robin, and when the step kernels and the
-        # collective share one, the queue executes them strictly in order — kernel, wait, gather,
-        # wait, kernel — with ~20 us of dependency latency on either side of the gather instead of
-        # overlapping it with the next kernel (measured in a world of one: 0.324 ms per step against
-        # 0.287 for the kernel alone).
-        self._compute_stream = None
         if self.overlap:
             n_loc = self.hi - self.lo
+            # Two (or `overlap_depth`) alternating sets of output buffers.  Measured on gfx950 (DESIGN.md
+            # §4): nothing overlaps with a step kernel of this workload for free — 4096 rods are exactly
+            # four resident waves on every SIMD — so a collective on a second stream either follows the
+            # kernel it depends on at ~37 us of cross-queue dependency latency per step (what the wait
+            # below amounts to: 0.324 against 0.287 ms per step in a world of one) or, left to run
+            # alongside the next kernel (a deeper ring, completion queried from the host instead of
+            # waited for on the stream), stretches that kernel by more (0.339 ms).  The wait stays.
+            if overlap_depth is None:
+                overlap_depth = int(os.environ.get("SOFTROD_SHARDED_DEPTH", "2"))
             d = max(2, int(overlap_depth))
             self._packed2 = [torch.empty((n_loc, w), dtype=torch.float32, device=dev) for _ in range(d)]
             self._global2 = [self._global] + [torch.empty_like(self._global) for _ in range(d - 1)]
             self._works = [None] * d
             self._k = 0
+        if transport not in ("rccl", "p2p"):
+            raise ValueError("transport must be 'rccl' (the group's all-gather) or 'p2p' (peer copies)")
+        self.transport = "rccl"
+        if transport == "p2p" and self.overlap:
+            self._setup_p2p()
+
+    # -- transport="p2p": every rank copies its rows into its block of every peer's buffer --------
+    def _setup_p2p(self) -> None:
+        """Exchange IPC handles of the output buffers and verify, with a round of test copies, that
+        every rank can write every peer's buffer; on any failure ALL ranks stay with the collective."""
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        dev = self.local.backend.device
+        ok, peers = 1.0, None
+        try:
+            mine = [reduce_tensor(g) for g in self._global2]
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=self.group)
+            peers = []                    # peers[k][p]: rank p's buffer k as a tensor in THIS process
+            for k in range(len(self._global2)):
+                row = []
+                for p in range(self.world):
+                    if p == self.rank:
+                        row.append(self._global2[k])
+                    else:
+                        fn, args = everyone[p][k]
+                        row.append(fn(*args))
+                peers.append(row)
+            # self-test: rank r writes r + 1 into its block of every rank's buffer 0
+            probe = torch.full((self.hi - self.lo, self._global.shape[1]), float(self.rank + 1), device=dev)
+            self.local.backend.scatter_rows(probe, [t.data_ptr() for t in peers[0]], self.lo)
+            torch.cuda.current_stream(dev).synchronize()
+        except Exception as exc:  # noqa: BLE001 - any failure means: use the collective
+            ok = 0.0
+            self._p2p_error = repr(exc)
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)     # (also the barrier before the check)
+        if float(flag.item()) > 0:
+            per = self.hi - self.lo
+            expect = torch.arange(1, self.world + 1, device=dev, dtype=torch.float32).repeat_interleave(per)
+            good = bool((self._global2[0][:, 0] == expect).all().item())
+            flag = torch.tensor([1.0 if good else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if float(flag.item()) > 0:
+            self._peer_global, self.transport = peers, "p2p"
+            self._peer_ptrs = [[t.data_ptr() for t in row] for row in peers]
 
     def _all_gather(self, packed: torch.Tensor) -> torch.Tensor:
         dist.all_gather_into_tensor(self._global, packed, group=self.group)
@@ -136,8 +197,6 @@ class ShardedVecEnv:
         zeros64 = torch.zeros(n, dtype=torch.float64, device=obs.device)
         zeros8 = torch.zeros(n, dtype=torch.uint8, device=obs.device)
         g = self._all_gather(pack_outputs(obs, zeros64, zeros8, zeros8))
-        if self._compute_stream is not None:       # the next steps run after this reset
-            self._compute_stream.wait_stream(torch.cuda.current_stream(obs.device))
         return unpack_outputs(g, self.obs_dim)[0], info
 
     def step(self, actions):
@@ -154,34 +213,18 @@ class ShardedVecEnv:
         o, r, te, tr = unpack_outputs(self._all_gather(packed), self.obs_dim)
         return o, r, te, tr, info
 
-    def _own_stream(self):
-        dev = self.local.backend.device
-        if dev.type != "cuda" or os.environ.get("SOFTROD_SHARDED_OWN_STREAM", "1") == "0":
-            return None
-        if self._compute_stream is None:
-            self._compute_stream = torch.cuda.Stream(device=dev)
-            self._compute_stream.wait_stream(torch.cuda.current_stream(dev))     # reset / earlier steps first
-        return self._compute_stream
-
     def _step_overlapped(self, a):
-        st = self._own_stream()
-        if st is None:
-            return self._step_overlapped_on_current_stream(a)
-        dev = self.local.backend.device
-        a = a.to(dev)
-        st.wait_stream(torch.cuda.current_stream(dev))     # whatever produced the actions
-        a.record_stream(st)
-        with torch.cuda.stream(st):
-            return self._step_overlapped_on_current_stream(a)
-
-    def _step_overlapped_on_current_stream(self, a):
         k = self._k
         if self._works[k] is not None:
-            # buffers k were last used two steps ago: their gather has long finished; this only
-            # orders the kernel below after it (a stream-level wait, not a host block on RCCL)
+            # buffers k were last used `depth` steps ago: this orders the kernel below after their
+            # gather (a stream-level wait, not a host block on RCCL)
             self._works[k].wait()
         packed, info = self.local.step_packed(a, self._packed2[k])
-        self._works[k] = dist.all_gather_into_tensor(self._global2[k], packed, group=self.group, async_op=True)
+        if self.transport == "p2p":
+            # in order behind the step kernel, on its stream: a few microseconds, no dependency to resolve
+            self.local.backend.scatter_rows(packed, self._peer_ptrs[k], self.lo)
+        else:
+            self._works[k] = dist.all_gather_into_tensor(self._global2[k], packed, group=self.group, async_op=True)
         self._k = (k + 1) % len(self._works)
         o, r, te, tr = unpack_outputs(self._global2[k], self.obs_dim)
         return o, r, te, tr, info
@@ -189,12 +232,12 @@ class ShardedVecEnv:
     def sync(self) -> None:
         """Make the outputs of the latest step() complete (overlap=True)."""
         if self.overlap:
-            if self._compute_stream is not None:
-                # the caller's stream continues after everything launched on the private one ...
-                torch.cuda.current_stream(self.local.backend.device).wait_stream(self._compute_stream)
             for w in self._works:
                 if w is not None:
-                    w.wait()       # ... and after the gathers
+                    w.wait()
+            if self.transport == "p2p":
+                torch.cuda.current_stream(self.local.backend.device).synchronize()
+                dist.barrier(group=self.group)     # this rank's rows have landed everywhere; now everybody's have
 
     def close(self):
         self.sync()

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 12
+#define SOFTROD_ABI_VERSION 13
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -453,6 +453,19 @@ int softrod_queue_status(softrod_handle* h, int32_t* consumed, int32_t* underflo
 int softrod_queue_status_begin(softrod_handle* h, void* stream);
 int softrod_queue_status_poll(softrod_handle* h, int wait, int32_t* consumed, int32_t* underflow);
 int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream);
+
+/* Multi-GPU without a collective call per step (no reference counterpart; gym_softrobot_amd/
+ * distributed.py, transport "p2p"): copy this handle's `n_envs` packed rows (`row_words` 32-bit
+ * words each, as softrod_step_packed wrote them) into rows first_row .. first_row + n_envs - 1 of
+ * EVERY buffer in `peer_buffers` (host array of n_peers <= SOFTROD_MAX_PEERS device pointers: the
+ * other ranks' output buffers, IPC-mapped, and this rank's own), with ONE small kernel on `stream`
+ * — enqueued right behind the step kernel it is a few microseconds in order, where a collective on
+ * a second stream costs this workload ~37 us of cross-queue dependency latency per step (DESIGN.md
+ * §4).  Between GPUs the stores travel over xGMI; they are visible to the peers once the stream has
+ * been synchronised (the caller's barrier).                                                     */
+#define SOFTROD_MAX_PEERS 16
+int softrod_scatter_rows(softrod_handle* h, const float* packed, const uint64_t* peer_buffers,
+                         int n_peers, int row_words, int64_t first_row, void* stream);
 
 /* Replaces: get_state() at reset (soft_pendulum.py:145-161,
  * soft_pendulum_3d.py:93-98).  prev_action is device [n_envs][action_dim]

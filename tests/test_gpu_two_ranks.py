@@ -114,6 +114,23 @@ def test_sharded_env_two_hip_ranks_with_a_masked_reset_mid_rollout(hip_lib, env_
     _worker(env_id, str(per), str(t1), str(t2))
 
 
+@pytest.mark.parametrize("env_id,per,t1,t2", [("SoftPendulum-v0", 96, 5, 6), ("OctoFlat-v0", 6, 2, 2)])
+def test_sharded_env_two_hip_ranks_p2p_transport(hip_lib, env_id, per, t1, t2):
+    """transport="p2p": no collective per step — every rank copies its packed rows into its block of
+    every peer's buffer (IPC-mapped device memory; here both ranks sit on cuda:0, so the mapping is
+    exercised and the copies are local), a barrier at sync().  Bit-equal to one process on every
+    gathered step, masked reset included."""
+    _worker(env_id, str(per), str(t1), str(t2), "off", "p2p")
+
+
+def test_bench_two_ranks_p2p_transport(hip_lib):
+    a = ("--steps", "12", "--warmup", "2", "--preheat", "30")
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "1024", "--transport", "p2p", *a)
+    one = _bench({}, "--gpus", "1", "--envs-per-gpu", "2048", *a)
+    assert two["config"]["transport"] == "p2p" and "peer copies" in two["config"]["sharding"]
+    assert two["config"]["last_step_checksum"] == one["config"]["last_step_checksum"]
+
+
 def test_sharded_env_two_hip_ranks_device_autoreset(hip_lib):
     """Device-side NEXT_STEP auto-reset on both ranks (3-step episodes, so every env restarts several
     times) against ONE process with host-driven auto-reset: the same draws, the same rows."""

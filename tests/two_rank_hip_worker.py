@@ -4,7 +4,7 @@ Launched by `python -m torch.distributed.run --nproc-per-node 2` on the 1-GPU bo
 cuda:0 (RCCL refuses two ranks on one device, so the packed rows travel over gloo), step their shard
 with the real HIP kernels through ShardedVecEnv(overlap=True), take a masked reset in the middle of
 the rollout, and rank 0 compares every gathered step bit for bit with ONE process stepping the whole
-batch on the same GPU.  argv: env-id envs-per-rank steps-before steps-after [autoreset]"""
+batch on the same GPU.  argv: env-id envs-per-rank steps-before steps-after [autoreset [transport]]"""
 import os
 import sys
 from pathlib import Path
@@ -43,6 +43,7 @@ def rollout(env, total, adim, amax, t1, t2, sharded):
 def main():
     env_id, per, t1, t2 = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     autoreset = sys.argv[5] if len(sys.argv) > 5 else "off"
+    transport = sys.argv[6] if len(sys.argv) > 6 else "rccl"
     kw = {} if autoreset == "off" else {"autoreset": autoreset}
     short = {}
     if autoreset != "off":      # 3-step episodes, so restarts cross the shard boundary many times
@@ -52,7 +53,8 @@ def main():
     dist.init_process_group("gloo")
     total = per * world
     local = gsa.make_vec(env_id, per, device=0, **kw, **short)
-    env = ShardedVecEnv(local, total, overlap=True)
+    env = ShardedVecEnv(local, total, overlap=True, transport=transport)
+    assert env.transport == transport, getattr(env, "_p2p_error", "transport fell back")
     got = rollout(env, total, local.action_dim, AMAX[env_id], t1, t2, True)
     ok = True
     if rank == 0:
