@@ -77,7 +77,7 @@ def _autoreset_worker(rank, world, port, total, T, q):
     dist.destroy_process_group()
 
 
-def _worker(rank, world, port, total, T, q, overlap=False):
+def _worker(rank, world, port, total, T, q, overlap=False, transport="rccl"):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -92,7 +92,9 @@ def _worker(rank, world, port, total, T, q, overlap=False):
     cfg.n_substeps = 40  # keep the CPU suite quick; the sharding logic does not depend on it
     local = gsa.VecSoftPendulumEnv(hi - lo, backend=OracleBackend(cfg))
     local.cfg.n_substeps = 40
-    env = ShardedVecEnv(local, total, overlap=overlap)
+    env = ShardedVecEnv(local, total, overlap=overlap, transport=transport)
+    if transport == "p2p":      # no device to map on a CPU box: every rank must have fallen back, together
+        assert env.transport == "rccl" and hasattr(env, "_p2p_error")
     obs0, _ = env.reset(seed=7)
     acts = np.random.default_rng(5).uniform(-22, 22, (T, total)).astype(np.float32)
     out = [obs0.clone().numpy()]
@@ -160,6 +162,27 @@ def test_world2_gloo_matches_single_process(oracle_built, overlap):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, q, overlap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _single(total, T)
+    np.testing.assert_array_equal(got[0], ref[0])
+    for g, r in zip(got[1:], ref[1:]):
+        for a, b in zip(g, r):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_p2p_transport_falls_back_to_the_collective_together(oracle_built):
+    """transport="p2p" needs IPC-mapped device buffers; where its set-up fails (here: no GPU) ALL ranks
+    agree to stay with the collective, and the run is the ordinary one."""
+    total, T, world = 6, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, q, True, "p2p")) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=240)
