@@ -58,6 +58,18 @@ def test_gpus_2_launches_itself_and_prints_one_line(oracle_built):
     assert line["config"]["last_step_checksum"] == one["config"]["last_step_checksum"]
 
 
+def test_gpus_2_with_the_p2p_transport_falls_back_on_a_box_without_a_gpu(oracle_built):
+    """`--transport p2p` where its set-up cannot work (no device memory to map): every rank stays with
+    the collective, the line says which transport ran, and the rows are the same."""
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--envs-per-gpu", "4", "--transport", "p2p"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    (line,) = _json_lines(p.stdout)
+    assert line["config"]["transport"] == "rccl" and "all_gather" in line["config"]["sharding"]
+    q = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--envs-per-gpu", "4"])
+    (ref,) = _json_lines(q.stdout)
+    assert line["config"]["last_step_checksum"] == ref["config"]["last_step_checksum"]
+
+
 def test_child_failure_propagates(oracle_built):
     # 3 envs do not split over 2 ranks: every rank exits non-zero before any line is printed
     p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "3", "--scaling", "strong",
