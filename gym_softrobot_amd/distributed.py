@@ -37,6 +37,9 @@ traces) — while a 4 us kernel in order behind the step kernel costs its 4 us.
 Ranks are not kept in lockstep by it (a rank may run ahead in an open-loop rollout; a consumer that
 reads every step's rows calls sync() every step and is in lockstep through the barrier).  RCCL
 stays the default, as BASELINE's north_star asks; `bench.py --transport p2p` measures the other.
+OPEN for p2p between different devices (not testable on a 1-GPU box, where both ranks share one L2):
+the reader's L2 does not snoop a peer's stores into its HBM, so the output buffers may need to be
+fine-grained allocations, or the reader an invalidating read, before this is correct there.
 """
 from __future__ import annotations
 
