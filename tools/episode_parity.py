@@ -38,6 +38,16 @@ from oracle import oracle_c  # noqa: E402
 FLOOR = 1e-3
 
 
+def rel_scale(a, b):
+    """max|a - b| / max|b|: relative to the field's own scale, no absolute floor (north_star's
+    tolerance is relative; `rel` below carries a 1e-3 floor for entries that pass through zero)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if not np.isfinite(b).all() or not np.isfinite(a).all():
+        return 0.0 if (np.isnan(a) == np.isnan(b)).all() else float("inf")
+    m = float(np.max(np.abs(b)))
+    return float(np.max(np.abs(a - b)) / m) if m > 0 else 0.0
+
+
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     with np.errstate(invalid="ignore"):
@@ -107,7 +117,8 @@ def run(kind, n, steps, script, window=0, with_control=True, **kw):
         if with_control:
             K.reset(ctrl[i], env, i)
     o_obs = obs0.cpu().numpy().copy()
-    curves = {k: [] for k in ("gpu_obs", "gpu_reward", "gpu_x", "ctl_obs", "ctl_reward", "ctl_x", "flags_equal")}
+    curves = {k: [] for k in ("gpu_obs", "gpu_reward", "gpu_x", "ctl_obs", "ctl_reward", "ctl_x", "flags_equal",
+                              "gpu_x_rel_scale", "ctl_x_rel_scale")}
     for t in range(steps):
         acts = np.asarray(script(t, o_obs), np.float32).reshape(n, env.action_dim)
         if window and t % window == 0 and t > 0:
@@ -115,7 +126,7 @@ def run(kind, n, steps, script, window=0, with_control=True, **kw):
         g_obs, g_rew, g_te, g_tr, _ = env.step(acts)
         g_obs, g_rew = g_obs.cpu().numpy(), g_rew.cpu().numpy()
         g_x = env.backend.state_numpy()["x"]
-        eo = er = ex = co = cr = cx = 0.0
+        eo = er = ex = co = cr = cx = xs = cs = 0.0
         same = True
         for i in range(n):
             o, rw, te, tr = K.step(rods[i], acts[i])
@@ -123,9 +134,10 @@ def run(kind, n, steps, script, window=0, with_control=True, **kw):
             o_obs[i] = o
             eo, er, ex = max(eo, rel(g_obs[i], o)), max(er, rel(g_rew[i], rw)), max(ex, rel(g_x[i], rods[i].get("x")))
             co, cr, cx = max(co, rel(c_o, o)), max(cr, rel(c_rw, rw)), max(cx, rel(ctrl[i].get("x"), rods[i].get("x")))
+            xs, cs = max(xs, rel_scale(g_x[i], rods[i].get("x"))), max(cs, rel_scale(ctrl[i].get("x"), rods[i].get("x")))
             same = same and bool(g_te[i]) == te and bool(g_tr[i]) == tr
         for k, v in (("gpu_obs", eo), ("gpu_reward", er), ("gpu_x", ex), ("ctl_obs", co), ("ctl_reward", cr),
-                     ("ctl_x", cx), ("flags_equal", same)):
+                     ("ctl_x", cx), ("flags_equal", same), ("gpu_x_rel_scale", xs), ("ctl_x_rel_scale", cs)):
             curves[k].append(v)
     env.close()
 
