@@ -676,8 +676,8 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
             // what the power controller leaves it (profiles/README.md r3h: 0.3008 -> 0.2846 ms, bit-
             // identical).  A DPP shift that would read a disabled lane returns 0 (bound_ctrl), exactly
             // what it returns past lane 63, and the element after the last node has no stiffness either
-            // way: results are unchanged.  (The 3-D loops carry the same mask, general_substeps; on
-            // OctoFlat's ghost slots it was measured and changes nothing: 9.355 / 9.36 ms.)
+            // way: results are unchanged.  (The 3-D loops carry the same mask, general_substeps, and so
+            // do OctoFlat's ghost slots, softrod_octo.hpp.)
             if (lane * EPL <= P.n_elem + (SOFTROD_PLANAR_EXEC_MASK == 2 ? 64 : 0)) {     // (2: the same code with no lane masked, an A/B control)
 #endif
                 planar_kinematic_n<EPL>(P.half_dt, K.hq_hdt, C, K, Z);

@@ -428,7 +428,16 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             time = clock_after(P, S, time, n_sub);
         }
     }
-    if (n_sub > 0 && !dead && live) {
+    // The ghost slots between the arms (5 of every 16 lanes at 10 elements) sit the loop out with EXEC
+    // cleared, like the idle lanes of the one-rod kernels (softrod_fast.hpp): lane 0 of every wave is
+    // a base node, so the rendezvous and the LDS posts are unaffected, and a DPP shift that would read
+    // a ghost returns 0 where it used to return the ghost's zeros.  Bit-identical; worth what the
+    // box's power budget makes of it: 9.47 -> 9.34 ms on one box, 9.36 / 9.355 on another that was
+    // already there (profiles/README.md r3k).
+#ifndef SOFTROD_OCTO_GHOST_MASK
+#define SOFTROD_OCTO_GHOST_MASK 1
+#endif
+    if (n_sub > 0 && !dead && live && (!SOFTROD_OCTO_GHOST_MASK || (arm_ok && r <= n))) {
         kinematic_n<1>(P.half_dt, C, L);
         head_normalize(H);                       // hk = dt/2 and zero loads: the head's first half step
         head_step();
