@@ -46,8 +46,25 @@ library they were measured on (softrod_source_hash); when it differs from the lo
 
 cpu_baseline: the repo's fp64 C oracle (a port/restatement, NOT PyElastica — see
 oracle/softrod_oracle.c) timed on this box's host cores with OpenMP over rods, rank 0,
-N=1 only, on a bounded sample of the same workload.  `cores` = the CPUs the process may
-really use (cgroup quota, else affinity), which is also the OpenMP thread count.
+N=1 only, on a bounded sample of the same workload: the SAME 4096 rods (SURVEY §8(d) /
+BASELINE.md §3), as many env.steps as fit ~10 s (at least 2), plus one rod on one thread for
+1 s.  `cores` = the CPUs the process may really use (cgroup quota, else affinity), which is
+also the OpenMP thread count.
+
+secondary (N=1, default): after the headline windows the same process measures BASELINE
+configs[2] (OctoArmSingle-v0, 100 elements x 4096 envs) and configs[4]'s per-GPU share
+(OctoFlat-v0 x 1024 envs), 10 timed steps each on the warm clock, and reports them under
+`secondary` with their own roofline blocks (hash-matched tables); the headline keys are untouched.
+
+N > 1: `per_rank` lists every rank's step-kernel time, what a step costs beyond it (the exchange:
+collective or peer copies, plus launch gaps) and `efficiency_vs_n1_kernel` = kernel time / step
+time; and, with the default transport, every rank then runs the same windows once more over
+transport "p2p" in a CHILD process of its own (`p2p_trial` in the line: a crash or a fall-back of
+the experimental transport cannot cost the headline measurement).
+
+methodology_version 4 (round 4).  3 = round 3: clock pre-heat + median of up to five windows;
+figures of rounds 1-2 (one window, no pre-heat) are not like for like.  `single_window` in the
+line is window 0 alone, whatever the window count.
 """
 from __future__ import annotations
 
@@ -68,6 +85,10 @@ N_SIMD = 1024                # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9             # MI355X_MICROARCH.md peak engine clock
 CYCLES_PER_FP64_WAVE_INSTR = 4.0   # wave64 fp64 op: 16 lanes per clock per SIMD
 VALU_PEAK_GINSTR = N_SIMD * CLOCK_HZ / CYCLES_PER_FP64_WAVE_INSTR / 1e9   # 614.4
+METHODOLOGY_VERSION = 4
+AMAX = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
+        "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0}
+TAPER_RATIO = 12.0           # base : tip radius of the tapered arm (octopus/arm_push_env.py:160-165: 0.012 : 0.001)
 
 
 def algorithmic_bytes_per_rod_substep(n_elem: int, sizeof_real: int = 8) -> int:
@@ -95,9 +116,9 @@ def usable_cpus() -> int:
     return n
 
 
-def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
-    """Time the C oracle (OpenMP over rods) on a bounded sample: 16 rods per core,
-    env.steps until ~budget_s of wall time (at least 2 steps)."""
+def cpu_baseline(cfg, cores: int, n_rods: int = ENVS_PER_GPU, budget_s: float = 10.0):
+    """Time the C oracle (OpenMP over rods) on the workload's own batch: `n_rods` rods (4096:
+    SURVEY §8(d)), env.steps until ~budget_s of wall time (at least 2)."""
     import numpy as np
 
     os.environ["OMP_NUM_THREADS"] = str(cores)
@@ -105,14 +126,16 @@ def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
     from oracle import oracle_c
 
     oracle_c.build()
-    n_rods = 16 * cores
     batch = oracle_c.OracleBatch(cfg, n_rods, omp=True)
     batch.reset([initial_angle(np_random(i)[0]) for i in range(n_rods)])
     acts = np.random.default_rng(1).uniform(-22, 22, (64, n_rods)).astype(np.float32)
-    batch.env_step(acts[0])  # warm-up
+    # warm-up on a slice of the time budget: one step of 4096 rods is ~1-3 s on 8-16 threads
+    t0 = time.perf_counter()
+    batch.env_step(acts[0])
+    per_step = time.perf_counter() - t0
     t0 = time.perf_counter()
     steps = 0
-    while steps < 2 or (time.perf_counter() - t0 < budget_s and steps < 60):
+    while steps < 2 or (time.perf_counter() - t0 + per_step < budget_s and steps < 60):
         batch.env_step(acts[1 + steps])
         steps += 1
     dt = time.perf_counter() - t0
@@ -134,8 +157,9 @@ def cpu_baseline(cfg, cores: int, budget_s: float = 12.0):
         "cores": cores,
         "kind": "port",
         "sample": f"{n_rods} rods x {steps} env.steps (400 substeps, 50 elements, fp64 C oracle, "
-                  f"OpenMP {cores} threads, {dt:.1f} s)",
+                  f"OpenMP {cores} threads, {dt:.1f} s; the batch the GPU line steps)",
         "single_thread_value": single,
+        "single_thread_sample": f"1 rod x {k} env.steps on 1 thread, {dt1:.1f} s",
         "measured_parallel_speedup": value / single,
         "affinity_cpus": len(os.sched_getaffinity(0)),
     }
@@ -167,6 +191,15 @@ def parse_args(argv=None):
     ap.add_argument("--actions", choices=["random", "zero"], default="random",
                     help="random (default): uniform in the action box; zero: SURVEY.md §8(d)'s zero-action run")
     ap.add_argument("--n-elems", type=int, default=None, help="elements per rod (env default if omitted)")
+    ap.add_argument("--taper", action="store_true",
+                    help=f"OctoArmSingle-v0 only: a TAPERED arm, radius falling {TAPER_RATIO:g}:1 from base to tip "
+                         "like the reference's muscle arms (octopus/arm_push_env.py:160-179) — the per-lane "
+                         "material-table instantiation of the step kernel")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N=1 headline run: skip the two secondary workloads (BASELINE configs[2], configs[4]'s share)")
+    ap.add_argument("--no-p2p-trial", action="store_true",
+                    help="N>1 with the default transport: skip the second measurement over transport p2p")
+    ap.add_argument("--trial-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--transport", choices=["rccl", "p2p"], default="rccl",
                     help="N > 1: how the packed rows reach the other ranks.  rccl (default, BASELINE's north_star): "
                          "one all_gather_into_tensor per step; p2p: every rank copies its rows into its block of "
@@ -327,6 +360,219 @@ def preheat(make_scratch, acts_dev, cap_ms: float, min_ms: float = 120.0, agree=
                      "what": "scratch batch of the same env/size, zero actions, not the measured batch"}
 
 
+def taper_profile(base_radius: float, n_elem: int):
+    """Element radii of the tapered arm: node radii falling linearly base -> base / TAPER_RATIO, element
+    value = mean of its two nodes (octopus/arm_push_env.py:163-165, scaled to this arm's base radius so
+    that the base rests on the plane like the uniform arm does)."""
+    import numpy as np
+
+    edge = np.linspace(base_radius, base_radius / TAPER_RATIO, n_elem + 1)
+    return (edge[:-1] + edge[1:]) / 2
+
+
+def workload_name(env_id: str, cfg, n_local: int, world: int = 1, taper: bool = False) -> str:
+    octo = env_id == "OctoFlat-v0"
+    return (f"{env_id}, {n_local} envs x " + (f"{int(cfg.n_arm)} arms x " if octo else "")
+            + f"{int(cfg.n_elem)} elements per GPU " + ("tapered " if taper else "")
+            + (f"(BASELINE configs[1]; x{world} GPUs)" if env_id == "SoftPendulum-v0"
+               else "(widened row of SURVEY §8; not the headline metric)"))
+
+
+def profile_key(env_id: str, n_elem: int, taper: bool = False) -> str:
+    return f"{env_id}|n_elem={n_elem}" + ("|taper" if taper else "")
+
+
+def roofline_block(env_id, cfg, n_local, kernel_ms, math_mode, lib_hash, hip, backend, taper=False):
+    """The `roofline` object of one workload: priced against the tracked rocprofv3 tables, used only
+    when they were measured on THIS env / size / build of the library."""
+    nsub = int(cfg.n_substeps)
+    octo = env_id == "OctoFlat-v0"
+    rods_per_env = int(cfg.n_arm) if octo else 1
+    rod_substeps = n_local * rods_per_env * nsub
+    # OctoFlat: n_arm rods + the rigid head (x, v, Q, w = 18 doubles read and written)
+    bytes_per_launch = n_local * nsub * (rods_per_env * algorithmic_bytes_per_rod_substep(int(cfg.n_elem))
+                                         + (2 * 18 * 8 if octo else 0))
+    kernel_s = kernel_ms * 1e-3
+    key = profile_key(env_id, int(cfg.n_elem), taper)
+    traffic_rec, traffic_why = fresh_or_none(load_profile_table("hbm_traffic.json", f"{key}|envs={n_local}"), lib_hash)
+    traffic = (traffic_rec or {}).get("hbm_bytes_per_launch")
+    valu_rec, valu_why = (None, "valu_counts.json holds the fast-math kernels only")
+    if math_mode == "fast":
+        valu_rec, valu_why = fresh_or_none(load_profile_table("valu_counts.json", key), lib_hash)
+    valu_per = (valu_rec or {}).get("valu_instr_per_rod_substep")
+    achieved = None if valu_per is None else valu_per * rod_substeps / kernel_s / 1e9
+    frac = None if achieved is None else achieved / VALU_PEAK_GINSTR
+    n_waves = 1
+    if octo:
+        n_waves = -(-int(cfg.n_arm) * int(backend.state()["arm_stride"]) // 64) if hip else 2
+    lanes = useful_lane_fraction(cfg, octo, n_waves)
+    busy_raw = (valu_rec or {}).get("valu_busy_frac")
+    busy = None if busy_raw is None else min(1.0, busy_raw)
+    return {
+        # what bounds a register-resident kernel: fp64 VALU issue slots (DESIGN.md §5)
+        "bound": "fp64_valu",
+        "achieved": achieved,
+        "peak": VALU_PEAK_GINSTR,
+        "unit": "G wave64-VALU-instr/s",
+        # nominal: every VALU wave-instruction priced at 4 cycles at the 2.4 GHz peak clock
+        "frac": frac,
+        # PRIMARY: the share of the kernel's own cycles in which the VALU was executing an instruction,
+        # from the profiler's cycle counters (clock-independent, and each instruction weighs what it
+        # really occupies the pipe for): SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of
+        # the hash-matched table; 1 - this is the idle share an implementation could still win back
+        "frac_cycle_weighted": busy,
+        "frac_withheld": valu_why,
+        "traffic": traffic,
+        "traffic_withheld": traffic_why,
+        # lanes that carry a node / lanes launched: `frac` counts every issued wave instruction
+        # as work, idle lanes included; frac x useful_lane_frac is the share of the chip's fp64
+        # LANE-slots that advance a node
+        "useful_lane_frac": lanes,
+        "frac_of_lane_slots": None if frac is None else frac * lanes,
+        "kernel": "softrod_octo_step_kernel" if octo else
+                  "softrod_step_window_kernel + softrod_step_fast_kernel (epilogue only)"
+                  if (env_id == "OctoArmSingle-v0" and 64 <= int(cfg.n_elem) <= 102 and math_mode == "fast") else
+                  (("softrod_step_fast_kernel" + (" (TAPER instantiation)" if taper else ""))
+                   if math_mode == "fast" else "softrod_step_libm_kernel"),
+        "kernel_ms_avg": kernel_ms,
+        "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz / {CYCLES_PER_FP64_WAVE_INSTR:g} cycles per "
+                           "wave64 fp64 instruction (= 78.6 TFLOP/s of FMAs, MI355X_MICROARCH.md).  `frac` prices EVERY "
+                           "VALU instruction at those 4 cycles; what the classes of the loop really occupy the pipe "
+                           "for: fp64 FMA / mul / add 4 cycles, b32 ops incl. the DPP wave shifts 2, the quarter-rate "
+                           "v_rsq_f64 / v_rcp_f64 seeds 16 (the SoftPendulum loop: ~83 fp64, 14 b32 DPP, 3 seeds per "
+                           "substep -> 408 cycles against the nominal 400).  `frac_cycle_weighted` needs no such "
+                           "prices: it is the measured busy share of the measured cycles",
+        # ONE measured sample of a pure stream of independent v_fma_f64 (tools/microbench/valu_issue.hip,
+        # four waves per SIMD: 4.2-4.6 cycles per instruction at the 1.9-2.0 GHz the clock settles at
+        # under that load).  Context only, NOT a ceiling: a mixed stream (mul/add/DPP next to the
+        # FMAs) draws less power, clocks at 2.25-2.3 GHz and can exceed it, as `achieved` does
+        "fma_stream_sample": {"value": 466.0, "unit": "G wave64-VALU-instr/s",
+                              "source": "profiles/history/r2j_valu_issue_microbench.txt",
+                              "note": "one sample at ~1.9-2.0 GHz; not a ceiling on `achieved`"},
+        "valu_instr_per_rod_substep": valu_per,
+        "valu_instr_source": (valu_rec or {}).get("source"),
+        "rod_substeps_per_launch": rod_substeps,
+        # (the cycle-weighted fraction again under its round-3 names; raw can exceed 1 by ~1 %:
+        # GRBM_GUI_ACTIVE / 8 is the mean over the XCDs' active cycles)
+        "profiled_valu_busy_frac": busy,
+        "profiled_valu_busy_frac_raw": busy_raw,
+        "hbm": {
+            "measured_traffic_GBs": None if traffic is None else traffic / kernel_s / 1e9,
+            "measured_traffic_frac_of_8TBs": None if traffic is None else traffic / kernel_s / 1e9 / HBM_PEAK_GBS,
+            "traffic_source": (traffic_rec or {}).get("source"),
+            "minimum_bytes_per_launch": n_local * rods_per_env * (18 * int(cfg.n_elem) + 6) * 8 * 2,
+            "streaming_model_GBs": bytes_per_launch / kernel_s / 1e9,
+            "streaming_model_bytes_per_launch": bytes_per_launch,
+            "streaming_model_note": "SURVEY 8d's algorithmic bytes (rods x substeps x 2(18n+6) x 8 B) / kernel "
+                                    "time: what a one-substep-per-pass implementation would have to move; this "
+                                    "kernel keeps the state in registers for all substeps, so the figure exceeds "
+                                    "the 8 TB/s peak by construction and is NOT a fraction of anything",
+        },
+    }
+
+
+# BASELINE.json configs[2] and configs[4]'s per-GPU share: measured after the headline, same process
+SECONDARY = (
+    dict(env_id="OctoArmSingle-v0", n_local=4096, extra={"n_elems": 100}, baseline="configs[2]"),
+    dict(env_id="OctoFlat-v0", n_local=1024, extra={}, baseline="configs[4], one GPU's share of 8192 envs"),
+)
+
+
+def secondary_workload(gsa, _capi, torch, device, math_mode, lib_hash, env_id, n_local, extra, baseline,
+                       steps: int = 10, warmup: int = 3):
+    """`steps` timed env.steps of one more workload on the already warm clock (the headline run has
+    just kept the GPU under load for ~1 s; `warmup` steps take the workload's own one-off costs)."""
+    import numpy as np
+
+    env = gsa.make_vec(env_id, n_local, device=device, math_mode=math_mode, **extra)
+    env.reset(seed=0)
+    adim = env.backend.action_dim
+    acts = np.random.default_rng(1).uniform(-AMAX[env_id], AMAX[env_id], (warmup + steps, n_local, adim)).astype(np.float32)
+    acts_dev = torch.from_numpy(acts).to(env.backend.device)
+    env.backend.set_timing(warmup + steps)
+    for t in range(warmup):
+        env.step(acts_dev[t])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(warmup, warmup + steps):
+        obs, rew, term, trunc, _ = env.step(acts_dev[t])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kt = env.backend.kernel_times_ms()
+    per_step = 2 if len(kt) == 2 * (warmup + steps) else 1      # the windowed arm runs two kernels per env.step
+    kernel_ms = float(np.sum(kt[per_step * warmup:])) / steps
+    cfg = env.cfg
+    out = {
+        "workload": workload_name(env_id, cfg, n_local),
+        "baseline_config": baseline,
+        "value": n_local * steps / elapsed, "unit": "env-steps/s",
+        "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "kernel_ms_avg": kernel_ms,
+        "substeps_per_env_step": int(cfg.n_substeps),
+        "non_finite_envs_at_end": int((~torch.isfinite(obs).all(dim=1)).sum().item()),
+        "last_step_checksum": float(torch.nan_to_num(obs.double()).sum().item()) + float(torch.nan_to_num(rew.double()).sum().item()),
+        "roofline": roofline_block(env_id, cfg, n_local, kernel_ms, "fast" if math_mode == _capi.MATH_FAST else "libm",
+                                   lib_hash, True, env.backend),
+    }
+    env.close()
+    return out
+
+
+def p2p_trial(args, rank: int, local_rank: int, world: int, script=None, timeout_s: float = 300.0):
+    """N > 1, after the headline (RCCL) measurement: every rank starts ONE child process that runs this
+    file again as the same rank of a second job over transport "p2p" (its own rendezvous port), so that
+    the driver's one run per N yields both transports — and a crash, a hang or a fall-back of the
+    experimental transport is a field of the line, not a lost measurement.  The parents have finished
+    their GPU work; they never exec, and they kill their child's process group at the timeout.
+    -> rank 0: the child's figures; other ranks: None."""
+    import signal
+    import subprocess
+
+    port = int(os.environ.get("MASTER_PORT", "29511")) + 1      # the job's port + 1
+    env = dict(os.environ, MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world))
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+              "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(Path(script or __file__).resolve()), "--gpus", str(world), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--env", args.env, "--scaling", args.scaling, "--math-mode", args.math_mode,
+           "--actions", args.actions, "--autoreset", args.autoreset, "--transport", "p2p", "--trial-child",
+           "--no-cpu-baseline", "--preheat", str(min(args.preheat, 200.0)), "--windows", str(args.windows)]
+    if args.envs_per_gpu is not None:
+        cmd += ["--envs-per-gpu", str(args.envs_per_gpu)]
+    if args.n_elems is not None:
+        cmd += ["--n-elems", str(args.n_elems)]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                            start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout_s)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        out, err = proc.communicate()
+        rc = 124
+    if rank != 0:
+        return None
+    res = {"what": "the same job once more over transport p2p, one child process per rank", "returncode": rc}
+    for ln in (out or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            try:
+                d = json.loads(ln)
+            except ValueError:
+                continue
+            res.update({"value": d["value"], "ms_per_step": d["ms_per_step"],
+                        "transport": d["config"]["transport"], "exchange_memory": d["config"].get("exchange_memory"),
+                        "transport_fallback_reason": d["config"].get("transport_fallback_reason"),
+                        "last_step_checksum": d["config"]["last_step_checksum"],
+                        "windows_value": d["windows"]["value"], "per_rank": d.get("per_rank")})
+    if "value" not in res:
+        res["stderr_tail"] = (err or "")[-1500:]
+    return res
+
+
 def main(argv=None, script=None) -> int:
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -360,10 +606,10 @@ def main(argv=None, script=None) -> int:
         # transport of the packed rows: RCCL ("nccl") unless told otherwise (two ranks on ONE device
         # need gloo: RCCL refuses two ranks per GPU)
         backend = os.environ.get("SOFTROD_BENCH_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        from gym_softrobot_amd.distributed import init_process_group
+
+        # RCCL's stream at high priority (SOFTROD_RCCL_HIGH_PRIORITY=0: normal): distributed.py says why
+        init_process_group(backend, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     n_local = args.envs_per_gpu or (1024 if args.env == "OctoFlat-v0" else ENVS_PER_GPU)
     if args.scaling == "strong":
@@ -375,6 +621,10 @@ def main(argv=None, script=None) -> int:
     R = args.windows if args.windows > 0 else max(1, min(5, (120 - W) // max(K, 1)))
     math_mode = _capi.MATH_FAST if args.math_mode == "fast" else _capi.MATH_LIBM
     extra = {} if args.n_elems is None else {"n_elems": args.n_elems}
+    if args.taper:
+        if args.env != "OctoArmSingle-v0":
+            raise SystemExit("--taper is the tapered OctoArmSingle-v0 arm")
+        extra["radius_profile"] = taper_profile(_capi.arm_single_config(1).base_radius, args.n_elems or 50)
     scratch_kw = dict(extra)
     T = W + R * K
     if args.autoreset == "auto":
@@ -390,8 +640,7 @@ def main(argv=None, script=None) -> int:
     env.reset(seed=0)                      # global env i seeded i
     lo, hi = env.lo, env.hi
     adim = local.backend.action_dim
-    amax = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
-            "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0}[args.env]
+    amax = AMAX[args.env]
     if args.actions == "zero":
         amax = 0.0
     # the truncation flag of SoftPendulum first fires on env.step #126; the default window
@@ -479,35 +728,27 @@ def main(argv=None, script=None) -> int:
     # what the last step returned, over ALL envs (gathered rows included): lets two runs be compared
     obs_checksum = float(torch.nan_to_num(obs.double()).sum().item()) + float(torch.nan_to_num(rew.double()).sum().item())
 
+    # N > 1: what every rank measured (its step-kernel time; the rest of its step is the exchange)
+    per_rank = None
+    my_kernel_ms = float(np.mean(kt[m * K:(m + 1) * K])) if len(kt) == R * K else float(np.mean(kt))
+    if distributed:
+        mine = {"rank": rank, "kernel_ms_avg": my_kernel_ms,
+                "kernel_ms_each_window": [float(np.mean(kt[w * K:(w + 1) * K])) for w in range(R)] if len(kt) == R * K else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    transport_ran = env.transport if distributed else None
+    exchange_memory = getattr(env, "exchange_memory", None)
+    p2p_error = getattr(env, "_p2p_error", None)
+
+    line = None
     if rank == 0:
         cfg = local.cfg
         nsub = int(cfg.n_substeps)
         octo = args.env == "OctoFlat-v0"
         rods_per_env = int(cfg.n_arm) if octo else 1
-        rod_substeps = n_local * rods_per_env * nsub
-        # OctoFlat: n_arm rods + the rigid head (x, v, Q, w = 18 doubles read and written)
-        bytes_per_launch = n_local * nsub * (rods_per_env * algorithmic_bytes_per_rod_substep(int(cfg.n_elem))
-                                             + (2 * 18 * 8 if octo else 0))
         per_win_kernel = [float(np.mean(kt[w * K:(w + 1) * K])) for w in range(R)] if len(kt) == R * K else []
         kernel_ms = per_win_kernel[m] if per_win_kernel else float(np.mean(kt))
-        kernel_s = kernel_ms * 1e-3
-        # tracked rocprofv3 evidence, keyed by workload: only a measurement of THIS env / size on THIS
-        # build of the library is used
-        traffic_rec, traffic_why = fresh_or_none(
-            load_profile_table("hbm_traffic.json", f"{args.env}|n_elem={int(cfg.n_elem)}|envs={n_local}"), lib_hash)
-        traffic = (traffic_rec or {}).get("hbm_bytes_per_launch")
-        valu_rec, valu_why = (None, "valu_counts.json holds the fast-math kernels only")
-        if args.math_mode == "fast":
-            valu_rec, valu_why = fresh_or_none(
-                load_profile_table("valu_counts.json", f"{args.env}|n_elem={int(cfg.n_elem)}"), lib_hash)
-        valu_per = (valu_rec or {}).get("valu_instr_per_rod_substep")
-        achieved = None if valu_per is None else valu_per * rod_substeps / kernel_s / 1e9
-        frac = None if achieved is None else achieved / VALU_PEAK_GINSTR
-        n_waves = 1
-        if octo:
-            n_waves = -(-int(cfg.n_arm) * int(local.backend.state()["arm_stride"]) // 64) if hip else 2
-        lanes = useful_lane_fraction(cfg, octo, n_waves)
-        busy_raw = (valu_rec or {}).get("valu_busy_frac")
+        ms_per_step = elapsed / K * 1e3
         line = {
             "metric": "env_steps_per_sec",
             "value": win_value[m],
@@ -515,17 +756,15 @@ def main(argv=None, script=None) -> int:
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": elapsed / K * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic" if hip else "TEST-DOUBLE (not a measurement)",
+            "methodology_version": METHODOLOGY_VERSION,
             "config": {
-                "workload": f"{args.env}, {n_local} envs x "
-                            + (f"{rods_per_env} arms x " if octo else "") + f"{int(cfg.n_elem)} elements per GPU "
-                            + (f"(BASELINE configs[1]; x{world} GPUs)" if args.env == "SoftPendulum-v0"
-                               else "(widened row of SURVEY §8; not the headline metric)"),
+                "workload": workload_name(args.env, cfg, n_local, world, args.taper),
                 "envs_total": n_total,
                 "substeps_per_env_step": nsub,
                 "math_mode": args.math_mode,
@@ -536,7 +775,11 @@ def main(argv=None, script=None) -> int:
                              + ("one packed all_gather per step" if env.transport == "rccl" else
                                 "peer copies of the packed rows per step (no collective), a barrier at sync")
                              ) if (world > 1 or force_dist) else "single GPU",
-                "transport": env.transport if (world > 1 or force_dist) else None,
+                "transport": transport_ran,
+                "exchange_memory": exchange_memory,
+                "transport_fallback_reason": p2p_error if (args.transport == "p2p" and transport_ran != "p2p") else None,
+                "rccl_stream_priority": ("high" if os.environ.get("SOFTROD_RCCL_HIGH_PRIORITY", "1") != "0" else "normal")
+                                        if distributed else None,
                 "rod_substeps_per_sec": (n_total * K - restarts) * rods_per_env * nsub / elapsed,
                 "non_finite_envs_at_end": n_bad, "last_step_checksum": obs_checksum,
                 "library_source_hash": lib_hash,
@@ -558,71 +801,54 @@ def main(argv=None, script=None) -> int:
                 # every launch of the measured batch, warm-up first (when there are few enough to print)
                 "kernel_ms_each": [round(float(x), 4) for x in kt_all] if len(kt_all) <= 256 else None,
             },
+            # window 0 alone: the one figure that does not depend on how many windows the arguments allow
+            "single_window": {"value": win_value[0], "ms_per_step": win_elapsed[0] / K * 1e3,
+                              "note": "the first timed window of K steps after the pre-heat and the warm-up"},
             "preheat": heat,
-            "roofline": {
-                # what bounds a register-resident kernel: fp64 VALU issue slots
-                "bound": "fp64_valu",
-                "achieved": achieved,
-                "peak": VALU_PEAK_GINSTR,
-                "unit": "G wave64-VALU-instr/s",
-                "frac": frac,
-                "frac_withheld": valu_why,
-                "traffic": traffic,
-                "traffic_withheld": traffic_why,
-                # lanes that carry a node / lanes launched: `frac` counts every issued wave instruction
-                # as work, idle lanes included; frac x useful_lane_frac is the share of the chip's fp64
-                # LANE-slots that advance a node
-                "useful_lane_frac": lanes,
-                "frac_of_lane_slots": None if frac is None else frac * lanes,
-                "kernel": "softrod_octo_step_kernel" if octo else
-                          "softrod_step_window_kernel + softrod_step_fast_kernel (epilogue only)"
-                          if (args.env == "OctoArmSingle-v0" and 64 <= int(cfg.n_elem) <= 102
-                              and args.math_mode == "fast") else
-                          ("softrod_step_fast_kernel" if args.math_mode == "fast" else "softrod_step_libm_kernel"),
-                "kernel_ms_avg": kernel_ms,
-                "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz / {CYCLES_PER_FP64_WAVE_INSTR:g} cycles per "
-                                   "wave64 fp64 instruction (= 78.6 TFLOP/s of FMAs, MI355X_MICROARCH.md)",
-                # ONE measured sample of a pure stream of independent v_fma_f64 (tools/microbench/valu_issue.hip,
-                # four waves per SIMD: 4.2-4.6 cycles per instruction at the 1.9-2.0 GHz the clock settles at
-                # under that load).  Context only, NOT a ceiling: a mixed stream (mul/add/DPP next to the
-                # FMAs) draws less power, clocks at 2.25-2.3 GHz and can exceed it, as `achieved` does
-                "fma_stream_sample": {"value": 466.0, "unit": "G wave64-VALU-instr/s",
-                                      "source": "profiles/r2j_valu_issue_microbench.txt",
-                                      "note": "one sample at ~1.9-2.0 GHz; not a ceiling on `achieved`"},
-                "valu_instr_per_rod_substep": valu_per,
-                "valu_instr_source": (valu_rec or {}).get("source"),
-                "rod_substeps_per_launch": rod_substeps,
-                # the same fraction from the profiler's own cycle counter (clock-independent), if tracked:
-                # SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).  The raw quotient can exceed 1
-                # by ~1 % (GRBM_GUI_ACTIVE / 8 is the mean over the XCDs' active cycles and the counter's
-                # 4-cycle granule is nominal); reported clamped, with the raw value beside it
-                "profiled_valu_busy_frac": None if busy_raw is None else min(1.0, busy_raw),
-                "profiled_valu_busy_frac_raw": busy_raw,
-                "hbm": {
-                    "measured_traffic_GBs": None if traffic is None else traffic / kernel_s / 1e9,
-                    "measured_traffic_frac_of_8TBs": None if traffic is None else traffic / kernel_s / 1e9 / HBM_PEAK_GBS,
-                    "traffic_source": (traffic_rec or {}).get("source"),
-                    "minimum_bytes_per_launch": n_local * rods_per_env * (18 * int(cfg.n_elem) + 6) * 8 * 2,
-                    "streaming_model_GBs": bytes_per_launch / kernel_s / 1e9,
-                    "streaming_model_bytes_per_launch": bytes_per_launch,
-                    "streaming_model_note": "SURVEY 8d's algorithmic bytes (rods x substeps x 2(18n+6) x 8 B) / kernel "
-                                            "time: what a one-substep-per-pass implementation would have to move; this "
-                                            "kernel keeps the state in registers for all substeps, so the figure exceeds "
-                                            "the 8 TB/s peak by construction and is NOT a fraction of anything",
-                },
-            },
+            "roofline": roofline_block(args.env, cfg, n_local, kernel_ms, args.math_mode, lib_hash, hip,
+                                       local.backend, args.taper),
         }
-        if world == 1 and not args.no_cpu_baseline and args.env == "SoftPendulum-v0" and hip:
-            line["cpu_baseline"] = cpu_baseline(cfg, usable_cpus())
-        else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        if per_rank is not None:
+            for r_ in per_rank:
+                r_["exchange_us_per_step"] = (ms_per_step - r_["kernel_ms_avg"]) * 1e3
+                r_["efficiency_vs_n1_kernel"] = r_["kernel_ms_avg"] / ms_per_step
+            line["per_rank"] = {
+                "ranks": per_rank,
+                "note": "kernel_ms_avg: each rank's step kernel (HIP events, median window); exchange_us_per_step = "
+                        "job ms_per_step - that rank's kernel time: the all-gather / peer copies plus launch gaps; "
+                        "efficiency_vs_n1_kernel = kernel time / step time (1.0 = the exchange costs nothing)",
+            }
 
+    # ---- N = 1: the other two single-GPU BASELINE workloads on the warm clock, then the CPU baseline
     env.close()
     if scratch is not None:
         scratch.close()
+        scratch = None
+    if rank == 0 and world == 1 and not distributed:
+        if (args.env == "SoftPendulum-v0" and hip and not args.no_secondary and args.n_elems is None
+                and args.envs_per_gpu is None and args.math_mode == "fast"):
+            line["secondary"] = [secondary_workload(gsa, _capi, torch, local_rank, math_mode, lib_hash, **spec)
+                                 for spec in SECONDARY]
+        if not args.no_cpu_baseline and args.env == "SoftPendulum-v0" and hip:
+            line["cpu_baseline"] = cpu_baseline(cfg, usable_cpus(), n_rods=ENVS_PER_GPU)
+        else:
+            line["cpu_baseline"] = None
+    elif rank == 0:
+        line["cpu_baseline"] = None
+
+    # ---- N > 1, default transport: the same windows once more over transport "p2p", in child processes
+    if (world > 1 and args.transport == "rccl" and not args.no_p2p_trial and not args.trial_child):
+        trial = p2p_trial(args, rank, local_rank, world, script)
+        if rank == 0:
+            line["p2p_trial"] = trial
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if distributed:
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as exc:  # noqa: BLE001 - the line is out; a group that cannot shut down is not a failed run
+            sys.stderr.write(f"bench.py: process group shutdown: {exc!r}\n")
     return 0
 
 

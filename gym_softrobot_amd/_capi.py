@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -456,7 +456,11 @@ _EXPORTS = {
     "softrod_reset_straight": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "softrod_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "softrod_step_packed": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
-    "softrod_scatter_rows": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int64, _VP]),
+    "softrod_scatter_rows": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_uint32, _VP]),
+    "softrod_exchange_alloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_void_p), _VP, C.POINTER(C.c_int)]),
+    "softrod_exchange_open": (C.c_int, [C.c_int, _VP, C.c_int, C.POINTER(C.c_void_p)]),
+    "softrod_exchange_close": (C.c_int, [C.c_int, _VP]),
+    "softrod_exchange_free": (C.c_int, [C.c_int, _VP]),
     "softrod_observe": (C.c_int, [_VP, _VP, _VP, _VP]),
     "softrod_substeps": (C.c_int, [_VP, _VP, C.c_int, _VP]),
     "softrod_state_view_get": (C.c_int, [_VP, C.POINTER(SoftrodStateView)]),

@@ -254,17 +254,41 @@ class HipRodBackend:
         )
         return out
 
-    def scatter_rows(self, packed: torch.Tensor, peer_ptrs, first_row: int) -> None:
+    def scatter_rows(self, packed: torch.Tensor, peer_ptrs, first_row: int, tag_word: int = -1, tag: int = 0) -> None:
         """softrod_scatter_rows: this batch's packed rows into rows first_row.. of every buffer in
-        `peer_ptrs` (device pointers: the ranks' output buffers), one small kernel on the current stream."""
+        `peer_ptrs` (device pointers: the ranks' exchange buffers), one small kernel on the current
+        stream; tag_word >= 0: word `tag_word` of every buffer receives `tag` once all rows have landed."""
         tab = np.ascontiguousarray(peer_ptrs, dtype=np.uint64)
         check(
             self._lib.softrod_scatter_rows(
                 self._h, packed.data_ptr(), tab.ctypes.data, int(tab.size), int(packed.shape[1]), int(first_row),
-                self._stream(),
+                int(tag_word), int(tag) & 0xFFFFFFFF, self._stream(),
             ),
             self._h,
         )
+
+    # -- exchange buffers of ShardedVecEnv(transport="p2p") (softrod_exchange_*) ------------------
+    def exchange_alloc(self, n_words: int):
+        """Uncached device memory the other GPUs may store into: (tensor float32[n_words] — a
+        zero-copy view —, device pointer, 64-byte IPC handle, memory kind)."""
+        ptr, kind = C.c_void_p(), C.c_int()
+        handle = (C.c_uint8 * 64)()
+        check(self._lib.softrod_exchange_alloc(self.device_index, int(n_words) * 4, C.byref(ptr), handle, C.byref(kind)))
+        t = torch.as_tensor(_DevArray(ptr.value, (int(n_words),), "<f4", self), device=self.device)
+        return t, int(ptr.value), bytes(handle), {1: "uncached", 2: "fine-grained"}[int(kind.value)]
+
+    def exchange_open(self, handle: bytes, owner_device: int) -> int:
+        """Map a peer process's exchange buffer; -> the device pointer valid in this process."""
+        ptr = C.c_void_p()
+        buf = (C.c_uint8 * 64).from_buffer_copy(handle)
+        check(self._lib.softrod_exchange_open(self.device_index, buf, int(owner_device), C.byref(ptr)))
+        return int(ptr.value)
+
+    def exchange_close(self, ptr: int) -> None:
+        check(self._lib.softrod_exchange_close(self.device_index, C.c_void_p(ptr)))
+
+    def exchange_free(self, ptr: int) -> None:
+        check(self._lib.softrod_exchange_free(self.device_index, C.c_void_p(ptr)))
 
     def substeps(self, actions, n: int) -> None:
         a = self._actions(actions) if actions is not None else None

@@ -42,6 +42,7 @@ struct softrod_handle {
     double* d_time_tab = nullptr;   // clock after k env.steps from a reset (clock_after, softrod_fast.hpp)
     double* d_mat = nullptr;        // [kMatRows][64] material table of a tapered rod
     double* d_sucker = nullptr;     // [SOFTROD_MAX_SUCKERS][N]
+    unsigned* d_ticket = nullptr;   // softrod_scatter_rows: blocks that have finished storing (tagged form)
     bool tapered = false;
     bool was_reset = false;
     bool basis_set = false;
@@ -299,10 +300,22 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
             else                                                                                    \
                 SR_LAUNCH(kRuntimeFeatures, kRuntimeEnv, EPL);                                      \
         } while (0)
-        if (h->tapered)      // per-lane material constants: the general instantiation only
-            hipLaunchKernelGGL((softrod_step_fast_kernel<kRuntimeFeatures, kRuntimeEnv, 1, true>), grid, block, 0, st,
-                               h->P, h->S, actions, obs, reward, term, trunc, aux, n_sub, epilogue, pack);
-        else if (h->epl == 2) SR_DISPATCH(2); else SR_DISPATCH(1);
+        if (h->tapered) {    // per-lane material constants (TAPER = true), one slot per lane
+#define SR_LAUNCH_TAPER(FEATS, ENV)                                                                 \
+            hipLaunchKernelGGL((softrod_step_fast_kernel<FEATS, ENV, 1, true>), grid, block, 0, st, h->P, h->S, \
+                               actions, obs, reward, term, trunc, aux, n_sub, epilogue, pack)
+            // the two tapered feature sets the reference holds on disk get their own instantiation: the
+            // OctoArmSingle set (a tapered arm on the plane, `bench.py --taper`) and the damped arm with
+            // ControllableFixConstraint suckers of arm_push_env.py:160-196 (its COOMM muscles are not on
+            // disk); any other mix takes the run-time mask
+            if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE && zup)
+                SR_LAUNCH_TAPER(SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup, SOFTROD_ENV_ARM_SINGLE);
+            else if (f == kFeaturesTaperedSuckerArm && e == SOFTROD_ENV_NONE)
+                SR_LAUNCH_TAPER(kFeaturesTaperedSuckerArm, SOFTROD_ENV_NONE);
+            else
+                SR_LAUNCH_TAPER(kRuntimeFeatures, kRuntimeEnv);
+#undef SR_LAUNCH_TAPER
+        } else if (h->epl == 2) SR_DISPATCH(2); else SR_DISPATCH(1);
 #undef SR_DISPATCH
 #undef SR_LAUNCH
     } else
@@ -536,6 +549,18 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
     if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_SOFT_ARM)
         return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
+    // The fast kernels expand theta / sin(theta + eps_sin) as (theta / sin theta)(1 - eps_sin cot theta)
+    // (eps_sin_factor, softrod_fast.hpp; the bke * rsq(D^2 + two_shift) term of softrod_planar.hpp), which
+    // holds while eps_sin << theta_min = sqrt(2 acos_shift), the smallest angle acos(.. - acos_shift)
+    // returns.  The reference's values (1e-14 against 1.4e-5) sit nine orders inside; a config outside
+    // — acos_shift = 0 with a straight joint sends cot theta to 1e150 and flips the sign of the bending
+    // stiffness — is refused here rather than integrated wrongly (the libm kernel evaluates the
+    // quotient as written and takes any values).
+    if (cfg->math_mode == SOFTROD_MATH_FAST &&
+        !(cfg->acos_shift > 0.0 && cfg->eps_sin >= 0.0 && cfg->eps_sin <= 1.0e-3 * std::sqrt(2.0 * cfg->acos_shift)))
+        return fail(nullptr, SOFTROD_EINVAL,
+                    "SOFTROD_MATH_FAST needs acos_shift > 0 and 0 <= eps_sin <= 1e-3 sqrt(2 acos_shift); "
+                    "use SOFTROD_MATH_LIBM for other values");
     {
         const bool muscles = (cfg->features & SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) != 0;
         if (muscles != (cfg->env_kind == SOFTROD_ENV_SOFT_ARM))
@@ -1076,18 +1101,40 @@ int softrod_step_packed(softrod_handle* h, const float* actions, float* packed, 
 
 namespace {
 struct PeerTable { float* p[SOFTROD_MAX_PEERS]; };
-// one thread per 32-bit word of the local rows; every peer's copy of the row block is written from it
+// One thread per 32-bit word of the local rows; every peer's copy of the row block is written from it
+// with SYSTEM-scope write-through stores (sc0 sc1: nothing of them stays behind in this GPU's L2).
+// tag_word >= 0: when every block's stores have been acknowledged, the LAST block to finish stores
+// `tag` into word `tag_word` of every peer buffer (system-scope release) — a reader that finds the tag
+// finds the rows (the buffers are uncached / fine-grained on the reader's side, softrod_exchange_alloc).
 __global__ void __launch_bounds__(256) softrod_scatter_rows_kernel(const float* __restrict__ packed, PeerTable peers,
-                                                                   int n_peers, size_t n_words, size_t offset) {
+                                                                   int n_peers, size_t n_words, size_t offset,
+                                                                   long long tag_word, unsigned tag,
+                                                                   unsigned* __restrict__ ticket) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_words) return;
-    const float v = packed[i];
-    for (int q = 0; q < n_peers; ++q) peers.p[q][offset + i] = v;
+    if (i < n_words) {
+        const float v = packed[i];
+        for (int q = 0; q < n_peers; ++q)
+            __hip_atomic_store(&peers.p[q][offset + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (tag_word < 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch (stream-ordered)
+            for (int q = 0; q < n_peers; ++q)
+                __hip_atomic_store(reinterpret_cast<unsigned*>(peers.p[q]) + tag_word, tag, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 }  // namespace
 
 int softrod_scatter_rows(softrod_handle* h, const float* packed, const uint64_t* peer_buffers, int n_peers,
-                         int row_words, int64_t first_row, void* stream) {
+                         int row_words, int64_t first_row, int64_t tag_word, uint32_t tag, void* stream) {
     if (!h || !packed || !peer_buffers) return fail(h, SOFTROD_EINVAL, "null argument");
     if (n_peers < 1 || n_peers > SOFTROD_MAX_PEERS || row_words < 1 || first_row < 0)
         return fail(h, SOFTROD_EINVAL, "need 1 <= n_peers <= SOFTROD_MAX_PEERS, row_words >= 1, first_row >= 0");
@@ -1097,12 +1144,90 @@ int softrod_scatter_rows(softrod_handle* h, const float* packed, const uint64_t*
         if (!peer_buffers[q]) return fail(h, SOFTROD_EINVAL, "null peer buffer");
         t.p[q] = reinterpret_cast<float*>(static_cast<uintptr_t>(peer_buffers[q]));
     }
+    if (tag_word >= 0 && !h->d_ticket) {
+        SR_HIP(h, hipMalloc((void**)&h->d_ticket, sizeof(unsigned)));
+        SR_HIP(h, hipMemset(h->d_ticket, 0, sizeof(unsigned)));
+    }
     const size_t n_words = (size_t)h->cfg.n_envs * (size_t)row_words;
     const unsigned blocks = (unsigned)((n_words + 255) / 256);
     hipLaunchKernelGGL(softrod_scatter_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, t,
-                       n_peers, n_words, (size_t)first_row * (size_t)row_words);
+                       n_peers, n_words, (size_t)first_row * (size_t)row_words, (long long)tag_word, (unsigned)tag,
+                       h->d_ticket);
     SR_HIP(h, hipGetLastError());
     return SOFTROD_OK;
+}
+
+// -- exchange buffers of transport "p2p": memory the OTHER GPUs store into -----------------------
+// A GPU's L2 does not snoop a peer's stores into its HBM: rows a peer has written are only certain to
+// be what a local kernel reads if the lines cannot sit in the local L2 — so these buffers are UNCACHED
+// (hipDeviceMallocUncached; fine-grained where that is refused), not ordinary coarse-grained
+// allocations, which are coherent across devices at kernel boundaries of the WRITER only.
+int softrod_exchange_alloc(int device, uint64_t bytes, void** dev_ptr, uint8_t* ipc_handle, int* memory_kind) {
+    if (!dev_ptr || bytes == 0) return fail(nullptr, SOFTROD_EINVAL, "null argument");
+    DeviceGuard guard_(device);
+    if (guard_.err != hipSuccess) return fail(nullptr, SOFTROD_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err));
+    void* p = nullptr;
+    int kind = SOFTROD_EXCHANGE_UNCACHED;
+    hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        kind = SOFTROD_EXCHANGE_FINEGRAINED;
+        e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) return fail(nullptr, SOFTROD_EHIP, std::string("hipExtMallocWithFlags: ") + hipGetErrorString(e));
+    e = hipMemset(p, 0, (size_t)bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && ipc_handle) {
+        hipIpcMemHandle_t hd;
+        static_assert(sizeof(hd) == SOFTROD_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+        e = hipIpcGetMemHandle(&hd, p);
+        if (e == hipSuccess) std::memcpy(ipc_handle, &hd, sizeof(hd));
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(nullptr, SOFTROD_EHIP, std::string("exchange buffer set-up: ") + hipGetErrorString(e));
+    }
+    *dev_ptr = p;
+    if (memory_kind) *memory_kind = kind;
+    return SOFTROD_OK;
+}
+
+int softrod_exchange_open(int device, const uint8_t* ipc_handle, int owner_device, void** dev_ptr) {
+    if (!ipc_handle || !dev_ptr) return fail(nullptr, SOFTROD_EINVAL, "null argument");
+    DeviceGuard guard_(device);
+    if (guard_.err != hipSuccess) return fail(nullptr, SOFTROD_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(guard_.err));
+    if (owner_device >= 0 && owner_device != device) {
+        int can = 0;
+        hipError_t e = hipDeviceCanAccessPeer(&can, device, owner_device);
+        if (e != hipSuccess || !can)
+            return fail(nullptr, SOFTROD_EHIP, "device " + std::to_string(device) + " cannot access peer " + std::to_string(owner_device));
+        e = hipDeviceEnablePeerAccess(owner_device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+            return fail(nullptr, SOFTROD_EHIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
+    hipIpcMemHandle_t hd;
+    std::memcpy(&hd, ipc_handle, sizeof(hd));
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(nullptr, SOFTROD_EHIP, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+    *dev_ptr = p;
+    return SOFTROD_OK;
+}
+
+int softrod_exchange_close(int device, void* dev_ptr) {
+    if (!dev_ptr) return SOFTROD_OK;
+    DeviceGuard guard_(device);
+    const hipError_t e = hipIpcCloseMemHandle(dev_ptr);
+    return e == hipSuccess ? SOFTROD_OK : fail(nullptr, SOFTROD_EHIP, std::string("hipIpcCloseMemHandle: ") + hipGetErrorString(e));
+}
+
+int softrod_exchange_free(int device, void* dev_ptr) {
+    if (!dev_ptr) return SOFTROD_OK;
+    DeviceGuard guard_(device);
+    (void)hipDeviceSynchronize();
+    const hipError_t e = hipFree(dev_ptr);
+    return e == hipSuccess ? SOFTROD_OK : fail(nullptr, SOFTROD_EHIP, std::string("hipFree: ") + hipGetErrorString(e));
 }
 
 int softrod_substeps(softrod_handle* h, const float* actions, int n, void* stream) {
@@ -1214,7 +1339,7 @@ int softrod_destroy(softrod_handle* h) {
     if (h->h_produced) (void)hipHostFree(h->h_produced);
     if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_time_tab, h->d_mat, h->d_sucker, h->d_basis, h->d_spline, h->d_init, h->d_mask};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_time_tab, h->d_mat, h->d_sucker, h->d_basis, h->d_spline, h->d_init, h->d_mask, h->d_ticket};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

@@ -515,6 +515,16 @@ __device__ __forceinline__ void general_substeps(const RodParams& P, const RodPa
     // and SoftPendulum3D 1.700 -> 1.687 ms on a box that holds these loops under its clock ceiling,
     // nothing (2.500 / 2.502, 1.685 / 1.684) on one that does not (profiles/README.md r3h / r3i).
     // Not with the spline muscles, whose rebuild runs prefix sums over the whole wave.
+    // INVARIANTS this branch rests on (it is lane-divergent control flow around code that holds
+    // barriers — laplace_filter_rates_lds7's __syncthreads — and cross-lane reads):
+    //   (1) every wave keeps at least one active lane: lane 0 carries node 0 of a rod (n_elem >= 2);
+    //   (2) every barrier inside the loop is reached the same number of times by every wave of the
+    //       workgroup: the trip counts (n_sub, filter_order) are kernel arguments, wave-uniform;
+    //   (3) a DPP / ds_bpermute read of an EXEC-disabled lane returns 0 (bound_ctrl:1; bpermute of an
+    //       inactive source) — the value the idle lanes used to hold.
+    // `make -C gym_softrobot_amd/csrc nomask` builds the library with every such mask off, and
+    // tests/test_gpu_mask_ab.py holds the two builds bit-identical on all four workloads, so a
+    // compiler or ISA change that breaks (1)-(3) fails a test instead of corrupting a rollout.
     if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) || slot_local<F>(P, lane * EPL) <= P.n_elem)
 #endif
     {
@@ -576,6 +586,9 @@ __device__ __attribute__((noinline)) void general_step_cold(const RodParams* __r
 #ifndef SOFTROD_CONTACT_WAVES
 #define SOFTROD_CONTACT_WAVES 2
 #endif
+#ifndef SOFTROD_RUNTIME_WAVES      // the run-time-mask instantiations (custom feature mixes, tapered rods)
+#define SOFTROD_RUNTIME_WAVES 2
+#endif
 // Two slots per lane need the whole 512-entry register file (1 wave per SIMD); the contact
 // and Laplace-filter instantiations trade a wave of occupancy for not spilling in the loop.
 // TAPER: the rod's radius varies along its length (softrod_set_radius_profile): material constants
@@ -590,8 +603,23 @@ __device__ unsigned long long g_phase_clock[16384][8];
 #define SR_PHASE(i) do {} while (0)
 #endif
 
+// Waves per SIMD the register allocator must leave room for, by instantiation.  The run-time-mask
+// instantiation carries EVERY feature's code (contact, Laplace filter, spline muscles, suckers) and,
+// with TAPER, per-lane material constants in registers instead of kernel arguments: at 3 waves
+// (168 VGPRs) it parked 237 VGPRs in scratch (1168 B per lane), at 2 waves (256 VGPRs) it fits like
+// the contact instantiations do.
+template <unsigned F, int EPL, bool TAPER>
+constexpr int fast_kernel_waves() {
+    if (EPL > 1) return 1;
+    if (F == kRuntimeFeatures) return SOFTROD_RUNTIME_WAVES;
+    if (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))
+        return SOFTROD_CONTACT_WAVES;
+    if (TAPER) return SOFTROD_CONTACT_WAVES;
+    return F == SOFTROD_FEATURES_SOFTPENDULUM ? SOFTROD_PLANAR_WAVES : SOFTROD_FAST_WAVES;
+}
+
 template <unsigned F, int E, int EPL, bool TAPER = false>
-__global__ void __launch_bounds__(kLanes, (EPL > 1 ? 1 : ((F != kRuntimeFeatures && (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))) ? SOFTROD_CONTACT_WAVES : (F == SOFTROD_FEATURES_SOFTPENDULUM ? SOFTROD_PLANAR_WAVES : SOFTROD_FAST_WAVES))))
+__global__ void __launch_bounds__(kLanes, (fast_kernel_waves<F, EPL, TAPER>()))
 softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,

@@ -51,6 +51,8 @@ constexpr int kLanes = 64;
 // the registered envs (so that unused features cost neither instructions nor registers)
 // plus one instantiation that reads the mask at run time (known-answer tests).
 constexpr unsigned kRuntimeFeatures = 0xFFFFFFFFu;
+// arm_push_env.py:160-196 without its COOMM muscles: AnalyticalLinearDamper + ControllableFixConstraint
+constexpr unsigned kFeaturesTaperedSuckerArm = SOFTROD_FEAT_ANALYTICAL_DAMPER | SOFTROD_FEAT_SUCKER_CONSTRAINT;
 // Internal pseudo-feature (never in softrod_config.features): the contact plane's normal is
 // exactly e_z, set by the host in RodParams.features and in the template mask.
 constexpr unsigned kFeatPlaneZup = 1u << 30;

@@ -433,7 +433,10 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     // a base node, so the rendezvous and the LDS posts are unaffected, and a DPP shift that would read
     // a ghost returns 0 where it used to return the ghost's zeros.  Bit-identical; worth what the
     // box's power budget makes of it: 9.47 -> 9.34 ms on one box, 9.36 / 9.355 on another that was
-    // already there (profiles/README.md r3k).
+    // already there (profiles/README.md r3k).  The invariants of softrod_fast.hpp's general_substeps
+    // apply: lane 0 of every wave stays active and reaches exchange()'s s_barrier / LDS rendezvous
+    // n_sub times like every other wave, and the __shfl_xor butterflies read 0 from a masked lane.
+    // A/B-checked against the unmasked build by tests/test_gpu_mask_ab.py.
 #ifndef SOFTROD_OCTO_GHOST_MASK
 #define SOFTROD_OCTO_GHOST_MASK 1
 #endif

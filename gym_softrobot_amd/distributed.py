@@ -15,40 +15,71 @@ the sharded env is exactly two device operations per rank: the kernel and the al
 
 Backend `nccl` is RCCL over xGMI on the MI355X node; `gloo` drives the same code in
 the CPU tests (tests/test_distributed_gloo.py).  `gather=False` leaves outputs sharded
-for a data-parallel consumer.
+for a data-parallel consumer.  `init_process_group()` below creates the RCCL group with a
+HIGH-PRIORITY collective stream: 4096 rods are exactly four resident waves on every SIMD, so an
+all-gather kernel on a normal-priority stream queues behind the next step kernel's waves.
 
 `overlap=True` (what `bench.py --gpus N` uses) takes the collective off the critical path:
 the all-gather of step t is issued asynchronously (it starts when step t's kernel has
 finished) and step t+1's kernel is launched without waiting for it, on alternating buffers.
-The tensors returned by `step` are then complete once `sync()` — or the step after next —
-has been called; a policy that needs them immediately calls `sync()` and loses nothing
-compared with `overlap=False`.
+With transport "rccl" the tensors returned by `step` are complete once `sync()` — or the step
+after next — has been called; a policy that needs them immediately calls `sync()` and loses
+nothing compared with `overlap=False`.
 
-`transport="p2p"` (opt-in; `overlap=True` only) replaces the collective by what it amounts to for
-rows this small: right behind its step kernel, ON THE SAME STREAM, every rank launches one small
-kernel (`softrod_scatter_rows`) that stores its packed rows into its block of every rank's output
-buffer (IPC-mapped device memory; between GPUs the stores travel point to point over xGMI) — no
-collective call per step, no second stream, no event.  `sync()` waits for this rank's stream and
-meets the other ranks at a barrier, after which everybody's rows have landed.  Why: 4096 rods are
-exactly four resident waves on every SIMD, so NOTHING overlaps with a step kernel for free — a
-collective (or a copy) on a second stream either waits its turn at ~37 us of cross-queue dependency
-latency per step, or runs alongside and stretches the step kernel by as much (kernel
-traces) — while a 4 us kernel in order behind the step kernel costs its 4 us.
-Ranks are not kept in lockstep by it (a rank may run ahead in an open-loop rollout; a consumer that
-reads every step's rows calls sync() every step and is in lockstep through the barrier).  RCCL
-stays the default, as BASELINE's north_star asks; `bench.py --transport p2p` measures the other.
-OPEN for p2p between different devices (not testable on a 1-GPU box, where both ranks share one L2):
-the reader's L2 does not snoop a peer's stores into its HBM, so the output buffers may need to be
-fine-grained allocations, or the reader an invalidating read, before this is correct there.
+`transport="p2p"` (opt-in, EXPERIMENTAL until it has run between different devices; needs
+`overlap=True`) replaces the collective by what it amounts to for rows this small: right behind its
+step kernel, ON THE SAME STREAM, every rank launches one small kernel (`softrod_scatter_rows`) that
+stores its packed rows into its block of every rank's exchange buffer (IPC-mapped device memory;
+between GPUs the stores travel point to point over xGMI) — no collective call per step, no second
+stream, no event.  Why: nothing overlaps with a step kernel of this workload for free — a collective
+(or a copy) on a second stream either waits its turn at ~37 us of cross-queue dependency latency per
+step, or runs alongside and stretches the step kernel by as much (kernel traces) —
+while a 4 us kernel in order behind the step kernel costs its 4 us.  Correct by construction:
+  * the exchange buffers are UNCACHED device allocations (`softrod_exchange_alloc`:
+    hipDeviceMallocUncached, fine-grained where that is refused), never ordinary torch tensors — a
+    GPU's L2 does not snoop a peer's stores into its HBM, and an uncached buffer has no line there to
+    go stale; peer access is enabled explicitly before a peer's handle is opened;
+  * the rows are stored system-scope write-through, and every call ends by storing a GENERATION word
+    per source rank behind the rows (system-scope release) once all of its rows have been acknowledged;
+  * `sync()` waits for this rank's stream, meets the other ranks at a barrier and then CHECKS the
+    generation words of the latest step from every rank (raises on a mismatch);
+  * the set-up self-test runs several rounds over the SAME buffers with a CHANGING pattern, so a
+    stale read of an earlier round fails it, and on any failure — on any rank, at any point of the
+    set-up, which every rank walks through to the end — ALL ranks stay with the collective.
+Completion contract of "p2p" (differs from "rccl"): the rows `step` returns are complete only after
+`sync()`, which all ranks must call at the same step indices (SPMD).  Buffer k is written again
+`depth` steps later by every rank, and a peer that has passed the barrier may launch that step: read
+the rows of step t on the env's stream (or finish reading) before calling the next `sync()`, and sync
+at least every `depth - 1` steps if the rows of every step are wanted.  RCCL stays the default, as
+BASELINE's north_star asks; `bench.py --transport p2p` measures the other.
 """
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Optional, Tuple
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+def init_process_group(backend: str = "nccl", device: Optional[torch.device] = None,
+                       high_priority: Optional[bool] = None, **kw) -> None:
+    """`dist.init_process_group` with, for RCCL ("nccl"), the collective stream created at HIGH
+    priority (ProcessGroupNCCL.Options.is_high_priority_stream) unless SOFTROD_RCCL_HIGH_PRIORITY=0:
+    the step kernels keep every SIMD's wave slots full, and the all-gather's few workgroups should be
+    dispatched ahead of the next step kernel's, not behind them."""
+    if high_priority is None:
+        high_priority = os.environ.get("SOFTROD_RCCL_HIGH_PRIORITY", "1") != "0"
+    if backend == "nccl":
+        if high_priority and hasattr(dist, "ProcessGroupNCCL"):
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            kw["pg_options"] = opts
+        if device is not None:
+            kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
 
 
 def packed_width(obs_dim: int) -> int:
@@ -92,11 +123,17 @@ def unpack_outputs(packed: torch.Tensor, obs_dim: int):
     return obs, reward, terminated, truncated
 
 
+class P2PError(RuntimeError):
+    """transport="p2p": a generation word did not hold the step every rank should have written."""
+
+
 class ShardedVecEnv:
     """Wraps this rank's local vec env (N/world envs) and presents the global batch.
 
     local_env: a VecRodEnvBase built with num_envs = N / world.
     """
+
+    SELF_TEST_ROUNDS = 5          # p2p set-up: rounds over the same buffers, a new pattern each
 
     def __init__(self, local_env, total_envs: int, group: Optional[dist.ProcessGroup] = None,
                  gather: bool = True, overlap: bool = False, force_collective: bool = False,
@@ -137,51 +174,127 @@ class ShardedVecEnv:
         if transport not in ("rccl", "p2p"):
             raise ValueError("transport must be 'rccl' (the group's all-gather) or 'p2p' (peer copies)")
         self.transport = "rccl"
-        if transport == "p2p" and self.overlap:
-            self._setup_p2p()
+        self._p2p_error: Optional[str] = None
+        self._exchange = None          # p2p: this rank's exchange buffers and the peers' mappings
+        if transport == "p2p":
+            if self.overlap:
+                self._setup_p2p()
+            else:
+                self._p2p_error = "transport='p2p' needs overlap=True and a process group of more than one rank"
+                warnings.warn(self._p2p_error + ": using the collective", RuntimeWarning, stacklevel=2)
 
     # -- transport="p2p": every rank copies its rows into its block of every peer's buffer --------
-    def _setup_p2p(self) -> None:
-        """Exchange IPC handles of the output buffers and verify, with a round of test copies, that
-        every rank can write every peer's buffer; on any failure ALL ranks stay with the collective."""
-        from torch.multiprocessing.reductions import reduce_tensor
-
+    def _agree(self, ok: bool) -> bool:
+        """True only when `ok` on EVERY rank (one small all-reduce; also a barrier)."""
         dev = self.local.backend.device
-        ok, peers = 1.0, None
-        try:
-            mine = [reduce_tensor(g) for g in self._global2]
-            everyone = [None] * self.world
-            dist.all_gather_object(everyone, mine, group=self.group)
-            peers = []                    # peers[k][p]: rank p's buffer k as a tensor in THIS process
-            for k in range(len(self._global2)):
-                row = []
-                for p in range(self.world):
-                    if p == self.rank:
-                        row.append(self._global2[k])
-                    else:
-                        fn, args = everyone[p][k]
-                        row.append(fn(*args))
-                peers.append(row)
-            # self-test: rank r writes r + 1 into its block of every rank's buffer 0
-            probe = torch.full((self.hi - self.lo, self._global.shape[1]), float(self.rank + 1), device=dev)
-            self.local.backend.scatter_rows(probe, [t.data_ptr() for t in peers[0]], self.lo)
-            torch.cuda.current_stream(dev).synchronize()
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item() > 0)
+
+    def _setup_p2p(self) -> None:
+        """Allocate the exchange buffers, exchange their IPC handles, map the peers' and verify with
+        SELF_TEST_ROUNDS rounds of test copies under a changing pattern that every rank reads what
+        every peer wrote.  Every rank walks through EVERY collective call of this function whatever
+        happened to it locally (a failure becomes a flag, never an early exit), so an asymmetric
+        failure cannot leave the others blocked in a collective; on any failure anywhere ALL ranks
+        stay with the all-gather and release what they had set up."""
+        be = self.local.backend
+        depth, w = len(self._global2), self._global.shape[1]
+        rows_words = self.total_envs * w
+        n_words = rows_words + self.world + (-(rows_words + self.world)) % 4     # + one generation word per rank
+        ex = {"tensors": [], "ptrs": [], "handles": [], "kind": None, "peer_ptrs": None, "opened": []}
+        ok, err = True, None
+        try:                                   # (1) local allocations
+            for _ in range(depth):
+                t, ptr, handle, kind = be.exchange_alloc(n_words)
+                ex["tensors"].append(t)
+                ex["ptrs"].append(ptr)
+                ex["handles"].append(handle)
+                ex["kind"] = kind
         except Exception as exc:  # noqa: BLE001 - any failure means: use the collective
-            ok = 0.0
-            self._p2p_error = repr(exc)
-        flag = torch.tensor([ok], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)     # (also the barrier before the check)
-        if float(flag.item()) > 0:
-            per = self.hi - self.lo
-            expect = torch.arange(1, self.world + 1, device=dev, dtype=torch.float32).repeat_interleave(per)
-            good = bool((self._global2[0][:, 0] == expect).all().item())
-            flag = torch.tensor([1.0 if good else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if float(flag.item()) > 0:
-            self._peer_global, self.transport = peers, "p2p"
-            self._peer_ptrs = [[t.data_ptr() for t in row] for row in peers]
+            ok, err = False, f"exchange_alloc: {exc!r}"
+        mine = {"ok": ok, "handles": ex["handles"] if ok else None, "device": getattr(be, "device_index", -1),
+                "pid": os.getpid()}
+        everyone = [None] * self.world         # (2) always entered
+        dist.all_gather_object(everyone, mine, group=self.group)
+        ok = all(e is not None and e["ok"] for e in everyone)
+        if ok:
+            try:                               # (3) map the peers' buffers
+                peer_ptrs = []
+                for k in range(depth):
+                    row = []
+                    for p in range(self.world):
+                        if p == self.rank:
+                            row.append(ex["ptrs"][k])
+                        else:
+                            q = be.exchange_open(everyone[p]["handles"][k], everyone[p]["device"])
+                            ex["opened"].append(q)
+                            row.append(q)
+                    peer_ptrs.append(row)
+                ex["peer_ptrs"] = peer_ptrs
+            except Exception as exc:  # noqa: BLE001
+                ok, err = False, f"exchange_open: {exc!r}"
+        ok = self._agree(ok)
+        # (4) self-test: round j writes the pattern of round j into buffer j % depth; a buffer is
+        # written in several rounds, so a reader served a stale copy of an earlier round fails
+        per = self.hi - self.lo
+        dev = be.device
+        for j in range(self.SELF_TEST_ROUNDS if ok else 0):
+            good = True
+            try:
+                k = j % depth
+                probe = torch.full((per, w), float(1000 * j + self.rank + 1), device=dev)
+                be.scatter_rows(probe, ex["peer_ptrs"][k], self.lo, rows_words + self.rank, 0x5E1F0000 + j)
+                torch.cuda.current_stream(dev).synchronize()
+                dist.barrier(group=self.group)
+                rows = ex["tensors"][k][:rows_words].view(self.total_envs, w)
+                expect = (1000.0 * j + torch.arange(1, self.world + 1, device=dev, dtype=torch.float32)
+                          ).repeat_interleave(per)
+                tags = ex["tensors"][k][rows_words:rows_words + self.world].view(torch.int32)
+                good = bool((rows == expect[:, None]).all().item()) and bool((tags == 0x5E1F0000 + j).all().item())
+                if not good:
+                    err = f"self-test round {j}: a peer's rows or generation word did not arrive"
+            except Exception as exc:  # noqa: BLE001
+                good, err = False, f"self-test round {j}: {exc!r}"
+            ok = self._agree(good)
+            if not ok:
+                break
+        if ok:
+            self._exchange = ex
+            self._rows_words = rows_words
+            self._global2 = [t[:rows_words].view(self.total_envs, w) for t in ex["tensors"]]
+            self._tags = [t[rows_words:rows_words + self.world].view(torch.int32) for t in ex["tensors"]]
+            self._global = self._global2[0]
+            self._gen = 0                      # generation of the next step
+            self._gen_of = [None] * depth      # generation last written into buffer k
+            self._last_k = None
+            self._verify = os.environ.get("SOFTROD_P2P_VERIFY", "1") != "0"
+            self.transport = "p2p"
+            self.exchange_memory = ex["kind"]
+        else:
+            self._p2p_error = err or "a peer could not set up its exchange buffers"
+            self._release_exchange(ex)
+
+    def _release_exchange(self, ex) -> None:
+        be = self.local.backend
+        for q in ex.get("opened", []):
+            try:
+                be.exchange_close(q)
+            except Exception:  # noqa: BLE001
+                pass
+        for ptr in ex.get("ptrs", []):
+            try:
+                be.exchange_free(ptr)
+            except Exception:  # noqa: BLE001
+                pass
+        ex["tensors"], ex["ptrs"], ex["opened"] = [], [], []
 
     def _all_gather(self, packed: torch.Tensor) -> torch.Tensor:
+        if self.transport == "p2p":            # resets: through the group, into ordinary memory
+            if getattr(self, "_reset_global", None) is None:
+                self._reset_global = torch.empty(tuple(self._global.shape), dtype=torch.float32, device=packed.device)
+            dist.all_gather_into_tensor(self._reset_global, packed, group=self.group)
+            return self._reset_global
         dist.all_gather_into_tensor(self._global, packed, group=self.group)
         return self._global
 
@@ -224,8 +337,13 @@ class ShardedVecEnv:
             self._works[k].wait()
         packed, info = self.local.step_packed(a, self._packed2[k])
         if self.transport == "p2p":
-            # in order behind the step kernel, on its stream: a few microseconds, no dependency to resolve
-            self.local.backend.scatter_rows(packed, self._peer_ptrs[k], self.lo)
+            # in order behind the step kernel, on its stream: a few microseconds, no dependency to
+            # resolve; the generation word of this rank follows the rows into every peer's buffer
+            self._gen = (self._gen + 1) & 0x7FFFFFFF
+            self.local.backend.scatter_rows(packed, self._exchange["peer_ptrs"][k], self.lo,
+                                            self._rows_words + self.rank, self._gen)
+            self._gen_of[k] = self._gen
+            self._last_k = k
         else:
             self._works[k] = dist.all_gather_into_tensor(self._global2[k], packed, group=self.group, async_op=True)
         self._k = (k + 1) % len(self._works)
@@ -233,7 +351,9 @@ class ShardedVecEnv:
         return o, r, te, tr, info
 
     def sync(self) -> None:
-        """Make the outputs of the latest step() complete (overlap=True)."""
+        """Make the outputs of the latest step() complete (overlap=True).  transport "p2p": a stream
+        synchronise, a barrier of the group (all ranks call sync() at the same step indices) and a
+        check of the latest step's generation words from every rank."""
         if self.overlap:
             for w in self._works:
                 if w is not None:
@@ -241,7 +361,20 @@ class ShardedVecEnv:
             if self.transport == "p2p":
                 torch.cuda.current_stream(self.local.backend.device).synchronize()
                 dist.barrier(group=self.group)     # this rank's rows have landed everywhere; now everybody's have
+                if self._verify and self._last_k is not None:
+                    tags = self._tags[self._last_k].cpu()
+                    want = self._gen_of[self._last_k]
+                    if not bool((tags == want).all()):
+                        raise P2PError(f"rank {self.rank}: generation words {tags.tolist()} of the latest step, "
+                                       f"expected {want} from every rank (ranks out of step, or a stale read)")
 
     def close(self):
         self.sync()
+        if self._exchange is not None:
+            if dist.is_initialized():
+                dist.barrier(group=self.group)     # nobody unmaps a buffer a peer may still write
+            ex, self._exchange = self._exchange, None
+            self._global2 = self._tags = None
+            self._global = None
+            self._release_exchange(ex)
         self.local.close()

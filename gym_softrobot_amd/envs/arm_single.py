@@ -45,7 +45,11 @@ class VecArmSingleEnv(VecRodEnvBase):
         numpy_output: bool = False,
         autoreset: bool = False,
         backend=None,
+        radius_profile=None,
     ):
+        """`radius_profile` (extension, n_elems radii): a TAPERED arm, as the reference's muscle arms
+        are built (`CosseratRod.straight_rod(base_radius=<array>)`, octopus/arm_push_env.py:160-179);
+        None = the uniform arm of build_arm."""
         if n_action != 7:
             raise NotImplementedError("the observation layout of the reference fixes n_action = 7")
         cfg = _capi.arm_single_config(
@@ -64,6 +68,8 @@ class VecArmSingleEnv(VecRodEnvBase):
         self.n_elems = n_elems
         self.n_seg = n_elems - 1
         self.policy_mode = policy_mode
+        if radius_profile is not None:
+            self.backend.set_radius_profile(np.asarray(radius_profile, np.float64))
 
     def _draw_reset(self, i):
         return None                                   # build_arm draws nothing from the RNG

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 13
+#define SOFTROD_ABI_VERSION 14
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -172,6 +172,10 @@ typedef struct softrod_config {
     double eps_rot_axis;  /* 1e-14 added to |w| before normalising the axis */
     double acos_shift;    /* 1e-10 subtracted inside arccos of _inv_rotate  */
     double eps_sin;       /* 1e-14 added inside sin of _inv_rotate          */
+                          /* SOFTROD_MATH_FAST expands theta / sin(theta + eps_sin) to
+                             first order in eps_sin: softrod_create refuses
+                             acos_shift <= 0 or eps_sin > 1e-3 sqrt(2 acos_shift)
+                             in that mode (SOFTROD_MATH_LIBM takes any values)  */
     int32_t time_two_half_adds; /* 1: t += dt/2 twice per substep; 0: += dt */
     int32_t damp_before_constrain; /* order inside PyElastica's constrain_rates
                                       operator group.  0 (default): registration
@@ -458,14 +462,36 @@ int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream);
  * distributed.py, transport "p2p"): copy this handle's `n_envs` packed rows (`row_words` 32-bit
  * words each, as softrod_step_packed wrote them) into rows first_row .. first_row + n_envs - 1 of
  * EVERY buffer in `peer_buffers` (host array of n_peers <= SOFTROD_MAX_PEERS device pointers: the
- * other ranks' output buffers, IPC-mapped, and this rank's own), with ONE small kernel on `stream`
+ * other ranks' exchange buffers, IPC-mapped, and this rank's own), with ONE small kernel on `stream`
  * — enqueued right behind the step kernel it is a few microseconds in order, where a collective on
  * a second stream costs this workload ~37 us of cross-queue dependency latency per step (DESIGN.md
- * §4).  Between GPUs the stores travel over xGMI; they are visible to the peers once the stream has
- * been synchronised (the caller's barrier).                                                     */
+ * §4).  The stores are system-scope write-through; between GPUs they travel over xGMI.
+ * tag_word >= 0: once ALL rows of this call have been acknowledged, 32-bit word `tag_word` of every
+ * peer buffer receives `tag` (system-scope release): the generation word of this rank in the
+ * receivers' buffers (distributed.py keeps `world` of them behind the rows and checks them in
+ * sync()).  tag_word < 0: rows only.                                                            */
 #define SOFTROD_MAX_PEERS 16
 int softrod_scatter_rows(softrod_handle* h, const float* packed, const uint64_t* peer_buffers,
-                         int n_peers, int row_words, int64_t first_row, void* stream);
+                         int n_peers, int row_words, int64_t first_row, int64_t tag_word,
+                         uint32_t tag, void* stream);
+
+/* Exchange buffers of transport "p2p": device memory that OTHER GPUs store into.  A GPU's L2 does
+ * not snoop a peer's stores into its HBM, so such a buffer must not be an ordinary (coarse-grained,
+ * L2-cached) allocation: softrod_exchange_alloc returns UNCACHED device memory
+ * (hipDeviceMallocUncached; *memory_kind = SOFTROD_EXCHANGE_FINEGRAINED where only
+ * hipDeviceMallocFinegrained is granted), zeroed, together with its 64-byte IPC handle (NULL: not
+ * wanted).  softrod_exchange_open maps a handle received from the process that owns `owner_device`
+ * (peer access device -> owner_device is enabled first when they differ; pass -1 to skip) and
+ * returns the pointer valid in THIS process; _close unmaps it, _free releases an allocation of
+ * _alloc.  No handle argument: these belong to the process, not to a batch.                     */
+#define SOFTROD_IPC_HANDLE_BYTES 64
+#define SOFTROD_EXCHANGE_UNCACHED 1
+#define SOFTROD_EXCHANGE_FINEGRAINED 2
+int softrod_exchange_alloc(int device, uint64_t bytes, void** dev_ptr, uint8_t* ipc_handle,
+                           int* memory_kind);
+int softrod_exchange_open(int device, const uint8_t* ipc_handle, int owner_device, void** dev_ptr);
+int softrod_exchange_close(int device, void* dev_ptr);
+int softrod_exchange_free(int device, void* dev_ptr);
 
 /* Replaces: get_state() at reset (soft_pendulum.py:145-161,
  * soft_pendulum_3d.py:93-98).  prev_action is device [n_envs][action_dim]
@@ -497,7 +523,7 @@ int softrod_last_kernel_ms(softrod_handle* h, float* ms);
 const char* softrod_last_error(softrod_handle* h);
 int softrod_destroy(softrod_handle* h);
 int softrod_abi_version(void);
-/* First 16 hex digits of the SHA-256 over the sources this library was built from (csrc/*.hpp in
+/* First 16 hex digits of the SHA-256 over the sources this library was built from (the .hpp files of csrc/ in
  * name order, softrod_capi.hip, include/softrod.h; the Makefile passes it as SOFTROD_SOURCE_HASH).
  * Profiles record it, and bench.py refuses to price a kernel against instruction counts / traffic
  * measured on a different build (profiles/valu_counts.json, hbm_traffic.json).  No reference

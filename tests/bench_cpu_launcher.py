@@ -29,8 +29,16 @@ def main() -> int:
     from tests.oracle_backend import OracleBackend
 
     def make_vec(env_id, n_local, device=0, math_mode=_capi.MATH_FAST, **extra):
-        assert env_id == "SoftPendulum-v0", "the double covers the headline workload only"
+        if env_id == "OctoFlat-v0":            # configs[4]'s shape: 8 arms + head per env, 12 substeps per env.step
+            cfg = _capi.octo_flat_config(n_local)
+            cfg.n_substeps = 12
+            env = gsa.VecOctoFlatEnv(n_local, backend=OracleBackend(cfg), autoreset=extra.pop("autoreset", False))
+            env.cfg.n_substeps = 12
+            return env
+        assert env_id == "SoftPendulum-v0", "the double covers the headline workload and OctoFlat only"
         kw = dict(time_step=1e-4, recording_fps=2000, n_elems=8)      # 5 substeps per env.step
+        if os.environ.get("SOFTROD_TEST_EPISODE_STEPS"):              # short episodes: truncation inside the run
+            kw["final_time"] = int(os.environ["SOFTROD_TEST_EPISODE_STEPS"]) * 5e-4 - 1e-9
         kw.update(extra)
         autoreset = kw.pop("autoreset", False)
         cfg = _capi.softpendulum_config(n_local, **kw)

@@ -38,6 +38,10 @@ class OracleBackend:
         self._prev = np.zeros((self.n_envs, self.action_dim), np.float32)
         self._queue = None          # device-side auto-reset emulation (softrod_queue_*)
 
+    def set_radius_profile(self, radius):
+        for r in self.rods:
+            r.set_radius_profile(radius)
+
     def state(self):
         return {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64), "control": self._ctrl}
 

@@ -70,6 +70,63 @@ def test_gpus_2_with_the_p2p_transport_falls_back_on_a_box_without_a_gpu(oracle_
     assert line["config"]["last_step_checksum"] == ref["config"]["last_step_checksum"]
 
 
+# ---- the driver's 8-GPU command lines, rehearsed on CPU: 8 gloo ranks, a handful of tiny rods each ----
+
+def _eight_vs_one(extra_args, per_rank_envs, extra_env=None, strong=False):
+    a = ["--steps", "4", "--warmup", "1", "--windows", "1"] + extra_args
+    total = per_rank_envs * 8
+    p = _run(["--gpus", "8", "--envs-per-gpu", str(total if strong else per_rank_envs)] + a, extra_env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    (line,) = _json_lines(p.stdout)
+    q = _run(["--gpus", "1", "--envs-per-gpu", str(total), "--no-cpu-baseline"] + a,
+             extra_env, timeout=600)
+    assert q.returncode == 0, q.stderr[-2000:]
+    (one,) = _json_lines(q.stdout)
+    assert line["n_gpus"] == 8 and line["config"]["envs_total"] == total == one["config"]["envs_total"]
+    # the rows of all 8 ranks reached rank 0 and are what one process stepping the whole batch returns
+    assert line["config"]["last_step_checksum"] == one["config"]["last_step_checksum"]
+    assert line["config"]["non_finite_envs_at_end"] == one["config"]["non_finite_envs_at_end"] == 0
+    # what every rank measured is in the line
+    ranks = line["per_rank"]["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8))
+    for r in ranks:
+        assert r["kernel_ms_avg"] > 0 and 0 < r["efficiency_vs_n1_kernel"] <= 1.0 + 1e-9
+        assert abs(r["exchange_us_per_step"] - (line["ms_per_step"] - r["kernel_ms_avg"]) * 1e3) < 1e-6
+    return line, one
+
+
+def test_gpus_8_softpendulum_weak_scaling_with_the_p2p_trial(oracle_built):
+    """BASELINE configs[3]'s shape: `python bench.py --gpus 8 ...` exactly as the driver runs it.  The
+    default transport is measured, then every rank's child runs the job again over transport p2p —
+    which on a box without a GPU falls back to the collective on every rank, says so, and returns the
+    same rows."""
+    line, one = _eight_vs_one([], 2)
+    assert line["scaling"] == "weak" and line["config"]["transport"] == "rccl"
+    t = line["p2p_trial"]
+    assert t["returncode"] == 0 and t["transport"] == "rccl" and t["transport_fallback_reason"]
+    assert t["last_step_checksum"] == line["config"]["last_step_checksum"]
+    assert len(t["per_rank"]["ranks"]) == 8
+
+
+def test_gpus_8_strong_scaling(oracle_built):
+    line, _ = _eight_vs_one(["--scaling", "strong", "--no-p2p-trial"], 2, strong=True)
+    assert line["scaling"] == "strong" and "p2p_trial" not in line
+
+
+def test_gpus_8_octoflat(oracle_built):
+    """BASELINE configs[4]'s shape: 8 arms + head per env, odd observation width (461) in the packed rows."""
+    line, _ = _eight_vs_one(["--env", "OctoFlat-v0", "--no-p2p-trial"], 1)
+    assert "OctoFlat-v0" in line["config"]["workload"]
+
+
+def test_gpus_8_device_autoreset_restarts_on_every_rank(oracle_built):
+    """3-step episodes: every env is truncated and restarts from its staged record inside the run, on
+    all 8 ranks; restarted steps are not counted as work, and the rows equal one process's."""
+    line, one = _eight_vs_one(["--autoreset", "device", "--no-p2p-trial"], 2, {"SOFTROD_TEST_EPISODE_STEPS": "3"})
+    assert line["config"]["autoreset"] == "device"
+    assert line["config"]["episode_restarts_not_counted"] == one["config"]["episode_restarts_not_counted"] >= 16
+
+
 def test_child_failure_propagates(oracle_built):
     # 3 envs do not split over 2 ranks: every rank exits non-zero before any line is printed
     p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "3", "--scaling", "strong",

@@ -94,7 +94,7 @@ def _worker(rank, world, port, total, T, q, overlap=False, transport="rccl"):
     local.cfg.n_substeps = 40
     env = ShardedVecEnv(local, total, overlap=overlap, transport=transport)
     if transport == "p2p":      # no device to map on a CPU box: every rank must have fallen back, together
-        assert env.transport == "rccl" and hasattr(env, "_p2p_error")
+        assert env.transport == "rccl" and env._p2p_error
     obs0, _ = env.reset(seed=7)
     acts = np.random.default_rng(5).uniform(-22, 22, (T, total)).astype(np.float32)
     out = [obs0.clone().numpy()]
@@ -252,3 +252,79 @@ def test_world2_gloo_device_autoreset_matches_single_process(oracle_built):
         for a, b in zip(got[t], (o, r, te, tr)):
             np.testing.assert_array_equal(a, b)
     assert restarted >= total       # episodes really ended and restarted on the way
+
+
+def _world8_worker(rank, world, port, total, q):
+    """8 ranks, 2 envs each: steps, a masked reset whose mask straddles several shard boundaries,
+    more steps; overlapped all-gather."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.distributed import ShardedVecEnv, shard_bounds
+    from tests.oracle_backend import OracleBackend
+
+    lo, hi = shard_bounds(total, world, rank)
+    cfg = _capi.softpendulum_config(hi - lo, n_elems=8)
+    cfg.n_substeps = 10
+    local = gsa.VecSoftPendulumEnv(hi - lo, n_elems=8, backend=OracleBackend(cfg))
+    local.cfg.n_substeps = 10
+    env = ShardedVecEnv(local, total, overlap=True)
+    out = _world8_rollout(env, total, True)
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _world8_rollout(env, total, sharded):
+    acts = np.random.default_rng(9).uniform(-22, 22, (6, total)).astype(np.float32)
+    # envs 1..2 (ranks 0|1), 5..8 (ranks 2|3|4) and 13, 15 (ranks 6, 7); ranks 5 resets nothing
+    mask = np.zeros(total, bool)
+    mask[[1, 2, 5, 6, 7, 8, 13, 15]] = True
+    obs0, _ = env.reset(seed=21)
+    out = [torch.as_tensor(obs0).clone().numpy()]
+    for t in range(6):
+        if t == 3:
+            o, _ = env.reset(mask=mask)
+            out.append(torch.as_tensor(o).clone().numpy())
+        o, r, te, tr, _ = env.step(acts[t])
+        if sharded:
+            env.sync()
+        out.append(tuple(torch.as_tensor(x).clone().numpy() for x in (o, r, te, tr)))
+    return out
+
+
+def test_world8_gloo_masked_reset_across_shard_boundaries(oracle_built):
+    """The world size of BASELINE configs[3] / configs[4]: 8 ranks.  A masked reset in the middle of
+    the rollout touches envs on both sides of three shard boundaries and skips one rank entirely;
+    every gathered record equals one process stepping all 16 envs."""
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from tests.oracle_backend import OracleBackend
+
+    total, world = 16, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=400)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = _capi.softpendulum_config(total, n_elems=8)
+    cfg.n_substeps = 10
+    env = gsa.VecSoftPendulumEnv(total, n_elems=8, backend=OracleBackend(cfg), numpy_output=True)
+    env.cfg.n_substeps = 10
+    ref = _world8_rollout(env, total, False)
+    assert len(got) == len(ref) == 8
+    for g, r in zip(got, ref):
+        g, r = (g if isinstance(g, tuple) else (g,)), (r if isinstance(r, tuple) else (r,))
+        for a, b in zip(g, r):
+            np.testing.assert_array_equal(a, b)
+    # the masked envs really restarted (fresh draws: their reset observation differs from the seeded one)
+    assert not np.array_equal(got[4][[1, 5, 15]], got[0][[1, 5, 15]])

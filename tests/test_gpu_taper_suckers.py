@@ -158,3 +158,38 @@ def test_snapshot_of_a_tapered_handle_is_refused_by_other_tapers(torch_gpu, hip_
             be.restore(snap)
     for be in (tapered, same, other, uniform):
         be.close()
+
+
+def test_tapered_arm_single_env_matches_oracle(torch_gpu, hip_lib, oracle_built):
+    """VecArmSingleEnv(radius_profile=...): the OctoArmSingle feature set (gravity, plane contact with
+    anisotropic friction, damper, rest-curvature actuation, reward/observation epilogue) on a rod tapered
+    12:1 like arm_push_env.py:160-165 — the tapered instantiation `bench.py --taper` measures — against
+    the oracle stepping the same env, three env.steps of 714 substeps."""
+    import gym_softrobot_amd as gsa
+    from tests.oracle_backend import OracleBackend
+
+    n, N = 50, 2
+    r0 = gsa._capi.arm_single_config(1).base_radius
+    edge = np.linspace(r0, r0 / 12.0, n + 1)
+    prof = (edge[:-1] + edge[1:]) / 2
+    env = gsa.make_vec("OctoArmSingle-v0", N, n_elems=n, radius_profile=prof)
+    ref = gsa.make_vec("OctoArmSingle-v0", N, n_elems=n, radius_profile=prof,
+                       backend=OracleBackend(gsa._capi.arm_single_config(N, n_elems=n)))
+    env.reset(seed=0)
+    ref.reset(seed=0)
+    acts = np.random.default_rng(5).uniform(-6, 6, (3, N, 7)).astype(np.float32)
+    for t in range(3):
+        o, r, te, tr, _ = env.step(acts[t])
+        o2, r2, te2, tr2, _ = ref.step(acts[t])
+        torch_gpu.cuda.synchronize()
+        np.testing.assert_allclose(o.cpu().numpy(), np.asarray(o2), rtol=RTOL, atol=2e-6, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(r.cpu().numpy(), np.asarray(r2), rtol=RTOL, atol=1e-8, err_msg=f"reward step {t}")
+        np.testing.assert_array_equal(te.cpu().numpy().astype(bool), np.asarray(te2).astype(bool))
+        np.testing.assert_array_equal(tr.cpu().numpy().astype(bool), np.asarray(tr2).astype(bool))
+    st = env.backend.state_numpy()
+    for i in range(N):
+        for name in ("x", "v", "w", "Q"):
+            np.testing.assert_allclose(st[name][i], ref.backend.rods[i].get(name), rtol=RTOL, atol=1e-8,
+                                       err_msg=f"{name} env {i}")
+    env.close()
+    ref.close()

@@ -137,3 +137,70 @@ def test_sharded_env_two_hip_ranks_device_autoreset(hip_lib):
     out = _worker("SoftPendulum-v0", "64", "7", "8", "device")
     flagged = int(out.split("flagged=")[1].split()[0])
     assert flagged >= 128 * 3
+
+
+def test_exchange_buffers_are_uncached_device_memory(hip_lib):
+    """transport="p2p" never hands a peer an ordinary (L2-cached) allocation to store into:
+    softrod_exchange_alloc returns uncached (or fine-grained) device memory, zeroed, with an IPC handle."""
+    import torch
+
+    import gym_softrobot_amd as gsa
+
+    env = gsa.make_vec("SoftPendulum-v0", 4, device=0)
+    be = env.backend
+    t, ptr, handle, kind = be.exchange_alloc(1024)
+    assert kind in ("uncached", "fine-grained") and len(handle) == 64 and any(handle) and ptr == t.data_ptr()
+    assert t.shape == (1024,) and float(t.abs().sum().item()) == 0.0
+    t[:] = torch.arange(1024, device=t.device, dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert float(t.sum().item()) == 1023 * 1024 / 2
+    # the tagged scatter into it: rows, then the generation word behind them
+    env.reset(seed=0)
+    packed = be.step_packed(torch.zeros(4, device=t.device))
+    w = packed.shape[1]
+    be.scatter_rows(packed, [ptr], 0, tag_word=4 * w + 0, tag=77)
+    torch.cuda.synchronize()
+    assert torch.equal(t[: 4 * w].view(4, w), packed) and int(t[4 * w : 4 * w + 1].view(torch.int32).item()) == 77
+    del t
+    be.exchange_free(ptr)
+    env.close()
+
+
+def test_sharded_env_p2p_reports_its_exchange_memory_and_checks_generations(hip_lib):
+    """World of one over the p2p transport (gloo group of one rank): the set-up self-test passes, the
+    buffers are uncached, sync() verifies the generation word, and a corrupted word is caught."""
+    out = subprocess.run([sys.executable, "-c", """
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+import gym_softrobot_amd as gsa
+from gym_softrobot_amd.distributed import ShardedVecEnv, P2PError
+dist.init_process_group("gloo")
+local = gsa.make_vec("SoftPendulum-v0", 64, device=0)
+env = ShardedVecEnv(local, 64, overlap=True, force_collective=True, transport="p2p")
+assert env.transport == "p2p", env._p2p_error
+assert env.exchange_memory in ("uncached", "fine-grained")
+env.reset(seed=0)
+ref = gsa.make_vec("SoftPendulum-v0", 64, device=0)
+ref.reset(seed=0)
+a = torch.linspace(-20, 20, 64, device="cuda")
+for t in range(5):
+    o, r, te, tr, _ = env.step(a)
+    env.sync()
+    o2, r2, _, _, _ = ref.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2) and torch.equal(r, r2)
+env._tags[env._last_k][0] = 12345          # a peer that did not deliver
+try:
+    env.sync()
+    raise SystemExit("a wrong generation word went unnoticed")
+except P2PError:
+    pass
+env._tags[env._last_k][0] = env._gen_of[env._last_k]
+env.close(); ref.close()
+dist.destroy_process_group()
+print("P2P-GEN-OK")
+""" % (str(ROOT), str(_free_port()))], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "P2P-GEN-OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

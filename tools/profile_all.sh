@@ -7,7 +7,7 @@
 # Copy the summaries to profiles/<tag>_<name>.json and fold them into the tables bench.py reads with
 # tools/update_profile_tables.py profiles/<tag>_*.json (entries carry the library's source hash).
 set -u
-TAG=${1:-r3a}; shift || true
+TAG=${1:-r4a}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 declare -A ARGS=(
@@ -16,11 +16,12 @@ declare -A ARGS=(
   [OctoArmSingle-v0]="--env OctoArmSingle-v0"
   [OctoArmSingle-v0_n100]="--env OctoArmSingle-v0 --n-elems 100"
   [OctoFlat-v0]="--env OctoFlat-v0"
+  [OctoArmSingle-v0_taper]="--env OctoArmSingle-v0 --taper"
   [SoftArmTracking-v0]="--env SoftArmTracking-v0"
 )
-NAMES=${*:-SoftPendulum-v0 SoftPendulum3D-v0 OctoArmSingle-v0 OctoArmSingle-v0_n100 OctoFlat-v0 SoftArmTracking-v0}
+NAMES=${*:-SoftPendulum-v0 SoftPendulum3D-v0 OctoArmSingle-v0 OctoArmSingle-v0_n100 OctoArmSingle-v0_taper OctoFlat-v0 SoftArmTracking-v0}
 for NAME in $NAMES; do
-  A="--no-cpu-baseline ${ARGS[$NAME]}"
+  A="--no-cpu-baseline --no-secondary ${ARGS[$NAME]}"
   OUT=$ROOT/gpurun_out/prof_${TAG}_$NAME
   rm -rf "$OUT"; mkdir -p "$OUT"
   timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- \

@@ -28,12 +28,13 @@ for f in sys.argv[1:]:
     h = d.get("library_source_hash")
     if not h:
         sys.exit(f"{f}: passes ran on different builds of the library (or no bench line): refused")
-    m = re.match(r"(\S+), (\d+) envs x (?:\d+ arms x )?(\d+) elements", d["workload"])
+    m = re.match(r"(\S+), (\d+) envs x (?:\d+ arms x )?(\d+) elements per GPU (tapered )?", d["workload"])
     env, envs, n_elem = m.group(1), int(m.group(2)), int(m.group(3))
+    key = f"{env}|n_elem={n_elem}" + ("|taper" if m.group(4) else "")      # bench.py profile_key()
     src = f"profiles/{f.name} ({d.get('command', 'tools/profile_all.sh')})"
     if "pmc3" in d:
         p = d["pmc3"]
-        valu[f"{env}|n_elem={n_elem}"] = {
+        valu[key] = {
             "valu_instr_per_rod_substep": p["valu_instr_per_rod_substep"], "valu_busy_frac": p["valu_busy_frac"],
             "valu_issue_frac_measured_cycles": p["valu_issue_frac_measured_cycles"],
             "cycles_per_env_step_per_xcd": p["cycles_per_env_step_per_xcd"],
@@ -41,7 +42,7 @@ for f in sys.argv[1:]:
             "registers": d.get("registers"), "source_hash": h, "source": src}
     if "hbm_bytes_per_launch" in d:
         per = int(d.get("step_kernels_per_env_step", 1))   # the windowed arm runs two kernels per env.step
-        hbm[f"{env}|n_elem={n_elem}|envs={envs}"] = {
+        hbm[f"{key}|envs={envs}"] = {
             "FETCH_SIZE_KiB_raw": d["FETCH_SIZE_KiB_per_launch_raw"] * per,
             "WRITE_SIZE_KiB_raw": d["WRITE_SIZE_KiB_per_launch_raw"] * per,
             "hbm_bytes_per_launch": d["hbm_bytes_per_launch"] * per,
