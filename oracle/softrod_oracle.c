@@ -1150,7 +1150,11 @@ int oracle_set(oracle_rod* r, const char* name, const double* in)
     if (!strcmp(name, "tangents")) SET3(tang, n);
     if (!strcmp(name, "kappa")) SET3(kappa, n - 1);
     if (!strcmp(name, "f_ext")) SET3(f_ext, n + 1);
+    /* damper coefficients: lets tools/sweep_switches.py try AnalyticalLinearDamper's other
+     * protocol (uniform: the same exp(-nu dt) on every rate) without a config field */
+    if (!strcmp(name, "damp_r")) SET3(damp_r, n);
 #undef SET3
+    if (!strcmp(name, "damp_t")) { r->damp_t = in[0]; return 0; }
     if (!strcmp(name, "time")) { r->time = in[0]; return 0; }
     if (!strcmp(name, "prev_kappa")) { for (int k = 0; k < n - 1; ++k) r->prev_kappa[k] = in[k]; return 0; }
     if (!strcmp(name, "prev_com")) { r->prev_com[0] = in[0]; r->prev_com[1] = in[1]; return 0; }

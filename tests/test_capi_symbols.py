@@ -99,7 +99,7 @@ def test_profile_tables_name_the_build_they_were_measured_on():
     for name in ("valu_counts.json", "hbm_traffic.json"):
         doc = json.loads((ROOT / "profiles" / name).read_text())
         entries = {k: v for k, v in doc.items() if not k.startswith("_")}
-        assert len(entries) == 6, name
+        assert len(entries) == 7, name        # six workloads + the tapered arm
         for k, v in entries.items():
             assert re.fullmatch(r"[0-9a-f]{16}", v["source_hash"]), (name, k)
             assert (ROOT / v["source"].split(" ")[0]).exists(), (name, k, v["source"])

@@ -33,7 +33,7 @@ for NAME in $NAMES; do
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o pmc --output-format csv -- \
       python3 "$ROOT/bench.py" $A > "$OUT/bench_pmc_write.log" 2>&1
   ( cd "$ROOT" && python3 tools/summarize_profile.py "$OUT" $A > "$OUT/summary.json" 2> "$OUT/summary.err" )
-  cp "$OUT"/trace/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
+  find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \; 2>/dev/null
   python3 - "$OUT/summary.json" "$NAME" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
