@@ -40,12 +40,17 @@ if str(ROOT) not in sys.path:
 
 SEEDS = (0, 1, 42, 123)
 RAW_SUBSTEPS = (1, 10, 100)
-# env id -> (action amplitude of the script, env.steps recorded with full state, steps run in total)
+# env id -> action amplitude of the script, env.steps recorded with full state, steps run in total, and
+# `strict_steps`: the env.steps up to which 1e-5 is demanded of ANY second implementation.  Beyond it
+# the records are kept and reported, not asserted: OctoFlat (8 arms + head, stiff joints, 2857 substeps
+# per env.step) amplifies a rounding-level difference to 1e-2 by step 3 — the oracle built with FMA
+# contraction against itself without, tools/episode_parity.py and DESIGN.md §3 — while the one-rod envs
+# hold 1e-7 or better over the whole episode under the same control.
 ENVS = {
-    "SoftPendulum-v0": dict(amax=22.0, state_steps=(1, 3, 10, 126), n_steps=126),
-    "SoftPendulum3D-v0": dict(amax=1.0, state_steps=(1, 3, 10, 126), n_steps=126),
-    "OctoArmSingle-v0": dict(amax=6.0, state_steps=(1, 3, 10, 126), n_steps=126),
-    "OctoFlat-v0": dict(amax=22.0, state_steps=(1, 3, 10), n_steps=10),
+    "SoftPendulum-v0": dict(amax=22.0, state_steps=(1, 3, 10, 126), n_steps=126, strict_steps=10),
+    "SoftPendulum3D-v0": dict(amax=1.0, state_steps=(1, 3, 10, 126), n_steps=126, strict_steps=10),
+    "OctoArmSingle-v0": dict(amax=6.0, state_steps=(1, 3, 10, 126), n_steps=126, strict_steps=10),
+    "OctoFlat-v0": dict(amax=22.0, state_steps=(1, 3, 10), n_steps=10, strict_steps=1),
 }
 
 # The recalled details a fixture can decide, as (name, candidates).  The first candidate of each is
@@ -370,6 +375,31 @@ def worst(dev: Dict[str, float], upto_step: Optional[int] = None, skip_time: boo
                 continue
         w = max(w, v)
     return w
+
+
+def strict_worst(dev: Dict[str, float], env_id: str, limit: Optional[int] = None) -> float:
+    """The figure held against 1e-5: raw substeps and env.steps <= the env's strict horizon (or
+    `limit`, if lower); the clock records of ALL steps are exact or not, and are included."""
+    n = ENVS[env_id]["strict_steps"] if limit is None else min(limit, ENVS[env_id]["strict_steps"])
+    return worst(dev, n)
+
+
+def horizon(dev: Dict[str, float], tol: float = 1e-5) -> int:
+    """Number of leading env.steps whose obs / reward / state records all stay within `tol`."""
+    t = 0
+    while any(k.startswith(f"step{t + 1}_") for k in dev):
+        if any(v > tol for k, v in dev.items() if k.startswith(f"step{t + 1}_")):
+            break
+        t += 1
+    return t
+
+
+def load_switches(directory, prefix: str = "pyelastica") -> Dict[str, object]:
+    """What tools/sweep_switches.py --write decided for these fixtures, else the shipped defaults."""
+    import json
+
+    f = Path(directory) / f"{prefix}_switches.json"
+    return dict(default_switches(), **(json.loads(f.read_text())["switches"] if f.exists() else {}))
 
 
 def fixture_files(directory, prefix: str = "pyelastica") -> List[Path]:
