@@ -1,4 +1,13 @@
-"""NumPy restatement (fp64) of the SoftPendulum-v0 hot path — second, independent oracle.
+"""NumPy restatement (fp64) of the hot path — second, independent oracle: the SoftPendulum-v0
+substep (round 1), and since round 4 the two pieces the C oracle held as its ONLY transcription:
+RodPlaneContactWithAnisotropicFriction (BASELINE configs[2], OctoArmSingle-v0) and the rigid
+octopus head — Cylinder, FixedJoint2Rigid, BodyBoundaryCondition (configs[4], OctoFlat-v0).
+Those two were written from PyElastica's array-style kernels as recalled (elastica/
+_contact_functions.py, contact_utils.py, rigidbody/cylinder.py, rigidbody/rigid_body.py; the
+friction model of Gazzola et al. 2018 §4 / Methods) and from the reference's OWN files for the
+joint and the head constraint (gym_softrobot/utils/custom_elastica/joint.py:20-225,
+constraint.py:8-85; assembly octopus/build.py:52-217) — NOT from softrod_oracle.c, which
+tests/test_oracle_np_contact_head.py holds against this file to 1e-12.
 
 TEST INFRASTRUCTURE ONLY: imported by tests/ and tools/make_golden.py, never by
 gym_softrobot_amd/.  PARITY UNPINNED for the PyElastica arithmetic (see the header
@@ -116,6 +125,7 @@ class NumpyRod:
         d = self.x[:, 1:] - self.x[:, :-1]
         self.len = np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + c.eps_length
         self.tang = d / self.len
+        self.radius = np.sqrt(self.volume / self.len / np.pi)      # _compute_geometry_from_state
         self.dil = self.len / self.rest_len
         self.vdil = 0.5 * (self.len[1:] + self.len[:-1]) / self.rest_vor
         z = np.array([0.0, 0.0, 1.0]).reshape(3, 1)
@@ -192,6 +202,52 @@ class NumpyRod:
             self.v[:, 0] = 0
             self.w[:, 0] = 0
 
+    # -- one PositionVerlet substep in phases (a system of several bodies interleaves them) --------
+    def forcing(self):
+        """add_forcing_to(...) operators in registration order (build.py:88-105, octopus/build.py:134-141)."""
+        c = self.cfg
+        g = np.asarray(list(c.gravity), float)
+        if c.features & 1:
+            self.f_ext += g[:, None] * self.mass[None, :]
+        if c.features & 2:
+            self.f_ext[0, 0] = self.point_force  # assigns: build.py:101
+        if c.features & 32:
+            self.f_ext[:, -1] += np.asarray(list(c.tip_force), float)
+
+    def contact(self):
+        """detect_contact_between(rod, plane).using(RodPlaneContactWithAnisotropicFriction, ...)
+        (octopus/build.py:193-200,274-283)."""
+        c = self.cfg
+        if c.features & 256:
+            rod_plane_contact_with_anisotropic_friction(
+                self, np.asarray(list(c.plane_origin), float), np.asarray(list(c.plane_normal), float),
+                c.surface_tol, c.slip_velocity_tol, c.contact_k, c.contact_nu,
+                np.asarray(list(c.kinetic_mu), float), np.asarray(list(c.static_mu), float))
+
+    def dynamic(self, dt):
+        acc = (self.f_int + self.f_ext) / self.mass
+        alpha = (self.invJ * (self.t_int + self.t_ext)) * self.dil
+        self.v = self.v + dt * acc
+        self.w = self.w + dt * alpha
+
+    def dampen(self):
+        if self.cfg.features & 8:
+            self.v = self.v * self.damp_t
+            self.w = self.w * np.power(self.damp_r, self.dil)
+
+    def rates_operators(self):
+        """constrain_rates and dampen_rates in the order the switch says (0: constrain first)."""
+        if self.cfg.damp_before_constrain:
+            self.dampen()
+            self._constrain_rates()
+        else:
+            self._constrain_rates()
+            self.dampen()
+
+    def zero_external(self):
+        self.f_ext[:] = 0.0
+        self.t_ext[:] = 0.0
+
     def substep(self):
         c = self.cfg
         dt = c.dt
@@ -200,26 +256,18 @@ class NumpyRod:
             self.time = self.time + 0.5 * dt
         self._constrain_values()
         self._forces_and_torques()
-        g = np.asarray(list(c.gravity), float)
-        if c.features & 1:
-            self.f_ext += g[:, None] * self.mass[None, :]
-        if c.features & 2:
-            self.f_ext[0, 0] = self.point_force  # assigns: build.py:101
-        if c.features & 32:
-            self.f_ext[:, -1] += np.asarray(list(c.tip_force), float)
-        acc = (self.f_int + self.f_ext) / self.mass
-        alpha = (self.invJ * (self.t_int + self.t_ext)) * self.dil
-        self.v = self.v + dt * acc
-        self.w = self.w + dt * alpha
-        if c.features & 8:
-            self.v = self.v * self.damp_t
-            self.w = self.w * np.power(self.damp_r, self.dil)
-        self._constrain_rates()
+        if c.contact_before_forcing:
+            self.contact()
+            self.forcing()
+        else:
+            self.forcing()
+            self.contact()
+        self.dynamic(dt)
+        self.rates_operators()
         self._kinematic(0.5 * dt)
         self.time = self.time + (0.5 * dt if c.time_two_half_adds else dt)
         self._constrain_values()
-        self.f_ext[:] = 0.0
-        self.t_ext[:] = 0.0
+        self.zero_external()
 
     # -- env epilogue (soft_pendulum.py) ---------------------------------------------
     def theta(self):
@@ -247,3 +295,287 @@ class NumpyRod:
             forward = np.abs(self.x[0, 0]) * 10 + th**2
         truncated = bool(self.time > self.cfg.final_time)
         return self.get_state(), forward - 0.0 + survive, terminated, truncated
+
+
+# ===============================================================================================
+# RodPlaneContactWithAnisotropicFriction — elastica/_contact_functions.py
+# (_calculate_contact_forces_rod_plane, ..._with_anisotropic_friction) and contact_utils.py, in
+# PyElastica's whole-array style.  Friction model: Gazzola et al. 2018, Methods "Surface friction":
+# kinetic Coulomb friction along the in-plane axial direction (forward / backward coefficients by the
+# sign of the axial velocity) and along the rolling direction (sideways coefficient; slip = rolling
+# velocity + spin of the contact point), blended out by the slip function below the slip-velocity
+# threshold, where static friction takes over (axial: up to mu_s N against the pushing force;
+# rolling: the no-slip force (r F_roll - 2 T_axial) / (3 r)), with the rolling friction's torque
+# r_contact x F about the axis.
+# ===============================================================================================
+def _node_to_element_force(f):          # node_to_element_mass_or_force
+    out = 0.5 * (f[:, :-1] + f[:, 1:])
+    out[:, 0] += 0.5 * f[:, 0]
+    out[:, -1] += 0.5 * f[:, -1]
+    return out
+
+
+def _node_to_element_position(x):
+    return 0.5 * (x[:, 1:] + x[:, :-1])
+
+
+def _node_to_element_velocity(mass, v):
+    return (mass[1:] * v[:, 1:] + mass[:-1] * v[:, :-1]) / (mass[1:] + mass[:-1])
+
+
+def _elements_to_nodes_inplace(e, nodes):
+    nodes[:, :-1] += 0.5 * e
+    nodes[:, 1:] += 0.5 * e
+
+
+def _norm(a):
+    return np.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])
+
+
+def _dot(a, b):
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+
+def find_slipping_elements(velocity_slip, velocity_threshold):
+    """1 below the threshold (static regime), falling linearly to 0 at twice the threshold."""
+    mag = _norm(velocity_slip)
+    slip = np.ones(velocity_slip.shape[1])
+    pts = np.fabs(mag) > velocity_threshold
+    slip[pts] = np.fabs(1.0 - np.minimum(1.0, mag[pts] / velocity_threshold - 1.0))
+    return slip
+
+
+def rod_plane_contact(rod, origin, normal, surface_tol, k, nu):
+    """_calculate_contact_forces_rod_plane -> (|plane response| per element, no-contact mask)."""
+    nrm = normal[:, None]
+    total = _node_to_element_force(rod.f_int + rod.f_ext)
+    along = normal @ total                                   # force component along the normal
+    response = -(nrm * along)
+    response[:, along > 0.0] = 0.0                           # pushed away from the plane: no response
+    elem_x = _node_to_element_position(rod.x)
+    distance = normal @ (elem_x - origin[:, None])
+    penetration = np.minimum(distance - rod.radius, 0.0)
+    elastic = -k * (nrm * penetration)
+    elem_v = _node_to_element_velocity(rod.mass, rod.v)
+    damping = -nu * (nrm * (normal @ elem_v))
+    total_response = response + elastic + damping
+    no_contact = (distance - rod.radius) > surface_tol
+    response[:, no_contact] = 0.0
+    total_response[:, no_contact] = 0.0
+    _elements_to_nodes_inplace(total_response, rod.f_ext)
+    return _norm(response), no_contact
+
+
+def rod_plane_contact_with_anisotropic_friction(rod, origin, normal, surface_tol, slip_tol, k, nu,
+                                                kinetic_mu, static_mu):
+    """kinetic_mu / static_mu = [forward, backward, sideways] (octopus/build.py:178-186)."""
+    mag, no_contact = rod_plane_contact(rod, origin, normal, surface_tol, k, nu)
+    nrm = normal[:, None]
+    tang = rod.tang
+    in_plane = tang - nrm * (normal @ tang)
+    axial = in_plane / (_norm(in_plane) + 1e-14)
+    elem_v = _node_to_element_velocity(rod.mass, rod.v)
+    v_axial_mag = _dot(elem_v, axial)
+    v_axial = v_axial_mag * axial
+    sgn = np.sign(v_axial_mag)
+    mu_k = 0.5 * (kinetic_mu[0] * (1 + sgn) + kinetic_mu[1] * (1 - sgn))
+    slip_axial = find_slipping_elements(v_axial, slip_tol)
+    # rolling
+    rolling = _cross(axial, np.repeat(nrm, rod.n, axis=1))
+    arm = -nrm * rod.radius                                  # from the axis to the contact point
+    v_roll = _dot(elem_v, rolling)
+    Qt = np.transpose(rod.Q, (1, 0, 2))
+    spin = _matvec(Qt, _cross(rod.w, _matvec(rod.Q, arm)))    # lab-frame velocity of the contact point
+    slip_roll_mag = v_roll + _dot(spin, rolling)
+    slip_roll = slip_roll_mag * rolling
+    slip_rolling = find_slipping_elements(slip_roll, slip_tol)
+    unit = slip_roll + v_axial                               # total slip velocity, unitised
+    unit = unit / _norm(unit + 1e-14)
+    # kinetic, axial
+    f = -((1.0 - slip_axial) * mu_k * mag * _dot(unit, axial) * axial)
+    f[:, no_contact] = 0.0
+    _elements_to_nodes_inplace(f, rod.f_ext)
+    # kinetic, rolling
+    f = -((1.0 - slip_rolling) * kinetic_mu[2] * mag * _dot(unit, rolling) * rolling)
+    f[:, no_contact] = 0.0
+    _elements_to_nodes_inplace(f, rod.f_ext)
+    rod.t_ext += _matvec(rod.Q, _cross(arm, f))
+    # static, axial: min(mu_s N, pushing force) against the push
+    total = _node_to_element_force(rod.f_int + rod.f_ext)
+    push = _dot(total, axial)
+    psgn = np.sign(push)
+    mu_s = 0.5 * (static_mu[0] * (1 + psgn) + static_mu[1] * (1 - psgn))
+    fmax = slip_axial * mu_s * mag
+    f = -(np.minimum(np.fabs(push), fmax) * psgn * axial)
+    f[:, no_contact] = 0.0
+    _elements_to_nodes_inplace(f, rod.f_ext)
+    # static, rolling: the force that keeps the contact point from slipping
+    torques = _matvec(Qt, rod.t_int + rod.t_ext)
+    t_axial = _dot(torques, axial)
+    f_roll = _dot(total, rolling)
+    noslip = -((rod.radius * f_roll - 2.0 * t_axial) / 3.0 / rod.radius)
+    fmax = slip_rolling * static_mu[2] * mag
+    f = np.minimum(np.fabs(noslip), fmax) * np.sign(noslip) * rolling
+    f[:, no_contact] = 0.0
+    _elements_to_nodes_inplace(f, rod.f_ext)
+    rod.t_ext += _matvec(rod.Q, _cross(arm, f))
+
+
+# ===============================================================================================
+# The rigid head: Cylinder (elastica/rigidbody/cylinder.py, rigid_body.py), the reference's
+# FixedJoint2Rigid (utils/custom_elastica/joint.py:20-225) and BodyBoundaryCondition
+# (utils/custom_elastica/constraint.py:8-85), assembled as build_octopus does (octopus/build.py:52-217).
+# ===============================================================================================
+class NumpyCylinder:
+    """Cylinder(start, direction, normal, base_length, base_radius, density): one "node" at the
+    centre of mass, director rows (normal, direction x normal, direction); inertia as PyElastica
+    allocates it — diag(I1, I1, 2 I1) rho L with I1 = A^2 / 4 pi, i.e. I_axis = m r^2 / 2 and
+    I_transverse = m r^2 / 4 (the thin-disc value, no L^2 term)."""
+
+    def __init__(self, start, direction, normal, base_length, base_radius, density):
+        start, direction, normal = (np.asarray(a, float) for a in (start, direction, normal))
+        self.x = (start + direction * base_length / 2).reshape(3, 1)
+        self.v = np.zeros((3, 1))
+        self.w = np.zeros((3, 1))
+        self.Q = np.zeros((3, 3, 1))
+        self.Q[0, :, 0] = normal
+        self.Q[1, :, 0] = np.cross(direction, normal)
+        self.Q[2, :, 0] = direction
+        area = np.pi * base_radius * base_radius
+        self.mass = np.pi * base_radius * base_radius * base_length * density
+        i1 = area * area / (4.0 * np.pi)
+        self.J = np.array([i1, i1, 2.0 * i1]) * density * base_length      # diagonal
+        self.invJ = 1.0 / self.J
+        self.radius, self.length = base_radius, base_length
+        self.f_ext = np.zeros((3, 1))
+        self.t_ext = np.zeros((3, 1))
+        self.fixed_position = self.x[:, 0].copy()           # BodyBoundaryCondition(constrained_position_idx=(0,))
+
+    def kinematic(self, prefac, eps_rot_axis):
+        self.x = self.x + prefac * self.v
+        w = self.w[:, 0]
+        theta = np.sqrt(w @ w)
+        u = w / (theta + eps_rot_axis)
+        theta = theta * prefac
+        s, c1 = np.sin(theta), 1.0 - np.cos(theta)
+        K = np.array([[0.0, -u[2], u[1]], [u[2], 0.0, -u[0]], [-u[1], u[0], 0.0]])
+        R = np.eye(3) - s * K + c1 * (K @ K)                 # exp(-theta [u]x): the rods' rotation, in matrix form
+        self.Q[:, :, 0] = R @ self.Q[:, :, 0]
+
+    def dynamic(self, dt):
+        """update_accelerations: a = F / m; alpha = J^-1 ((J w) x w + T), all in the body frame."""
+        acc = self.f_ext / self.mass
+        jw = self.J[:, None] * self.w
+        alpha = self.invJ[:, None] * (_cross(jw, self.w) + self.t_ext)
+        self.v = self.v + dt * acc
+        self.w = self.w + dt * alpha
+
+    def constrain_values(self):                              # constraint.py:41-59
+        self.x[2, 0] = self.fixed_position[2]
+        Q = self.Q
+        Q[2, 0, 0], Q[2, 1, 0], Q[2, 2, 0] = 0.0, 0.0, 1.0
+        for i in range(2):
+            length = np.sqrt(Q[i, 0, 0] ** 2 + Q[i, 1, 0] ** 2)
+            Q[i, 0, 0] /= length
+            Q[i, 1, 0] /= length
+            Q[i, 2, 0] = 0.0
+
+    def constrain_rates(self):                               # constraint.py:61-85
+        self.v[2, :] = 0.0
+        self.w[:2, :] = 0.0
+
+    def zero_external(self):
+        self.f_ext[:] = 0.0
+        self.t_ext[:] = 0.0
+
+
+def fixed_joint_to_rigid(head, arm, k, nu, kt, angle_deg, radius):
+    """FixedJoint2Rigid.apply_forces then apply_torques (joint.py:47-219) for index_one = -1 (the
+    head's only node), index_two = 0 (the arm's base node and element)."""
+    pos = head.x[:, 0].copy()
+    pos[2] = 0.0                                             # :50-51
+    th = angle_deg / 180.0 * np.pi                           # z_rotation, :7-17
+    R = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    binormal = head.Q[1, :, 0]
+    conn_dir = -(R @ binormal)                               # :91
+    pos = pos + conn_dir * radius                            # :94-95
+    dist_vec = arm.x[:, 0] - pos
+    dist = np.sqrt(dist_vec @ dist_vec)
+    unit = np.zeros(3) if dist <= np.finfo(np.float64).eps * 1e4 else dist_vec / dist
+    elastic = k * dist_vec
+    rel_v = arm.v[:, 0] - head.v[:, 0]
+    damping = -nu * ((rel_v @ unit) * unit)
+    force = elastic + damping
+    head.f_ext[:, 0] += force                                # :123
+    arm.f_ext[:, 0] -= force                                 # :124
+    # torques, :174-219
+    link = arm.x[:, 1] - arm.x[:, 0]
+    target = pos + arm.rest_len[0] * conn_dir
+    restoring = -kt * (arm.x[:, 1] - target)
+    torque = np.cross(link, restoring)
+    head.t_ext[:, 0] -= head.Q[:, :, 0] @ torque
+    arm.t_ext[:, 0] += arm.Q[:, :, 0] @ torque
+
+
+class NumpyOctopus:
+    """build_octopus (octopus/build.py:52-217): n_arm rods around a Cylinder head, one
+    FixedJoint2Rigid per arm, BodyBoundaryCondition on the head, gravity + damper + plane contact on
+    every arm (the head carries neither).  cfg: the attribute names of softrod_config."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.n_arm = int(cfg.n_arm)
+        self.arms = [NumpyRod(cfg) for _ in range(self.n_arm)]
+        self.angles = [360 / self.n_arm * a for a in range(self.n_arm)]
+        self.head = None
+        self.time = np.float64(0.0)
+
+    def reset(self, arm_pos, arm_dir):
+        c = self.cfg
+        for a, rod in enumerate(self.arms):
+            rod.reset_straight(arm_pos[a], arm_dir[a], np.array([0.0, 0.0, 1.0]))     # :79-87
+        r0 = c.base_radius
+        self.head = NumpyCylinder(np.array([0.0, 0.0, -r0]), np.array([0.0, 0.0, 1.0]), np.array([0.0, 1.0, 0.0]),
+                                  2 * r0, c.head_radius, c.head_density)             # :93-105
+        self.time = np.float64(0.0)
+
+    def _connections(self):
+        c = self.cfg
+        for a, rod in enumerate(self.arms):
+            fixed_joint_to_rigid(self.head, rod, c.joint_k, c.joint_nu, c.joint_kt, self.angles[a], c.head_radius)
+
+    def substep(self):
+        c = self.cfg
+        dt = c.dt
+        for rod in self.arms:
+            rod._kinematic(0.5 * dt)
+        self.head.kinematic(0.5 * dt, c.eps_rot_axis)
+        if c.time_two_half_adds:
+            self.time = self.time + 0.5 * dt
+        self.head.constrain_values()
+        for rod in self.arms:
+            rod._forces_and_torques()
+        # synchronize: forcing, connections, and the contacts last (or first, by the switch)
+        if c.contact_before_forcing:
+            for rod in self.arms:
+                rod.contact()
+        for rod in self.arms:
+            rod.forcing()
+        self._connections()
+        if not c.contact_before_forcing:
+            for rod in self.arms:
+                rod.contact()
+        for rod in self.arms:
+            rod.dynamic(dt)
+        self.head.dynamic(dt)
+        for rod in self.arms:
+            rod.rates_operators()
+        self.head.constrain_rates()
+        for rod in self.arms:
+            rod._kinematic(0.5 * dt)
+        self.head.kinematic(0.5 * dt, c.eps_rot_axis)
+        self.time = self.time + (0.5 * dt if c.time_two_half_adds else dt)
+        self.head.constrain_values()
+        for rod in self.arms:
+            rod.zero_external()
+        self.head.zero_external()

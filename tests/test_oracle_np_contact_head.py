@@ -1,0 +1,315 @@
+"""The C oracle's plane contact / anisotropic friction and rigid octopus head against their SECOND
+transcription (oracle/softrod_oracle_np.py, written in PyElastica's whole-array style from the
+recalled PyElastica kernels, Gazzola et al. 2018 and the reference's own joint.py / constraint.py —
+not from softrod_oracle.c): 200 substeps of a sliding, rolling, bent arm in every friction regime
+and of the 8-arm octopus, equal to 1e-12 of each field's scale.  A slip in either transcription
+(an index, a sign, a forward/backward coefficient, the order of the friction stages, the joint's
+lever arm) shows here; what both recall wrongly about PyElastica does not — that is what
+tests/test_pyelastica_fixtures.py is for.
+
+Plus known answers for the pieces that had none (VERDICT r3 "next" #3): the Cylinder's mass and
+inertia (m = rho pi r^2 L, I_axis = m r^2 / 2) through its constant-force and constant-torque
+response and through momentum conservation of the jointed system, and the bend-twist coupling
+term kappa x B kappa on a uniform helix state (closed form for the first substep)."""
+import numpy as np
+import pytest
+
+TOL = 1e-12
+FLOOR = {"x": 1e-2, "v": 1e-2, "w": 1e-1, "Q": 1.0}
+
+
+def _close(a, b, name, tol=TOL):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    scale = max(FLOOR[name[-1]] if name[-1] in FLOOR else 1.0, float(np.abs(b).max()))
+    assert a.shape == b.shape, name
+    err = float(np.abs(a - b).max()) / scale
+    assert err <= tol, f"{name}: C and NumPy differ by {err:.2e} of scale {scale:.2e}"
+
+
+def _arm_cfg(**kw):
+    from gym_softrobot_amd import _capi
+
+    cfg = _capi.arm_single_config(1, n_elems=kw.pop("n_elems", 20))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _pair(cfg, start=(0.0, 0.0, 0.0)):
+    from oracle import oracle_c
+    from oracle.softrod_oracle_np import NumpyRod
+
+    c_rod, n_rod = oracle_c.OracleRod(cfg), NumpyRod(cfg)
+    args = (np.array(start, float), np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0]))
+    c_rod.reset_straight(*args)
+    n_rod.reset_straight(*args)
+    return c_rod, n_rod
+
+
+def _inject(c_rod, n_rod, v=None, w=None, rest_kappa=None):
+    n = n_rod.n
+    if v is not None:
+        vv = np.repeat(np.asarray(v, float)[:, None], n + 1, axis=1) * np.linspace(1.0, 0.6, n + 1)
+        c_rod.set("v", vv)
+        n_rod.v = vv.copy()
+    if w is not None:
+        ww = np.repeat(np.asarray(w, float)[:, None], n, axis=1)
+        c_rod.set("w", ww)
+        n_rod.w = ww.copy()
+    if rest_kappa is not None:
+        rk = np.zeros((3, n - 1))
+        rk[0] = rest_kappa * np.sin(np.linspace(0, 3.0, n - 1))
+        rk[1] = 0.5 * rest_kappa * np.cos(np.linspace(0, 2.0, n - 1))
+        c_rod.set("rest_kappa", rk)
+        n_rod.rest_kappa = rk.copy()
+
+
+def _run_and_compare(c_rod, n_rod, n_sub, every=50, tol=TOL):
+    done = 0
+    while done < n_sub:
+        k = min(every, n_sub - done)
+        c_rod.substeps(0.0, k)
+        for _ in range(k):
+            n_rod.substep()
+        done += k
+        for name in ("x", "v", "Q", "w"):
+            _close(getattr(n_rod, name), c_rod.get(name), f"after {done} substeps: {name}", tol)
+    assert np.isfinite(n_rod.x).all()
+
+
+CASES = {
+    # forward sliding + sideways rolling + spin about the axis + actuation: kinetic regime on both axes
+    "sliding forward, rolling, spinning, bent": dict(v=(0.3, 0.2, 0.0), w=(0.0, 0.0, 8.0), rest_kappa=6.0),
+    # backward: the other axial coefficient
+    "sliding backward": dict(v=(-0.25, -0.1, 0.0), w=(0.0, 0.0, -3.0), rest_kappa=0.0),
+    # out-of-plane bending actuation lifts part of the arm off the plane: contact mask changes along the rod
+    "partial lift-off": dict(v=(0.05, 0.0, 0.3), w=(0.5, -0.5, 0.0), rest_kappa=10.0),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES), ids=list(CASES))
+def test_arm_on_the_plane_c_equals_numpy(oracle_built, case):
+    c_rod, n_rod = _pair(_arm_cfg())
+    _inject(c_rod, n_rod, **CASES[case])
+    _run_and_compare(c_rod, n_rod, 200)
+    assert np.abs(n_rod.v).max() > 1e-3                # it really moved
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_static_and_transition_regime_c_equals_numpy(oracle_built, seed):
+    """The static friction branches (slip function 1 below slip_velocity_tol = 1e-8, blending to 0 at
+    twice that) on crafted states: node velocities and spins of the order of the threshold, so that
+    along the rod the slip functions take every value in [0, 1], under random actuation that pushes in
+    both axial directions and rolls both ways.  Compared after 1, 2 and 3 substeps at 1e-12.  (Not
+    over 200 substeps from rest: there the law's discontinuities — sign() of a quantity that is pure
+    rounding noise, the threshold itself — amplify the last bit to O(1) within 200 substeps in ANY two
+    evaluations; the FMA build of the C oracle against the plain one does exactly the same.)"""
+    rng = np.random.default_rng(seed)
+    c_rod, n_rod = _pair(_arm_cfg())
+    n = n_rod.n
+    v = rng.normal(0.0, 1.2e-8, (3, n + 1))
+    v[2] *= 0.1
+    w = rng.normal(0.0, 1.5e-6, (3, n))                       # contact-point spin r w ~ 1e-8
+    rk = np.zeros((3, n - 1))
+    rk[0] = rng.uniform(-3, 3) * np.sin(np.linspace(0, rng.uniform(1, 6), n - 1) + rng.uniform(0, 3))
+    rk[1] = rng.uniform(-0.3, 0.3) * np.cos(np.linspace(0, 2.0, n - 1))
+    for name, val in (("v", v), ("w", w), ("rest_kappa", rk)):
+        c_rod.set(name, val)
+    n_rod.v, n_rod.w, n_rod.rest_kappa = v.copy(), w.copy(), rk.copy()
+    for k in (1, 2, 3):
+        c_rod.substeps(0.0, 1)
+        n_rod.substep()
+        for name in ("x", "v", "Q", "w"):
+            a, b = getattr(n_rod, name), c_rod.get(name)
+            # velocities here are 1e-8..1e-4: compare to the field's own scale, no floor
+            err = np.abs(a - b).max() / np.abs(b).max()
+            assert err <= 1e-11, f"substep {k}: {name} differs by {err:.2e}"
+
+
+def test_arm_dropped_onto_the_plane_c_equals_numpy(oracle_built):
+    """Starts 3 mm above the plane (no contact: distance - radius > surface_tol), falls, lands."""
+    c_rod, n_rod = _pair(_arm_cfg(), start=(0.0, 0.0, 0.003))
+    _inject(c_rod, n_rod, v=(0.1, 0.05, 0.0), w=None, rest_kappa=1.0)
+    _run_and_compare(c_rod, n_rod, 400, every=100, tol=1e-11)      # (the landing passes through the static regime)
+    assert n_rod.x[2].min() < 0.0015                   # it came down
+
+
+@pytest.mark.parametrize("switch", ["contact_before_forcing", "damp_before_constrain"])
+def test_order_switches_mean_the_same_in_both(oracle_built, switch):
+    c_rod, n_rod = _pair(_arm_cfg(**{switch: 1}))
+    _inject(c_rod, n_rod, **CASES["sliding forward, rolling, spinning, bent"])
+    _run_and_compare(c_rod, n_rod, 100)
+
+
+def _octo_pair(n_arm=8, **kw):
+    from scipy.spatial.transform import Rotation as Rot
+
+    from gym_softrobot_amd import _capi
+    from oracle import oracle_c
+    from oracle.softrod_oracle_np import NumpyOctopus
+
+    cfg = _capi.octo_flat_config(1, n_arm=n_arm)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    c_oct = oracle_c.OracleOcto(cfg)
+    c_oct.reset(np.array([1.0, 1.0]))
+    n_oct = NumpyOctopus(cfg)
+    pos = [Rot.from_euler("z", 360 / n_arm * a, degrees=True).apply([cfg.head_radius, 0.0, 0.0]) for a in range(n_arm)]
+    dirs = [Rot.from_euler("z", 360 / n_arm * a, degrees=True).apply([1.0, 0.0, 0.0]) for a in range(n_arm)]
+    n_oct.reset(pos, dirs)
+    return cfg, c_oct, n_oct
+
+
+def _compare_octo(c_oct, n_oct, tag, tol=TOL):
+    for a in range(n_oct.n_arm):
+        arm = c_oct.arm(a)
+        for name in ("x", "v", "Q", "w"):
+            _close(getattr(n_oct.arms[a], name), arm.get(name), f"{tag}: arm {a} {name}", tol)
+    h = c_oct.head()
+    _close(n_oct.head.x[:, 0], h["x"], f"{tag}: head x", tol)
+    _close(n_oct.head.v[:, 0], h["v"], f"{tag}: head v", tol)
+    _close(n_oct.head.Q[:, :, 0], h["Q"], f"{tag}: head Q", tol)
+    _close(n_oct.head.w[:, 0], h["w"], f"{tag}: head w", tol)
+
+
+def test_octopus_c_equals_numpy(oracle_built):
+    """8 arms + head, every arm actuated differently, the head kicked and spun: 200 substeps."""
+    cfg, c_oct, n_oct = _octo_pair()
+    n = int(cfg.n_elem)
+    for a in range(8):
+        rk = np.zeros((3, n - 1))
+        rk[0] = (4.0 + a) * np.sin(np.linspace(0, 2.5, n - 1) + 0.3 * a) * (-1) ** a
+        c_oct.arm(a).set("rest_kappa", rk)
+        n_oct.arms[a].rest_kappa = rk.copy()
+    h = c_oct.head()
+    v0, w0 = np.array([0.05, -0.03, 0.0]), np.array([0.0, 0.0, 1.5])
+    c_oct.set_head(h["x"], v0, h["Q"], w0)
+    n_oct.head.v[:, 0], n_oct.head.w[:, 0] = v0, w0
+    _compare_octo(c_oct, n_oct, "at reset")
+    # 1e-10: the joints' stiffness (1e6 N/m on nodes of 1e-4 kg) turns the last bit of a position into
+    # 1e-11 of a velocity; the difference does not grow (1e-11 still after 1000 substeps)
+    for done in (50, 100, 150, 200):
+        c_oct.substeps(50)
+        for _ in range(50):
+            n_oct.substep()
+        _compare_octo(c_oct, n_oct, f"after {done} substeps", tol=1e-10)
+    assert abs(n_oct.head.x[0, 0]) > 1e-5 and float(n_oct.time) == pytest.approx(c_oct.time, abs=0)
+
+
+# ---- known answers -------------------------------------------------------------------------------
+
+def test_cylinder_mass_and_inertia_known_answers(oracle_built):
+    """m = rho pi r^2 L and I_axis = m r^2 / 2 (I_transverse = m r^2 / 4 as PyElastica allocates it),
+    statically in both transcriptions and dynamically: constant force -> v = F t / m, constant axial
+    torque -> w = T t / I_axis, both exact for PositionVerlet."""
+    from oracle.softrod_oracle_np import NumpyCylinder
+
+    cfg, c_oct, n_oct = _octo_pair()
+    r, L, rho = cfg.head_radius, 2 * cfg.base_radius, cfg.head_density
+    m = rho * np.pi * r * r * L
+    h = c_oct.head()
+    assert h["mass"] == pytest.approx(m, rel=1e-14) and n_oct.head.mass == pytest.approx(m, rel=1e-14)
+    np.testing.assert_allclose(h["J"], [m * r * r / 4, m * r * r / 4, m * r * r / 2], rtol=1e-13)
+    np.testing.assert_allclose(n_oct.head.J, h["J"], rtol=1e-14)
+    cyl = NumpyCylinder(np.array([0.0, 0.0, -cfg.base_radius]), np.array([0.0, 0.0, 1.0]), np.array([0.0, 1.0, 0.0]),
+                        L, r, rho)
+    F, T, dt, n_sub = np.array([0.02, -0.01, 0.0]), 3e-4, 7e-5, 500
+    for _ in range(n_sub):
+        cyl.kinematic(0.5 * dt, 1e-14)
+        cyl.f_ext[:, 0] = F
+        cyl.t_ext[:, 0] = [0.0, 0.0, T]          # body frame; the axis is director row 2
+        cyl.dynamic(dt)
+        cyl.kinematic(0.5 * dt, 1e-14)
+    t = n_sub * dt
+    np.testing.assert_allclose(cyl.v[:, 0], F * t / m, rtol=1e-12)
+    np.testing.assert_allclose(cyl.x[:2, 0], 0.5 * F[:2] * t * t / m, rtol=1e-12)       # symplectic: exact for constant a
+    assert cyl.w[2, 0] == pytest.approx(T * t / (m * r * r / 2), rel=1e-12) and abs(cyl.w[:2, 0]).max() == 0.0
+    # the axis turned by T t^2 / 2 I about z
+    ang = 0.5 * T * t * t / (m * r * r / 2)
+    assert np.arctan2(-cyl.Q[0, 0, 0], cyl.Q[0, 1, 0]) == pytest.approx(ang, rel=1e-9)    # d1 = (-sin, cos, 0): counter-clockwise
+
+
+def test_head_mass_enters_the_dynamics_momentum_is_conserved(oracle_built):
+    """A kicked head drags its arms through the joints.  No gravity, no plane, no damper: the joints'
+    forces are equal and opposite, so m_head v_head + sum m_i v_i keeps its initial value m_head v0 —
+    with the head's mass as allocated (a wrong dynamic mass breaks it).  C oracle and NumPy twin."""
+    kw = dict(damping_constant=0.0)
+    cfg, c_oct, n_oct = _octo_pair(**kw)
+    for obj in (cfg, n_oct.cfg):
+        obj.gravity[2] = 0.0
+        obj.plane_origin[2] = -10.0          # far below: nothing touches it
+    from oracle import oracle_c
+
+    c_oct = oracle_c.OracleOcto(cfg)
+    c_oct.reset(np.array([1.0, 1.0]))
+    h = c_oct.head()
+    v0 = np.array([0.2, 0.1, 0.0])
+    c_oct.set_head(h["x"], v0, h["Q"], h["w"])
+    n_oct.head.v[:, 0] = v0
+    p0 = h["mass"] * v0
+    c_oct.substeps(300)
+    for _ in range(300):
+        n_oct.substep()
+    hc = c_oct.head()
+    p_c = hc["mass"] * hc["v"] + sum((c_oct.arm(a).get("mass") * c_oct.arm(a).get("v")).sum(axis=1) for a in range(8))
+    p_n = n_oct.head.mass * n_oct.head.v[:, 0] + sum((r.mass * r.v).sum(axis=1) for r in n_oct.arms)
+    np.testing.assert_allclose(p_c[:2], p0[:2], rtol=1e-9)
+    np.testing.assert_allclose(p_n[:2], p0[:2], rtol=1e-9)
+    assert np.linalg.norm(hc["v"][:2]) < 0.9 * np.linalg.norm(v0[:2])      # the arms did take momentum from it
+
+
+def _helix_state(n, rest_len, kappa):
+    """Directors and nodes of a rod whose discrete curvature is exactly `kappa` (material frame) at
+    every interior vertex and whose shear / stretch strain is zero: Q_{k+1} = R(kappa D) Q_k with the
+    rotation convention of the kinematic update, x_{k+1} = x_k + l d3_k."""
+    kappa = np.asarray(kappa, float)
+    th = np.linalg.norm(kappa) * rest_len
+    u = kappa / np.linalg.norm(kappa)
+    K = np.array([[0.0, -u[2], u[1]], [u[2], 0.0, -u[0]], [-u[1], u[0], 0.0]])
+    R = np.eye(3) - np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+    Q = np.zeros((3, 3, n))
+    Q[:, :, 0] = np.array([[0.0, 0.0, 1.0], [0.0, -1.0, 0.0], [1.0, 0.0, 0.0]])     # d3 = +x at the base
+    for k in range(n - 1):
+        Q[:, :, k + 1] = R @ Q[:, :, k]
+    x = np.zeros((3, n + 1))
+    for k in range(n):
+        x[:, k + 1] = x[:, k] + rest_len * Q[2, :, k]
+    return x, Q
+
+
+def test_bend_twist_coupling_known_answer_on_a_helix(oracle_built):
+    """kappa = (k1, 0, k3) uniform, rest curvature zero, B = diag(EI, EI, GJ): the bending couple
+    m = B kappa is uniform, so its difference vanishes in the interior, sigma = 0, the rod is at rest —
+    what remains of the torque balance is the coupling term (kappa x m) D = (0, k1 k3 (EI - GJ) D, 0).
+    After ONE substep from rest every interior element has omega = dt J^-1 (kappa x m) D exactly
+    (to the 1e-9 the 1e-10 shift inside arccos costs).  C oracle and NumPy twin."""
+    from gym_softrobot_amd import _capi
+    from oracle import oracle_c
+    from oracle.softrod_oracle_np import NumpyRod
+
+    n = 24
+    cfg = _capi.softpendulum_config(1, n_elems=n)
+    cfg.features = 0                                   # no gravity, no BC, no damper: a free rod
+    cfg.env_kind = _capi.ENV_NONE
+    k1, k3 = 1.3, 2.1
+    rest_len = cfg.base_length / n
+    x, Q = _helix_state(n, rest_len, (k1, 0.0, k3))
+    c_rod, n_rod = oracle_c.OracleRod(cfg), NumpyRod(cfg)
+    for rod in (c_rod, n_rod):
+        rod.reset_straight(np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0]))
+    c_rod.set("x", x)
+    c_rod.set("Q", Q)
+    n_rod.x, n_rod.Q = x.copy(), Q.copy()
+    c_rod.substeps(0.0, 1)
+    n_rod.substep()
+    kap = c_rod.get("kappa")
+    np.testing.assert_allclose(kap, np.repeat([[k1], [0.0], [k3]], n - 1, axis=1), atol=2e-8)
+    A = np.pi * cfg.base_radius ** 2
+    I1 = A * A / (4 * np.pi)
+    EI, GJ = cfg.youngs_modulus * I1, cfg.shear_modulus * 2 * I1
+    J2 = I1 * cfg.density * rest_len
+    want = cfg.dt * k1 * k3 * (EI - GJ) * rest_len / J2          # omega_2 of an interior element
+    assert abs(want) > 1e-3                                       # the term is not small here
+    for w in (c_rod.get("w"), n_rod.w):
+        np.testing.assert_allclose(w[1, 1:-1], want, rtol=1e-7)
+        assert np.abs(w[0, 1:-1]).max() < 1e-7 * abs(want) and np.abs(w[2, 1:-1]).max() < 1e-7 * abs(want)
