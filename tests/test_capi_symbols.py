@@ -108,3 +108,19 @@ def test_profile_tables_name_the_build_they_were_measured_on():
     stale, why = bench.fresh_or_none(rec, "fedcba9876543210")
     assert stale is None and "re-run" in why
     assert bench.fresh_or_none(None, "0123456789abcdef")[0] is None
+
+
+def test_docs_quote_the_header_abi_version():
+    """INTEGRATION.md's binding snippet asserts the ABI version of the header it was written
+    against (it said 11 under a header at 13 in round 3)."""
+    header = (ROOT / "include" / "softrod.h").read_text()
+    ver = int(re.search(r"#define SOFTROD_ABI_VERSION (\d+)", header).group(1))
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    assert int(re.search(r"softrod_abi_version\(\) == (\d+)", doc).group(1)) == ver
+    assert f"ABI v{ver}" in doc
+    from gym_softrobot_amd import _capi
+
+    assert _capi.ABI_VERSION == ver
+    import ctypes
+
+    assert f"{ctypes.sizeof(_capi.SoftrodConfig)} bytes" in doc
