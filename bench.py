@@ -55,6 +55,8 @@ secondary (N=1, default): after the headline windows the same process measures B
 configs[2] (OctoArmSingle-v0, 100 elements x 4096 envs) and configs[4]'s per-GPU share
 (OctoFlat-v0 x 1024 envs), 10 timed steps each on the warm clock, and reports them under
 `secondary` with their own roofline blocks (hash-matched tables); the headline keys are untouched.
+`pcie_inclusive` (same condition): the headline workload driven from pinned HOST buffers in a closed
+loop — what a caller that hands over NumPy arrays gets; never `value`.
 
 N > 1: `per_rank` lists every rank's step-kernel time, what a step costs beyond it (the exchange:
 collective or peer copies, plus launch gaps) and `efficiency_vs_n1_kernel` = kernel time / step
@@ -519,6 +521,40 @@ def secondary_workload(gsa, _capi, torch, device, math_mode, lib_hash, env_id, n
     return out
 
 
+def pcie_inclusive(gsa, torch, device, math_mode, n_local, steps: int = 40, warmup: int = 5):
+    """The same workload when the caller holds HOST buffers (the reference's own situation: NumPy in,
+    NumPy out): per env.step the actions cross PCIe from pinned memory, the step runs, obs / reward /
+    flags come back into pinned memory, and the host waits for them before it can act again (a closed
+    loop: one stream synchronisation per step, so the launch latency is exposed too).  Reported beside
+    `value`, never as `value` (which is measured with inputs resident in HBM)."""
+    import numpy as np
+
+    env = gsa.make_vec("SoftPendulum-v0", n_local, device=device, math_mode=math_mode)
+    env.reset(seed=0)
+    dev = env.backend.device
+    acts = torch.from_numpy(np.random.default_rng(1).uniform(-22, 22, (warmup + steps, n_local, 1)).astype(np.float32)).pin_memory()
+    a_dev = torch.empty((n_local, 1), dtype=torch.float32, device=dev)
+    host = None
+    for t in range(warmup + steps):
+        if t == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        a_dev.copy_(acts[t], non_blocking=True)
+        out = env.step(a_dev)[:4]
+        if host is None:
+            host = [torch.empty(o.shape, dtype=o.dtype).pin_memory() for o in out]
+        for h, o in zip(host, out):
+            h.copy_(o, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()        # the host reads the outputs before its next action
+    elapsed = time.perf_counter() - t0
+    moved = acts[0].numel() * 4 + sum(h.numel() * h.element_size() for h in host)
+    env.close()
+    return {"value": n_local * steps / elapsed, "unit": "env-steps/s", "ms_per_step": elapsed / steps * 1e3,
+            "steps": steps, "bytes_over_pcie_per_step": moved,
+            "what": "pinned host actions -> device, step, obs/reward/flags -> pinned host, stream sync, every step "
+                    "(closed loop); the headline `value` has its inputs resident in HBM and is open loop"}
+
+
 def p2p_trial(args, rank: int, local_rank: int, world: int, script=None, timeout_s: float = 300.0):
     """N > 1, after the headline (RCCL) measurement: every rank starts ONE child process that runs this
     file again as the same rank of a second job over transport "p2p" (its own rendezvous port), so that
@@ -829,6 +865,7 @@ def main(argv=None, script=None) -> int:
                 and args.envs_per_gpu is None and args.math_mode == "fast"):
             line["secondary"] = [secondary_workload(gsa, _capi, torch, local_rank, math_mode, lib_hash, **spec)
                                  for spec in SECONDARY]
+            line["pcie_inclusive"] = pcie_inclusive(gsa, torch, local_rank, math_mode, n_local)
         if not args.no_cpu_baseline and args.env == "SoftPendulum-v0" and hip:
             line["cpu_baseline"] = cpu_baseline(cfg, usable_cpus(), n_rods=ENVS_PER_GPU)
         else:
@@ -838,6 +875,9 @@ def main(argv=None, script=None) -> int:
 
     # ---- N > 1, default transport: the same windows once more over transport "p2p", in child processes
     if (world > 1 and args.transport == "rccl" and not args.no_p2p_trial and not args.trial_child):
+        if rank == 0:      # (a copy for the log, should the trial take the job down: stdout still gets ONE line, below)
+            sys.stderr.write("bench.py: headline before the p2p trial: " + json.dumps(line) + "\n")
+            sys.stderr.flush()
         trial = p2p_trial(args, rank, local_rank, world, script)
         if rank == 0:
             line["p2p_trial"] = trial

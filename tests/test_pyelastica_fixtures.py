@@ -123,3 +123,32 @@ def test_hip_replays_oracle_made_fixtures(hip_lib, oracle_made, math_mode):
     state read-back for one-rod envs and for the 8-arm octopus) against oracle-made files."""
     files = [f for f in oracle_made if not (math_mode == 0 and "OctoFlat" in f.name)]   # OctoFlat: fast mode only
     _check(pin.HipDriver, files, None, math_mode=math_mode)
+
+
+@pytest.mark.skipif(not Path("/root/reference/gym_softrobot").exists(), reason="needs the reference checkout (build container)")
+def test_pyelastica_driver_runs_the_reference_env_code(tmp_path):
+    """The driver that will record the pin is exercised NOW on the reference's real env classes:
+    tools/refshim.py stands in for gymnasium / elastica / numba with a stepper that integrates nothing,
+    and `record_case(PyElasticaDriver)` must run through reset, 100 raw substeps under a zero action,
+    the second reset and two env.steps for all four envs, reading the attributes the reference's
+    classes really keep (`shearable_rod(s)`, `rigid_rod`, `simulator`, `do_step`, `time`, `set_action`,
+    the observation dict of FlatEnv).  Recorded numbers are meaningless here; shapes and clocks are not."""
+    import json
+    import subprocess
+
+    out = tmp_path / "shapes.json"
+    p = subprocess.run([sys.executable, str(ROOT / "tests" / "pyelastica_driver_shim_worker.py"), str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(out.read_text())
+    assert set(d) == set(pin.ENVS)
+    for env_id, n, obs_dim, adim, step_time in (("SoftPendulum-v0", 50, 4, 1, 0.04), ("SoftPendulum3D-v0", 50, 9, 2, 0.04),
+                                                ("OctoArmSingle-v0", 50, 25, 7, 714 * 7e-5)):
+        s = d[env_id]
+        assert s["_source"] == "pyelastica" and s["reset_obs"] == [obs_dim] and s["obs"] == [2, obs_dim]
+        assert s["actions"] == [2, adim] and s["sub100_x"] == [3, n + 1] and s["step1_Q"] == [3, 3, n]
+        assert s["_time"][0] == pytest.approx(step_time, rel=1e-9)
+    o = d["OctoFlat-v0"]
+    assert o["obs"] == [2, 461] and o["sub100_x"] == [8, 3, 11] and o["step1_w"] == [8, 3, 10]
+    assert o["step1_head_x"] == [3] and o["step1_head_Q"] == [3, 3] and o["actions"] == [2, 24]
+    assert o["_time"][0] == pytest.approx(2857 * 7e-5, rel=1e-9)

@@ -235,19 +235,40 @@ class PyElasticaDriver:
     `shearable_rods` + `rigid_rod` (flat_env.py:179-218)."""
 
     kind = "pyelastica"
+    # gym_softrobot/__init__.py:6-9,27-30,74-80: the entry points of the four ids (no kwargs)
+    ENTRY = {"SoftPendulum-v0": ("gym_softrobot.envs.soft_pendulum.soft_pendulum", "SoftPendulumEnv"),
+             "SoftPendulum3D-v0": ("gym_softrobot.envs.soft_pendulum_3d.soft_pendulum_3d", "SoftPendulum3DEnv"),
+             "OctoArmSingle-v0": ("gym_softrobot.envs.octopus.arm_single_env", "ArmSingleEnv"),
+             "OctoFlat-v0": ("gym_softrobot.envs.octopus.flat_env", "FlatEnv")}
 
     def __init__(self, env_id: str, reference: str = "/root/reference"):
         if reference not in sys.path:
             sys.path.insert(0, reference)
         import elastica  # noqa: F401  (fails here -> this driver cannot be used in this container)
-        import gymnasium as gym
-
-        import gym_softrobot  # noqa: F401  (registers the env ids, gym_softrobot/__init__.py)
 
         self.env_id = env_id
-        self.env = gym.make(env_id).unwrapped
+        self.env = self._make(env_id)
         self.octo = env_id == "OctoFlat-v0"
         self.adim = int(np.prod(self.env.action_space.shape))
+
+    def _make(self, env_id):
+        """`gym.make(id).unwrapped` as a user of the reference gets it; where gymnasium's registry is not
+        available (tests/test_pyelastica_fixtures.py runs this driver over tools/refshim.py's stand-ins)
+        the registered entry point itself — the same class, gymnasium's wrappers do not touch the physics."""
+        import importlib
+
+        try:
+            import gymnasium as gym
+
+            import gym_softrobot  # noqa: F401  (registers the env ids, gym_softrobot/__init__.py)
+
+            return gym.make(env_id).unwrapped
+        except (AttributeError, ImportError):
+            module, cls = self.ENTRY[env_id]
+            return getattr(importlib.import_module(module), cls)()
+
+    def _post_reset(self) -> None:
+        pass
 
     def _obs(self, obs):
         if isinstance(obs, dict):                       # FlatEnv: {"individual": (n_arm, w), "shared": (13,)}
@@ -257,6 +278,7 @@ class PyElasticaDriver:
 
     def reset(self, seed: int):
         obs, _ = self.env.reset(seed=int(seed))
+        self._post_reset()
         return self._obs(obs)
 
     def step(self, action):
