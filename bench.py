@@ -862,7 +862,7 @@ def main(argv=None, script=None) -> int:
         scratch = None
     if rank == 0 and world == 1 and not distributed:
         if (args.env == "SoftPendulum-v0" and hip and not args.no_secondary and args.n_elems is None
-                and args.envs_per_gpu is None and args.math_mode == "fast"):
+                and args.envs_per_gpu in (None, ENVS_PER_GPU) and args.math_mode == "fast"):
             line["secondary"] = [secondary_workload(gsa, _capi, torch, local_rank, math_mode, lib_hash, **spec)
                                  for spec in SECONDARY]
             line["pcie_inclusive"] = pcie_inclusive(gsa, torch, local_rank, math_mode, n_local)

@@ -61,6 +61,16 @@ def test_bench_two_ranks_softpendulum(hip_lib):
     _check_pair(two, one, 4096, 12)
     assert two["windows"]["count"] == one["windows"]["count"] == 5
     assert one["roofline"]["frac"] is None or 0.2 < one["roofline"]["frac"] < 1.0
+    # what every rank measured, and the second measurement over transport p2p (each rank's child process)
+    ranks = two["per_rank"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(0 < r["efficiency_vs_n1_kernel"] <= 1.0 for r in ranks)
+    t = two["p2p_trial"]
+    assert t["returncode"] == 0 and t["transport"] == "p2p" and t["exchange_memory"] in ("uncached", "fine-grained"), t
+    assert t["last_step_checksum"] == two["config"]["last_step_checksum"] and t["value"] > 0
+    assert "secondary" not in two and "secondary" in one and len(one["secondary"]) == 2
+    for sec in one["secondary"]:
+        assert sec["value"] > 0 and sec["non_finite_envs_at_end"] == 0 and sec["kernel_ms_avg"] > 0
+    assert one["pcie_inclusive"]["value"] > 0 and one["pcie_inclusive"]["ms_per_step"] > one["roofline"]["kernel_ms_avg"]
 
 
 def test_bench_two_ranks_strong_scaling(hip_lib):
@@ -68,7 +78,7 @@ def test_bench_two_ranks_strong_scaling(hip_lib):
     --envs-per-gpu envs over the ranks (2 x 1024 here) and must return what one rank returns for
     the same 2048 envs."""
     a = ("--steps", "10", "--warmup", "2", "--envs-per-gpu", "2048", "--preheat", "30")
-    two = _bench(TWO_ON_ONE, "--gpus", "2", "--scaling", "strong", *a)
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--scaling", "strong", "--no-p2p-trial", *a)
     one = _bench({}, "--gpus", "1", *a)
     assert two["scaling"] == "strong" and two["n_gpus"] == 2 and two["config"]["envs_total"] == 2048
     assert two["config"]["last_step_checksum"] == one["config"]["last_step_checksum"]
@@ -78,7 +88,7 @@ def test_bench_two_ranks_strong_scaling(hip_lib):
 def test_bench_two_ranks_octoflat(hip_lib):
     """configs[4]'s shape at world 2: 2 x 512 OctoFlat envs (8 arms + head each) against 1 x 1024."""
     a = ("--env", "OctoFlat-v0", "--steps", "3", "--warmup", "1", "--windows", "1", "--preheat", "40")
-    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "512", *a)
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "512", "--no-p2p-trial", *a)
     one = _bench({}, "--gpus", "1", "--envs-per-gpu", "1024", *a)
     _check_pair(two, one, 1024, 3)
 
@@ -87,7 +97,7 @@ def test_bench_two_ranks_device_autoreset_across_the_shard_boundary(hip_lib):
     """140 steps: every env is truncated on step 126 and restarts on 127 from its staged record, on
     both ranks; the restarted envs' rows are gathered like any other."""
     a = ("--steps", "140", "--warmup", "2", "--autoreset", "device", "--preheat", "20")
-    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "1024", *a)
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "1024", "--no-p2p-trial", *a)
     one = _bench({}, "--gpus", "1", "--envs-per-gpu", "2048", *a)
     _check_pair(two, one, 2048, 140)
     assert two["config"]["autoreset"] == "device"
