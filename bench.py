@@ -170,10 +170,12 @@ def cpu_baseline(cfg, cores: int, n_rods: int = ENVS_PER_GPU, budget_s: float = 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 20 + 100 env.steps stay inside one SoftPendulum episode (truncation fires on step
-    # 126), and the warm-up covers the ~20 launches the GPU clock takes to settle after the reset
-    # (profiles/README.md r1f: 0.38 ms per launch at first, 0.34 ms from then on)
-    ap.add_argument("--steps", type=int, default=100)
+    # defaults: 20 warm-up + 5 windows of 20 env.steps stay inside one SoftPendulum episode (truncation
+    # fires on step 126).  Five windows, not one of 100 steps: `value` is the median window, so ONE host
+    # hiccup (r4b: a 1.5 ms env.step() call idled the GPU, the clock dropped, the next 20 launches ran
+    # 3-10 % slow and a single 100-step window read 12.9 M where the five-window runs read 13.97 M)
+    # cannot set the figure
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=None,
                     help=f"default {ENVS_PER_GPU}; OctoFlat-v0: 1024 (BASELINE configs[4]: 8192 envs on 8 GPUs)")
