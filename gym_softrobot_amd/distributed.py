@@ -241,21 +241,25 @@ class ShardedVecEnv:
         dev = be.device
         for j in range(self.SELF_TEST_ROUNDS if ok else 0):
             good = True
-            try:
-                k = j % depth
-                probe = torch.full((per, w), float(1000 * j + self.rank + 1), device=dev)
-                be.scatter_rows(probe, ex["peer_ptrs"][k], self.lo, rows_words + self.rank, 0x5E1F0000 + j)
-                torch.cuda.current_stream(dev).synchronize()
-                dist.barrier(group=self.group)
-                rows = ex["tensors"][k][:rows_words].view(self.total_envs, w)
-                expect = (1000.0 * j + torch.arange(1, self.world + 1, device=dev, dtype=torch.float32)
-                          ).repeat_interleave(per)
-                tags = ex["tensors"][k][rows_words:rows_words + self.world].view(torch.int32)
-                good = bool((rows == expect[:, None]).all().item()) and bool((tags == 0x5E1F0000 + j).all().item())
-                if not good:
-                    err = f"self-test round {j}: a peer's rows or generation word did not arrive"
+            k = j % depth
+            try:                               # local work only inside the try blocks: the barrier and the
+                probe = torch.full((per, w), float(1000 * j + self.rank + 1), device=dev)      # agreement below
+                be.scatter_rows(probe, ex["peer_ptrs"][k], self.lo, rows_words + self.rank, 0x5E1F0000 + j)       # are reached
+                torch.cuda.current_stream(dev).synchronize()                                                     # by every rank
             except Exception as exc:  # noqa: BLE001
                 good, err = False, f"self-test round {j}: {exc!r}"
+            dist.barrier(group=self.group)     # everybody's stores of this round have been issued and waited for
+            if good:
+                try:
+                    rows = ex["tensors"][k][:rows_words].view(self.total_envs, w)
+                    expect = (1000.0 * j + torch.arange(1, self.world + 1, device=dev, dtype=torch.float32)
+                              ).repeat_interleave(per)
+                    tags = ex["tensors"][k][rows_words:rows_words + self.world].view(torch.int32)
+                    good = bool((rows == expect[:, None]).all().item()) and bool((tags == 0x5E1F0000 + j).all().item())
+                    if not good:
+                        err = f"self-test round {j}: a peer's rows or generation word did not arrive"
+                except Exception as exc:  # noqa: BLE001
+                    good, err = False, f"self-test round {j}: {exc!r}"
             ok = self._agree(good)
             if not ok:
                 break

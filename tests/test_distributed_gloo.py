@@ -328,3 +328,92 @@ def test_world8_gloo_masked_reset_across_shard_boundaries(oracle_built):
             np.testing.assert_array_equal(a, b)
     # the masked envs really restarted (fresh draws: their reset observation differs from the seeded one)
     assert not np.array_equal(got[4][[1, 5, 15]], got[0][[1, 5, 15]])
+
+
+def _p2p_failure_worker(rank, world, port, total, mode, q):
+    """transport="p2p" set-up with a backend double whose exchange calls fail at a chosen point on
+    a chosen rank: every rank must come out with the collective, nobody may hang."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes
+
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.distributed import ShardedVecEnv, shard_bounds
+    from tests.oracle_backend import OracleBackend
+
+    class Double(OracleBackend):
+        device_index = 0
+        freed, closed = 0, 0
+
+        def exchange_alloc(self, n_words):
+            if mode == "alloc_fails_on_rank_1" and rank == 1:
+                raise RuntimeError("no uncached memory here")
+            t = torch.zeros(n_words)
+            self._keep = getattr(self, "_keep", []) + [t]
+            return t, t.data_ptr(), bytes(64), "uncached"
+
+        def exchange_open(self, handle, owner_device):
+            if mode == "open_fails_on_rank_0" and rank == 0:
+                raise RuntimeError("peer access refused")
+            return 0xDEAD0000 + owner_device
+
+        def exchange_close(self, ptr):
+            Double.closed += 1
+
+        def exchange_free(self, ptr):
+            Double.freed += 1
+
+        def scatter_rows(self, packed, peer_ptrs, first_row, tag_word=-1, tag=0):
+            # a transport that only ever reaches this rank's own buffer: the self-test must notice
+            mine = [t for t in self._keep if t.data_ptr() in peer_ptrs][0]
+            w = packed.shape[1]
+            mine[first_row * w:(first_row + packed.shape[0]) * w] = packed.reshape(-1)
+            if tag_word >= 0:
+                mine[tag_word:tag_word + 1].view(torch.int32)[0] = ctypes.c_int32(tag).value
+
+    lo, hi = shard_bounds(total, world, rank)
+    cfg = _capi.softpendulum_config(hi - lo, n_elems=8)
+    cfg.n_substeps = 5
+    local = gsa.VecSoftPendulumEnv(hi - lo, n_elems=8, backend=Double(cfg))
+    local.cfg.n_substeps = 5
+    env = ShardedVecEnv(local, total, overlap=True, transport="p2p")
+    assert env.transport == "rccl" and env._p2p_error, (rank, env.transport)
+    obs0, _ = env.reset(seed=3)
+    o, r, te, tr, _ = env.step(np.linspace(-5, 5, total).astype(np.float32))
+    env.sync()
+    q.put((rank, env._p2p_error, Double.freed, Double.closed, o.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,who_says", [("alloc_fails_on_rank_1", "exchange_alloc"),
+                                           ("open_fails_on_rank_0", "exchange_open"),
+                                           ("self_test_fails", "self-test round 0")])
+def test_p2p_setup_failures_leave_every_rank_on_the_collective(oracle_built, mode, who_says):
+    """an asymmetric failure in the p2p set-up must not leave the other ranks blocked in a
+    collective.  A failing allocation on one rank, a failing mapping on another, and a transport whose
+    stores never reach the peers (the self-test's job): all ranks fall back together, release what
+    they had allocated or mapped, and the run is the ordinary one."""
+    total, world = 6, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2p_failure_worker, args=(r, world, port, total, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    errs = [g[1] for g in got]
+    assert any(who_says in e for e in errs), errs         # the rank it happened on names it; the others know a peer failed
+    for rank, err, freed, closed, obs in got:
+        allocated = 0 if (mode == "alloc_fails_on_rank_1" and rank == 1) else 2
+        assert freed == allocated, (mode, rank, freed)
+        if mode == "self_test_fails":
+            assert closed == 2 * (world - 1)               # every peer mapping of both buffers was unmapped again
+    for g in got[1:]:
+        np.testing.assert_array_equal(g[4], got[0][4])     # and the gathered rows are the same everywhere
