@@ -313,3 +313,51 @@ def test_bend_twist_coupling_known_answer_on_a_helix(oracle_built):
     for w in (c_rod.get("w"), n_rod.w):
         np.testing.assert_allclose(w[1, 1:-1], want, rtol=1e-7)
         assert np.abs(w[0, 1:-1]).max() < 1e-7 * abs(want) and np.abs(w[2, 1:-1]).max() < 1e-7 * abs(want)
+
+
+def _flat_arm(gx=0.0, gy=0.0, **kw):
+    """A straight, unactuated arm lying on the plane under gravity (gx, gy, -9.81): a body force along
+    the axis (gx) or across it (gy).  No damper, so that the textbook accelerations are exact."""
+    cfg = _arm_cfg(damping_constant=0.0, **kw)
+    cfg.gravity[0], cfg.gravity[1] = gx, gy
+    return cfg
+
+
+def _both(cfg, n_sub):
+    c_rod, n_rod = _pair(cfg)
+    c_rod.substeps(0.0, n_sub)
+    for _ in range(n_sub):
+        n_rod.substep()
+    return {"v": c_rod.get("v"), "w": c_rod.get("w"), "x": c_rod.get("x")}, {"v": n_rod.v, "w": n_rod.w, "x": n_rod.x}
+
+
+def test_static_axial_friction_holds_a_push_below_mu_s_n(oracle_built):
+    """Static friction, axial branch: a rod at rest pushed along its axis with F = m gx feels
+    -min(|F|, mu_s N) sign(F): below mu_s_forward g = 1.75 m/s^2 (mu_s = 2 mu_k, build.py:262-268) the
+    friction cancels the push EXACTLY and nothing moves, forward and backward (mu_s_backward = 2.62);
+    above it the rod breaks away and then slides against the KINETIC coefficient."""
+    mu = 0.35 / (2.0 * 2.0 * 9.81 * 0.1)
+    for gx in (1.0, -1.0, -2.0):                      # -2.0 is below the backward threshold 3 mu g = 2.62 only
+        for got in _both(_flat_arm(gx=gx), 300):
+            assert np.abs(got["v"][0]).max() < 1e-12 and np.abs(got["x"][0] - np.linspace(0, 0.35, 21)).max() < 1e-12
+    t = 300 * 7e-5
+    for got in _both(_flat_arm(gx=3.0), 300):         # 3.0 > 2 mu g = 1.75: breaks away, then kinetic friction mu g
+        v = got["v"][0].mean()
+        assert v == pytest.approx((3.0 - mu * 9.81) * t, rel=2e-3)
+
+
+def test_static_rolling_friction_rolls_without_slipping(oracle_built):
+    """Static friction, rolling branch: a rod at rest pushed ACROSS its axis with F = m gy (below the
+    sideways threshold) is held by the no-slip force -(r F - 2 T) / 3r = -F / 3: it accelerates at
+    2 F / 3 m — a solid cylinder rolling without slipping, I = m r^2 / 2 — and spins at v / r, with
+    the contact point at rest to rounding.  Both transcriptions."""
+    gy, n_sub = 0.5, 500
+    t = n_sub * 7e-5
+    for got in _both(_flat_arm(gy=gy), n_sub):
+        vy = got["v"][1]
+        assert vy.min() == pytest.approx(2.0 / 3.0 * gy * t, rel=1e-6) and vy.max() == pytest.approx(vy.min(), rel=1e-9)
+        assert np.abs(got["v"][0]).max() < 1e-12
+        r = 0.35 * 0.02
+        spin = got["w"][2]                             # about the axis (d3 = +x): rolling towards +y turns about -x
+        np.testing.assert_allclose(spin * r, -vy[:-1], rtol=1e-6)
+        assert np.abs(vy[:-1] + spin * r).max() < 1e-9 * abs(vy).max()      # the contact point does not slip
