@@ -193,3 +193,31 @@ def test_tapered_arm_single_env_matches_oracle(torch_gpu, hip_lib, oracle_built)
                                        err_msg=f"{name} env {i}")
     env.close()
     ref.close()
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+def test_known_answer_rolling_without_slipping_on_the_gpu(torch_gpu, hip_lib, math_mode):
+    """The static rolling-friction branch as a physics known answer on the HIP kernels themselves (no
+    oracle involved): an unactuated arm on the plane pushed across its axis by a body force m gy rolls
+    without slipping at 2 gy / 3 and spins at v / r; pushed along its axis below mu_s g it stays put."""
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.backend import HipRodBackend
+
+    n_sub, dt, r = 500, 7e-5, 0.35 * 0.02
+    for gx, gy in ((0.0, 0.5), (1.0, 0.0)):
+        cfg = _capi.arm_single_config(3, n_elems=20, math_mode=math_mode)
+        cfg.damping_constant = 0.0
+        cfg.gravity[0], cfg.gravity[1] = gx, gy
+        be = HipRodBackend(cfg, 0)
+        be.reset_straight(np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0]))
+        be.substeps(None, n_sub)
+        torch_gpu.cuda.synchronize()
+        st = be.state_numpy()
+        for e in range(3):
+            if gy:
+                vy = st["v"][e, 1]
+                np.testing.assert_allclose(vy, 2.0 / 3.0 * gy * n_sub * dt, rtol=1e-6)
+                np.testing.assert_allclose(st["w"][e, 2] * r, -vy[:-1], rtol=1e-6)
+            else:
+                assert np.abs(st["v"][e, 0]).max() < 1e-12
+        be.close()
