@@ -62,6 +62,14 @@ def test_create_rejects_bad_config_and_never_falls_back(hip_lib):
     assert hip_lib.softrod_create(C.byref(cfg), 0, C.byref(h)) == -1
     assert b"SOFTROD_MATH_FAST" in hip_lib.softrod_last_error(None)
     assert not h.value
+    # the fast kernels linearise theta / sin(theta + eps_sin) in eps_sin; a config where that
+    # does not hold (acos_shift = 0: a straight joint would flip the sign of the bending stiffness) is
+    # refused in fast mode — before any device is looked for — and left to the libm kernel
+    for field, value in (("acos_shift", 0.0), ("eps_sin", 1e-6), ("eps_sin", -1e-14)):
+        cfg = _capi.softpendulum_config(4)
+        setattr(cfg, field, value)
+        assert hip_lib.softrod_create(C.byref(cfg), 0, C.byref(h)) == -1, (field, value)
+        assert b"eps_sin" in hip_lib.softrod_last_error(None) and not h.value
 
 
 def test_backend_refuses_to_run_without_gpu():

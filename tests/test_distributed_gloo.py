@@ -417,3 +417,20 @@ def test_p2p_setup_failures_leave_every_rank_on_the_collective(oracle_built, mod
             assert closed == 2 * (world - 1)               # every peer mapping of both buffers was unmapped again
     for g in got[1:]:
         np.testing.assert_array_equal(g[4], got[0][4])     # and the gathered rows are the same everywhere
+
+
+def test_p2p_without_overlap_warns_and_uses_the_collective(oracle_built):
+    """transport="p2p" needs overlap=True and a process group; asked for without them it says so
+    (a RuntimeWarning, `_p2p_error`) instead of silently running the collective."""
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.distributed import ShardedVecEnv
+    from tests.oracle_backend import OracleBackend
+
+    cfg = _capi.softpendulum_config(2, n_elems=8)
+    local = gsa.VecSoftPendulumEnv(2, n_elems=8, backend=OracleBackend(cfg))
+    with pytest.warns(RuntimeWarning, match="overlap=True"):
+        env = ShardedVecEnv(local, 2, transport="p2p")
+    assert env.transport == "rccl" and "overlap=True" in env._p2p_error
+    with pytest.raises(ValueError):
+        ShardedVecEnv(local, 2, transport="carrier pigeon")
