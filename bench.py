@@ -49,7 +49,8 @@ oracle/softrod_oracle.c) timed on this box's host cores with OpenMP over rods, r
 N=1 only, on a bounded sample of the same workload: the SAME 4096 rods (SURVEY §8(d) /
 BASELINE.md §3), as many env.steps as fit ~10 s (at least 2), plus one rod on one thread for
 1 s.  `cores` = the CPUs the process may really use (cgroup quota, else affinity), which is
-also the OpenMP thread count.
+also the OpenMP thread count.  `cpu_baseline.parity_vs_oracle`: max |d obs| / |obs| of
+the HIP path against that oracle after 1 / 3 / 100 env.steps on the first 16 envs of the batch.
 
 secondary (N=1, default): after the headline windows the same process measures BASELINE
 configs[2] (OctoArmSingle-v0, 100 elements x 4096 envs) and configs[4]'s per-GPU share
@@ -165,6 +166,49 @@ def cpu_baseline(cfg, cores: int, n_rods: int = ENVS_PER_GPU, budget_s: float = 
         "measured_parallel_speedup": value / single,
         "affinity_cpus": len(os.sched_getaffinity(0)),
     }
+
+
+def parity_vs_oracle(gsa, torch, device, math_mode, cfg, n_envs: int = 16, steps=(1, 3, 100)):
+    """BASELINE.md §3's last item: max |d obs| / |obs| of the HIP path against the CPU oracle after 1 / 3 /
+    100 env.steps, on the first `n_envs` envs of the benchmark's batch (same seeds i -> theta0_i, same
+    action script; an env's trajectory does not depend on the batch it is stepped in — bitwise,
+    tests/test_gpu_parity.py).  The oracle is the CHECKER here, as in smoke()."""
+    import numpy as np
+
+    from gym_softrobot_amd.seeding import initial_angle, np_random
+    from oracle import oracle_c
+
+    T = max(steps)
+    acts = np.random.default_rng(1).uniform(-22, 22, (T, ENVS_PER_GPU, 1)).astype(np.float32)[:, :n_envs, 0]
+    env = gsa.make_vec("SoftPendulum-v0", n_envs, device=device, math_mode=math_mode)
+    env.reset(seed=0)
+    rods = []
+    for i in range(n_envs):
+        c1 = cfg.copy()
+        c1.n_envs = 1
+        r = oracle_c.OracleRod(c1)
+        r.reset_pendulum(initial_angle(np_random(i)[0]))
+        rods.append(r)
+    out = {"envs": n_envs, "steps": list(steps), "max_rel_obs": [], "max_rel_reward": [], "flags_equal": True,
+           "tolerance": 1e-5,
+           "definition": "max over envs and entries of |hip - oracle| / max(|oracle|, 1e-3); oracle = this repo's "
+                         "fp64 restatement of PyElastica (parity against PyElastica itself is unpinned)"}
+    for t in range(T):
+        o, r, te, tr, _ = env.step(torch.from_numpy(acts[t].copy()).to(env.backend.device))
+        ref = [rod.env_step(acts[t, i]) for i, rod in enumerate(rods)]
+        if (t + 1) in steps:
+            torch.cuda.synchronize()
+            ho, hr = o.cpu().numpy().astype(np.float64), r.cpu().numpy()
+            ro = np.stack([x[0] for x in ref]).astype(np.float64)
+            rr = np.array([x[1] for x in ref])
+            out["max_rel_obs"].append(float((np.abs(ho - ro) / np.maximum(np.abs(ro), 1e-3)).max()))
+            out["max_rel_reward"].append(float((np.abs(hr - rr) / np.maximum(np.abs(rr), 1e-3)).max()))
+            out["flags_equal"] = out["flags_equal"] and bool(
+                (te.cpu().numpy().astype(bool) == np.array([x[2] for x in ref])).all()
+                and (tr.cpu().numpy().astype(bool) == np.array([x[3] for x in ref])).all())
+    out["within_tolerance"] = bool(max(out["max_rel_obs"] + out["max_rel_reward"]) <= out["tolerance"] and out["flags_equal"])
+    env.close()
+    return out
 
 
 def parse_args(argv=None):
@@ -870,6 +914,7 @@ def main(argv=None, script=None) -> int:
             line["pcie_inclusive"] = pcie_inclusive(gsa, torch, local_rank, math_mode, n_local)
         if not args.no_cpu_baseline and args.env == "SoftPendulum-v0" and hip:
             line["cpu_baseline"] = cpu_baseline(cfg, usable_cpus(), n_rods=ENVS_PER_GPU)
+            line["cpu_baseline"]["parity_vs_oracle"] = parity_vs_oracle(gsa, torch, local_rank, math_mode, cfg)
         else:
             line["cpu_baseline"] = None
     elif rank == 0:

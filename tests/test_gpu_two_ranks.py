@@ -214,3 +214,28 @@ print("P2P-GEN-OK")
 """ % (str(ROOT), str(_free_port()))], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0 and "P2P-GEN-OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_driver_line_carries_cpu_baseline_and_parity_vs_oracle(hip_lib):
+    """`python bench.py --steps 20 --warmup 5` as the driver runs it at N = 1: one JSON line with the
+    contract's keys, `roofline`, `secondary`, `pcie_inclusive`, and `cpu_baseline` on the 4096 rods
+    with BASELINE.md §3's parity figures (HIP vs the oracle after 1 / 3 / 100 env.steps) inside 1e-5."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "20", "--warmup", "5"], env=env,
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    (line,) = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert line["metric"] == "env_steps_per_sec" and line["n_gpus"] == 1 and line["dtype"] == "f64"
+    assert line["methodology_version"] == 4 and line["windows"]["count"] == 5
+    assert line["value"] == sorted(line["windows"]["value"])[2] and line["single_window"]["value"] == line["windows"]["value"][0]
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "4096 rods" in cb["sample"]
+    pv = cb["parity_vs_oracle"]
+    assert pv["steps"] == [1, 3, 100] and pv["within_tolerance"] and pv["flags_equal"], pv
+    assert max(pv["max_rel_obs"]) <= 1e-5 and max(pv["max_rel_reward"]) <= 1e-5
+    r = line["roofline"]
+    assert r["bound"] == "fp64_valu" and (r["frac"] is None or 0.5 < r["frac"] < 1.05)
+    assert r["frac"] is None or (r["frac_cycle_weighted"] is not None and 0.5 < r["frac_cycle_weighted"] <= 1.0)
+    assert [s["baseline_config"][:10] for s in line["secondary"]] == ["configs[2]", "configs[4]"]
