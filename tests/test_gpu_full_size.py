@@ -106,3 +106,39 @@ def test_config5_share_1024_octoflat_envs(torch_gpu, hip_lib, oracle_built):
         np.testing.assert_allclose(obs[i], flat, rtol=RTOL, atol=2e-6)
         np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-6)
         assert bool(term[i]) == te and bool(trunc[i]) == tr
+
+
+def test_config4_total_batch_32768_softpendulum_envs_on_one_gpu(torch_gpu, hip_lib, oracle_built):
+    """BASELINE configs[3]'s TOTAL batch (8 x 4096 envs) resident on one GPU (453 MB of state): the
+    envs the eight shards would own are the same envs — env i seeded i whatever batch it sits in —
+    so the first and last envs of every shard must equal, bit for bit, a small batch holding just
+    them; spot parity against the oracle at both ends; finite everywhere."""
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd.seeding import initial_angle, np_random
+
+    n, T = 32768, 3
+    acts = np.random.default_rng(1).uniform(-22, 22, (T, n, 1)).astype(np.float32)
+    env = gsa.make_vec("SoftPendulum-v0", n)
+    obs0, _ = env.reset(seed=0)
+    full = []
+    for t in range(T):
+        o, r, te, tr, _ = env.step(acts[t])
+        full.append((o.cpu().numpy().copy(), r.cpu().numpy().copy()))
+    assert np.isfinite(full[-1][0]).all() and np.isfinite(full[-1][1]).all()
+    env.close()
+    spots = np.array([s * 4096 + k for s in range(8) for k in (0, 4095)])      # both ends of every shard
+    for i in spots[[0, 7, 15]]:                                                   # each spot: its own env, seeded i
+        small = gsa.make_vec("SoftPendulum-v0", 1)
+        small.reset(seed=int(i))
+        for t in range(T):
+            o, r, _, _, _ = small.step(acts[t, i:i + 1])
+            np.testing.assert_array_equal(o.cpu().numpy()[0], full[t][0][i])
+            assert float(r.cpu().numpy()[0]) == full[t][1][i]
+        small.close()
+    for i in (0, n - 1):
+        rod = oracle_built.OracleRod(gsa._capi.softpendulum_config(1))
+        rod.reset_pendulum(initial_angle(np_random(int(i))[0]))
+        for t in range(T):
+            o, r, te, tr = rod.env_step(acts[t, i, 0])
+        np.testing.assert_allclose(full[-1][0][i], o, rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(full[-1][1][i], r, rtol=RTOL, atol=1e-9)
