@@ -1,0 +1,61 @@
+"""An INDEPENDENT known answer for the rod's internal force / torque balance in the geometrically
+nonlinear regime (TEST INFRASTRUCTURE): the static equilibrium of the discrete Cosserat rod of
+Gazzola et al. 2018 — n straight elements with rest length l, bending hinges at the n - 1 interior
+nodes, shear and stretch strains sigma = e Q t - z, stress n = S sigma, lab-frame force Q^T n / e,
+couples B kappa / eps^3 — clamped at its first element and loaded by a dead tip force F, solved
+DIRECTLY as a small nonlinear system (scipy fsolve) instead of by time stepping:
+
+    in-plane, element j at director angle t_j (t_0 = 0), local force components (F sin t_j, F cos t_j):
+      sigma_3 = e F sin t / EA,  sigma_1 = e F cos t / (alpha_c G A),  e = |(1 + sigma_3, sigma_1)|
+      edge_j  = l [(1 + sigma_3) d3 + sigma_1 d1']                        (d3 = (cos t, sin t), d1' = (-sin t, cos t))
+      hinge k: EI (t_k - t_{k-1}) / (l eps_k^3) = F (x_tip - x_k),         eps_k = (e_k + e_{k-1}) / 2
+
+No time integrator, no damper, no rotation update is involved, so agreement with a stepper's
+settled or fixed-point state checks its sigma, S, Q^T n / e, kappa = -log(Q+ Q^T) / D (the
+theta / sin theta factor at finite joint angles), the eps^3 on the couple and the shear couple's
+lever arm at once.  The C oracle settles onto this solution to 1e-11 of the tip position."""
+import numpy as np
+from scipy.optimize import fsolve
+
+
+def solve(n, F, EI, GA, EA, L=1.0):
+    """-> (theta[n], nodes x[2, n+1]) of the clamped rod under the tip force (0, F)."""
+    l = L / n
+
+    def edges(t):
+        e = np.ones_like(t)
+        for _ in range(8):                      # sigma = e Q F / S with e = |sigma + z|: a contraction (e - 1 ~ 1e-4)
+            s3 = e * F * np.sin(t) / EA
+            s1 = e * F * np.cos(t) / GA
+            e = np.sqrt((1 + s3) ** 2 + s1 ** 2)
+        ex = l * ((1 + s3) * np.cos(t) - s1 * np.sin(t))
+        ey = l * ((1 + s3) * np.sin(t) + s1 * np.cos(t))
+        return ex, ey, e
+
+    def residual(th):
+        t = np.concatenate([[0.0], th])
+        ex, _, e = edges(t)
+        arm = np.cumsum(ex[::-1])[::-1]         # x_tip - x_k for k = 0 .. n-1
+        eps = 0.5 * (e[1:] + e[:-1])
+        return EI * (t[1:] - t[:-1]) / l / eps ** 3 - F * arm[1:]
+
+    th = fsolve(residual, np.linspace(0.02, 0.9, n - 1), xtol=1e-14, full_output=False)
+    assert np.abs(residual(th)).max() < 1e-10 * max(F, 1e-30)
+    t = np.concatenate([[0.0], th])
+    ex, ey, _ = edges(t)
+    x = np.zeros((2, n + 1))
+    x[0, 1:], x[1, 1:] = np.cumsum(ex), np.cumsum(ey)
+    return t, x
+
+
+def state(n, F, EI, GA, EA, L=1.0):
+    """The equilibrium as a rod state in the frame of reset_straight(direction +x, normal +z):
+    x (3, n+1), Q (3, 3, n) with rows d1 = z, d2 = d3 x d1, d3 = (cos t, sin t, 0)."""
+    t, x2 = solve(n, F, EI, GA, EA, L)
+    x = np.zeros((3, n + 1))
+    x[:2] = x2
+    Q = np.zeros((3, 3, n))
+    Q[0, 2, :] = 1.0
+    Q[1, 0, :], Q[1, 1, :] = np.sin(t), -np.cos(t)
+    Q[2, 0, :], Q[2, 1, :] = np.cos(t), np.sin(t)
+    return t, x, Q

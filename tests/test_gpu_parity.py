@@ -1292,3 +1292,40 @@ def test_contact_kernels_ignore_non_finite_padding(torch_gpu, hip_lib):
             assert bool(torch_gpu.isfinite(a[0]).all())
         clean.close()
         dirty.close()
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+@pytest.mark.parametrize("alpha", [1.0, 10.0])
+def test_known_answer_discrete_elastica_is_a_fixed_point_on_the_gpu(torch_gpu, hip_lib, math_mode, alpha):
+    """K16b on the HIP kernels themselves (no oracle involved): a rod placed in the directly solved
+    large-deflection equilibrium of the discrete Cosserat rod (tests/elastica_chain.py; tip angles of
+    26 and 82 degrees) stays there — after one substep without a damper its rates are 1e-9 of what
+    the tip force alone would cause.  Checks sigma, S, Q^T n / e, kappa = -log(Q+ Q^T) / D at finite
+    joint angles, the eps^3 on the couple and the shear couple's lever arm against an INDEPENDENT
+    solution; and a settled run ends on it."""
+    from gym_softrobot_amd import _capi
+    from tests.elastica_chain import state
+
+    n, E, r = 12, 1e7, 0.02
+    A = np.pi * r * r
+    I = A * A / (4 * np.pi)
+    G, F = E / 3.0, alpha * E * I
+    cfg = _capi.softpendulum_config(3, n_elems=n, math_mode=math_mode)
+    cfg.env_kind = _capi.ENV_NONE
+    cfg.features = _capi.FEAT_FIXED_BC | _capi.FEAT_TIP_FORCE
+    cfg.base_radius, cfg.youngs_modulus, cfg.shear_modulus, cfg.damping_constant = r, E, G, 0.0
+    cfg.tip_force[1] = F
+    be = _backend(cfg)
+    be.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    _, x, Q = state(n, F, E * I, 27.0 / 28.0 * G * A, E * A)
+    _inject(be, "position", x)
+    _inject(be, "director", Q.reshape(9, n))
+    be.substeps(None, 1)
+    torch_gpu.cuda.synchronize()
+    st = be.state_numpy()
+    m_node = cfg.density * A * (1.0 / n)
+    J1 = I * cfg.density * (1.0 / n)
+    assert np.abs(st["v"]).max() < 1e-9 * cfg.dt * F / m_node
+    assert np.abs(st["w"]).max() < 1e-9 * cfg.dt * F * (1.0 / n) / J1
+    np.testing.assert_allclose(st["x"][0, :, 1:], x[:, 1:], rtol=1e-12, atol=1e-15)
+    be.close()

@@ -442,3 +442,66 @@ def test_k15_axial_wave_first_mode(oracle_built):
     period = _period_from_zero_crossings(np.array(t), np.array(y))
     assert 1.0 / period == pytest.approx(f1, rel=5e-4)
     assert np.abs(rod.get("v")[1:]).max() < 1e-12 and np.abs(rod.get("w")).max() < 1e-12    # pure stretch
+
+
+# ---- K16: large-deflection statics against an independent solution of the discrete equations ------
+
+def _elastica_case(n, alpha, damping=0.0):
+    """A slender clamped rod (r / L = 0.02) under the dead tip load F = alpha EI / L^2."""
+    E, r, L = 1e7, 0.02, 1.0
+    A = np.pi * r * r
+    I = A * A / (4 * np.pi)
+    G = E / 3.0
+    F = alpha * E * I / L ** 2
+    feats = _capi.FEAT_FIXED_BC | _capi.FEAT_TIP_FORCE | (_capi.FEAT_ANALYTICAL_DAMPER if damping else 0)
+    cfg = _free_cfg(n_elem=n, dt=1e-4, features=feats)
+    cfg.base_radius, cfg.youngs_modulus, cfg.shear_modulus, cfg.damping_constant = r, E, G, damping
+    cfg.tip_force[1] = F
+    return cfg, (n, F, E * I, 27.0 / 28.0 * G * A, E * A)
+
+
+def test_k16_large_deflection_cantilever_settles_on_the_discrete_elastica(oracle_built):
+    """Dynamic relaxation from the straight rod under F = 5 EI / L^2 and 10 EI / L^2 (tip angles of 70
+    and 82 degrees; the continuum elastica's tip deflection is 0.7138 L and 0.8106 L, Mattiasson 1981)
+    ends on the directly solved equilibrium of the discrete rod to 1e-9 of the tip position."""
+    from tests.elastica_chain import solve
+
+    for alpha in (5.0, 10.0):
+        cfg, args = _elastica_case(10, alpha, damping=1.0)
+        rod = oracle_built.OracleRod(cfg)
+        rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+        rod.substeps(0.0, 200000)
+        assert np.abs(rod.get("v")).max() < 1e-8
+        _, x = solve(*args)
+        got = rod.get("x")
+        np.testing.assert_allclose(got[:2, -1], x[:, -1], rtol=1e-9)
+        np.testing.assert_allclose(got[:2], x, atol=1e-9)
+        assert abs(got[2]).max() == 0.0
+        assert 0.6 < got[1, -1] < 0.82                   # (10 elements: 8 % short of the continuum, like K2's O(1/n))
+
+
+@pytest.mark.parametrize("alpha", [1.0, 10.0])
+def test_k16b_the_discrete_elastica_is_a_fixed_point_of_both_transcriptions(oracle_built, alpha):
+    """Put each transcription INTO the solved equilibrium (positions, directors; at rest): one substep
+    without a damper must leave it there — the accelerations it computes are 1e-9 of what the tip
+    force alone would cause.  C oracle and NumPy twin; the GPU kernels in tests/test_gpu_parity.py."""
+    from oracle.softrod_oracle_np import NumpyRod
+    from tests.elastica_chain import state
+
+    cfg, args = _elastica_case(12, alpha)
+    n, F = args[0], args[1]
+    _, x, Q = state(*args)
+    c_rod, n_rod = oracle_built.OracleRod(cfg), NumpyRod(cfg)
+    for rod in (c_rod, n_rod):
+        rod.reset_straight(np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0]))
+    c_rod.set("x", x)
+    c_rod.set("Q", Q)
+    n_rod.x, n_rod.Q = x.copy(), Q.copy()
+    c_rod.substeps(0.0, 1)
+    n_rod.substep()
+    m_node = c_rod.get("mass")[1]
+    J1 = c_rod.get("J")[0, 0]
+    v_scale = cfg.dt * F / m_node                         # what the unbalanced tip force would do in one substep
+    w_scale = cfg.dt * F * (1.0 / n) / J1
+    for v, w in ((c_rod.get("v"), c_rod.get("w")), (n_rod.v, n_rod.w)):
+        assert np.abs(v).max() < 1e-9 * v_scale and np.abs(w).max() < 1e-9 * w_scale
