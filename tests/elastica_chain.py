@@ -48,14 +48,23 @@ def solve(n, F, EI, GA, EA, L=1.0):
     return t, x
 
 
-def state(n, F, EI, GA, EA, L=1.0):
+def state(n, F, EI, GA, EA, L=1.0, phi=0.0):
     """The equilibrium as a rod state in the frame of reset_straight(direction +x, normal +z):
-    x (3, n+1), Q (3, 3, n) with rows d1 = z, d2 = d3 x d1, d3 = (cos t, sin t, 0)."""
+    x (3, n+1), Q (3, 3, n) with rows d1, d2 = d3 x d1, d3, for the tip force F (0, cos phi, sin phi).
+    phi = 0: bending in the x-y plane about d1 = z.  phi != 0: the same planar solution turned about
+    the rod's rest axis — the cross-section is circular, so it is an equilibrium too — with the frames
+    carried along WITHOUT twist from the clamped base frame (every element's frame is the base frame
+    turned about the fixed bending axis x cross f), so that the curvature has components on BOTH d1
+    and d2: the 3-D form of the same check."""
     t, x2 = solve(n, F, EI, GA, EA, L)
+    c, s = np.cos(phi), np.sin(phi)
     x = np.zeros((3, n + 1))
-    x[:2] = x2
+    x[0], x[1], x[2] = x2[0], c * x2[1], s * x2[1]
+    b = np.array([0.0, -s, c])                              # bending axis x_hat x f_hat
+    K = np.array([[0.0, -b[2], b[1]], [b[2], 0.0, -b[0]], [-b[1], b[0], 0.0]])
+    base = np.array([[0.0, 0.0, 1.0], [0.0, -1.0, 0.0], [1.0, 0.0, 0.0]])      # rows d1, d2, d3 of reset_straight
     Q = np.zeros((3, 3, n))
-    Q[0, 2, :] = 1.0
-    Q[1, 0, :], Q[1, 1, :] = np.sin(t), -np.cos(t)
-    Q[2, 0, :], Q[2, 1, :] = np.cos(t), np.sin(t)
+    for k in range(n):
+        R = np.eye(3) + np.sin(t[k]) * K + (1 - np.cos(t[k])) * (K @ K)      # rotation about b by t_k
+        Q[:, :, k] = base @ R.T                                                # each director (a row) turned
     return t, x, Q

@@ -1295,8 +1295,9 @@ def test_contact_kernels_ignore_non_finite_padding(torch_gpu, hip_lib):
 
 
 @pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+@pytest.mark.parametrize("phi", [0.0, 0.7], ids=["planar", "turned"])
 @pytest.mark.parametrize("alpha", [1.0, 10.0])
-def test_known_answer_discrete_elastica_is_a_fixed_point_on_the_gpu(torch_gpu, hip_lib, math_mode, alpha):
+def test_known_answer_discrete_elastica_is_a_fixed_point_on_the_gpu(torch_gpu, hip_lib, math_mode, alpha, phi):
     """K16b on the HIP kernels themselves (no oracle involved): a rod placed in the directly solved
     large-deflection equilibrium of the discrete Cosserat rod (tests/elastica_chain.py; tip angles of
     26 and 82 degrees) stays there — after one substep without a damper its rates are 1e-9 of what
@@ -1314,10 +1315,10 @@ def test_known_answer_discrete_elastica_is_a_fixed_point_on_the_gpu(torch_gpu, h
     cfg.env_kind = _capi.ENV_NONE
     cfg.features = _capi.FEAT_FIXED_BC | _capi.FEAT_TIP_FORCE
     cfg.base_radius, cfg.youngs_modulus, cfg.shear_modulus, cfg.damping_constant = r, E, G, 0.0
-    cfg.tip_force[1] = F
+    cfg.tip_force[1], cfg.tip_force[2] = F * np.cos(phi), F * np.sin(phi)      # phi != 0: curvature on d1 AND d2
     be = _backend(cfg)
     be.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
-    _, x, Q = state(n, F, E * I, 27.0 / 28.0 * G * A, E * A)
+    _, x, Q = state(n, F, E * I, 27.0 / 28.0 * G * A, E * A, phi=phi)
     _inject(be, "position", x)
     _inject(be, "director", Q.reshape(9, n))
     be.substeps(None, 1)

@@ -480,8 +480,9 @@ def test_k16_large_deflection_cantilever_settles_on_the_discrete_elastica(oracle
         assert 0.6 < got[1, -1] < 0.82                   # (10 elements: 8 % short of the continuum, like K2's O(1/n))
 
 
+@pytest.mark.parametrize("phi", [0.0, 0.7], ids=["in the x-y plane", "bending plane turned: kappa on d1 and d2"])
 @pytest.mark.parametrize("alpha", [1.0, 10.0])
-def test_k16b_the_discrete_elastica_is_a_fixed_point_of_both_transcriptions(oracle_built, alpha):
+def test_k16b_the_discrete_elastica_is_a_fixed_point_of_both_transcriptions(oracle_built, alpha, phi):
     """Put each transcription INTO the solved equilibrium (positions, directors; at rest): one substep
     without a damper must leave it there — the accelerations it computes are 1e-9 of what the tip
     force alone would cause.  C oracle and NumPy twin; the GPU kernels in tests/test_gpu_parity.py."""
@@ -490,7 +491,9 @@ def test_k16b_the_discrete_elastica_is_a_fixed_point_of_both_transcriptions(orac
 
     cfg, args = _elastica_case(12, alpha)
     n, F = args[0], args[1]
-    _, x, Q = state(*args)
+    cfg.tip_force[1], cfg.tip_force[2] = F * np.cos(phi), F * np.sin(phi)
+    _, x, Q = state(*args, phi=phi)
+    assert phi == 0.0 or (np.abs(x[2]).max() > 0.05 and np.abs(Q[0, 0]).max() > 0.05)      # really out of the x-y plane
     c_rod, n_rod = oracle_built.OracleRod(cfg), NumpyRod(cfg)
     for rod in (c_rod, n_rod):
         rod.reset_straight(np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0]))
@@ -505,3 +508,6 @@ def test_k16b_the_discrete_elastica_is_a_fixed_point_of_both_transcriptions(orac
     w_scale = cfg.dt * F * (1.0 / n) / J1
     for v, w in ((c_rod.get("v"), c_rod.get("w")), (n_rod.v, n_rod.w)):
         assert np.abs(v).max() < 1e-9 * v_scale and np.abs(w).max() < 1e-9 * w_scale
+    kap = c_rod.get("kappa")
+    if phi:
+        assert np.abs(kap[0]).min() > 1e-3 and np.abs(kap[1]).min() > 1e-3 and np.abs(kap[2]).max() < 1e-9   # two bending components, no twist
