@@ -1330,3 +1330,46 @@ def test_known_answer_discrete_elastica_is_a_fixed_point_on_the_gpu(torch_gpu, h
     assert np.abs(st["w"]).max() < 1e-9 * cfg.dt * F * (1.0 / n) / J1
     np.testing.assert_allclose(st["x"][0, :, 1:], x[:, 1:], rtol=1e-12, atol=1e-15)
     be.close()
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["libm", "fast"])
+def test_known_answer_angular_momentum_of_a_tumbling_rod_on_the_gpu(torch_gpu, hip_lib, math_mode):
+    """K17 on the HIP kernels themselves (no oracle involved): a free rod that tumbles, bends in two
+    planes, twists, stretches and shears conserves its linear momentum to rounding and its total angular
+    momentum sum m x cross v + sum Q^T (J omega / e) to the integrator's 2e-9 over 2000 substeps."""
+    from gym_softrobot_amd import _capi
+    from tests.test_oracle_physics import momenta, tumbling_rod_state
+
+    n, r, rho = 16, 0.03, 1000.0
+    cfg = _capi.softpendulum_config(2, n_elems=n, math_mode=math_mode)
+    cfg.env_kind, cfg.features, cfg.dt, cfg.damping_constant = _capi.ENV_NONE, 0, 2e-5, 0.0
+    cfg.base_radius, cfg.youngs_modulus, cfg.shear_modulus = r, 1e6, 1e6 / 3
+    be = _backend(cfg)
+    be.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    st = be.state_numpy()
+    v, w = tumbling_rod_state(st["x"][0], st["Q"][0])
+    _inject(be, "velocity", v)
+    _inject(be, "omega", w)
+    A = np.pi * r * r
+    I1 = A * A / (4 * np.pi)
+    l0 = 1.0 / n
+    mass = np.full(n + 1, rho * A * l0)
+    mass[[0, -1]] *= 0.5
+    J = np.array([I1, I1, 2 * I1])[:, None] * rho * l0 * np.ones((1, n))
+
+    def now():
+        s = be.state_numpy()
+        x = s["x"][0]
+        dil = np.linalg.norm(x[:, 1:] - x[:, :-1], axis=0) / l0
+        return momenta(x, s["v"][0], s["Q"][0], s["w"][0], mass, J, dil)
+
+    be.substeps(None, 1)
+    torch_gpu.cuda.synchronize()
+    P0, L0 = now()
+    be.substeps(None, 2000)
+    torch_gpu.cuda.synchronize()
+    P1, L1 = now()
+    assert np.abs(P1 - P0).max() <= 1e-12 * np.abs(P0).max()
+    assert np.abs(L1 - L0).max() / np.abs(L0).max() < 5e-9
+    assert np.abs(be.state_numpy()["kappa"][0]).max() > 0.05
+    be.close()
