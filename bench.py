@@ -462,6 +462,10 @@ def roofline_block(env_id, cfg, n_local, kernel_ms, math_mode, lib_hash, hip, ba
         "achieved": achieved,
         "peak": VALU_PEAK_GINSTR,
         "unit": "G wave64-VALU-instr/s",
+        # the same two numbers in the contract's TFLOP/s: a wave64 instruction is 64 lanes, an FMA 2 flops —
+        # what the issue slots the kernel fills would deliver if every one of them held an FMA (30 % do)
+        "achieved_tflops_fma_equivalent": None if achieved is None else achieved * 128.0 / 1e3,
+        "peak_tflops": VALU_PEAK_GINSTR * 128.0 / 1e3,
         # nominal: every VALU wave-instruction priced at 4 cycles at the 2.4 GHz peak clock
         "frac": frac,
         # PRIMARY: the share of the kernel's own cycles in which the VALU was executing an instruction,
