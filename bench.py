@@ -605,6 +605,24 @@ def pcie_inclusive(gsa, torch, device, math_mode, n_local, steps: int = 40, warm
                     "(closed loop); the headline `value` has its inputs resident in HBM and is open loop"}
 
 
+def single_env_latency(gsa, np, steps: int = 60, warmup: int = 5):
+    """BASELINE configs[0]'s shape on the GPU: ONE SoftPendulum-v0 env through the drop-in Gymnasium
+    surface (`make(id)`, NumPy action in, NumPy observation out, a host synchronisation every step) —
+    what a user of the reference gets who changes nothing but the import.  One wavefront runs the 400
+    substeps alone, so this is a latency, not a throughput."""
+    env = gsa.make("SoftPendulum-v0")
+    env.reset(seed=0)
+    acts = np.random.default_rng(1).uniform(-22, 22, (warmup + steps, 1)).astype(np.float32)
+    for t in range(warmup + steps):
+        if t == warmup:
+            t0 = time.perf_counter()
+        obs, rew, term, trunc, info = env.step(acts[t])
+    elapsed = time.perf_counter() - t0
+    env.close()
+    return {"ms_per_env_step": elapsed / steps * 1e3, "env_steps_per_s": steps / elapsed, "steps": steps,
+            "what": "gym_softrobot_amd.make('SoftPendulum-v0'): one env, NumPy in / out, synchronised every step"}
+
+
 def p2p_trial(args, rank: int, local_rank: int, world: int, script=None, timeout_s: float = 300.0):
     """N > 1, after the headline (RCCL) measurement: every rank starts ONE child process that runs this
     file again as the same rank of a second job over transport "p2p" (its own rendezvous port), so that
@@ -916,6 +934,7 @@ def main(argv=None, script=None) -> int:
             line["secondary"] = [secondary_workload(gsa, _capi, torch, local_rank, math_mode, lib_hash, **spec)
                                  for spec in SECONDARY]
             line["pcie_inclusive"] = pcie_inclusive(gsa, torch, local_rank, math_mode, n_local)
+            line["single_env"] = single_env_latency(gsa, np)
         if not args.no_cpu_baseline and args.env == "SoftPendulum-v0" and hip:
             line["cpu_baseline"] = cpu_baseline(cfg, usable_cpus(), n_rods=ENVS_PER_GPU)
             line["cpu_baseline"]["parity_vs_oracle"] = parity_vs_oracle(gsa, torch, local_rank, math_mode, cfg)
