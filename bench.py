@@ -633,7 +633,19 @@ def p2p_trial(args, rank: int, local_rank: int, world: int, script=None, timeout
     import signal
     import subprocess
 
-    port = int(os.environ.get("MASTER_PORT", "29511")) + 1      # the job's port + 1
+    import socket
+
+    import torch.distributed as dist
+
+    # a rendezvous port of the trial's own: rank 0 asks the OS for a free one and tells the others over
+    # the parents' process group (which is still up)
+    box = [None]
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            box[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(box, src=0)
+    port = int(box[0])
     env = dict(os.environ, MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world))
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
               "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
