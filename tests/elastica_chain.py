@@ -68,3 +68,42 @@ def state(n, F, EI, GA, EA, L=1.0, phi=0.0):
         R = np.eye(3) + np.sin(t[k]) * K + (1 - np.cos(t[k])) * (K @ K)      # rotation about b by t_k
         Q[:, :, k] = base @ R.T                                                # each director (a row) turned
     return t, x, Q
+
+
+def bending_modes(n, EI, GA, rhoA, rhoI, L=1.0):
+    """Small planar vibrations of the clamped discrete rod about the straight state, as a generalised
+    eigenproblem assembled here from the discrete energies (nothing of a stepper involved):
+        V = 1/2 sum_k GA l (y'_k - theta_k)^2 + 1/2 sum_k EI (theta_{k+1} - theta_k)^2 / l,  y'_k = (y_{k+1} - y_k) / l
+        T = 1/2 sum_k m_k ydot_k^2 + 1/2 sum_k (rhoI l) thetadot_k^2,   m_k = rhoA l (half at both ends)
+    with y_0 = theta_0 = 0.  -> (omega[...], modes as (y[n+1], theta[n]) columns, mass matrix diag)."""
+    from scipy.linalg import eigh
+
+    l = L / n
+    ny, nd = n + 1, 2 * n + 1
+    K = np.zeros((nd, nd))
+    for k in range(n):
+        g = np.zeros(nd)
+        g[k + 1], g[k], g[ny + k] = 1 / l, -1 / l, -1.0
+        K += GA * l * np.outer(g, g)
+    for k in range(n - 1):
+        b = np.zeros(nd)
+        b[ny + k + 1], b[ny + k] = 1.0, -1.0
+        K += EI / l * np.outer(b, b)
+    m = np.full(ny, rhoA * l)
+    m[[0, -1]] *= 0.5
+    Md = np.concatenate([m, np.full(n, rhoI * l)])
+    free = [i for i in range(nd) if i not in (0, ny)]
+    w2, V = eigh(K[np.ix_(free, free)], np.diag(Md[free]))
+    modes = np.zeros((nd, len(free)))
+    modes[free] = V
+    return np.sqrt(w2), modes, Md
+
+
+def frequency_from_samples(q, h, dt):
+    """omega of a pure cosine sampled every h, from q(t+h) + q(t-h) = 2 cos(w_d h) q(t), corrected for the
+    position-Verlet step dt: sin(w_d dt / 2) = w dt / 2."""
+    q = np.asarray(q)
+    c = (q[2:] + q[:-2]) / (2 * q[1:-1])
+    sel = np.abs(q[1:-1]) > 0.3 * np.abs(q).max()
+    wd = np.arccos(np.clip(c[sel], -1.0, 1.0)).mean() / h
+    return 2.0 / dt * np.sin(wd * dt / 2), float(np.std(c[sel]))

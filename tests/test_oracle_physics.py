@@ -581,3 +581,83 @@ def test_k17_angular_momentum_of_a_free_tumbling_rod(oracle_built):
             assert np.abs(Ln1 - Ln0).max() / np.abs(Ln0).max() < 2e-9
     assert drift[1e-5] < 0.6 * drift[2e-5]          # it shrinks with the step (first order over a fixed time): the integrator's
                                                     # error, not a term that is missing from the balance
+
+
+# ---- K18: the discrete rod's own bending modes ------------------------------------------------------
+
+def _mode_case(n=16):
+    E, r, L, rho = 1e6, 0.05, 1.0, 1000.0
+    A = np.pi * r * r
+    I = A * A / (4 * np.pi)
+    return dict(n=n, E=E, r=r, G=E / 3.0, A=A, I=I, rho=rho, L=L)
+
+
+def mode_state(c, mode, amp=1e-6):
+    """(omega, x (3, n+1), Q (3, 3, n), projector) for the rod displaced along bending mode `mode`."""
+    from tests.elastica_chain import bending_modes
+
+    n = c["n"]
+    om, modes, Md = bending_modes(n, c["E"] * c["I"], 27.0 / 28.0 * c["G"] * c["A"], c["rho"] * c["A"], c["rho"] * c["I"], c["L"])
+    phi = modes[:, mode] * (amp / np.abs(modes[: n + 1, mode]).max())
+    x = np.zeros((3, n + 1))
+    x[0] = np.linspace(0.0, c["L"], n + 1)
+    x[1] = phi[: n + 1]
+    th = phi[n + 1:]
+    Q = np.zeros((3, 3, n))
+    Q[0, 2, :] = 1.0
+    Q[1, 0, :], Q[1, 1, :] = np.sin(th), -np.cos(th)
+    Q[2, 0, :], Q[2, 1, :] = np.cos(th), np.sin(th)
+
+    def project(xx, QQ):                         # modal coordinate phi^T M u
+        u = np.concatenate([xx[1], np.arctan2(QQ[2, 1, :], QQ[2, 0, :])])
+        return float(phi @ (Md * u))
+    return om[mode], x, Q, project
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_k18_bending_modes_of_the_discrete_rod(oracle_built, mode):
+    """The clamped rod released from one of its own small-amplitude bending modes — the eigenvector of
+    a mass / stiffness pair assembled independently from the discrete energies (tests/elastica_chain.py:
+    node masses with half end masses, element inertia rho I l, shear alpha_c G A, hinges EI / l) —
+    oscillates in that mode alone at that eigenfrequency: 1e-8 (3e-10 measured for the first mode; the
+    continuum Euler-Bernoulli value is 6 % away at 16 elements, which is why K3's tolerance is 5e-3)."""
+    from tests.elastica_chain import frequency_from_samples
+
+    c = _mode_case()
+    om, x, Q, project = mode_state(c, mode)
+    dt = 2e-5 if mode == 0 else 5e-6
+    cfg = _free_cfg(n_elem=c["n"], dt=dt, features=_capi.FEAT_FIXED_BC)
+    cfg.base_radius, cfg.youngs_modulus, cfg.shear_modulus = c["r"], c["E"], c["G"]
+    rod = oracle_built.OracleRod(cfg)
+    rod.reset_straight([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    rod.set("x", x)
+    rod.set("Q", Q)
+    every = 10
+    q = [project(rod.get("x"), rod.get("Q"))]
+    for _ in range(int(1.2 * 2 * np.pi / om / dt / every)):
+        rod.substeps(0.0, every)
+        q.append(project(rod.get("x"), rod.get("Q")))
+    w, purity = frequency_from_samples(q, every * dt, dt)
+    assert purity < 1e-9                         # one mode only: the eigenvector is the scheme's own
+    assert w == pytest.approx(om, rel=1e-8)
+
+
+def test_k18b_first_bending_mode_on_the_numpy_twin(oracle_built):
+    from oracle.softrod_oracle_np import NumpyRod
+    from tests.elastica_chain import frequency_from_samples
+
+    c = _mode_case(12)
+    om, x, Q, project = mode_state(c, 0)
+    dt = 1e-4
+    cfg = _free_cfg(n_elem=c["n"], dt=dt, features=_capi.FEAT_FIXED_BC)
+    cfg.base_radius, cfg.youngs_modulus, cfg.shear_modulus = c["r"], c["E"], c["G"]
+    rod = NumpyRod(cfg)
+    rod.reset_straight(np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0]))
+    rod.x, rod.Q = x.copy(), Q.copy()
+    every, q = 20, [project(x, Q)]
+    for _ in range(int(0.45 * 2 * np.pi / om / dt / every)):
+        for _ in range(every):
+            rod.substep()
+        q.append(project(rod.x, rod.Q))
+    w, purity = frequency_from_samples(q, every * dt, dt)
+    assert purity < 1e-8 and w == pytest.approx(om, rel=1e-7)
