@@ -73,12 +73,16 @@ def init_process_group(backend: str = "nccl", device: Optional[torch.device] = N
     if high_priority is None:
         high_priority = os.environ.get("SOFTROD_RCCL_HIGH_PRIORITY", "1") != "0"
     if backend == "nccl":
-        if high_priority and hasattr(dist, "ProcessGroupNCCL"):
-            opts = dist.ProcessGroupNCCL.Options()
-            opts.is_high_priority_stream = True
-            kw["pg_options"] = opts
         if device is not None:
             kw["device_id"] = device
+        if high_priority and hasattr(dist, "ProcessGroupNCCL"):
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                dist.init_process_group(backend, pg_options=opts, **kw)
+                return
+            except TypeError as exc:      # a torch build whose init_process_group takes no pg_options
+                warnings.warn(f"RCCL group at normal stream priority ({exc})", RuntimeWarning, stacklevel=2)
     dist.init_process_group(backend, **kw)
 
 
