@@ -105,7 +105,7 @@ class SoftrodConfig(C.Structure):
         ("time_two_half_adds", C.c_int32),
         ("damp_before_constrain", C.c_int32),
         ("contact_before_forcing", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("damper_protocol", C.c_int32),
         ("plane_origin", C.c_double * 3),
         ("plane_normal", C.c_double * 3),
         ("contact_k", C.c_double),

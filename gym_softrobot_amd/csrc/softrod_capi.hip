@@ -152,8 +152,8 @@ void fill_params(const softrod_config& c, RodParams& P) {
     // element mass seen by the damper: 0.5(m_k+m_{k+1}), ends augmented by half their
     // outer node -> rho*V for every element of a uniform rod
     const double me = P.mass_node;
-    for (int i = 0; i < 3; ++i) {
-        P.damp_logr[i] = -c.damping_constant * c.dt * me * P.invJ[i];
+    for (int i = 0; i < 3; ++i) {      // (damper_protocol 1: the uniform protocol, the same exp(-nu dt) on every rate)
+        P.damp_logr[i] = c.damper_protocol == 1 ? -c.damping_constant * c.dt : -c.damping_constant * c.dt * me * P.invJ[i];
         P.damp_r[i] = std::exp(P.damp_logr[i]);
     }
     P.eps_length = c.eps_length;
@@ -549,6 +549,8 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
     if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_SOFT_ARM)
         return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
+    if (cfg->damper_protocol != 0 && cfg->damper_protocol != 1)
+        return fail(nullptr, SOFTROD_EINVAL, "damper_protocol: 0 (per unit mass) or 1 (uniform)");
     // The fast kernels expand theta / sin(theta + eps_sin) as (theta / sin theta)(1 - eps_sin cot theta)
     // (eps_sin_factor, softrod_fast.hpp; the bke * rsq(D^2 + two_shift) term of softrod_planar.hpp), which
     // holds while eps_sin << theta_min = sqrt(2 acos_shift), the smallest angle acos(.. - acos_shift)
@@ -1042,8 +1044,8 @@ int softrod_set_radius_profile(softrod_handle* h, const double* radius) {
         double me = 0.5 * (mass[(size_t)k + 1] + mass[(size_t)k]);
         if (k == 0) me += 0.5 * mass[0];
         if (k == n - 1) me += 0.5 * mass[(size_t)n];
-        const double l0 = -c.damping_constant * c.dt * me * T[(size_t)kMatInvJ0 * W + k];
-        const double l2 = -c.damping_constant * c.dt * me * T[(size_t)kMatInvJ2 * W + k];
+        const double l0 = c.damper_protocol == 1 ? -c.damping_constant * c.dt : -c.damping_constant * c.dt * me * T[(size_t)kMatInvJ0 * W + k];
+        const double l2 = c.damper_protocol == 1 ? -c.damping_constant * c.dt : -c.damping_constant * c.dt * me * T[(size_t)kMatInvJ2 * W + k];
         T[(size_t)kMatDampLog0 * W + k] = l0; T[(size_t)kMatDampLog2 * W + k] = l2;
         T[(size_t)kMatDampR0 * W + k] = std::exp(l0); T[(size_t)kMatDampR2 * W + k] = std::exp(l2);
     }

@@ -188,7 +188,11 @@ typedef struct softrod_config {
     int32_t contact_before_forcing; /* order inside synchronize(): 0 (default) =
                                        registration order, gravity then contact
                                        (octopus/build.py:236-283)              */
-    int32_t reserved1;
+    int32_t damper_protocol;  /* AnalyticalLinearDamper: 0 (default) = the per-unit-mass protocol the bare
+                                 `damping_constant=` keyword selects (build.py:108-113): v *= exp(-nu dt),
+                                 omega *= exp(-nu dt m_elem J^-1)^dilatation; 1 = the uniform protocol
+                                 (`uniform_damping_constant=`): exp(-nu dt) on every rate.  A switch for
+                                 tools/sweep_switches.py like the ones above (was reserved1: same layout) */
     double plane_origin[3];   /* (0, 0, -r0)            octopus/build.py:244   */
     double plane_normal[3];   /* (0, 0, 1)              octopus/build.py:233   */
     double contact_k;         /* 1e2                    :241                    */

@@ -180,8 +180,8 @@ static void straight_rod(oracle_rod* r, const double start[3],
         double me = 0.5 * (r->mass[k + 1] + r->mass[k]);
         if (k == 0) me += 0.5 * r->mass[0];
         if (k == n - 1) me += 0.5 * r->mass[n];
-        for (int i = 0; i < 3; ++i)
-            r->damp_r[i][k] = exp(-c->damping_constant * c->dt * me * r->invJ[i][k]);
+        for (int i = 0; i < 3; ++i)     /* damper_protocol 1: `uniform_damping_constant=`, exp(-nu dt) on every rate */
+            r->damp_r[i][k] = c->damper_protocol == 1 ? r->damp_t : exp(-c->damping_constant * c->dt * me * r->invJ[i][k]);
     }
     /* constraint targets: ConstraintBase is handed position[..., idx] and
      * directors[..., idx] at finalize (build.py:81-85) */

@@ -106,6 +106,8 @@ class NumpyRod:
         me[0] += 0.5 * self.mass[0]
         me[-1] += 0.5 * self.mass[-1]
         self.damp_r = np.exp(-c.damping_constant * c.dt * me * self.invJ)
+        if getattr(c, "damper_protocol", 0) == 1:      # uniform protocol: the same exp(-nu dt) on every rate
+            self.damp_r = np.full_like(self.damp_r, self.damp_t)
         self.fixed_pos = self.x[:, 0].copy()
         self.fixed_dir = self.Q[:, :, 0].copy()
         self.time = np.float64(0.0)

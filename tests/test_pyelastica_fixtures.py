@@ -152,3 +152,40 @@ def test_pyelastica_driver_runs_the_reference_env_code(tmp_path):
     assert o["obs"] == [2, 461] and o["sub100_x"] == [8, 3, 11] and o["step1_w"] == [8, 3, 10]
     assert o["step1_head_x"] == [3] and o["step1_head_Q"] == [3, 3] and o["actions"] == [2, 24]
     assert o["_time"][0] == pytest.approx(2857 * 7e-5, rel=1e-9)
+
+
+FLIPPED = {
+    "alpha_c + damp order + damper protocol": {"alpha_c": 4.0 / 3.0, "damp_before_constrain": 1, "damper_protocol": "uniform"},
+    "shear modulus + contact order + clock": {"shear_modulus_over_E": 1.0 / 1.5, "contact_before_forcing": 1, "time_two_half_adds": 0},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", list(FLIPPED), ids=list(FLIPPED))
+def test_hip_follows_every_switch_the_sweep_can_select(hip_lib, oracle_built, tmp_path, which):
+    """Whatever combination of recalled details a PyElastica fixture turns out to demand, the product
+    path must need no kernel work: every switch of tools/pyelastica_pin.SWITCHES is a field of
+    softrod_config that the HIP library honours like the oracle does.  Oracle-made fixtures with three
+    switches flipped at a time are replayed through the HIP library under the same switches (1e-5,
+    strict horizons) — and are NOT matched under the shipped defaults."""
+    import make_pyelastica_golden as gen
+
+    sw = FLIPPED[which]
+    flips = []
+    for k, v in sw.items():
+        flips += ["--flip", f"{k}={v}" if isinstance(v, str) else f"{k}={v!r}"]
+    assert gen.main(["--source", "oracle", "--out", str(tmp_path), "--prefix", "flipped", "--seeds", "1",
+                     "--steps", "3"] + flips) == 0
+    files = pin.fixture_files(tmp_path, "flipped")
+    assert len(files) == 4
+    _check(pin.HipDriver, files, sw, math_mode=1)
+    one_rod = [f for f in files if "OctoFlat" not in f.name]
+    _check(pin.HipDriver, one_rod, sw, math_mode=0)
+    mismatched = 0
+    for f in files:
+        fx = dict(np.load(f, allow_pickle=False))
+        drv = pin.HipDriver(str(fx["env_id"]), None, math_mode=1)
+        dev = pin.compare_case(drv, fx)
+        drv.close()
+        mismatched += not pin.strict_worst(dev, str(fx["env_id"])) <= TOL
+    assert mismatched >= 3                     # the defaults do not reproduce these files

@@ -54,9 +54,10 @@ ENVS = {
 }
 
 # The recalled details a fixture can decide, as (name, candidates).  The first candidate of each is
-# what the repo ships (gym_softrobot_amd/_capi.py _common / *_config).  `shear_modulus_over_E` and
-# `damper_protocol` are not config fields: the first scales cfg.shear_modulus, the second overrides
-# the oracle's rotational damper coefficients after every reset (uniform = exp(-nu dt) on all rates).
+# what the repo ships (gym_softrobot_amd/_capi.py _common / *_config).  Every one is a field of
+# softrod_config — honoured by the oracle, the NumPy twin AND the HIP library, so whatever combination a
+# PyElastica fixture selects needs no kernel work — except `shear_modulus_over_E`, which scales
+# cfg.shear_modulus.
 SWITCHES = {
     "alpha_c": (27.0 / 28.0, 4.0 / 3.0, 5.0 / 6.0, 1.0),
     "shear_modulus_over_E": (1.0 / 3.0, 1.0 / 1.5),
@@ -141,6 +142,7 @@ class _RepoDriver:
                   "eps_length", "eps_rot_axis", "acos_shift", "eps_sin"):
             setattr(cfg, k, type(getattr(cfg, k))(self.sw[k]))
         cfg.shear_modulus = float(cfg.youngs_modulus) * float(self.sw["shear_modulus_over_E"])
+        cfg.damper_protocol = {"per_unit_mass": 0, "uniform": 1}[self.sw["damper_protocol"]]
 
     def _after_reset(self) -> None:
         pass
@@ -171,12 +173,6 @@ class OracleDriver(_RepoDriver):
         r = self.env.backend.rods[0]
         return [r.arm(a) for a in range(r.n_arm)] if self.octo else [r]
 
-    def _after_reset(self) -> None:
-        if self.sw["damper_protocol"] == "uniform":      # AnalyticalLinearDamper(uniform_damping_constant=...)
-            for rod in self._rods():
-                dt = rod.get("damp_t") if hasattr(rod, "get") else None
-                rod.set("damp_r", np.full((3, rod.n), float(dt[0])))
-
     def substeps(self, n: int) -> None:
         r = self.env.backend.rods[0]
         if self.octo:
@@ -202,8 +198,6 @@ class HipDriver(_RepoDriver):
     def __init__(self, env_id, switches=None, math_mode=None):
         self._math_mode = math_mode
         super().__init__(env_id, switches)
-        if self.sw["damper_protocol"] != "per_unit_mass":
-            raise NotImplementedError("the HIP library implements the per-unit-mass damper protocol only")
 
     def _backend(self, cfg):
         from gym_softrobot_amd.backend import HipRodBackend
