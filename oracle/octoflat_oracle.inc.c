@@ -174,20 +174,25 @@ static void octo_substep(oracle_octo* o)
     const int na = o->n_arm;
     for (int a = 0; a < na; ++a) kinematic_step(o->arm[a], 0.5 * dt);
     head_kinematic(&o->head, 0.5 * dt, o->cfg.eps_rot_axis);
-    o->time += 0.5 * dt;
+    if (o->cfg.time_two_half_adds) o->time += 0.5 * dt;
     head_constrain_values(&o->head);
     for (int a = 0; a < na; ++a) { compute_internal_forces(o->arm[a]); compute_internal_torques(o->arm[a]); }
-    /* synchronize: joints, gravity, contact (registration order) */
+    /* synchronize: joints, gravity, contact (registration order); with the switch
+     * contact_before_forcing the contact runs before the forcing group: joints, contact, gravity —
+     * the plane's response then sees the joint load but not the weight */
     for (int a = 0; a < na; ++a) joint_apply(o, a);
+    if (o->cfg.contact_before_forcing)
+        for (int a = 0; a < na; ++a) plane_contact(o->arm[a]);
     for (int a = 0; a < na; ++a) apply_forcing(o->arm[a]);
-    for (int a = 0; a < na; ++a) plane_contact(o->arm[a]);
+    if (!o->cfg.contact_before_forcing)
+        for (int a = 0; a < na; ++a) plane_contact(o->arm[a]);
     for (int a = 0; a < na; ++a) dynamic_step(o->arm[a], dt);
     head_dynamic(&o->head, dt);
     head_constrain_rates(&o->head);
     for (int a = 0; a < na; ++a) dampen_rates(o->arm[a]);
     for (int a = 0; a < na; ++a) kinematic_step(o->arm[a], 0.5 * dt);
     head_kinematic(&o->head, 0.5 * dt, o->cfg.eps_rot_axis);
-    o->time += 0.5 * dt;
+    o->time += o->cfg.time_two_half_adds ? 0.5 * dt : dt;
     head_constrain_values(&o->head);
     for (int a = 0; a < na; ++a) {
         oracle_rod* r = o->arm[a];

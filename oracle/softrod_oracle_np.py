@@ -557,13 +557,14 @@ class NumpyOctopus:
         self.head.constrain_values()
         for rod in self.arms:
             rod._forces_and_torques()
-        # synchronize: forcing, connections, and the contacts last (or first, by the switch)
+        # synchronize: joints, gravity, contact (registration order, octopus/build.py:117-200); with the
+        # switch the contact runs before the forcing group: joints, contact, gravity
+        self._connections()
         if c.contact_before_forcing:
             for rod in self.arms:
                 rod.contact()
         for rod in self.arms:
             rod.forcing()
-        self._connections()
         if not c.contact_before_forcing:
             for rod in self.arms:
                 rod.contact()

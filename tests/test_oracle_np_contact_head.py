@@ -361,3 +361,26 @@ def test_static_rolling_friction_rolls_without_slipping(oracle_built):
         spin = got["w"][2]                             # about the axis (d3 = +x): rolling towards +y turns about -x
         np.testing.assert_allclose(spin * r, -vy[:-1], rtol=1e-6)
         assert np.abs(vy[:-1] + spin * r).max() < 1e-9 * abs(vy).max()      # the contact point does not slip
+
+
+def test_octopus_contact_order_and_clock_switches_mean_the_same_in_both(oracle_built):
+    """contact_before_forcing = 1 on the multi-body system: joints, contact, gravity (the plane's
+    response sees the joint load but not the weight); time_two_half_adds = 0: one += dt per substep."""
+    cfg, c_oct, n_oct = _octo_pair(contact_before_forcing=1, time_two_half_adds=0)
+    n = int(cfg.n_elem)
+    for a in range(8):
+        rk = np.zeros((3, n - 1))
+        rk[0] = (3.0 + a) * np.cos(np.linspace(0, 2.0, n - 1) + 0.4 * a)
+        c_oct.arm(a).set("rest_kappa", rk)
+        n_oct.arms[a].rest_kappa = rk.copy()
+    c_oct.substeps(120)
+    for _ in range(120):
+        n_oct.substep()
+    _compare_octo(c_oct, n_oct, "after 120 substeps", tol=1e-10)
+    assert float(n_oct.time) == c_oct.time
+    # and it is a different trajectory from the default order's
+    _, d_oct, _ = _octo_pair()
+    for a in range(8):
+        d_oct.arm(a).set("rest_kappa", c_oct.arm(a).get("rest_kappa"))
+    d_oct.substeps(120)
+    assert np.abs(d_oct.arm(0).get("x") - c_oct.arm(0).get("x")).max() > 1e-9
