@@ -61,11 +61,23 @@ loop — what a caller that hands over NumPy arrays gets; never `value`.
 
 N > 1: `per_rank` lists every rank's step-kernel time, what a step costs beyond it (the exchange:
 collective or peer copies, plus launch gaps) and `efficiency_vs_n1_kernel` = kernel time / step
-time; and, with the default transport, every rank then runs the same windows once more over
-transport "p2p" in a CHILD process of its own (`p2p_trial` in the line: a crash or a fall-back of
-the experimental transport cannot cost the headline measurement).
+time; and, with the default transport, AFTER rank 0 has printed the line every rank runs the same
+windows once more over transport "p2p" in a child process of its own, bounded by 90 s (a crash, a hang
+or a fall-back of the experimental transport cannot cost the headline measurement: it is out already).
+The trial's figures go to stderr as `bench.py: p2p_trial: {...}` and to gpurun_out/p2p_trial_N<world>.json.
 
-methodology_version 4 (round 4).  3 = round 3: clock pre-heat + median of up to five windows;
+sustained (N=1, default; round 5): after everything else ONE more leg keeps the GPU under continuous load
+for >= 2 s — ~7000 env.steps of the headline workload with device-side NEXT_STEP auto-reset (episodes
+end every 125 steps and restart from staged draws without a host round trip) — so that an outside
+observer sampling the GPU (the driver's smi samples) sees it busy; its env-steps/s is reported beside,
+never instead of, the median-window `value`, together with the shader clock and socket power read
+from sysfs (or rocm-smi) near the start and the end of the leg.  `policy_in_loop` (same condition): the
+closed RL loop on the device — observations -> a 2 x 64 tanh MLP (torch, the same stream, no host
+synchronisation) -> actions -> softrod_step, with device auto-reset — i.e. what examples/
+soft_pendulum_3d/train_ppo.py's rollout costs per env.step when the policy lives next to the envs.
+
+methodology_version 5 (round 5: `secondary` gains the libm-mode SoftPendulum entry, `sustained`,
+`policy_in_loop`; the headline windows are those of version 4).  3 = round 3: clock pre-heat + median of up to five windows;
 figures of rounds 1-2 (one window, no pre-heat) are not like for like.  `single_window` in the
 line is window 0 alone, whatever the window count.
 """
@@ -88,7 +100,7 @@ N_SIMD = 1024                # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9             # MI355X_MICROARCH.md peak engine clock
 CYCLES_PER_FP64_WAVE_INSTR = 4.0   # wave64 fp64 op: 16 lanes per clock per SIMD
 VALU_PEAK_GINSTR = N_SIMD * CLOCK_HZ / CYCLES_PER_FP64_WAVE_INSTR / 1e9   # 614.4
-METHODOLOGY_VERSION = 4
+METHODOLOGY_VERSION = 5
 AMAX = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
         "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0}
 TAPER_RATIO = 12.0           # base : tip radius of the tapered arm (octopus/arm_push_env.py:160-165: 0.012 : 0.001)
@@ -245,6 +257,8 @@ def parse_args(argv=None):
                          "material-table instantiation of the step kernel")
     ap.add_argument("--no-secondary", action="store_true",
                     help="N=1 headline run: skip the two secondary workloads (BASELINE configs[2], configs[4]'s share)")
+    ap.add_argument("--no-sustained", action="store_true",
+                    help="N=1 headline run: skip the closing >= 2 s continuous-load leg")
     ap.add_argument("--no-p2p-trial", action="store_true",
                     help="N>1 with the default transport: skip the second measurement over transport p2p")
     ap.add_argument("--trial-child", action="store_true", help=argparse.SUPPRESS)
@@ -265,13 +279,15 @@ def self_launch(args, script=None, argv=None) -> int:
     """`python bench.py --gpus N` (N > 1, not under torchrun): start the N ranks as a CHILD
     `python -m torch.distributed.run` — this parent has not imported torch or touched the GPU,
     and it never exec()s — relay rank 0's JSON line on stdout (everything else of the child's
-    stdout goes to stderr) and return the child's exit code.  The child runs in its own process
-    group and is killed as a group when it exceeds SOFTROD_BENCH_LAUNCH_TIMEOUT seconds (default
-    1800) or when this parent is interrupted.  `script` (tests only): the file the ranks run,
+    stdout goes to stderr) as soon as it arrives, and return the child's exit code.  The child runs
+    in its own process group and is killed as a group when it exceeds SOFTROD_BENCH_LAUNCH_TIMEOUT
+    seconds (default 1800) or when this parent is interrupted; a job killed at the limit AFTER its line
+    was relayed (a hung p2p trial, a hung shutdown) still counts as measured (return code 0).  `script` (tests only): the file the ranks run,
     default this one."""
     import signal
     import socket
     import subprocess
+    import threading
 
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -281,34 +297,77 @@ def self_launch(args, script=None, argv=None) -> int:
            str(Path(script or __file__).resolve())] + list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
-    try:
-        out, _ = proc.communicate(timeout=float(os.environ.get("SOFTROD_BENCH_LAUNCH_TIMEOUT", "1800")))
-    except BaseException as exc:           # timeout, KeyboardInterrupt: do not leave ranks behind
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True, bufsize=1)
+    limit = float(os.environ.get("SOFTROD_BENCH_LAUNCH_TIMEOUT", "1800"))
+    timed_out = threading.Event()
+
+    def kill_tree():
+        """torchrun starts its workers in process groups of their own: killing torchrun's group alone would
+        orphan them (and they hold the stdout pipe open).  Collect the descendants FIRST (by parent pid,
+        from /proc), then kill the group and every one of them."""
+        kids, todo = [], [proc.pid]
+        try:
+            ppid = {}
+            for d in os.listdir("/proc"):
+                if d.isdigit():
+                    try:
+                        ppid[int(d)] = int(Path("/proc", d, "stat").read_text().rsplit(")", 1)[1].split()[1])
+                    except (OSError, ValueError, IndexError):
+                        pass
+            while todo:
+                cur = todo.pop()
+                for pid, par in ppid.items():
+                    if par == cur and pid not in kids:
+                        kids.append(pid)
+                        todo.append(pid)
+        except OSError:
+            pass
         try:
             os.killpg(proc.pid, signal.SIGKILL)
         except OSError:
             pass
+        for pid in kids:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass
+
+    def watchdog():
+        try:
+            proc.wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            timed_out.set()
+            kill_tree()
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    n_json = 0
+    try:
+        # rank 0's line is relayed THE MOMENT it arrives, not when the child job ends: what follows it in
+        # the ranks (the p2p trial, the shutdown of the process group) cannot hold it back or lose it
+        for ln in proc.stdout:
+            txt = ln.strip()
+            is_line = False
+            if txt.startswith("{") and '"metric"' in txt:
+                try:
+                    json.loads(txt)
+                    is_line = True
+                except ValueError:
+                    pass
+            if is_line:
+                n_json += 1
+                print(txt, flush=True)
+            else:
+                sys.stderr.write(ln)
+        proc.wait()
+    except BaseException as exc:           # KeyboardInterrupt, a broken pipe: do not leave ranks behind
+        kill_tree()
         proc.wait()
         sys.stderr.write(f"bench.py: child launch aborted ({type(exc).__name__})\n")
-        if isinstance(exc, subprocess.TimeoutExpired):
-            return 124
         raise
-    n_json = 0
-    for ln in out.splitlines(keepends=True):
-        txt = ln.strip()
-        is_line = False
-        if txt.startswith("{") and '"metric"' in txt:
-            try:
-                json.loads(txt)
-                is_line = True
-            except ValueError:
-                pass
-        if is_line:
-            n_json += 1
-            print(txt, flush=True)
-        else:
-            sys.stderr.write(ln)
+    if timed_out.is_set():
+        sys.stderr.write(f"bench.py: child launch exceeded {limit:g} s and was killed"
+                         + (" (the headline line had been relayed)" if n_json else "") + "\n")
+        return 0 if n_json == 1 else 124
     rc = proc.returncode
     if rc == 0 and n_json != 1:
         sys.stderr.write(f"bench.py: expected one JSON line from rank 0, saw {n_json}\n")
@@ -527,14 +586,21 @@ def roofline_block(env_id, cfg, n_local, kernel_ms, math_mode, lib_hash, hip, ba
 SECONDARY = (
     dict(env_id="OctoArmSingle-v0", n_local=4096, extra={"n_elems": 100}, baseline="configs[2]"),
     dict(env_id="OctoFlat-v0", n_local=1024, extra={}, baseline="configs[4], one GPU's share of 8192 envs"),
+    # the headline workload on the kernel that evaluates the substep literally as PyElastica writes it (libm
+    # sin / cos / acos / exp, IEEE division, no planar specialisation): what the fast-math reformulations buy
+    dict(env_id="SoftPendulum-v0", n_local=ENVS_PER_GPU, extra={}, math_mode="libm",
+         baseline="configs[1] in math_mode libm (the reference-literal arithmetic; not the headline)"),
 )
 
 
 def secondary_workload(gsa, _capi, torch, device, math_mode, lib_hash, env_id, n_local, extra, baseline,
-                       steps: int = 10, warmup: int = 3):
+                       steps: int = 10, warmup: int = 3, **override):
     """`steps` timed env.steps of one more workload on the already warm clock (the headline run has
     just kept the GPU under load for ~1 s; `warmup` steps take the workload's own one-off costs)."""
     import numpy as np
+
+    if "math_mode" in override:
+        math_mode = _capi.MATH_FAST if override["math_mode"] == "fast" else _capi.MATH_LIBM
 
     env = gsa.make_vec(env_id, n_local, device=device, math_mode=math_mode, **extra)
     env.reset(seed=0)
@@ -557,6 +623,7 @@ def secondary_workload(gsa, _capi, torch, device, math_mode, lib_hash, env_id, n
     out = {
         "workload": workload_name(env_id, cfg, n_local),
         "baseline_config": baseline,
+        "math_mode": "fast" if math_mode == _capi.MATH_FAST else "libm",
         "value": n_local * steps / elapsed, "unit": "env-steps/s",
         "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
@@ -605,6 +672,190 @@ def pcie_inclusive(gsa, torch, device, math_mode, n_local, steps: int = 40, warm
                     "(closed loop); the headline `value` has its inputs resident in HBM and is open loop"}
 
 
+def gpu_sensors(torch, device_index: int):
+    """Shader clock (MHz), socket power (W) and the busy percentage of the GPU this process steps on,
+    read from sysfs (the amdgpu node whose PCI address is the torch device's), with `rocm-smi` as the
+    fall-back for the clock and power.  Every field is None where the box does not let an ordinary
+    user read it; `source` says where the numbers came from.  Cheap (a few file reads): it can be
+    called while the stream is busy."""
+    import glob
+    import re
+    import subprocess
+
+    out = {"sclk_mhz": None, "power_w": None, "gpu_busy_percent": None, "source": None}
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        want = "%04x:%02x:%02x" % (int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+    except Exception:  # noqa: BLE001
+        want = None
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    pick = None
+    for c in cards:
+        try:
+            addr = os.path.basename(os.path.realpath(c))
+        except OSError:
+            continue
+        if want is not None and addr.lower().startswith(want):
+            pick = c
+            break
+    if pick is None and len(cards) == 1:
+        pick = cards[0]
+    if pick is not None:
+        try:
+            for ln in Path(pick, "pp_dpm_sclk").read_text().splitlines():
+                if ln.rstrip().endswith("*"):
+                    out["sclk_mhz"] = float(re.search(r"(\d+(?:\.\d+)?)\s*mhz", ln.lower()).group(1))
+            out["source"] = "sysfs " + pick
+        except (OSError, AttributeError, ValueError):
+            pass
+        for name in ("power1_average", "power1_input"):
+            hits = glob.glob(os.path.join(pick, "hwmon", "hwmon*", name))
+            if hits:
+                try:
+                    out["power_w"] = int(Path(hits[0]).read_text()) / 1e6
+                    out["source"] = "sysfs " + pick
+                    break
+                except (OSError, ValueError):
+                    pass
+        try:
+            out["gpu_busy_percent"] = float(Path(pick, "gpu_busy_percent").read_text())
+        except (OSError, ValueError):
+            pass
+    if out["sclk_mhz"] is None and out["power_w"] is None:
+        try:
+            txt = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showuse", "--json"],
+                                 capture_output=True, text=True, timeout=20).stdout
+            card = next(iter(json.loads(txt).values()))
+            for k, v in card.items():
+                kl = k.lower()
+                if "sclk" in kl and "clock" in kl:
+                    m = re.search(r"(\d+(?:\.\d+)?)", str(v))
+                    out["sclk_mhz"] = float(m.group(1)) if m else None
+                elif "power" in kl and "(w)" in kl and out["power_w"] is None:
+                    out["power_w"] = float(v)
+                elif "gpu use" in kl:
+                    out["gpu_busy_percent"] = float(v)
+            out["source"] = "rocm-smi"
+        except Exception as exc:  # noqa: BLE001
+            out["source"] = f"unreadable ({type(exc).__name__})"
+    return out
+
+
+def sustained_leg(gsa, torch, device, math_mode, n_local, min_seconds: float = 2.2, max_steps: int = 20000):
+    """The GPU under CONTINUOUS load for >= `min_seconds`, so that an observer outside this process (the
+    driver samples the GPU's busy state) has something to see: the headline workload, random actions from
+    a ring of 120 pre-staged steps, device-side NEXT_STEP auto-reset (episodes truncate on step 126 and
+    restart from staged draws: no host round trip, no idle gap), as many env.steps as `min_seconds`
+    takes at the headline's rate.  Restarting env-steps are not counted as work.  Reported BESIDE the
+    median-window `value`, never instead of it."""
+    import numpy as np
+
+    env = gsa.make_vec("SoftPendulum-v0", n_local, device=device, math_mode=math_mode, autoreset="device")
+    env.reset(seed=0)
+    dev = env.backend.device
+    ring = torch.from_numpy(np.random.default_rng(1).uniform(-22, 22, (120, n_local, 1)).astype(np.float32)).to(dev)
+    # rate probe: 60 steps (also this env's one-off costs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(60):
+        env.step(ring[t])
+    torch.cuda.synchronize()
+    per_step = (time.perf_counter() - t0) / 60
+    steps = int(min(max_steps, max(500, min_seconds / max(per_step, 1e-6) * 1.05)))
+    r0 = int(env.backend.queue_status()[0].sum())
+    sensors = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        env.step(ring[t % 120])
+        if t == steps // 8:
+            sensors["near_start"] = gpu_sensors(torch, device)
+        elif t == steps - steps // 8:
+            sensors["near_end"] = gpu_sensors(torch, device)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    restarts = int(env.backend.queue_status()[0].sum()) - r0
+    env.close()
+    return {"value": (n_local * steps - restarts) / elapsed, "unit": "env-steps/s", "steps": steps,
+            "seconds": elapsed, "ms_per_step": elapsed / steps * 1e3,
+            "episode_restarts_not_counted": restarts, "autoreset": "device",
+            "sensors": sensors,
+            "what": "continuous load for the driver's GPU-busy samples: the headline workload with device-side "
+                    "auto-reset for >= 2 s; beside `value` (the median 20-step window), never instead of it"}
+
+
+def make_policy(torch, device, obs_dim: int, act_dim: int, amax: float, hidden: int = 64, seed: int = 0):
+    """A 2 x `hidden` tanh MLP with fixed random weights (the shape of SB3's default PPO MlpPolicy used by
+    /root/reference/examples/soft_pendulum_3d/train_ppo.py:26-38): float32 obs -> float32 actions in
+    [-amax, amax].  NaN observations (a rod the integrator lost; the env restarts on the next step) give
+    action 0."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    w1 = (torch.randn(obs_dim, hidden, generator=g) / obs_dim ** 0.5).to(device)
+    w2 = (torch.randn(hidden, hidden, generator=g) / hidden ** 0.5).to(device)
+    w3 = (torch.randn(hidden, act_dim, generator=g) / hidden ** 0.5).to(device)
+    b1, b2, b3 = (torch.zeros(k, device=device) for k in (hidden, hidden, act_dim))
+
+    def policy(obs):
+        with torch.no_grad():
+            h = torch.tanh(torch.addmm(b1, torch.nan_to_num(obs), w1))
+            h = torch.tanh(torch.addmm(b2, h, w2))
+            return amax * torch.tanh(torch.addmm(b3, h, w3))
+    return policy
+
+
+def policy_loop(torch, env, policy, obs, steps: int, sync_every_call: bool = False, record=None):
+    """obs -> policy -> env.step -> obs ..., everything enqueued on ONE stream with no host
+    synchronisation (`sync_every_call` adds a device synchronise after every call: the control of
+    tests/test_gpu_policy_loop.py, which must be bit-identical).  `record`: list that receives a host copy
+    of (obs, reward, terminated, truncated) of every step."""
+    for _ in range(steps):
+        a = policy(obs)
+        if sync_every_call:
+            torch.cuda.synchronize()
+        obs, rew, term, trunc, _ = env.step(a)
+        if sync_every_call:
+            torch.cuda.synchronize()
+        if record is not None:
+            record.append(tuple(x.detach().cpu().clone() for x in (obs, rew, term, trunc)))
+    return obs
+
+
+def policy_in_loop(gsa, torch, device, math_mode, n_local, steps: int = 1500, warmup: int = 60):
+    """N2's "real RL throughput": the closed loop on the device (see make_policy / policy_loop), device
+    auto-reset on.  Reported next to `pcie_inclusive` (the closed loop through HOST buffers)."""
+    env = gsa.make_vec("SoftPendulum-v0", n_local, device=device, math_mode=math_mode, autoreset="device")
+    obs, _ = env.reset(seed=0)
+    policy = make_policy(torch, env.backend.device, env.obs_dim, env.action_dim, 22.0)
+    obs = policy_loop(torch, env, policy, obs, warmup)
+    r0 = int(env.backend.queue_status()[0].sum())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    obs = policy_loop(torch, env, policy, obs, steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    restarts = int(env.backend.queue_status()[0].sum()) - r0
+    checksum = float(torch.nan_to_num(obs.double()).sum().item())
+    env.close()
+    return {"value": (n_local * steps - restarts) / elapsed, "unit": "env-steps/s", "steps": steps,
+            "ms_per_step": elapsed / steps * 1e3, "episode_restarts_not_counted": restarts,
+            "policy": "2 x 64 tanh MLP, fixed random weights, torch on the env's stream, no host synchronisation",
+            "autoreset": "device", "last_obs_checksum": checksum,
+            "what": "obs -> MLP -> actions -> softrod_step in a closed loop on the device (what an on-device "
+                    "PPO rollout pays per env.step); the headline `value` is open loop on pre-staged actions"}
+
+
+def guarded(fn, *a, **kw):
+    """An add-on of the line (secondary workloads, PCIe leg, CPU baseline, ...) must not cost the measured
+    headline: its exception becomes its entry."""
+    try:
+        return fn(*a, **kw)
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+
+        sys.stderr.write(f"bench.py: add-on {getattr(fn, '__name__', fn)} failed: {exc!r}\n{traceback.format_exc()}")
+        return {"error": repr(exc)}
+
+
 def single_env_latency(gsa, np, steps: int = 60, warmup: int = 5):
     """BASELINE configs[0]'s shape on the GPU: ONE SoftPendulum-v0 env through the drop-in Gymnasium
     surface (`make(id)`, NumPy action in, NumPy observation out, a host synchronisation every step) —
@@ -623,13 +874,16 @@ def single_env_latency(gsa, np, steps: int = 60, warmup: int = 5):
             "what": "gym_softrobot_amd.make('SoftPendulum-v0'): one env, NumPy in / out, synchronised every step"}
 
 
-def p2p_trial(args, rank: int, local_rank: int, world: int, script=None, timeout_s: float = 300.0):
+def p2p_trial(args, rank: int, local_rank: int, world: int, script=None, timeout_s: float = 90.0):
     """N > 1, after the headline (RCCL) measurement: every rank starts ONE child process that runs this
     file again as the same rank of a second job over transport "p2p" (its own rendezvous port), so that
     the driver's one run per N yields both transports — and a crash, a hang or a fall-back of the
-    experimental transport is a field of the line, not a lost measurement.  The parents have finished
-    their GPU work; they never exec, and they kill their child's process group at the timeout.
-    -> rank 0: the child's figures; other ranks: None."""
+    experimental transport is a reported fact, not a lost measurement (rank 0 has printed the headline
+    before this runs).  The parents have finished their GPU work; they never exec.  The child is NOT
+    detached: it stays in the launcher's process group (a killed torchrun / self_launch takes it down
+    too), asks the kernel to SIGKILL it when its parent dies (PR_SET_PDEATHSIG), and is killed by its
+    parent at the timeout.  -> rank 0: the child's figures; other ranks: None."""
+    import ctypes
     import signal
     import subprocess
 
@@ -658,16 +912,19 @@ def p2p_trial(args, rank: int, local_rank: int, world: int, script=None, timeout
         cmd += ["--envs-per-gpu", str(args.envs_per_gpu)]
     if args.n_elems is not None:
         cmd += ["--n-elems", str(args.n_elems)]
+    prctl = ctypes.CDLL(None, use_errno=True).prctl       # resolved BEFORE the fork: the hook below only calls it
+    PR_SET_PDEATHSIG = 1
+
+    def die_with_parent():
+        prctl(PR_SET_PDEATHSIG, int(signal.SIGKILL))
+
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
-                            start_new_session=True)
+                            preexec_fn=die_with_parent)
     try:
         out, err = proc.communicate(timeout=timeout_s)
         rc = proc.returncode
     except subprocess.TimeoutExpired:
-        try:
-            os.killpg(proc.pid, signal.SIGKILL)
-        except OSError:
-            pass
+        proc.kill()
         out, err = proc.communicate()
         rc = 124
     if rank != 0:
@@ -753,6 +1010,10 @@ def main(argv=None, script=None) -> int:
     # world > 1: kernel-packed rows + one all-gather per step, issued asynchronously so that the
     # next step's kernel does not wait for it (ShardedVecEnv overlap; the final sync is timed)
     env = ShardedVecEnv(local, n_total, overlap=True, force_collective=force_dist, transport=args.transport)
+    if getattr(env, "transport", "rccl") == "p2p":
+        # the timed windows read nothing between two sync() calls (the checksum is taken after the closing
+        # sync), so the every-step interval of the p2p contract does not apply (distributed.py)
+        env.p2p_enforce_sync_interval = False
     env.reset(seed=0)                      # global env i seeded i
     lo, hi = env.lo, env.hi
     adim = local.backend.action_dim
@@ -941,30 +1202,43 @@ def main(argv=None, script=None) -> int:
         scratch.close()
         scratch = None
     if rank == 0 and world == 1 and not distributed:
-        if (args.env == "SoftPendulum-v0" and hip and not args.no_secondary and args.n_elems is None
-                and args.envs_per_gpu in (None, ENVS_PER_GPU) and args.math_mode == "fast"):
-            line["secondary"] = [secondary_workload(gsa, _capi, torch, local_rank, math_mode, lib_hash, **spec)
+        full = (args.env == "SoftPendulum-v0" and hip and not args.no_secondary and args.n_elems is None
+                and args.envs_per_gpu in (None, ENVS_PER_GPU) and args.math_mode == "fast")
+        if full:
+            line["secondary"] = [guarded(secondary_workload, gsa, _capi, torch, local_rank, math_mode, lib_hash, **spec)
                                  for spec in SECONDARY]
-            line["pcie_inclusive"] = pcie_inclusive(gsa, torch, local_rank, math_mode, n_local)
-            line["single_env"] = single_env_latency(gsa, np)
+            line["pcie_inclusive"] = guarded(pcie_inclusive, gsa, torch, local_rank, math_mode, n_local)
+            line["policy_in_loop"] = guarded(policy_in_loop, gsa, torch, local_rank, math_mode, n_local)
+            line["single_env"] = guarded(single_env_latency, gsa, np)
         if not args.no_cpu_baseline and args.env == "SoftPendulum-v0" and hip:
-            line["cpu_baseline"] = cpu_baseline(cfg, usable_cpus(), n_rods=ENVS_PER_GPU)
-            line["cpu_baseline"]["parity_vs_oracle"] = parity_vs_oracle(gsa, torch, local_rank, math_mode, cfg)
+            line["cpu_baseline"] = guarded(cpu_baseline, cfg, usable_cpus(), n_rods=ENVS_PER_GPU)
+            line["cpu_baseline"]["parity_vs_oracle"] = guarded(parity_vs_oracle, gsa, torch, local_rank, math_mode, cfg)
         else:
             line["cpu_baseline"] = None
+        if full and not args.no_sustained:
+            # LAST: >= 2 s of continuous GPU work for the driver's GPU-busy samples (the timed windows
+            # above are ~30 ms in all)
+            line["sustained"] = guarded(sustained_leg, gsa, torch, local_rank, math_mode, n_local)
+            if "value" in line["sustained"]:
+                line["sustained"]["ratio_to_value"] = line["sustained"]["value"] / line["value"]
     elif rank == 0:
         line["cpu_baseline"] = None
 
-    # ---- N > 1, default transport: the same windows once more over transport "p2p", in child processes
-    if (world > 1 and args.transport == "rccl" and not args.no_p2p_trial and not args.trial_child):
-        if rank == 0:      # (a copy for the log, should the trial take the job down: stdout still gets ONE line, below)
-            sys.stderr.write("bench.py: headline before the p2p trial: " + json.dumps(line) + "\n")
-            sys.stderr.flush()
-        trial = p2p_trial(args, rank, local_rank, world, script)
-        if rank == 0:
-            line["p2p_trial"] = trial
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), flush=True)       # the headline is OUT before anything experimental runs
+    # ---- N > 1, default transport: the same windows once more over transport "p2p", in child processes,
+    # AFTER the line (a hang of the never-cross-device-tested transport must not hold the line
+    # back); bounded, children die with their parent; the figures go to stderr and gpurun_out/
+    if (world > 1 and args.transport == "rccl" and not args.no_p2p_trial and not args.trial_child):
+        trial = guarded(p2p_trial, args, rank, local_rank, world, script)
+        if rank == 0:
+            sys.stderr.write("bench.py: p2p_trial: " + json.dumps(trial) + "\n")
+            sys.stderr.flush()
+            try:
+                (ROOT / "gpurun_out").mkdir(exist_ok=True)
+                (ROOT / "gpurun_out" / f"p2p_trial_N{world}.json").write_text(json.dumps(trial, indent=1))
+            except OSError:
+                pass
     if distributed:
         try:
             dist.barrier()

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -467,6 +467,7 @@ _EXPORTS = {
     "softrod_set_timing": (C.c_int, [_VP, C.c_int]),
     "softrod_kernel_times_ms": (C.c_int, [_VP, _VP, C.c_int, C.POINTER(C.c_int)]),
     "softrod_last_kernel_ms": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "softrod_kernel_tier": (C.c_char_p, [_VP]),
     "softrod_last_error": (C.c_char_p, [_VP]),
     "softrod_destroy": (C.c_int, [_VP]),
 }

@@ -417,6 +417,11 @@ class HipRodBackend:
             "time": st["time"].index_select(0, idx).cpu().numpy(),
         }
 
+    def kernel_tier(self) -> str:
+        """softrod_kernel_tier: which step kernel this batch runs (follows from the config alone; the
+        A/B switches in the environment count only under SOFTROD_DEBUG_SWITCHES=1)."""
+        return self._lib.softrod_kernel_tier(self._h).decode()
+
     def octo_state_numpy(self) -> Dict[str, np.ndarray]:
         """Host copy of an OctoFlat batch: arms as x,v (N,A,3,n+1), Q (N,A,3,3,n), w (N,A,3,n),
         kappa/rest_kappa (N,A,3,n-1); head as x,v,w (N,3), Q (N,3,3); target (N,2); time (N,)."""

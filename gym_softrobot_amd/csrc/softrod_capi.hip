@@ -30,6 +30,7 @@ struct softrod_handle {
     bool octo_one_env_per_block = false;  // A/B switch SOFTROD_OCTO_ONE_ENV_PER_BLOCK, read once in softrod_create
     bool window_paired = true;            // A/B switch SOFTROD_WINDOW_PAIRED=0: one rod per workgroup with s_barrier
     bool octo_one_wave = false;           // A/B switch SOFTROD_OCTO_ONE_WAVE: softrod_octo1w.hpp (one wave per env, two slots per lane)
+    std::string tier;                     // softrod_kernel_tier
     RodParams P{};
     StatePtrs S{};
     double* d_init = nullptr;     // [N][18] staging for reset
@@ -623,20 +624,26 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         h->nw = (cfg->n_arm * h->P.seg + kLanes - 1) / kLanes;
         h->init_stride = (size_t)cfg->n_arm * 18 + 2;
     }
-    if (const char* one = std::getenv("SOFTROD_OCTO_ONE_ENV_PER_BLOCK"))   // A/B switch for profiling and tests
+    // A/B switches for profiling and tests.  A product library must not change its kernel tier because of a
+    // stray environment variable: they are read only when SOFTROD_DEBUG_SWITCHES=1 is set as well
+    // (tests/test_gpu_debug_switches.py), and softrod_kernel_tier() reports what was selected.
+    const char* dbg = std::getenv("SOFTROD_DEBUG_SWITCHES");
+    const bool debug_switches = dbg && dbg[0] == '1';
+    auto debug_env = [&](const char* name) -> const char* { return debug_switches ? std::getenv(name) : nullptr; };
+    if (const char* one = debug_env("SOFTROD_OCTO_ONE_ENV_PER_BLOCK"))
         h->octo_one_env_per_block = one[0] == '1';
-    if (const char* one = std::getenv("SOFTROD_WINDOW_PAIRED"))            // A/B switch (softrod_window.hpp)
+    if (const char* one = debug_env("SOFTROD_WINDOW_PAIRED"))              // softrod_window.hpp
         h->window_paired = one[0] != '0';
-    if (const char* one = std::getenv("SOFTROD_OCTO_ONE_WAVE"))            // A/B switch (softrod_octo1w.hpp)
+    if (const char* one = debug_env("SOFTROD_OCTO_ONE_WAVE"))              // softrod_octo1w.hpp
         h->octo_one_wave = one[0] == '1';
     {   // two-window form: ArmSingle with the e_z contact, 64..102 elements
         const int halo = kLanes - (cfg->n_elem + 2) / 2;     // the narrower of the two halos
-        const char* off = std::getenv("SOFTROD_NO_WINDOW");  // A/B switch for profiling and tests
+        const char* off = debug_env("SOFTROD_NO_WINDOW");
         if (h->epl == 2 && cfg->features == SOFTROD_FEATURES_ARM_SINGLE && cfg->env_kind == SOFTROD_ENV_ARM_SINGLE &&
             cfg->math_mode == SOFTROD_MATH_FAST && (h->P.features & kFeatPlaneZup) && !(off && off[0] == '1') &&
             halo >= 3 * kWindowRho)
             h->window_refresh = halo / kWindowRho;    // the front (< 3.25 nodes per substep) stays in the halo
-        if (const char* r = std::getenv("SOFTROD_WINDOW_REFRESH")) if (h->window_refresh > 0) h->window_refresh = std::atoi(r);
+        if (const char* r = debug_env("SOFTROD_WINDOW_REFRESH")) if (h->window_refresh > 0) h->window_refresh = std::atoi(r);
     }
     const size_t adim = (size_t)softrod_config_action_dim(cfg);
     const size_t rowb = N * kLanes * h->epl * h->nw * sizeof(double);
@@ -663,6 +670,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     alloc((void**)&h->S.head, 20 * N * sizeof(double));
     alloc((void**)&h->d_spline, (size_t)(SOFTROD_MAX_SPLINE_PIECES + 1 + SOFTROD_MAX_SPLINE_PIECES * 4 * 4) * sizeof(double));
     h->P.spline = h->d_spline;
+    alloc((void**)&h->d_ticket, sizeof(unsigned));    // softrod_scatter_rows' arrival counter, zero
     alloc((void**)&h->d_params, sizeof(RodParams));
     if (rc == SOFTROD_OK && hipMemcpy(h->d_params, &h->P, sizeof(RodParams), hipMemcpyHostToDevice) != hipSuccess)
         rc = SOFTROD_EHIP;
@@ -744,46 +752,95 @@ int softrod_reset_octo(softrod_handle* h, const double* arm_start, const double*
 }
 
 // ---- device-side auto-reset ------------------------------------------------------------------
+namespace {
+// Everything softrod_autoreset_enable allocates, released (idempotent; also softrod_destroy's path).
+void autoreset_release(softrod_handle* h) {
+    void* dbufs[] = {h->d_queue, h->d_consumed, h->d_produced, h->d_underflow, h->d_flags, h->d_stage, h->d_where};
+    for (void* p : dbufs) if (p) (void)hipFree(p);
+    void* hbufs[] = {h->h_queue, h->h_produced, h->h_stage, h->h_where, h->h_status};
+    for (void* p : hbufs) if (p) (void)hipHostFree(p);
+    if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
+    if (h->ev_status) (void)hipEventDestroy(h->ev_status);
+    h->d_queue = nullptr; h->d_consumed = nullptr; h->d_produced = nullptr; h->d_underflow = nullptr;
+    h->d_flags = nullptr; h->d_stage = nullptr; h->d_where = nullptr;
+    h->h_queue = nullptr; h->h_produced = nullptr; h->h_stage = nullptr; h->h_where = nullptr; h->h_status = nullptr;
+    h->ev_queue = nullptr; h->ev_status = nullptr;
+    h->stage_cap = 0;
+    h->q_depth = 0;
+}
+
+int autoreset_allocate(softrod_handle* h, int depth, int fail_at) {
+    int calls = 0;
+    // fail_at > 0: the fail_at-th HIP call of this function "fails" without being made (failure injection
+    // of tests/test_gpu_debug_switches.py; 0 in production)
+#define SR_Q(call)                                                                                  \
+    do {                                                                                            \
+        if (++calls == fail_at) return fail(h, SOFTROD_EHIP, "softrod_autoreset_enable: injected failure at call " + std::to_string(calls)); \
+        SR_HIP(h, call);                                                                            \
+    } while (0)
+    const size_t N = (size_t)h->cfg.n_envs;
+    const size_t qb = (size_t)depth * N * h->init_stride * sizeof(double);
+    SR_Q(hipMalloc((void**)&h->d_queue, qb));
+    SR_Q(hipMemset(h->d_queue, 0, qb));
+    SR_Q(hipHostMalloc((void**)&h->h_queue, qb));
+    SR_Q(hipMalloc((void**)&h->d_consumed, N * sizeof(int)));
+    SR_Q(hipMalloc((void**)&h->d_produced, N * sizeof(int)));
+    SR_Q(hipMalloc((void**)&h->d_underflow, sizeof(int)));
+    SR_Q(hipMalloc((void**)&h->d_flags, 2 * N));
+    SR_Q(hipMemset(h->d_consumed, 0, N * sizeof(int)));
+    SR_Q(hipMemset(h->d_produced, 0, N * sizeof(int)));
+    SR_Q(hipMemset(h->d_underflow, 0, sizeof(int)));
+    SR_Q(hipMemset(h->d_flags, 0, 2 * N));
+    SR_Q(hipHostMalloc((void**)&h->h_produced, N * sizeof(int)));
+    std::memset(h->h_produced, 0, N * sizeof(int));
+    SR_Q(hipEventCreateWithFlags(&h->ev_queue, hipEventDisableTiming));
+    h->stage_cap = 2 * N;     // pushes of more records than this upload the whole ring instead
+    SR_Q(hipHostMalloc((void**)&h->h_stage, h->stage_cap * h->init_stride * sizeof(double)));
+    SR_Q(hipHostMalloc((void**)&h->h_where, h->stage_cap * sizeof(int2)));
+    SR_Q(hipMalloc((void**)&h->d_stage, h->stage_cap * h->init_stride * sizeof(double)));
+    SR_Q(hipMalloc((void**)&h->d_where, h->stage_cap * sizeof(int2)));
+    SR_Q(hipHostMalloc((void**)&h->h_status, (N + 1) * sizeof(int)));
+    SR_Q(hipEventCreateWithFlags(&h->ev_status, hipEventDisableTiming));
+    // the device copy of the state pointers is the LAST thing to change: a failure above leaves it
+    // (and h->S) exactly as it was, so the handle keeps stepping without auto-reset
+    StatePtrs S = h->S;
+    S.needs_reset = h->d_flags;
+    S.skip = h->d_flags + N;
+    S.queue = h->d_queue;
+    S.q_consumed = h->d_consumed;
+    S.q_produced = h->d_produced;
+    S.q_underflow = h->d_underflow;
+    S.q_depth = depth;
+    S.q_record = (int)h->init_stride;
+    SR_Q(hipMemcpy(h->d_state, &S, sizeof(StatePtrs), hipMemcpyHostToDevice));
+    h->S = S;
+    h->seen_consumed.assign(N, 0);
+    h->q_depth = depth;
+    return SOFTROD_OK;
+#undef SR_Q
+}
+}  // namespace
+
 int softrod_autoreset_enable(softrod_handle* h, int depth) {
     if (!h || depth < 1 || depth > 4096) return fail(h, SOFTROD_EINVAL, "need 1 <= depth <= 4096");
     if (h->q_depth) return fail(h, SOFTROD_EINVAL, "auto-reset is already enabled");
     if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no episodes");
     SR_ON_DEVICE(h);
-    const size_t N = (size_t)h->cfg.n_envs;
-    const size_t qb = (size_t)depth * N * h->init_stride * sizeof(double);
-    SR_HIP(h, hipMalloc((void**)&h->d_queue, qb));
-    SR_HIP(h, hipMemset(h->d_queue, 0, qb));
-    SR_HIP(h, hipHostMalloc((void**)&h->h_queue, qb));
-    SR_HIP(h, hipMalloc((void**)&h->d_consumed, N * sizeof(int)));
-    SR_HIP(h, hipMalloc((void**)&h->d_produced, N * sizeof(int)));
-    SR_HIP(h, hipMalloc((void**)&h->d_underflow, sizeof(int)));
-    SR_HIP(h, hipMalloc((void**)&h->d_flags, 2 * N));
-    SR_HIP(h, hipMemset(h->d_consumed, 0, N * sizeof(int)));
-    SR_HIP(h, hipMemset(h->d_produced, 0, N * sizeof(int)));
-    SR_HIP(h, hipMemset(h->d_underflow, 0, sizeof(int)));
-    SR_HIP(h, hipMemset(h->d_flags, 0, 2 * N));
-    SR_HIP(h, hipHostMalloc((void**)&h->h_produced, N * sizeof(int)));
-    std::memset(h->h_produced, 0, N * sizeof(int));
-    SR_HIP(h, hipEventCreateWithFlags(&h->ev_queue, hipEventDisableTiming));
-    h->stage_cap = 2 * N;     // pushes of more records than this upload the whole ring instead
-    SR_HIP(h, hipHostMalloc((void**)&h->h_stage, h->stage_cap * h->init_stride * sizeof(double)));
-    SR_HIP(h, hipHostMalloc((void**)&h->h_where, h->stage_cap * sizeof(int2)));
-    SR_HIP(h, hipMalloc((void**)&h->d_stage, h->stage_cap * h->init_stride * sizeof(double)));
-    SR_HIP(h, hipMalloc((void**)&h->d_where, h->stage_cap * sizeof(int2)));
-    SR_HIP(h, hipHostMalloc((void**)&h->h_status, (N + 1) * sizeof(int)));
-    SR_HIP(h, hipEventCreateWithFlags(&h->ev_status, hipEventDisableTiming));
-    h->seen_consumed.assign(N, 0);
-    h->q_depth = depth;
-    h->S.needs_reset = h->d_flags;
-    h->S.skip = h->d_flags + N;
-    h->S.queue = h->d_queue;
-    h->S.q_consumed = h->d_consumed;
-    h->S.q_produced = h->d_produced;
-    h->S.q_underflow = h->d_underflow;
-    h->S.q_depth = depth;
-    h->S.q_record = (int)h->init_stride;
-    SR_HIP(h, hipMemcpy(h->d_state, &h->S, sizeof(StatePtrs), hipMemcpyHostToDevice));
-    return SOFTROD_OK;
+    // SOFTROD_DEBUG_FAIL_AUTORESET_CALL=k (honoured only with SOFTROD_DEBUG_SWITCHES=1): the k-th HIP call of
+    // the set-up fails, for the test that a failed enable leaves nothing allocated and can be retried
+    int fail_at = 0;
+    {
+        const char* dbg = std::getenv("SOFTROD_DEBUG_SWITCHES");
+        const char* k = (dbg && dbg[0] == '1') ? std::getenv("SOFTROD_DEBUG_FAIL_AUTORESET_CALL") : nullptr;
+        if (k) fail_at = std::atoi(k);
+    }
+    const int rc = autoreset_allocate(h, depth, fail_at);
+    if (rc != SOFTROD_OK) {
+        const std::string why = h->err;
+        autoreset_release(h);      // nothing of the failed attempt stays allocated; a retry starts clean
+        h->err = why;
+    }
+    return rc;
 }
 
 namespace {
@@ -1146,10 +1203,9 @@ int softrod_scatter_rows(softrod_handle* h, const float* packed, const uint64_t*
         if (!peer_buffers[q]) return fail(h, SOFTROD_EINVAL, "null peer buffer");
         t.p[q] = reinterpret_cast<float*>(static_cast<uintptr_t>(peer_buffers[q]));
     }
-    if (tag_word >= 0 && !h->d_ticket) {
-        SR_HIP(h, hipMalloc((void**)&h->d_ticket, sizeof(unsigned)));
-        SR_HIP(h, hipMemset(h->d_ticket, 0, sizeof(unsigned)));
-    }
+    // h->d_ticket was allocated and zeroed in softrod_create (a lazy hipMemset on the null stream is not
+    // ordered before a launch on a non-blocking stream); ONE ticket per handle: tagged scatters of one
+    // handle must be stream-ordered with each other (include/softrod.h)
     const size_t n_words = (size_t)h->cfg.n_envs * (size_t)row_words;
     const unsigned blocks = (unsigned)((n_words + 255) / 256);
     hipLaunchKernelGGL(softrod_scatter_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, t,
@@ -1325,21 +1381,46 @@ int softrod_last_kernel_ms(softrod_handle* h, float* ms) {
 
 const char* softrod_last_error(softrod_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
+// Mirrors launch_step's choice (the env.step form: epilogue = 1).
+const char* softrod_kernel_tier(softrod_handle* h) {
+    if (!h) return "";
+    const bool zup = (h->P.features & kFeatPlaneZup) != 0;
+    const unsigned f = h->cfg.features;
+    const int e = h->cfg.env_kind;
+    std::string t;
+    if (is_octo(h)) {
+        if (zup && h->nw == 2 && h->octo_one_wave && h->P.n_arm * h->P.seg == 2 * kLanes && !(h->P.seg & 1))
+            t = "softrod_octo1w_step_kernel<zup,1 wave,1 env/wg>";
+        else if (zup && h->nw == 2 && !h->octo_one_env_per_block)
+            t = "softrod_octo_step_kernel<zup,2 waves,4 envs/wg>";
+        else
+            t = std::string("softrod_octo_step_kernel<") + (zup ? "zup," : "general plane,") +
+                (h->nw <= 2 ? "2" : "8") + " waves max,1 env/wg>";
+    } else if (h->window_refresh > 0) {
+        t = std::string("softrod_step_window_kernel<ArmSingle,") + (h->window_paired ? "4 rods/wg" : "1 rod/wg,s_barrier") +
+            "> refresh=" + std::to_string(h->window_refresh) + " + softrod_step_fast_kernel<ArmSingle,epl=2> epilogue";
+    } else if (h->cfg.math_mode == SOFTROD_MATH_FAST) {
+        const char* spec = "runtime mask";
+        if (h->tapered) {
+            if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE && zup) spec = "ArmSingle";
+            else if (f == kFeaturesTaperedSuckerArm && e == SOFTROD_ENV_NONE) spec = "damped sucker arm";
+        } else if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM) spec = "SoftPendulum";
+        else if (f == SOFTROD_FEATURES_SOFTPENDULUM3D && e == SOFTROD_ENV_SOFTPENDULUM3D) spec = "SoftPendulum3D";
+        else if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE && zup) spec = "ArmSingle";
+        else if (f == SOFTROD_FEATURES_SOFT_ARM && e == SOFTROD_ENV_SOFT_ARM) spec = "SoftArm";
+        t = std::string("softrod_step_fast_kernel<") + spec + ",epl=" + std::to_string(h->tapered ? 1 : h->epl) +
+            (h->tapered ? ",taper>" : ">");
+    } else
+        t = "softrod_step_libm_kernel";
+    h->tier = t;
+    return h->tier.c_str();
+}
+
 int softrod_destroy(softrod_handle* h) {
     if (!h) return SOFTROD_OK;
     DeviceGuard guard_(h->device);
     (void)hipDeviceSynchronize();
-    void* qbufs[] = {h->d_queue, h->d_consumed, h->d_produced, h->d_underflow, h->d_flags};
-    for (void* p : qbufs) (void)hipFree(p);
-    if (h->h_queue) (void)hipHostFree(h->h_queue);
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
-    if (h->h_where) (void)hipHostFree(h->h_where);
-    if (h->h_status) (void)hipHostFree(h->h_status);
-    (void)hipFree(h->d_stage);
-    (void)hipFree(h->d_where);
-    if (h->ev_status) (void)hipEventDestroy(h->ev_status);
-    if (h->h_produced) (void)hipHostFree(h->h_produced);
-    if (h->ev_queue) (void)hipEventDestroy(h->ev_queue);
+    autoreset_release(h);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
                     h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_time_tab, h->d_mat, h->d_sucker, h->d_basis, h->d_spline, h->d_init, h->d_mask, h->d_ticket};
     for (void* p : bufs) (void)hipFree(p);

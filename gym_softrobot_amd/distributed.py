@@ -47,11 +47,19 @@ while a 4 us kernel in order behind the step kernel costs its 4 us.  Correct by 
     stale read of an earlier round fails it, and on any failure — on any rank, at any point of the
     set-up, which every rank walks through to the end — ALL ranks stay with the collective.
 Completion contract of "p2p" (differs from "rccl"): the rows `step` returns are complete only after
-`sync()`, which all ranks must call at the same step indices (SPMD).  Buffer k is written again
-`depth` steps later by every rank, and a peer that has passed the barrier may launch that step: read
-the rows of step t on the env's stream (or finish reading) before calling the next `sync()`, and sync
-at least every `depth - 1` steps if the rows of every step are wanted.  RCCL stays the default, as
-BASELINE's north_star asks; `bench.py --transport p2p` measures the other.
+`sync()`, which all ranks must call at the same step indices (SPMD).  Buffer k = t mod `depth` is written
+again by every rank at step t + depth, and a peer that has passed the barrier of a `sync()` runs ahead up to
+its next `sync()`.  With a `sync()` every s steps, after the one at step T the peers may already be writing
+steps T+1 .. T+s while this rank reads:
+  * the rows of the LATEST step only (step T) stay intact if s <= depth - 1;
+  * the rows of EVERY step since the previous sync (T-s+1 .. T) stay intact only if 2 s <= depth
+    (`p2p_sync_interval()`; the default depth of 2 means: sync after every step).
+`step` counts the steps since the last `sync()` and raises `P2PError` beyond floor(depth / 2) unless
+`p2p_enforce_sync_interval` is set to False by a caller that reads nothing between syncs (`bench.py`'s
+timed windows read the last step's rows once, after the closing sync).  `sync()` checks the generation
+words of EVERY step launched since the previous sync whose buffer has not been reused since.  Read the rows
+on the env's stream (or finish reading) before the next `sync()`.  RCCL stays the default, as BASELINE's
+north_star asks; `bench.py --transport p2p` measures the other.
 """
 from __future__ import annotations
 
@@ -81,8 +89,16 @@ def init_process_group(backend: str = "nccl", device: Optional[torch.device] = N
                 opts.is_high_priority_stream = True
                 dist.init_process_group(backend, pg_options=opts, **kw)
                 return
-            except TypeError as exc:      # a torch build whose init_process_group takes no pg_options
-                warnings.warn(f"RCCL group at normal stream priority ({exc})", RuntimeWarning, stacklevel=2)
+            except Exception as exc:  # noqa: BLE001 - ANY failure of the options path (a torch build without
+                # pg_options, an Options object the backend refuses, ...) must not abort the job: the
+                # priority is an optimisation (+15 us per step instead of +30), the group is not
+                warnings.warn(f"RCCL group at normal stream priority: the high-priority path failed with {exc!r}",
+                              RuntimeWarning, stacklevel=2)
+                if dist.is_initialized():      # a half-made default group would make the retry fail
+                    try:
+                        dist.destroy_process_group()
+                    except Exception:  # noqa: BLE001
+                        pass
     dist.init_process_group(backend, **kw)
 
 
@@ -276,6 +292,8 @@ class ShardedVecEnv:
             self._gen = 0                      # generation of the next step
             self._gen_of = [None] * depth      # generation last written into buffer k
             self._last_k = None
+            self._since_sync = []              # buffers written since the last sync(), oldest first
+            self.p2p_enforce_sync_interval = True
             self._verify = os.environ.get("SOFTROD_P2P_VERIFY", "1") != "0"
             self.transport = "p2p"
             self.exchange_memory = ex["kind"]
@@ -284,18 +302,33 @@ class ShardedVecEnv:
             self._release_exchange(ex)
 
     def _release_exchange(self, ex) -> None:
+        """Three phases: every rank unmaps the peers' buffers; all ranks meet; only then does anybody free
+        its own (freeing exported memory a peer still has mapped — or is still storing self-test rows
+        into — is undefined behaviour for HIP IPC).  Every rank calls this at the same point of the
+        set-up / of close(), so the meeting is a collective every rank reaches."""
         be = self.local.backend
         for q in ex.get("opened", []):
             try:
                 be.exchange_close(q)
             except Exception:  # noqa: BLE001
                 pass
+        ex["opened"] = []
+        try:
+            torch.cuda.current_stream(be.device).synchronize()       # this rank's own stores into peers have drained
+        except Exception:  # noqa: BLE001
+            pass
+        if dist.is_initialized() and self.world > 1:
+            try:
+                dist.barrier(group=self.group)
+            except Exception as exc:  # noqa: BLE001 - a dead group: the processes are going down anyway
+                warnings.warn(f"p2p release: barrier failed ({exc!r}); freeing the exchange buffers regardless",
+                              RuntimeWarning, stacklevel=2)
         for ptr in ex.get("ptrs", []):
             try:
                 be.exchange_free(ptr)
             except Exception:  # noqa: BLE001
                 pass
-        ex["tensors"], ex["ptrs"], ex["opened"] = [], [], []
+        ex["tensors"], ex["ptrs"] = [], []
 
     def _all_gather(self, packed: torch.Tensor) -> torch.Tensor:
         if self.transport == "p2p":            # resets: through the group, into ordinary memory
@@ -345,6 +378,10 @@ class ShardedVecEnv:
             self._works[k].wait()
         packed, info = self.local.step_packed(a, self._packed2[k])
         if self.transport == "p2p":
+            if self.p2p_enforce_sync_interval and len(self._since_sync) >= self.p2p_sync_interval():
+                raise P2PError(f"transport p2p with {len(self._works)} buffer sets: sync() at least every "
+                               f"{self.p2p_sync_interval()} step(s), or a peer overwrites rows this rank has not "
+                               "read yet (set p2p_enforce_sync_interval = False only if nothing is read between syncs)")
             # in order behind the step kernel, on its stream: a few microseconds, no dependency to
             # resolve; the generation word of this rank follows the rows into every peer's buffer
             self._gen = (self._gen + 1) & 0x7FFFFFFF
@@ -352,16 +389,25 @@ class ShardedVecEnv:
                                             self._rows_words + self.rank, self._gen)
             self._gen_of[k] = self._gen
             self._last_k = k
+            self._since_sync = [b for b in self._since_sync if b != k] + [k]     # a reused buffer holds the newer step only
         else:
             self._works[k] = dist.all_gather_into_tensor(self._global2[k], packed, group=self.group, async_op=True)
         self._k = (k + 1) % len(self._works)
         o, r, te, tr = unpack_outputs(self._global2[k], self.obs_dim)
         return o, r, te, tr, info
 
+    def p2p_sync_interval(self, every_step: bool = True) -> int:
+        """Largest number of steps between two sync() calls that keeps rows intact under transport
+        "p2p": those of every step since the previous sync (2 s <= depth), or of the latest step only
+        (s <= depth - 1).  See the module docstring."""
+        depth = len(self._works) if self.overlap else 1
+        return max(1, depth // 2) if every_step else max(1, depth - 1)
+
     def sync(self) -> None:
         """Make the outputs of the latest step() complete (overlap=True).  transport "p2p": a stream
         synchronise, a barrier of the group (all ranks call sync() at the same step indices) and a
-        check of the latest step's generation words from every rank."""
+        check of the generation words, from every rank, of every step launched since the previous
+        sync() whose buffer has not been reused since."""
         if self.overlap:
             for w in self._works:
                 if w is not None:
@@ -369,20 +415,24 @@ class ShardedVecEnv:
             if self.transport == "p2p":
                 torch.cuda.current_stream(self.local.backend.device).synchronize()
                 dist.barrier(group=self.group)     # this rank's rows have landed everywhere; now everybody's have
-                if self._verify and self._last_k is not None:
-                    tags = self._tags[self._last_k].cpu()
-                    want = self._gen_of[self._last_k]
-                    if not bool((tags == want).all()):
-                        raise P2PError(f"rank {self.rank}: generation words {tags.tolist()} of the latest step, "
-                                       f"expected {want} from every rank (ranks out of step, or a stale read)")
+                written, self._since_sync = self._since_sync, []
+                if self._verify:
+                    for k in written:
+                        tags = self._tags[k].cpu()
+                        want = self._gen_of[k]
+                        if not bool((tags == want).all()):
+                            raise P2PError(f"rank {self.rank}: generation words {tags.tolist()} in buffer {k}, "
+                                           f"expected {want} from every rank (ranks out of step, or a stale read)")
 
     def close(self):
-        self.sync()
-        if self._exchange is not None:
-            if dist.is_initialized():
-                dist.barrier(group=self.group)     # nobody unmaps a buffer a peer may still write
-            ex, self._exchange = self._exchange, None
-            self._global2 = self._tags = None
-            self._global = None
-            self._release_exchange(ex)
-        self.local.close()
+        try:
+            self.sync()
+        finally:       # a P2PError out of the last sync must not leak the exchange buffers or the local env
+            try:
+                if self._exchange is not None:
+                    ex, self._exchange = self._exchange, None
+                    self._global2 = self._tags = None
+                    self._global = None
+                    self._release_exchange(ex)     # unmap, meet, free
+            finally:
+                self.local.close()

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 14
+#define SOFTROD_ABI_VERSION 15
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -473,7 +473,9 @@ int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream);
  * tag_word >= 0: once ALL rows of this call have been acknowledged, 32-bit word `tag_word` of every
  * peer buffer receives `tag` (system-scope release): the generation word of this rank in the
  * receivers' buffers (distributed.py keeps `world` of them behind the rows and checks them in
- * sync()).  tag_word < 0: rows only.                                                            */
+ * sync()).  tag_word < 0: rows only.  The tagged form counts arrivals in ONE per-handle word
+ * (allocated and zeroed in softrod_create): tagged scatters of one handle must be stream-ordered
+ * with each other — two in flight on different streams would corrupt each other's tag.         */
 #define SOFTROD_MAX_PEERS 16
 int softrod_scatter_rows(softrod_handle* h, const float* packed, const uint64_t* peer_buffers,
                          int n_peers, int row_words, int64_t first_row, int64_t tag_word,
@@ -523,6 +525,16 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out);
 int softrod_set_timing(softrod_handle* h, int n_launches);
 int softrod_kernel_times_ms(softrod_handle* h, float* out_ms, int cap, int* count);
 int softrod_last_kernel_ms(softrod_handle* h, float* ms);
+
+/* Which step-kernel tier softrod_step launches for this handle, as a short stable string: the
+ * kernel template's name, its specialisation and the workgroup shape, e.g.
+ * "softrod_step_fast_kernel<SoftPendulum,epl=1> planar" or "softrod_octo_step_kernel<zup,2 waves,4 envs/wg>".
+ * The tier follows from softrod_config alone.  The A/B switches of the measurement builds
+ * (SOFTROD_OCTO_ONE_WAVE, SOFTROD_OCTO_ONE_ENV_PER_BLOCK, SOFTROD_NO_WINDOW, SOFTROD_WINDOW_PAIRED,
+ * SOFTROD_WINDOW_REFRESH) are honoured by softrod_create ONLY when SOFTROD_DEBUG_SWITCHES=1 is set as
+ * well, so a stray variable cannot change what a product process runs; this call is how a host (and
+ * tests/test_gpu_debug_switches.py) sees the outcome.  No reference counterpart (ABI v15).        */
+const char* softrod_kernel_tier(softrod_handle* h);
 
 const char* softrod_last_error(softrod_handle* h);
 int softrod_destroy(softrod_handle* h);

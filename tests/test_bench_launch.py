@@ -30,6 +30,14 @@ def _json_lines(out):
     return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
 
 
+def _p2p_trial(stderr):
+    """The trial's figures: written to stderr AFTER rank 0 printed the line (bench.py)."""
+    tag = "bench.py: p2p_trial: "
+    hits = [l[len(tag):] for l in stderr.splitlines() if l.startswith(tag)]
+    assert len(hits) == 1, stderr[-2000:]
+    return json.loads(hits[0])
+
+
 def test_single_process_line_has_the_contract_fields(oracle_built):
     p = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--envs-per-gpu", "4", "--no-cpu-baseline"])
     assert p.returncode == 0, p.stderr[-2000:]
@@ -82,6 +90,7 @@ def _eight_vs_one(extra_args, per_rank_envs, extra_env=None, strong=False):
              extra_env, timeout=600)
     assert q.returncode == 0, q.stderr[-2000:]
     (one,) = _json_lines(q.stdout)
+    line["_stderr"] = p.stderr
     assert line["n_gpus"] == 8 and line["config"]["envs_total"] == total == one["config"]["envs_total"]
     # the rows of all 8 ranks reached rank 0 and are what one process stepping the whole batch returns
     assert line["config"]["last_step_checksum"] == one["config"]["last_step_checksum"]
@@ -99,10 +108,11 @@ def test_gpus_8_softpendulum_weak_scaling_with_the_p2p_trial(oracle_built):
     """BASELINE configs[3]'s shape: `python bench.py --gpus 8 ...` exactly as the driver runs it.  The
     default transport is measured, then every rank's child runs the job again over transport p2p —
     which on a box without a GPU falls back to the collective on every rank, says so, and returns the
-    same rows."""
+    same rows.  The trial runs AFTER the line is out, bounded, in children that die with their parents."""
     line, one = _eight_vs_one([], 2)
     assert line["scaling"] == "weak" and line["config"]["transport"] == "rccl"
-    t = line["p2p_trial"]
+    assert "p2p_trial" not in line            # the headline is printed BEFORE the experimental transport runs
+    t = _p2p_trial(line["_stderr"])
     assert t["returncode"] == 0 and t["transport"] == "rccl" and t["transport_fallback_reason"]
     assert t["last_step_checksum"] == line["config"]["last_step_checksum"]
     assert len(t["per_rank"]["ranks"]) == 8
@@ -110,7 +120,7 @@ def test_gpus_8_softpendulum_weak_scaling_with_the_p2p_trial(oracle_built):
 
 def test_gpus_8_strong_scaling(oracle_built):
     line, _ = _eight_vs_one(["--scaling", "strong", "--no-p2p-trial"], 2, strong=True)
-    assert line["scaling"] == "strong" and "p2p_trial" not in line
+    assert line["scaling"] == "strong" and "bench.py: p2p_trial:" not in line["_stderr"]
 
 
 def test_gpus_8_octoflat(oracle_built):

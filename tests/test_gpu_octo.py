@@ -117,9 +117,12 @@ def test_octo_one_wave_variant_matches_oracle_and_the_two_wave_kernel(torch_gpu,
     cfg = _capi.octo_flat_config(n)
     cfg.n_substeps = n_sub
     two = HipRodBackend(cfg, device=0)
+    monkeypatch.setenv("SOFTROD_DEBUG_SWITCHES", "1")      # the A/B switches count only with this one
     monkeypatch.setenv("SOFTROD_OCTO_ONE_WAVE", "1")       # read once, in softrod_create
     one = HipRodBackend(cfg, device=0)
     monkeypatch.delenv("SOFTROD_OCTO_ONE_WAVE")
+    monkeypatch.delenv("SOFTROD_DEBUG_SWITCHES")
+    assert "octo1w" in one.kernel_tier() and "2 waves,4 envs/wg" in two.kernel_tier()
     tg = _targets(n, 11)
     oracles = []
     for be in (one, two):

@@ -1012,9 +1012,11 @@ def test_two_window_kernel_for_long_arms(torch_gpu, hip_lib, oracle_built, n_ele
         r.reset_arm()
     outs = {}
     for name, env in (("window", {}), ("barrier", {"SOFTROD_WINDOW_PAIRED": "0"}), ("two-slot", {"SOFTROD_NO_WINDOW": "1"})):
+        monkeypatch.setenv("SOFTROD_DEBUG_SWITCHES", "1")      # the A/B switches count only with this one
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         be = HipRodBackend(cfg, 0)
+        assert ("window" in be.kernel_tier()) == (name != "two-slot"), be.kernel_tier()
         be.reset_straight(np.zeros((n, 3)), np.tile([1.0, 0, 0], (n, 1)), np.tile([0, 0, 1.0], (n, 1)))
         be.observe(None)
         res = []
@@ -1025,6 +1027,7 @@ def test_two_window_kernel_for_long_arms(torch_gpu, hip_lib, oracle_built, n_ele
         be.close()
         for k in env:
             monkeypatch.delenv(k)
+        monkeypatch.delenv("SOFTROD_DEBUG_SWITCHES")
     for t in range(2):
         for i, r in enumerate(rods):
             o, rw, te, tr = r.env_step_arm(acts[t, i])

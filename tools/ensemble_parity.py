@@ -1,0 +1,450 @@
+#!/usr/bin/env python3
+"""Ensemble (statistical) parity for the regimes where trajectory parity is impossible.
+
+    python tools/ensemble_parity.py > profiles/parity_ensemble.json        (on the MI355X box)
+
+Two regimes leave rtol 1e-5 along a trajectory for ANY two correct evaluations of the same
+algorithm: OctoFlat-v0 over whole 2857-substep env.steps (the friction law's
+stick / slip switches amplify the last bit), and the stabilised inverted SoftPendulum-v0 past
+step ~107 (unstable equilibrium, e^{3.8 t}).  What an RL user consumes there is not one
+trajectory but the distribution over many envs, so that is what is compared here:
+
+  A  the fp64 C oracle (oracle/softrod_oracle.c, -ffp-contract=off)           -- the reference side
+  B  the CONTROL: the same source built with FMA contraction                  -- a second correct rounding
+  H  the HIP library through the C-ABI (gym_softrobot_amd.make_vec)           -- the product
+
+All three step the SAME envs (same seeds / targets, same action script; the closed-loop pendulum
+scenario lets each implementation feed its OWN observations back through the PD law, as a policy
+would).  Per env.step and per statistic two things are recorded for H-vs-A and B-vs-A:
+
+  * the two-sample Kolmogorov-Smirnov distance of the marginal distributions over envs
+    (flat_env.py:315-408 outputs: reward, head displacement, arm-crossing count, the largest
+    |omega| of any arm element, distance to the target, fraction terminated;
+    soft_pendulum.py:196-251 outputs: x0, v0, theta, reward, fraction terminated; plus the largest
+    |omega| and the largest element stretch of the rod), and
+  * quantiles of the PAIRED divergence |s_H[i] - s_A[i]| (and |s_B[i] - s_A[i]|): how fast the
+    product leaves the oracle's trajectory, next to how fast another rounding of the oracle does.
+
+tests/test_gpu_ensemble_parity.py asserts the bands stated in BANDS below on exactly this record.
+Follows the 3-step shape of /root/reference/tests/envs/test_determinism.py:46-54, on a population.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+from oracle import oracle_c  # noqa: E402
+
+QS = (0.5, 0.9, 0.99)
+
+# The asserted bands (tests/test_gpu_ensemble_parity.py).  Calibrated on the control B-vs-A, run the
+# same way in the same process: see DESIGN.md §3 "Ensemble parity".
+BANDS = {
+    # marginal distributions: two-sample KS distance below the alpha = 0.001 critical value
+    # c(alpha) * sqrt(2 / n), c = 1.95 (the samples are paired, so this is generous by construction;
+    # the achieved distances are recorded)
+    "ks_c_alpha": 1.95,
+    # paired divergence: every recorded quantile of |H - A| within `factor` x the same quantile of
+    # |B - A| or the statistic's absolute floor, whichever is larger.  Achieved (profiles/
+    # parity_ensemble.json, `headline.worst_paired_ratio`): OctoFlat <= 2.4 over all steps, statistics
+    # and quantiles; the inverted pendulum ~2 in the median and <= 10 in the worst 99 % quantile — its
+    # e^{3.8 t} growth turns the fast-math kernel's slightly larger rounding differences (reciprocal
+    # square roots, the planar specialisation's dropped exact zeros) into a head start of a few steps
+    "paired_factor": {"OctoFlat-v0": 4.0, "SoftPendulum-v0": 16.0},
+    # ensemble means: |mean_H - mean_A| <= `mean_sigmas` standard errors of the oracle ensemble
+    "mean_sigmas": 0.5,
+}
+
+
+def workers() -> int:
+    return max(1, len(os.sched_getaffinity(0)))
+
+
+def pmap(fn, items):
+    """ctypes releases the GIL inside the oracle calls: plain threads spread the envs over the cores."""
+    with ThreadPoolExecutor(workers()) as ex:
+        return list(ex.map(fn, items))
+
+
+def ks_distance(a, b) -> float:
+    a, b = np.sort(np.asarray(a, np.float64)), np.sort(np.asarray(b, np.float64))
+    allv = np.concatenate([a, b])
+    ca = np.searchsorted(a, allv, side="right") / a.size
+    cb = np.searchsorted(b, allv, side="right") / b.size
+    return float(np.max(np.abs(ca - cb)))
+
+
+def compare(stat_a, stat_x, keep=None):
+    """One statistic, one env.step: KS distance of the marginals, paired-divergence quantiles, means —
+    over the envs in `keep` (those whose integration has not blown up on either side)."""
+    a, x = np.asarray(stat_a, np.float64), np.asarray(stat_x, np.float64)
+    ok = np.isfinite(a) & np.isfinite(x)
+    if keep is not None:
+        ok &= keep
+    d = np.abs(a[ok] - x[ok]) if ok.any() else np.zeros(1)
+    return {"ks": ks_distance(a[ok], x[ok]) if ok.any() else 0.0,
+            "paired_q": [float(np.quantile(d, q)) for q in QS],
+            "paired_max": float(d.max()),
+            "mean": float(x[ok].mean()) if ok.any() else float("nan"),
+            "mean_ref": float(a[ok].mean()) if ok.any() else float("nan"),
+            "std_ref": float(a[ok].std()) if ok.any() else float("nan"),
+            "envs_compared": int(ok.sum()),
+            "nonfinite": [int((~np.isfinite(a)).sum()), int((~np.isfinite(x)).sum())]}
+
+
+BLOWN_OMEGA = 1.0e4     # rad/s: |omega| dt / 2 > 0.5 rad per half step at dt = 1e-4 — the explicit integrator has lost the
+                        # rod (healthy OctoFlat ensembles stay below 3e2); such a rod reaches NaN within a few env.steps
+BLOWN_STRETCH = 3.0     # longest element / rest length: healthy pendulum ensembles stay below 1.8 (q99 1.4), a lost rod
+                        # shows 4 .. 70 for a few env.steps and then NaN
+BLOWN_LAG = 3           # env.steps within which the other implementation must have lost the same rod
+
+
+def blown_mask(impl_series):
+    """[T, n] bool: the env's integration has blown up at or before step t (non-finite output, or an
+    angular rate no time step of this size can follow).  Sticky: a lost rod stays lost."""
+    w = impl_series["omega_max"]
+    bad = ~np.isfinite(w) | (w > BLOWN_OMEGA)
+    if "stretch_max" in impl_series:
+        bad |= ~(impl_series["stretch_max"] <= BLOWN_STRETCH)
+    for k, v in impl_series.items():
+        if not k.startswith("_"):
+            bad |= ~np.isfinite(v) & (k != "crossings")     # crossings are NaN by construction once terminated
+    return np.maximum.accumulate(bad, axis=0)
+
+
+def blowup_record(blown_a, blown_x, term_a, term_x):
+    """Blow-up is an EVENT of the env (the explicit integrator loses the rod when it whips), the step on
+    which the first NaN then appears is an accident of rounding.  Per step: how many envs each side has
+    lost, how many it reports terminated, and whether every env lost (or reported NaN) by one side is lost
+    by the other within BLOWN_LAG steps."""
+    T = blown_a.shape[0]
+    rows = []
+    for t in range(T):
+        hi = min(T - 1, t + BLOWN_LAG)
+        final = t + BLOWN_LAG > T - 1           # the horizon ends inside the lag: inclusion cannot be decided
+        miss_x = np.nonzero(blown_a[t] & ~blown_x[hi])[0]
+        miss_a = np.nonzero(blown_x[t] & ~blown_a[hi])[0]
+        nan_not_lost = np.nonzero((term_x[t] > 0) & ~blown_a[hi])[0]
+        rows.append({"step": t + 1, "lost_ref": int(blown_a[t].sum()), "lost": int(blown_x[t].sum()),
+                     "terminated_ref": int((term_a[t] > 0).sum()), "terminated": int((term_x[t] > 0).sum()),
+                     "lost_by_ref_only_after_lag": [] if final else miss_x.tolist(),
+                     "lost_by_this_only_after_lag": [] if final else miss_a.tolist(),
+                     "terminated_here_but_healthy_in_ref_after_lag": [] if final else nan_not_lost.tolist()})
+    return rows
+
+
+def summarise(series, n):
+    """series[impl][stat] -> array [T, n].  Returns per statistic and step the H-vs-A and B-vs-A records
+    (on the envs neither side has lost), and the blow-up records."""
+    out = {}
+    blown = {k: blown_mask(v) for k, v in series.items()}
+    for stat in series["A"]:
+        rows = []
+        T = len(series["A"][stat])
+        for t in range(T):
+            row = {"step": t + 1}
+            for impl, key in (("H", "hip"), ("B", "control")):
+                if impl in series:
+                    row[key] = compare(series["A"][stat][t], series[impl][stat][t], ~blown["A"][t] & ~blown[impl][t])
+            rows.append(row)
+        out[stat] = rows
+    blow = {key: blowup_record(blown["A"], blown[impl], series["A"]["terminated"], series[impl]["terminated"])
+            for impl, key in (("H", "hip"), ("B", "control")) if impl in series}
+    return out, blow
+
+
+# ------------------------------------------------------------------------------------ OctoFlat-v0
+
+OCTO_STATS = ("reward", "head_displacement", "crossings", "omega_max", "target_distance", "terminated")
+
+
+def _octo_record(rec, rew, head_xy, head0, cross, wmax, target, term):
+    rec["reward"].append(np.asarray(rew, np.float64))
+    rec["head_displacement"].append(np.linalg.norm(head_xy - head0, axis=1))
+    rec["crossings"].append(np.asarray(cross, np.float64))
+    rec["omega_max"].append(np.asarray(wmax, np.float64))
+    rec["target_distance"].append(np.linalg.norm(target - head_xy, axis=1))
+    rec["terminated"].append(np.asarray(term, np.float64))
+
+
+def octo_oracle(cfg, targets, acts, variant):
+    """A (variant=False) or B ("fma"): n OracleOcto envs for T whole env.steps, threads over envs."""
+    T, n = acts.shape[:2]
+    envs = [oracle_c.OracleOcto(cfg, variant=variant) for _ in range(n)]
+    for o, tg in zip(envs, targets):
+        o.reset(tg)
+    head0 = np.stack([o.head()["x"][:2].copy() for o in envs])
+    rec = {k: [] for k in OCTO_STATS}
+
+    def one(args):
+        i, t = args
+        o = envs[i]
+        _, rw, te, _ = o.env_step(acts[t, i])
+        w = max(float(np.max(np.linalg.norm(o.arm(a).get("w"), axis=0))) for a in range(o.n_arm))
+        return rw, o.head()["x"][:2].copy(), o.crossings(), w, te
+
+    for t in range(T):
+        res = pmap(one, [(i, t) for i in range(n)])
+        _octo_record(rec, [r[0] for r in res], np.stack([r[1] for r in res]), head0, [r[2] for r in res],
+                     [r[3] for r in res], targets, [r[4] for r in res])
+    return {k: np.stack(v) for k, v in rec.items()}
+
+
+def octo_hip(n, acts, seed, math_mode=None):
+    """H: the product path.  The crossing count is recovered from the reward the kernel wrote
+    (flat_env.py:347-367: reward = forward + survive, survive = -0.02 * crossings unless the head is
+    within 0.1 of the target), forward recomputed from the head positions."""
+    import gym_softrobot_amd as gsa
+
+    kw = {} if math_mode is None else {"math_mode": math_mode}
+    env = gsa.make_vec("OctoFlat-v0", n, device=0, numpy_output=True, **kw)
+    env.reset(seed=seed)
+    targets = env.targets.copy()
+    st = env.backend.octo_state_numpy()
+    head0 = st["head_x"][:, :2].copy()
+    before = head0.copy()
+    rec = {k: [] for k in OCTO_STATS}
+    dt_step = float(env.cfg.n_substeps) * float(env.cfg.dt)
+    for t in range(acts.shape[0]):
+        _, rew, term, _, _ = env.step(acts[t])
+        st = env.backend.octo_state_numpy()
+        xy = st["head_x"][:, :2].copy()
+        dist = np.linalg.norm(targets - xy, axis=1)
+        forward = (dist - np.linalg.norm(targets - before, axis=1)) / dt_step
+        survive = np.asarray(rew, np.float64) - forward
+        cross = np.where(np.asarray(term, bool), np.nan, np.rint(-survive / 0.02))
+        wmax = np.linalg.norm(st["w"], axis=2).max(axis=(1, 2))
+        _octo_record(rec, rew, xy, head0, cross, wmax, targets, term)
+        before = xy
+    cfg = env.cfg.copy()
+    env.close()
+    return {k: np.stack(v) for k, v in rec.items()}, targets, cfg
+
+
+def run_octo(n=256, steps=6, amax=22.0, seed=0, with_hip=True, with_control=True, cfg=None, targets=None):
+    acts = np.random.default_rng(1234).uniform(-amax, amax, (steps, n, 24)).astype(np.float32)
+    series = {}
+    if with_hip:
+        series["H"], targets, cfg = octo_hip(n, acts, seed)
+    series["A"] = octo_oracle(cfg, targets, acts, False)
+    if with_control:
+        oracle_c.build_fma()
+        series["B"] = octo_oracle(cfg, targets, acts, "fma")
+    stats, blow = summarise(series, n)
+    return {"env": "OctoFlat-v0", "envs": n, "steps": steps, "substeps_per_step": int(cfg.n_substeps),
+            "action_amplitude": amax, "stats": stats, "blowup": blow}, series
+
+
+# -------------------------------------------------------------------------------- SoftPendulum-v0
+
+PEND_STATS = ("x0", "v0", "theta", "reward", "omega_max", "stretch_max", "terminated")
+
+
+def pd_law(obs, prev_th):
+    """The stabilising script of tools/episode_parity.py: keeps the inverted pendulum near its
+    unstable equilibrium."""
+    x, v, th = (obs[:, k].astype(np.float64) for k in (0, 1, 3))
+    dth = np.zeros_like(th) if prev_th is None else (th - prev_th) / 0.04
+    a = np.clip(100.0 * th + 20.0 * dth + 10.0 * x + 8.0 * v, -22, 22).astype(np.float32)
+    return a[:, None], th.copy()
+
+
+class _ThreadedBatch:
+    """n pendulum rods of one oracle build, stepped in chunks on plain threads."""
+
+    def __init__(self, cfg, n, variant, seed):
+        from gym_softrobot_amd.seeding import initial_angle, np_random
+
+        nw = min(workers(), n)
+        bounds = np.linspace(0, n, nw + 1).astype(int)
+        self.chunks = []
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            b = oracle_c.OracleBatch(cfg, int(hi - lo), omp=variant)
+            b.reset([initial_angle(np_random(seed + i)[0]) for i in range(lo, hi)])
+            self.chunks.append((int(lo), int(hi), b))
+        self.n = n
+
+    def observe(self):
+        return np.concatenate([np.stack([r.observe() for r in b.rods]) for _, _, b in self.chunks])
+
+    def extremes(self):
+        """Per rod: the largest |omega| of elements 1.. (element 0's director is only partly constrained,
+        build.py:71-74 leaves row 1 alone, and its rate is 1e4 rad/s in a healthy rod) and the longest
+        element over its rest length."""
+        rods = [r for _, _, b in self.chunks for r in b.rods]
+        with np.errstate(invalid="ignore"):
+            w = np.array([np.max(np.linalg.norm(r.get("w")[:, 1:], axis=0)) for r in rods])
+            s = np.array([np.max(np.linalg.norm(np.diff(r.get("x"), axis=1), axis=0) / r.get("rest_lengths")) for r in rods])
+        return w, s
+
+    def env_step(self, actions):
+        res = pmap(lambda c: c[2].env_step(actions[c[0]:c[1]]), self.chunks)
+        return tuple(np.concatenate([r[k] for r in res]) for k in range(4))
+
+
+def _pend_record(rec, obs, rew, term, wmax, smax):
+    rec["omega_max"].append(np.asarray(wmax, np.float64))
+    rec["stretch_max"].append(np.asarray(smax, np.float64))
+    rec["x0"].append(obs[:, 0].astype(np.float64))
+    rec["v0"].append(obs[:, 1].astype(np.float64))
+    rec["theta"].append(obs[:, 3].astype(np.float64))
+    rec["reward"].append(np.asarray(rew, np.float64))
+    rec["terminated"].append(np.asarray(term, np.float64))
+
+
+def run_pendulum(n=512, steps=126, closed_loop=True, seed=0, with_hip=True, with_control=True, cfg=None, math_mode=None):
+    """closed_loop: every implementation feeds its OWN observation through the PD law (what a policy
+    does).  Open loop: the law runs on A's observations and all three get A's actions (the
+    scenario of tests/test_gpu_episode_parity.py, whose control leaves 1e-5 after 107 steps)."""
+    impls = {}
+    env = None
+    if with_hip:
+        import gym_softrobot_amd as gsa
+
+        kw = {} if math_mode is None else {"math_mode": math_mode}
+        env = gsa.make_vec("SoftPendulum-v0", n, device=0, numpy_output=True, **kw)
+        obs_h, _ = env.reset(seed=seed)
+        cfg = env.cfg.copy()
+        impls["H"] = {"obs": np.asarray(obs_h).copy(), "prev": None}
+    a_batch = _ThreadedBatch(cfg, n, False, seed)
+    impls["A"] = {"obs": a_batch.observe(), "prev": None, "batch": a_batch}
+    if with_control:
+        oracle_c.build_fma()
+        b_batch = _ThreadedBatch(cfg, n, "fma", seed)
+        impls["B"] = {"obs": b_batch.observe(), "prev": None, "batch": b_batch}
+    series = {k: {s: [] for s in PEND_STATS} for k in impls}
+    rest_len = float(cfg.base_length) / int(cfg.n_elem)
+    for t in range(steps):
+        act_a, th_a = pd_law(impls["A"]["obs"], impls["A"]["prev"])
+        for k, im in impls.items():
+            if closed_loop:
+                act, im["prev"] = pd_law(im["obs"], im["prev"])
+            else:
+                act, im["prev"] = act_a, th_a
+            if k == "H":
+                obs, rew, term, _, _ = env.step(act)
+                obs, rew, term = np.asarray(obs).copy(), np.asarray(rew).copy(), np.asarray(term).copy()
+                st = env.backend.state_numpy()
+                with np.errstate(invalid="ignore"):
+                    wmax = np.linalg.norm(st["w"][:, :, 1:], axis=1).max(axis=1)
+                    smax = (np.linalg.norm(np.diff(st["x"], axis=2), axis=1) / rest_len).max(axis=1)
+            else:
+                obs, rew, term, _ = im["batch"].env_step(act)
+                wmax, smax = im["batch"].extremes()
+            im["obs"] = obs
+            _pend_record(series[k], obs, rew, term, wmax, smax)
+    if env is not None:
+        env.close()
+    series = {k: {s: np.stack(v) for s, v in d.items()} for k, d in series.items()}
+    stats, blow = summarise(series, n)
+    return {"env": "SoftPendulum-v0", "envs": n, "steps": steps, "closed_loop": bool(closed_loop),
+            "math_mode": "default (fast)" if math_mode is None else int(math_mode), "stats": stats, "blowup": blow}, series
+
+
+# ---------------------------------------------------------------------------------------- verdict
+
+FLOORS = {   # absolute floors of the paired band, per statistic (units of the statistic)
+    "reward": 1e-6, "head_displacement": 1e-8, "omega_max": 1e-6, "target_distance": 1e-8, "terminated": 0.0,
+    "crossings": 1.0,                           # an integer: one crossing
+    "stretch_max": 1e-7,
+    "x0": 5e-7, "v0": 5e-6, "theta": 5e-7,      # float32 observations: a few ulps of their scale
+}
+
+
+def check(doc, bands=BANDS, need_hip=True):
+    """Returns the list of band violations of one scenario record (empty = green)."""
+    bad = []
+    for stat, rows in doc["stats"].items():
+        for row in rows:
+            if "hip" not in row:
+                if need_hip:
+                    bad.append(f"{stat} step {row['step']}: no HIP record")
+                continue
+            h, c = row["hip"], row.get("control")
+            n = max(1, h["envs_compared"])
+            ks_crit = bands["ks_c_alpha"] * np.sqrt(2.0 / n)
+            if h["ks"] > ks_crit:
+                bad.append(f"{stat} step {row['step']}: KS {h['ks']:.4f} > {ks_crit:.4f}")
+            se = h["std_ref"] / np.sqrt(n)
+            if abs(h["mean"] - h["mean_ref"]) > bands["mean_sigmas"] * se + FLOORS[stat]:
+                bad.append(f"{stat} step {row['step']}: mean {h['mean']:.6g} vs {h['mean_ref']:.6g} (se {se:.3g})")
+            if c is not None:
+                factor = bands["paired_factor"][doc["env"]]
+                for q, hq, cq in zip(QS, h["paired_q"], c["paired_q"]):
+                    if hq > max(factor * cq, FLOORS[stat]):
+                        bad.append(f"{stat} step {row['step']}: paired q{q} {hq:.3e} vs control {cq:.3e}")
+    # blow-up events: the same envs are lost, within BLOWN_LAG steps; no env is reported NaN while the oracle
+    # still integrates it healthily BLOWN_LAG steps later; the lost fraction stays within the band
+    for row in (doc.get("blowup") or {}).get("hip", []):
+        for key in ("lost_by_ref_only_after_lag", "lost_by_this_only_after_lag", "terminated_here_but_healthy_in_ref_after_lag"):
+            if row[key]:
+                bad.append(f"blow-up step {row['step']}: {key} {row[key]}")
+    return bad
+
+
+def headline(doc):
+    """Compact per-scenario figures for profiles/README.md / DESIGN.md."""
+    out = {}
+    worst = 0.0
+    for stat, rows in doc["stats"].items():
+        last = rows[-1]
+        out[stat] = {"step": last["step"]}
+        for key in ("hip", "control"):
+            if key in last:
+                out[stat][key] = {"ks_max_over_steps": max(r[key]["ks"] for r in rows),
+                                  "paired_q50_last": last[key]["paired_q"][0],
+                                  "paired_q99_last": last[key]["paired_q"][2],
+                                  "mean_last": last[key]["mean"]}
+        out[stat]["mean_ref_last"] = last["hip" if "hip" in last else "control"]["mean_ref"]
+        if "hip" in last and "control" in last:
+            ratios = [h / c for r in rows for h, c in zip(r["hip"]["paired_q"], r["control"]["paired_q"])
+                      if h > FLOORS[stat] and c > 0]
+            out[stat]["paired_ratio_hip_over_control"] = {"max": max(ratios, default=0.0),
+                                                          "median": float(np.median(ratios)) if ratios else 0.0}
+            worst = max(worst, max(ratios, default=0.0))
+    out["worst_paired_ratio"] = worst
+    n = doc["envs"]
+    out["ks_critical_value"] = BANDS["ks_c_alpha"] * float(np.sqrt(2.0 / n))
+    for key in ("hip", "control"):
+        rows = (doc.get("blowup") or {}).get(key)
+        if rows:
+            out[f"blowup_{key}_last"] = {k: rows[-1][k] for k in ("lost_ref", "lost", "terminated_ref", "terminated")}
+            out[f"blowup_{key}_same_envs_within_lag"] = not any(
+                r["lost_by_ref_only_after_lag"] or r["lost_by_this_only_after_lag"]
+                or r["terminated_here_but_healthy_in_ref_after_lag"] for r in rows)
+    return out
+
+
+def main():
+    from gym_softrobot_amd import _capi
+
+    oracle_c.build()
+    n_octo = int(os.environ.get("ENSEMBLE_OCTO_ENVS", 256))
+    t_octo = int(os.environ.get("ENSEMBLE_OCTO_STEPS", 6))
+    n_pend = int(os.environ.get("ENSEMBLE_PEND_ENVS", 512))
+    doc = {"what": __doc__.split("\n\n")[0], "library_source_hash": _capi.library_source_hash(),
+           "host_threads": workers(), "bands": BANDS, "floors": FLOORS, "quantiles": QS, "scenarios": {}}
+    for name, (rec, _) in (
+        ("OctoFlat-v0 whole steps, random +-22", run_octo(n_octo, t_octo, 22.0)),
+        ("OctoFlat-v0 whole steps, random +-5 (gentle)", run_octo(n_octo, t_octo, 5.0)),
+        ("SoftPendulum-v0 stabilised, closed loop (own observations)", run_pendulum(n_pend, 126, True)),
+        ("SoftPendulum-v0 stabilised, open loop (oracle's actions)", run_pendulum(n_pend, 126, False)),
+        ("SoftPendulum-v0 stabilised, closed loop, libm kernel (the substep as PyElastica writes it)",
+         run_pendulum(n_pend, 126, True, math_mode=_capi.MATH_LIBM)),
+    ):
+        rec["violations"] = check(rec)
+        rec["headline"] = headline(rec)
+        doc["scenarios"][name] = rec
+    print(json.dumps(doc, indent=1))
+
+
+if __name__ == "__main__":
+    main()
