@@ -588,19 +588,19 @@ SECONDARY = (
     dict(env_id="OctoFlat-v0", n_local=1024, extra={}, baseline="configs[4], one GPU's share of 8192 envs"),
     # the headline workload on the kernel that evaluates the substep literally as PyElastica writes it (libm
     # sin / cos / acos / exp, IEEE division, no planar specialisation): what the fast-math reformulations buy
-    dict(env_id="SoftPendulum-v0", n_local=ENVS_PER_GPU, extra={}, math_mode="libm",
+    dict(env_id="SoftPendulum-v0", n_local=ENVS_PER_GPU, extra={}, force_math_mode="libm",
          baseline="configs[1] in math_mode libm (the reference-literal arithmetic; not the headline)"),
 )
 
 
 def secondary_workload(gsa, _capi, torch, device, math_mode, lib_hash, env_id, n_local, extra, baseline,
-                       steps: int = 10, warmup: int = 3, **override):
+                       steps: int = 10, warmup: int = 3, force_math_mode=None):
     """`steps` timed env.steps of one more workload on the already warm clock (the headline run has
     just kept the GPU under load for ~1 s; `warmup` steps take the workload's own one-off costs)."""
     import numpy as np
 
-    if "math_mode" in override:
-        math_mode = _capi.MATH_FAST if override["math_mode"] == "fast" else _capi.MATH_LIBM
+    if force_math_mode is not None:
+        math_mode = _capi.MATH_FAST if force_math_mode == "fast" else _capi.MATH_LIBM
 
     env = gsa.make_vec(env_id, n_local, device=device, math_mode=math_mode, **extra)
     env.reset(seed=0)

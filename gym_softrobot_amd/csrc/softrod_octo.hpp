@@ -222,6 +222,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     const bool arm_ok = arm < P.n_arm;
     if constexpr (SOFTROD_OCTO_CONTACT_LDS && (F & kFeatPlaneZup) != 0) stage_contact_params(P);   // (barriers follow)
     if (tid < 2 * MAXW * 4) (&xch[0][0][0])[tid] = 0.0;   // rows of absent waves read as zero loads
+    if constexpr (EPB == 1) __syncthreads();     // the staged tables are there before any wave reads them (EPB > 1: below)
     if (EPB > 1 && tid < 2 * MAXW) (&flag_[es][0][0])[tid] = 0;
     // per-env "any thread of the env": the workgroup barrier when the env IS the workgroup; with
     // several envs per workgroup every wave takes the same barriers and the answer is per slot
@@ -294,7 +295,28 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     int parity = 0;
     int posted = 0;          // EPB > 1: substeps whose joint loads this wave has posted per buffer pair
 
+    // SOFTROD_OCTO_DIAG (diagnostic builds of tools/octo_budget.sh / octo_ab.sh ONLY; results are wrong with any
+    // bit set): 1 = no joint evaluation (zero loads are posted), 2 = no head step, 4 = no exchange (no rendezvous,
+    // no LDS reads), 8 = no in-wave reduction (lane 0 posts its own arm's load).  The instruction budget of the
+    // substep is the difference of their hot-path counts (tools/hot_path_isa.py), the cost of a block in time the
+    // difference of their timings (profiles/README.md r5).
+#ifndef SOFTROD_OCTO_DIAG
+#define SOFTROD_OCTO_DIAG 0
+#endif
+// SOFTROD_OCTO_BASE_MASK (A/B switch, default 0 = off; bit 1: the joint evaluation, bit 2: the head's step run
+// with EXEC restricted to the base lanes, 4 of 64 — only they consume the head's state inside the loop; the head
+// is broadcast from lane 0 after the loop).  The idea: the instruction count is unchanged (a wave instruction
+// costs its issue slot whatever its mask) but masked lanes do not switch, and this kernel runs against the
+// board's power limit.  MEASURED AND NOT ADOPTED (round 5, profiles/README.md "OctoFlat budget"): 9.26-9.29 ms
+// against 9.31-9.34 ms per launch on one box (-0.5 %, inside the box-to-box spread), and with BOTH bits set the
+// one-arm shape (OctoFlatLite-v0, one wave per env) aborts on the GPU while either bit alone passes - a
+// code-generation hazard nobody needs for half a per cent.
+#ifndef SOFTROD_OCTO_BASE_MASK
+#define SOFTROD_OCTO_BASE_MASK 0
+#endif
     auto joints = [&](double (&f)[1][3], double (&tq)[1][3], const LaneN<1>& Lc, const double (&xn)[1][3]) {
+        double part[3] = {0.0, 0.0, 0.0};
+        if ((SOFTROD_OCTO_DIAG & 1) == 0 && (!(SOFTROD_OCTO_BASE_MASK & 1) || base)) {
         // FixedJoint2Rigid.apply_forces (joint.py:48-123): spring + normal damping between the
         // arm's node 0 and the point head_radius along the arm's direction from the head axis.
         // The head's d2 lies in the plane (constrain_values), so the direction has no z part.
@@ -341,10 +363,11 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         // lane, in a fixed order; lane 0 posts the wave's three numbers in LDS.  They are consumed
         // after the arms' contact and rate update (head_update below), which hides the round trip
         // and lets the waves of the env reach the barrier together.
-        double part[3] = {base ? fj[0] : 0.0, base ? fj[1] : 0.0, base ? tj[2] : 0.0};
+        part[0] = base ? fj[0] : 0.0; part[1] = base ? fj[1] : 0.0; part[2] = base ? tj[2] : 0.0;
+        }
 #pragma unroll
         for (int off = 16; off < kLanes; off <<= 1) {
-            if (off >= P.seg) {
+            if ((SOFTROD_OCTO_DIAG & 8) == 0 && off >= P.seg) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) part[i] += __shfl_xor(part[i], off);
             }
@@ -379,6 +402,8 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     double pend[MAXW == 2 ? 2 : 1][3] = {};
     double hk = P.half_dt;
     auto head_step = [&]() {
+        if constexpr ((SOFTROD_OCTO_DIAG & 2) != 0) return;
+        if constexpr ((SOFTROD_OCTO_BASE_MASK & 2) != 0) { if (!base) return; }
         double tot[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) tot[i] = (MAXW == 2) ? pend[0][i] + pend[MAXW == 2 ? 1 : 0][i] : pend[0][i];
@@ -388,6 +413,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         head_kinematic(hk, H);
     };
     auto exchange = [&]() {       // after the arms' kinematic step: everyone has posted
+        if constexpr ((SOFTROD_OCTO_DIAG & 4) != 0) return;
         if constexpr (EPB == 1) __syncthreads();
         else {                    // the partner wave runs on this SIMD: wait for its flag, not for a barrier
             while (__hip_atomic_load(&flag_[es][parity][wave ^ 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= posted)
@@ -457,6 +483,14 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             head_step();
         }
         time = clock_after(P, S, time, n_sub);
+    }
+    if constexpr ((SOFTROD_OCTO_BASE_MASK & 2) != 0) {
+        // only the base lanes stepped the head inside the loop: everybody gets lane 0's for the epilogue
+        // (all base lanes hold the same bits: the same operands in the same order)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { H.x[i] = __shfl(H.x[i], 0); H.v[i] = __shfl(H.v[i], 0); H.w[i] = __shfl(H.w[i], 0); }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H.Q[i] = __shfl(H.Q[i], 0);
     }
     if (live) {
         store_lane<1, F>(S, NR, row, lane, L);

@@ -376,12 +376,13 @@ class ShardedVecEnv:
             # buffers k were last used `depth` steps ago: this orders the kernel below after their
             # gather (a stream-level wait, not a host block on RCCL)
             self._works[k].wait()
+        if (self.transport == "p2p" and self.p2p_enforce_sync_interval
+                and len(self._since_sync) >= self.p2p_sync_interval()):       # refused BEFORE anything is stepped
+            raise P2PError(f"transport p2p with {len(self._works)} buffer sets: sync() at least every "
+                           f"{self.p2p_sync_interval()} step(s), or a peer overwrites rows this rank has not "
+                           "read yet (set p2p_enforce_sync_interval = False only if nothing is read between syncs)")
         packed, info = self.local.step_packed(a, self._packed2[k])
         if self.transport == "p2p":
-            if self.p2p_enforce_sync_interval and len(self._since_sync) >= self.p2p_sync_interval():
-                raise P2PError(f"transport p2p with {len(self._works)} buffer sets: sync() at least every "
-                               f"{self.p2p_sync_interval()} step(s), or a peer overwrites rows this rank has not "
-                               "read yet (set p2p_enforce_sync_interval = False only if nothing is read between syncs)")
             # in order behind the step kernel, on its stream: a few microseconds, no dependency to
             # resolve; the generation word of this rank follows the rows into every peer's buffer
             self._gen = (self._gen + 1) & 0x7FFFFFFF
@@ -416,6 +417,8 @@ class ShardedVecEnv:
                 torch.cuda.current_stream(self.local.backend.device).synchronize()
                 dist.barrier(group=self.group)     # this rank's rows have landed everywhere; now everybody's have
                 written, self._since_sync = self._since_sync, []
+                if not written and self._last_k is not None:
+                    written = [self._last_k]       # nothing new: the latest step's rows are checked again
                 if self._verify:
                     for k in written:
                         tags = self._tags[k].cpu()

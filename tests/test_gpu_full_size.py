@@ -142,3 +142,60 @@ def test_config4_total_batch_32768_softpendulum_envs_on_one_gpu(torch_gpu, hip_l
             o, r, te, tr = rod.env_step(acts[t, i, 0])
         np.testing.assert_allclose(full[-1][0][i], o, rtol=RTOL, atol=1e-7)
         np.testing.assert_allclose(full[-1][1][i], r, rtol=RTOL, atol=1e-9)
+
+
+def test_config5_full_8192_octoflat_envs_on_one_gpu(torch_gpu, hip_lib, oracle_built):
+    """BASELINE configs[4] at its REAL size: all 8192 OctoFlat envs (65 536 arms + 8192 heads, 2048
+    workgroups of four envs: eight resident rounds at one workgroup per CU) resident on ONE GPU — the batch
+    the eight shards would own, env i seeded i whatever batch it sits in.  One whole env.step of 2857
+    substeps: finite everywhere, bitwise repeatable, the first and last envs of every 1024-env shard equal
+    — bit for bit — a small batch holding just them (batch independence at the shard ends), and three
+    spot envs against the oracle for that first step (the horizon at which trajectory parity holds for
+    OctoFlat: DESIGN.md §3; the regimes after it are tests/test_gpu_ensemble_parity.py's).
+    Reference: /root/reference/gym_softrobot/envs/octopus/flat_env.py:58-61,78,315-408."""
+    import gym_softrobot_amd as gsa
+
+    n = 8192
+    acts = np.random.default_rng(5).uniform(-22, 22, (n, 24)).astype(np.float32)
+
+    def one_step(idx):
+        env = gsa.make_vec("OctoFlat-v0", len(idx), numpy_output=True)
+        assert env.backend.kernel_tier() == "softrod_octo_step_kernel<zup,2 waves,4 envs/wg>"
+        env.reset(seed=[int(i) for i in idx])
+        o, r, te, tr, info = env.step(acts[idx])
+        res = (o.copy(), r.copy(), te.copy(), tr.copy())
+        tg, st = env.targets.copy(), env.backend.octo_state_numpy()
+        env.close()
+        return res, tg, st
+
+    full, targets, st = one_step(np.arange(n))
+    again, _, st2 = one_step(np.arange(n))
+    for x, y in zip(full, again):                                      # bitwise run-to-run
+        np.testing.assert_array_equal(x, y)
+    for k in ("x", "v", "w", "Q", "head_x", "head_v", "head_Q", "head_w"):
+        np.testing.assert_array_equal(st[k], st2[k])
+    obs, rew, term, trunc = full
+    assert obs.shape == (n, 461) and np.isfinite(obs).all() and np.isfinite(rew).all()
+    assert not trunc.any() and not term.any()
+    np.testing.assert_allclose(st["time"], 2857 * 7.0e-5, rtol=1e-12)
+    Q = st["Q"]                                                         # (N, A, 3, 3, n): directors stay orthonormal
+    QQt = np.einsum("eaimk,eajmk->eaijk", Q, Q)
+    assert np.abs(QQt - np.eye(3)[None, None, :, :, None]).max() < 1e-10
+    hq = st["head_Q"]                                                   # BodyBoundaryCondition: d3 = e_z, d1, d2 unit in the plane
+    assert np.abs(hq[:, 2] - np.array([0.0, 0.0, 1.0])).max() == 0.0 and np.abs(hq[:, :2, 2]).max() == 0.0
+    assert np.abs(np.linalg.norm(hq[:, :2, :2], axis=2) - 1.0).max() < 1e-14
+    assert np.abs(st["head_x"][:, 2]).max() == 0.0 and np.abs(st["head_v"][:, 2]).max() == 0.0
+    # the arm-crossing penalty did its work somewhere in the batch (reward = forward - 0.02 * crossings)
+    assert (rew < -0.05).any()
+    spots = np.array([s * 1024 + k for s in range(8) for k in (0, 1023)])    # both ends of every shard
+    few, _, _ = one_step(spots)
+    for x, y in zip(full, few):
+        np.testing.assert_array_equal(x[spots], y)
+    for i in (0, 4095, 8191):
+        o = oracle_built.OracleOcto(gsa._capi.octo_flat_config(1))
+        o.reset(targets[i])
+        ob, rw, te, tr = o.env_step(acts[i])
+        flat = np.concatenate([ob["individual"].ravel(), ob["shared"]])
+        np.testing.assert_allclose(obs[i], flat, rtol=RTOL, atol=2e-6)
+        np.testing.assert_allclose(rew[i], rw, rtol=RTOL, atol=1e-6)
+        assert bool(term[i]) == te and bool(trunc[i]) == tr

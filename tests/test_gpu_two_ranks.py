@@ -210,6 +210,26 @@ for t in range(5):
     o2, r2, _, _, _ = ref.step(a)
     torch.cuda.synchronize()
     assert torch.equal(o, o2) and torch.equal(r, r2)
+# the completion contract (ADVICE r4): with depth 2 the rows of every step stay intact only with a sync()
+# after every step; a second step without one is refused unless the caller says it reads nothing in between
+assert env.p2p_sync_interval() == 1 and env.p2p_sync_interval(every_step=False) == 1
+env.step(a)
+try:
+    env.step(a)
+    raise SystemExit("two steps without sync() went through")
+except P2PError as exc:
+    assert "sync()" in str(exc)
+env.sync()
+env.p2p_enforce_sync_interval = False
+env.step(a); env.step(a); env.step(a)
+env.sync()                                  # checks the generation words of BOTH buffers written since
+env.p2p_enforce_sync_interval = True
+ref.step(a); ref.step(a); ref.step(a); ref.step(a)
+o, r, te, tr, _ = env.step(a)
+env.sync()
+o2, r2, _, _, _ = ref.step(a)
+torch.cuda.synchronize()
+assert torch.equal(o, o2) and torch.equal(r, r2)
 env._tags[env._last_k][0] = 12345          # a peer that did not deliver
 try:
     env.sync()

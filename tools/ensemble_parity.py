@@ -61,6 +61,9 @@ BANDS = {
     "paired_factor": {"OctoFlat-v0": 4.0, "SoftPendulum-v0": 16.0},
     # ensemble means: |mean_H - mean_A| <= `mean_sigmas` standard errors of the oracle ensemble
     "mean_sigmas": 0.5,
+    # north_star's tolerance: a paired divergence within rtol 1e-5 of the statistic's ensemble scale
+    # (max(|mean|, std) at that step) is parity and passes whatever the control shows
+    "parity_rtol": 1e-5,
 }
 
 
@@ -378,8 +381,11 @@ def check(doc, bands=BANDS, need_hip=True):
                 bad.append(f"{stat} step {row['step']}: mean {h['mean']:.6g} vs {h['mean_ref']:.6g} (se {se:.3g})")
             if c is not None:
                 factor = bands["paired_factor"][doc["env"]]
+                # a paired divergence below north_star's own tolerance (rtol 1e-5 of the statistic's scale over
+                # the ensemble) is plain parity: the band only judges what has left it
+                parity = bands["parity_rtol"] * max(abs(h["mean_ref"]), h["std_ref"])
                 for q, hq, cq in zip(QS, h["paired_q"], c["paired_q"]):
-                    if hq > max(factor * cq, FLOORS[stat]):
+                    if hq > max(factor * cq, FLOORS[stat], parity):
                         bad.append(f"{stat} step {row['step']}: paired q{q} {hq:.3e} vs control {cq:.3e}")
     # blow-up events: the same envs are lost, within BLOWN_LAG steps; no env is reported NaN while the oracle
     # still integrates it healthily BLOWN_LAG steps later; the lost fraction stays within the band
