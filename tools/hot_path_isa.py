@@ -80,9 +80,6 @@ def hot_path(ins, labels):
                 continue
             if kind in ("s_cbranch_vccz", "s_cbranch_vccnz") and vcc is not None:
                 taken = (kind == "s_cbranch_vccnz") == vcc
-            elif kind in ("s_cbranch_execnz", "s_cbranch_vccnz", "s_cbranch_scc1", "s_branch") and tgt <= pc and \
-                    any(x.startswith("s_sleep") for x in ins[tgt:pc + 1]) and pc - tgt < 200:
-                taken = False      # a spin-wait (the rendezvous of the OctoFlat kernel): met at once
             elif kind == "s_cbranch_execnz" and pc - 30 < tgt <= pc:
                 taken = False      # a spin-wait (the flag rendezvous of the OctoFlat kernel): met at once
             else:
