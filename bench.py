@@ -61,7 +61,8 @@ loop — what a caller that hands over NumPy arrays gets; never `value`.
 
 N > 1: `per_rank` lists every rank's step-kernel time, what a step costs beyond it (the exchange:
 collective or peer copies, plus launch gaps) and `efficiency_vs_n1_kernel` = kernel time / step
-time; and, with the default transport, AFTER rank 0 has printed the line every rank runs the same
+time.  `--p2p-trial` (opt-in since round 5: the transport has never run between different devices, and
+the driver's N = 1, 2, 4, 8 runs share one node): AFTER rank 0 has printed the line every rank runs the same
 windows once more over transport "p2p" in a child process of its own, bounded by 90 s (a crash, a hang
 or a fall-back of the experimental transport cannot cost the headline measurement: it is out already).
 The trial's figures go to stderr as `bench.py: p2p_trial: {...}` and to gpurun_out/p2p_trial_N<world>.json.
@@ -259,8 +260,12 @@ def parse_args(argv=None):
                     help="N=1 headline run: skip the two secondary workloads (BASELINE configs[2], configs[4]'s share)")
     ap.add_argument("--no-sustained", action="store_true",
                     help="N=1 headline run: skip the closing >= 2 s continuous-load leg")
-    ap.add_argument("--no-p2p-trial", action="store_true",
-                    help="N>1 with the default transport: skip the second measurement over transport p2p")
+    ap.add_argument("--p2p-trial", action="store_true",
+                    help="N>1 with the default transport: AFTER the line is printed, run the same windows once more over "
+                         "the experimental transport p2p in child processes (bounded by 90 s; figures on stderr).  "
+                         "Opt-in since round 5: the transport has never run between different devices, and the "
+                         "driver's N = 1, 2, 4, 8 runs share one node")
+    ap.add_argument("--no-p2p-trial", action="store_true", help=argparse.SUPPRESS)    # (round 4's switch: the default now)
     ap.add_argument("--trial-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--transport", choices=["rccl", "p2p"], default="rccl",
                     help="N > 1: how the packed rows reach the other ranks.  rccl (default, BASELINE's north_star): "
@@ -1229,7 +1234,7 @@ def main(argv=None, script=None) -> int:
     # ---- N > 1, default transport: the same windows once more over transport "p2p", in child processes,
     # AFTER the line (a hang of the never-cross-device-tested transport must not hold the line
     # back); bounded, children die with their parent; the figures go to stderr and gpurun_out/
-    if (world > 1 and args.transport == "rccl" and not args.no_p2p_trial and not args.trial_child):
+    if (world > 1 and args.transport == "rccl" and args.p2p_trial and not args.no_p2p_trial and not args.trial_child):
         trial = guarded(p2p_trial, args, rank, local_rank, world, script)
         if rank == 0:
             sys.stderr.write("bench.py: p2p_trial: " + json.dumps(trial) + "\n")

@@ -105,11 +105,11 @@ def _eight_vs_one(extra_args, per_rank_envs, extra_env=None, strong=False):
 
 
 def test_gpus_8_softpendulum_weak_scaling_with_the_p2p_trial(oracle_built):
-    """BASELINE configs[3]'s shape: `python bench.py --gpus 8 ...` exactly as the driver runs it.  The
-    default transport is measured, then every rank's child runs the job again over transport p2p —
+    """BASELINE configs[3]'s shape: `python bench.py --gpus 8 ...` as the driver runs it, plus `--p2p-trial`
+    (opt-in since round 5).  The default transport is measured, then every rank's child runs the job again over transport p2p —
     which on a box without a GPU falls back to the collective on every rank, says so, and returns the
     same rows.  The trial runs AFTER the line is out, bounded, in children that die with their parents."""
-    line, one = _eight_vs_one([], 2)
+    line, one = _eight_vs_one(["--p2p-trial"], 2)
     assert line["scaling"] == "weak" and line["config"]["transport"] == "rccl"
     assert "p2p_trial" not in line            # the headline is printed BEFORE the experimental transport runs
     t = _p2p_trial(line["_stderr"])
@@ -119,20 +119,20 @@ def test_gpus_8_softpendulum_weak_scaling_with_the_p2p_trial(oracle_built):
 
 
 def test_gpus_8_strong_scaling(oracle_built):
-    line, _ = _eight_vs_one(["--scaling", "strong", "--no-p2p-trial"], 2, strong=True)
+    line, _ = _eight_vs_one(["--scaling", "strong"], 2, strong=True)
     assert line["scaling"] == "strong" and "bench.py: p2p_trial:" not in line["_stderr"]
 
 
 def test_gpus_8_octoflat(oracle_built):
     """BASELINE configs[4]'s shape: 8 arms + head per env, odd observation width (461) in the packed rows."""
-    line, _ = _eight_vs_one(["--env", "OctoFlat-v0", "--no-p2p-trial"], 1)
+    line, _ = _eight_vs_one(["--env", "OctoFlat-v0"], 1)
     assert "OctoFlat-v0" in line["config"]["workload"]
 
 
 def test_gpus_8_device_autoreset_restarts_on_every_rank(oracle_built):
     """3-step episodes: every env is truncated and restarts from its staged record inside the run, on
     all 8 ranks; restarted steps are not counted as work, and the rows equal one process's."""
-    line, one = _eight_vs_one(["--autoreset", "device", "--no-p2p-trial"], 2, {"SOFTROD_TEST_EPISODE_STEPS": "3"})
+    line, one = _eight_vs_one(["--autoreset", "device"], 2, {"SOFTROD_TEST_EPISODE_STEPS": "3"})
     assert line["config"]["autoreset"] == "device"
     assert line["config"]["episode_restarts_not_counted"] == one["config"]["episode_restarts_not_counted"] >= 16
 

@@ -62,7 +62,7 @@ def _check_pair(two, one, total, steps):
 def test_bench_two_ranks_softpendulum(hip_lib):
     """configs[3]'s shape at world 2: 2 x 2048 envs against 1 x 4096."""
     a = ("--steps", "12", "--warmup", "2")
-    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "2048", *a)
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--envs-per-gpu", "2048", "--p2p-trial", *a)
     one = _bench({}, "--gpus", "1", "--envs-per-gpu", "4096", *a)
     _check_pair(two, one, 4096, 12)
     assert two["windows"]["count"] == one["windows"]["count"] == 5
