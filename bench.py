@@ -67,7 +67,8 @@ windows once more over transport "p2p" in a child process of its own, bounded by
 or a fall-back of the experimental transport cannot cost the headline measurement: it is out already).
 The trial's figures go to stderr as `bench.py: p2p_trial: {...}` and to gpurun_out/p2p_trial_N<world>.json.
 
-sustained (N=1, default; round 5): after everything else ONE more leg keeps the GPU under continuous load
+sustained (default; round 5; N > 1: every rank on its own GPU, no exchange, rank 0's figure in the line):
+after everything else ONE more leg keeps the GPU under continuous load
 for >= 2 s — ~7000 env.steps of the headline workload with device-side NEXT_STEP auto-reset (episodes
 end every 125 steps and restart from staged draws without a host round trip) — so that an outside
 observer sampling the GPU (the driver's smi samples) sees it busy; its env-steps/s is reported beside,
@@ -1206,6 +1207,19 @@ def main(argv=None, script=None) -> int:
     if scratch is not None:
         scratch.close()
         scratch = None
+    if (distributed and world > 1 and args.env == "SoftPendulum-v0" and hip and not args.no_sustained
+            and not args.trial_child and args.math_mode == "fast" and args.scaling == "weak"
+            and args.envs_per_gpu in (None, ENVS_PER_GPU) and args.n_elems is None):
+        # N > 1: EVERY rank keeps its GPU under continuous load for >= 2 s on a shard-sized batch of its own
+        # (no exchange, no collective: a rank that fails here cannot block another), so that the driver's
+        # GPU-busy samples see all N GPUs; rank 0's figure goes into the line, the others' to stderr
+        mine = guarded(sustained_leg, gsa, torch, local_rank, math_mode, n_local)
+        sys.stderr.write(f"bench.py: sustained rank {rank}: " + json.dumps(mine) + "\n")
+        sys.stderr.flush()
+        if rank == 0:
+            line["sustained"] = dict(mine, note=f"rank 0's GPU; all {world} ranks ran this leg at about the same time, each on "
+                                                "its own shard-sized batch with no exchange (their figures: stderr, "
+                                                "`bench.py: sustained rank k: {...}`); not a whole-job figure")
     if rank == 0 and world == 1 and not distributed:
         full = (args.env == "SoftPendulum-v0" and hip and not args.no_secondary and args.n_elems is None
                 and args.envs_per_gpu in (None, ENVS_PER_GPU) and args.math_mode == "fast")

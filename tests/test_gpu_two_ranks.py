@@ -45,6 +45,7 @@ def _bench(extra_env, *args, timeout=900):
     trials = [json.loads(l[len(tag):]) for l in out.stderr.splitlines() if l.startswith(tag)]
     if trials:
         line["_p2p_trial"] = trials[-1]
+    line["_stderr"] = out.stderr
     return line
 
 
@@ -80,6 +81,20 @@ def test_bench_two_ranks_softpendulum(hip_lib):
     assert one["policy_in_loop"]["value"] > 0 and one["sustained"]["seconds"] >= 2.0
     assert 0.85 < one["sustained"]["ratio_to_value"] < 1.1, one["sustained"]
     assert one["pcie_inclusive"]["value"] > 0 and one["pcie_inclusive"]["ms_per_step"] > one["roofline"]["kernel_ms_avg"]
+
+
+def test_bench_two_ranks_default_sizes_keep_every_gpu_busy(hip_lib):
+    """`python bench.py --gpus 2 --steps K --warmup W` at the DEFAULT batch (2 x 4096 envs: the driver's command):
+    after the windows every rank runs the >= 2 s `sustained` leg on its own GPU with no exchange (what the driver's
+    GPU-busy samples see); rank 0's figure is in the line, every rank's on stderr; no p2p trial unless asked for."""
+    two = _bench(TWO_ON_ONE, "--gpus", "2", "--steps", "10", "--warmup", "2")
+    assert two["n_gpus"] == 2 and two["config"]["envs_total"] == 8192 and two["config"]["transport"] == "rccl"
+    su = two["sustained"]
+    assert su["seconds"] >= 2.0 and su["value"] > 0 and "rank 0" in su["note"], su
+    tag = "bench.py: sustained rank "
+    ranks = sorted(int(l[len(tag):].split(":")[0]) for l in two["_stderr"].splitlines() if l.startswith(tag))
+    assert ranks == [0, 1], two["_stderr"][-1500:]
+    assert "_p2p_trial" not in two
 
 
 def test_bench_two_ranks_strong_scaling(hip_lib):
