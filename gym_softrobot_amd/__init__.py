@@ -23,17 +23,7 @@ from .render import RendererType  # noqa: E402
 # gym_softrobot/__init__.py:83 sets POVRAY; the matplotlib session is the one provided here
 RENDERER_CONFIG = RendererType.MATPLOTLIB
 
-# gym_softrobot/__init__.py:27-30,74-80
-register(id="SoftPendulum-v0", entry_point=SoftPendulumEnv)
-register(id="SoftPendulum3D-v0", entry_point=SoftPendulum3DEnv)
-register(id="OctoArmSingle-v0", entry_point=ArmSingleEnv)
-# gym_softrobot/__init__.py:6-15
-register(id="OctoFlat-v0", entry_point=FlatEnv)
-register(id="OctoFlatLite-v0", entry_point=FlatEnv, kwargs=dict(n_arm=1, n_action=8))
-# gym_softrobot/__init__.py:60-63
-register(id="SoftArmTracking-v0", entry_point=SoftArmTrackingEnv)
-
-# the batched form of every id registered above: (class, the registration's kwargs)
+# the batched form of every id: (class, the registration's kwargs)
 _VEC = {
     "SoftPendulum-v0": (VecSoftPendulumEnv, {}),
     "SoftPendulum3D-v0": (VecSoftPendulum3DEnv, {}),
@@ -42,6 +32,16 @@ _VEC = {
     "OctoFlatLite-v0": (VecOctoFlatEnv, dict(n_arm=1, n_action=8)),   # gym_softrobot/__init__.py:11-15
     "SoftArmTracking-v0": (VecSoftArmTrackingEnv, {}),
 }
+
+# gym_softrobot/__init__.py:27-30,74-80
+register(id="SoftPendulum-v0", entry_point=SoftPendulumEnv, vector_entry_point=VecSoftPendulumEnv)
+register(id="SoftPendulum3D-v0", entry_point=SoftPendulum3DEnv, vector_entry_point=VecSoftPendulum3DEnv)
+register(id="OctoArmSingle-v0", entry_point=ArmSingleEnv, vector_entry_point=VecArmSingleEnv)
+# gym_softrobot/__init__.py:6-15
+register(id="OctoFlat-v0", entry_point=FlatEnv, vector_entry_point=VecOctoFlatEnv)
+register(id="OctoFlatLite-v0", entry_point=FlatEnv, kwargs=dict(n_arm=1, n_action=8), vector_entry_point=VecOctoFlatEnv)
+# gym_softrobot/__init__.py:60-63
+register(id="SoftArmTracking-v0", entry_point=SoftArmTrackingEnv, vector_entry_point=VecSoftArmTrackingEnv)
 
 
 def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002

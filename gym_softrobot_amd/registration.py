@@ -17,14 +17,20 @@ except ImportError:
     _gymnasium = None
 
 
-def register(id: str, entry_point: Callable, kwargs=None) -> None:  # noqa: A002
-    _REGISTRY[id] = {"entry_point": entry_point, "kwargs": dict(kwargs or {})}
+def register(id: str, entry_point: Callable, kwargs=None, vector_entry_point: Callable = None) -> None:  # noqa: A002
+    """`vector_entry_point`: the batched (N envs on one GPU) class of the id — what Gymnasium 1.0's
+    `gymnasium.make_vec(id, num_envs=N, vectorization_mode="vector_entry_point")` instantiates."""
+    _REGISTRY[id] = {"entry_point": entry_point, "kwargs": dict(kwargs or {}), "vector_entry_point": vector_entry_point}
     if _gymnasium is not None:
         gid = f"{NAMESPACE}/{id}"
         if gid not in _gymnasium.registry:
             # no max_episode_steps: the reference registers none either, truncation is the env's own
             # (gym_softrobot/__init__.py:74-76, soft_pendulum.py:226-229)
-            _gymnasium.register(id=gid, entry_point=entry_point, kwargs=dict(kwargs or {}))
+            extra = {} if vector_entry_point is None else {"vector_entry_point": vector_entry_point}
+            try:
+                _gymnasium.register(id=gid, entry_point=entry_point, kwargs=dict(kwargs or {}), **extra)
+            except TypeError:          # a Gymnasium older than 1.0: no vector_entry_point
+                _gymnasium.register(id=gid, entry_point=entry_point, kwargs=dict(kwargs or {}))
 
 
 def make(id: str, **kwargs):  # noqa: A002

@@ -9,6 +9,7 @@ reference imports — written from Gymnasium 1.0's documented behaviour:
   gymnasium.registry            dict id -> EnvSpec(id, entry_point, kwargs, max_episode_steps)
   gymnasium.register(...)       adds a spec; a duplicate id is an error
   gymnasium.make(id, **kw)      spec.entry_point(**{**spec.kwargs, **kw}); "module:Class" strings are resolved
+  gymnasium.make_vec(id, num_envs, vectorization_mode)   spec.vector_entry_point(num_envs=..., **kwargs)
   gymnasium.Env                 reset(seed=...) seeds `np_random` with Generator(PCG64(SeedSequence(seed)));
                                 `unwrapped`, `close`
   gymnasium.spaces.Box / Dict   shape / dtype / low / high, seed, sample, contains
@@ -21,8 +22,9 @@ import numpy as np
 
 
 class EnvSpec:
-    def __init__(self, id, entry_point, kwargs=None, max_episode_steps=None):  # noqa: A002
+    def __init__(self, id, entry_point, kwargs=None, max_episode_steps=None, vector_entry_point=None):  # noqa: A002
         self.id, self.entry_point, self.kwargs, self.max_episode_steps = id, entry_point, dict(kwargs or {}), max_episode_steps
+        self.vector_entry_point = vector_entry_point
 
     def make(self, **kw):
         return make(self.id, **kw)
@@ -31,10 +33,21 @@ class EnvSpec:
 registry = {}
 
 
-def register(id, entry_point=None, kwargs=None, max_episode_steps=None, **_):  # noqa: A002
+def register(id, entry_point=None, kwargs=None, max_episode_steps=None, vector_entry_point=None, **_):  # noqa: A002
     if id in registry:
         raise ValueError(f"Cannot re-register id: {id}")
-    registry[id] = EnvSpec(id, entry_point, kwargs, max_episode_steps)
+    registry[id] = EnvSpec(id, entry_point, kwargs, max_episode_steps, vector_entry_point)
+
+
+def make_vec(id, num_envs=1, vectorization_mode=None, vector_kwargs=None, **kw):  # noqa: A002
+    """Gymnasium 1.0: with a registered `vector_entry_point` (mode None or "vector_entry_point") the batched class
+    is instantiated as vector_entry_point(num_envs=num_envs, **spec.kwargs, **kw)."""
+    spec = registry[id]
+    if spec.vector_entry_point is None or vectorization_mode not in (None, "vector_entry_point"):
+        raise NotImplementedError("the stand-in only knows vector_entry_point")
+    env = spec.vector_entry_point(num_envs=num_envs, **{**spec.kwargs, **(vector_kwargs or {}), **kw})
+    env.spec = spec
+    return env
 
 
 def make(id, **kw):  # noqa: A002
@@ -164,7 +177,7 @@ def install():
     """Put the stand-in into sys.modules (before gym_softrobot_amd is imported)."""
     g = types.ModuleType("gymnasium")
     g.__version__ = "1.0.0-standin"
-    g.registry, g.register, g.make, g.Env, g.EnvSpec = registry, register, make, Env, EnvSpec
+    g.registry, g.register, g.make, g.make_vec, g.Env, g.EnvSpec = registry, register, make, make_vec, Env, EnvSpec
     sp = types.ModuleType("gymnasium.spaces")
     sp.Space, sp.Box, sp.Dict = Space, Box, Dict
     g.spaces = sp

@@ -45,6 +45,7 @@ out = {"ids": ours, "have": spaces.HAVE_GYMNASIUM,
        "entry": {k: reg[k].entry_point.__name__ for k in ours},
        "kwargs": {k: reg[k].kwargs for k in ours},
        "max_steps": [reg[k].max_episode_steps for k in ours],
+       "vec": {k: reg[k].vector_entry_point.__name__ for k in ours},
        "subclass": all(issubclass(reg[k].entry_point, gymnasium.Env) for k in ours),
        "own_registry": gsa.registered()}
 # registering the package twice (a re-import under another name, importlib.reload) must not raise
@@ -64,6 +65,11 @@ print(json.dumps(out))
     assert res["kwargs"]["gym_softrobot_amd/OctoFlatLite-v0"] == {"n_arm": 1, "n_action": 8}
     assert all(v == {} for k, v in res["kwargs"].items() if "Lite" not in k)
     assert res["max_steps"] == [None] * 6          # no TimeLimit wrapper: truncation is the env's own (soft_pendulum.py:226-229)
+    # Gymnasium 1.0's make_vec(..., vectorization_mode="vector_entry_point") gets the batched HIP classes
+    assert res["vec"] == {
+        "gym_softrobot_amd/OctoArmSingle-v0": "VecArmSingleEnv", "gym_softrobot_amd/OctoFlat-v0": "VecOctoFlatEnv",
+        "gym_softrobot_amd/OctoFlatLite-v0": "VecOctoFlatEnv", "gym_softrobot_amd/SoftArmTracking-v0": "VecSoftArmTrackingEnv",
+        "gym_softrobot_amd/SoftPendulum-v0": "VecSoftPendulumEnv", "gym_softrobot_amd/SoftPendulum3D-v0": "VecSoftPendulum3DEnv"}
 
 
 def test_without_gymnasium_the_package_registry_alone_serves_make():
@@ -134,6 +140,15 @@ env = gsa.make("{env_id}")
 j, _ = env.reset(seed=0)
 env.close()
 assert np.array_equal(flat(j), flat(i1))
+# Gymnasium 1.0's vector front door: make_vec -> the batched HIP env; env 0 of the batch is the single env
+vec = gymnasium.make_vec("gym_softrobot_amd/{env_id}", num_envs=3, vectorization_mode="vector_entry_point", numpy_output=True)
+assert vec.num_envs == 3 and type(vec.backend).__name__ == "HipRodBackend"
+vo, _ = vec.reset(seed=0)
+assert np.array_equal(np.asarray(vo)[0], flat(i1).astype(np.float32)) or "{env_id}".startswith("OctoFlat")
+acts = np.stack([vec.single_action_space.sample() for _ in range(3)])
+o, r, te, tr, info = vec.step(acts)
+assert np.asarray(o).shape[0] == 3 and np.asarray(r).shape == (3,) and isinstance(info, dict)
+vec.close()
 print(json.dumps({{"tier": tier}}))
 """)
     assert "kernel" in res["tier"]
