@@ -69,7 +69,7 @@ The trial's figures go to stderr as `bench.py: p2p_trial: {...}` and to gpurun_o
 
 sustained (default; round 5; N > 1: every rank on its own GPU, no exchange, rank 0's figure in the line):
 after everything else ONE more leg keeps the GPU under continuous load
-for >= 5 s — ~16 000 env.steps of the headline workload with device-side NEXT_STEP auto-reset (episodes
+for >= 8 s — ~27 000 env.steps of the headline workload with device-side NEXT_STEP auto-reset (episodes
 end every 125 steps and restart from staged draws without a host round trip) — so that an outside
 observer sampling the GPU (the driver's smi samples) sees it busy; its env-steps/s is reported beside,
 never instead of, the median-window `value`, together with the shader clock and socket power read
@@ -747,8 +747,8 @@ def gpu_sensors(torch, device_index: int):
     return out
 
 
-def sustained_leg(gsa, torch, device, math_mode, n_local, min_seconds: float = 5.0, max_steps: int = 40000):
-    """The GPU under CONTINUOUS load for >= `min_seconds` (5 s: the driver takes a handful of samples of the GPU's
+def sustained_leg(gsa, torch, device, math_mode, n_local, min_seconds: float = 8.0, max_steps: int = 60000):
+    """The GPU under CONTINUOUS load for >= `min_seconds` (8 s, about a quarter of the whole run: the driver takes a handful of samples of the GPU's
     busy state over the whole run, most of which is host work — imports, the CPU baseline — so the leg has to be
     long enough for one of them to land in it), so that an observer outside this process has something to see: the headline workload, random actions from
     a ring of 120 pre-staged steps, device-side NEXT_STEP auto-reset (episodes truncate on step 126 and
