@@ -449,7 +449,18 @@ def main():
         rec["violations"] = check(rec)
         rec["headline"] = headline(rec)
         doc["scenarios"][name] = rec
-    print(json.dumps(doc, indent=1))
+    print(json.dumps(_compact(doc), separators=(",", ":")))
+
+
+def _compact(x):
+    """Six significant digits per float: the record is evidence, not a fixture (2.3 MB -> 0.6 MB)."""
+    if isinstance(x, float):
+        return float(f"{x:.6g}") if np.isfinite(x) else x
+    if isinstance(x, dict):
+        return {k: _compact(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_compact(v) for v in x]
+    return x
 
 
 if __name__ == "__main__":
