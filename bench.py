@@ -842,9 +842,32 @@ def policy_in_loop(gsa, torch, device, math_mode, n_local, steps: int = 1500, wa
     elapsed = time.perf_counter() - t0
     restarts = int(env.backend.queue_status()[0].sum()) - r0
     checksum = float(torch.nan_to_num(obs.double()).sum().item())
+    # the same loop as ONE HIP graph per env.step (policy kernels + softrod_step captured once, replayed;
+    # the queue top-ups stay outside): north_star's "hipGraphs for launch-bound inner loops"
+    graph = {}
+    try:
+        replay = env.capture_policy_step(policy)
+        for _ in range(warmup):
+            replay()
+        r1 = int(env.backend.queue_status()[0].sum())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        rs = int(env.backend.queue_status()[0].sum()) - r1
+        graph = {"graph_value": (n_local * steps - rs) / el, "graph_ms_per_step": el / steps * 1e3,
+                 "graph_episode_restarts_not_counted": rs,
+                 "graph_note": "policy kernels + softrod_step captured once into a HIP graph, one graph launch per env.step "
+                               "(VecRodEnvBase.capture_policy_step; bit-identical to the eager loop).  No faster: the "
+                               "eager loop is GPU-bound at every batch measured (64 .. 4096 envs: the host enqueues "
+                               "ahead of the kernels); what the graph buys is host time, one call per step instead of ten"}
+    except Exception as exc:  # noqa: BLE001
+        graph = {"graph_error": repr(exc)}
     env.close()
     return {"value": (n_local * steps - restarts) / elapsed, "unit": "env-steps/s", "steps": steps,
-            "ms_per_step": elapsed / steps * 1e3, "episode_restarts_not_counted": restarts,
+            "ms_per_step": elapsed / steps * 1e3, "episode_restarts_not_counted": restarts, **graph,
             "policy": "2 x 64 tanh MLP, fixed random weights, torch on the env's stream, no host synchronisation",
             "autoreset": "device", "last_obs_checksum": checksum,
             "what": "obs -> MLP -> actions -> softrod_step in a closed loop on the device (what an on-device "

@@ -393,6 +393,45 @@ class VecRodEnvBase:
             infos,
         )
 
+    def capture_policy_step(self, policy):
+        """One HIP graph for `actions = policy(obs); step(actions)` — the launch-bound tail of an on-device
+        rollout (a small policy is half a dozen tiny kernels per step) becomes ONE graph launch per env.step.
+        `softrod_step` is capturable: it enqueues kernels on the caller's stream and does nothing else (no
+        allocation, no synchronisation, no host read) while timing is off.
+
+        policy: obs (N, obs_dim) float32 device tensor -> actions (N, action_dim) float32, pure device work.
+        Returns replay() -> (obs, reward, terminated, truncated): the backend's resident output tensors, overwritten
+        by every replay (as `step` does).  The observation the policy reads is the one the previous step wrote —
+        call `reset` BEFORE capturing.  Needs autoreset off or "device" (the host-driven NEXT_STEP mode reads flags
+        back every step and cannot live in a graph); the queue top-ups of the device mode stay outside the graph
+        and run between replays.  Results are bit-identical to the eager loop (tests/test_gpu_policy_loop.py)."""
+        import torch
+
+        if self.autoreset:
+            raise NotImplementedError("capture_policy_step needs autoreset=False or autoreset='device'")
+        be = self.backend
+        if hasattr(be, "set_timing"):
+            be.set_timing(0)                      # event records around the kernel are not part of the graph
+        side = torch.cuda.Stream(device=be.device)
+        side.wait_stream(torch.cuda.current_stream(be.device))
+        with torch.cuda.stream(side):             # warm-up off the capture: the POLICY only (lazy BLAS handles,
+            for _ in range(3):                    # allocator pools); it is a pure function of the observation, and
+                policy(be.obs)                    # softrod_step has nothing lazy to warm up, so no state moves
+        torch.cuda.current_stream(be.device).wait_stream(side)
+        torch.cuda.synchronize(be.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            be.step(policy(be.obs))
+
+        def replay():
+            graph.replay()
+            if self.device_autoreset:
+                self._top_up_tick()
+            return be.obs, be.reward, be.terminated.view(torch.bool), be.truncated.view(torch.bool)
+
+        replay.graph = graph
+        return replay
+
     def step_packed(self, actions, out=None):
         """step() with every per-env output in one (N, packed_width) float32 buffer written
         by the kernel itself (distributed.unpack_outputs gives views); no host auto-reset."""

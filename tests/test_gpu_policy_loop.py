@@ -74,3 +74,60 @@ def test_policy_loop_on_a_side_stream(bench_mod):
     for t, (x, y) in enumerate(zip(a, b)):
         for u, v in zip(x, y):
             assert np.array_equal(u.numpy(), v.numpy(), equal_nan=True), f"step {t + 1}"
+
+
+@pytest.mark.parametrize("env_id,n,steps,amax,kw", [
+    ("SoftPendulum-v0", 1024, 140, 22.0, {"autoreset": "device"}),                      # crosses the episode end on step 126
+    ("SoftPendulum-v0", 256, 30, 22.0, {"autoreset": "device", "final_time": 0.19}),    # 5-step episodes: restarts + top-ups between replays
+    ("SoftPendulum3D-v0", 256, 20, 1.0, {}),
+    ("OctoFlat-v0", 8, 2, 22.0, {}),
+], ids=["pendulum-episode", "pendulum-short-episodes", "pendulum3d-no-autoreset", "octoflat"])
+def test_policy_step_as_one_hip_graph_equals_the_eager_loop(bench_mod, env_id, n, steps, amax, kw):
+    """`capture_policy_step`: policy + softrod_step captured ONCE into a HIP graph (north_star: hipGraphs for the
+    launch-bound inner loop) and replayed per env.step — bit-identical to the eager loop, auto-reset and its queue
+    top-ups (outside the graph, between replays) included."""
+    import torch
+
+    import gym_softrobot_amd as gsa
+
+    def eager():
+        env = gsa.make_vec(env_id, n, device=0, **kw)
+        obs, _ = env.reset(seed=5)
+        policy = bench_mod.make_policy(torch, env.backend.device, env.obs_dim, env.action_dim, amax)
+        rec = []
+        bench_mod.policy_loop(torch, env, policy, obs, steps, record=rec)
+        env.close()
+        return rec
+
+    def graphed():
+        env = gsa.make_vec(env_id, n, device=0, **kw)
+        env.reset(seed=5)
+        policy = bench_mod.make_policy(torch, env.backend.device, env.obs_dim, env.action_dim, amax)
+        replay = env.capture_policy_step(policy)
+        rec = []
+        for _ in range(steps):
+            out = replay()
+            rec.append(tuple(x.detach().cpu().clone() for x in out))
+        torch.cuda.synchronize()
+        env.close()
+        return rec
+
+    a, b = eager(), graphed()
+    assert len(a) == len(b) == steps
+    for t, (x, y) in enumerate(zip(a, b)):
+        for name, u, v in zip(("obs", "reward", "terminated", "truncated"), x, y):
+            assert np.array_equal(u.numpy(), v.numpy().astype(u.numpy().dtype), equal_nan=True), f"step {t + 1}: {name} differs"
+    if kw.get("autoreset") and (steps > 126 or "final_time" in kw):
+        assert any(bool(x[3].any()) for x in b), "the graphed loop was meant to cross episode ends"
+
+
+def test_capture_refuses_host_autoreset(bench_mod):
+    import torch
+
+    import gym_softrobot_amd as gsa
+
+    env = gsa.make_vec("SoftPendulum-v0", 4, device=0, autoreset=True)
+    env.reset(seed=0)
+    with pytest.raises(NotImplementedError):
+        env.capture_policy_step(bench_mod.make_policy(torch, env.backend.device, 4, 1, 22.0))
+    env.close()
