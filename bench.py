@@ -771,16 +771,33 @@ def sustained_leg(gsa, torch, device, math_mode, n_local, min_seconds: float = 8
     steps = int(min(max_steps, max(500, min_seconds / max(per_step, 1e-6) * 1.05)))
     r0 = int(env.backend.queue_status()[0].sum())
     sensors = {}
+    smi = None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(steps):
         env.step(ring[t % 120])
         if t == steps // 8:
             sensors["near_start"] = gpu_sensors(torch, device)
+        elif t == steps // 2:
+            # what `rocm-smi` itself says in the middle of the leg (the tool an outside observer is likely to
+            # use), started as a child process and collected after the leg: it must not stall the launch loop
+            try:
+                import subprocess
+
+                smi = subprocess.Popen(["rocm-smi", "--showuse", "--showpower", "--json"], stdout=subprocess.PIPE,
+                                       stderr=subprocess.DEVNULL, text=True)
+            except OSError:
+                smi = None
         elif t == steps - steps // 8:
             sensors["near_end"] = gpu_sensors(torch, device)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if smi is not None:
+        try:
+            out, _ = smi.communicate(timeout=30)
+            sensors["rocm_smi_mid_leg"] = json.loads(out)
+        except Exception as exc:  # noqa: BLE001
+            sensors["rocm_smi_mid_leg"] = {"error": repr(exc)}
     restarts = int(env.backend.queue_status()[0].sum()) - r0
     env.close()
     return {"value": (n_local * steps - restarts) / elapsed, "unit": "env-steps/s", "steps": steps,

@@ -285,5 +285,5 @@ def test_driver_line_carries_cpu_baseline_and_parity_vs_oracle(hip_lib):
     assert [s["baseline_config"][:10] for s in line["secondary"]] == ["configs[2]", "configs[4]", "configs[1]"]
     assert line["secondary"][2]["math_mode"] == "libm"
     su = line["sustained"]
-    assert su["seconds"] >= 2.0 and 0.85 < su["ratio_to_value"] < 1.1 and set(su["sensors"]) == {"near_start", "near_end"}, su
+    assert su["seconds"] >= 2.0 and 0.85 < su["ratio_to_value"] < 1.1 and {"near_start", "near_end"} <= set(su["sensors"]), su
     assert line["policy_in_loop"]["value"] > 0 and line["policy_in_loop"]["ms_per_step"] > line["roofline"]["kernel_ms_avg"]
