@@ -260,7 +260,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true",
                     help="N=1 headline run: skip the two secondary workloads (BASELINE configs[2], configs[4]'s share)")
     ap.add_argument("--no-sustained", action="store_true",
-                    help="N=1 headline run: skip the closing >= 2 s continuous-load leg")
+                    help="N=1 headline run: skip the closing >= 8 s continuous-load leg")
     ap.add_argument("--p2p-trial", action="store_true",
                     help="N>1 with the default transport: AFTER the line is printed, run the same windows once more over "
                          "the experimental transport p2p in child processes (bounded by 90 s; figures on stderr).  "
@@ -678,6 +678,27 @@ def pcie_inclusive(gsa, torch, device, math_mode, n_local, steps: int = 40, warm
                     "(closed loop); the headline `value` has its inputs resident in HBM and is open loop"}
 
 
+def profiler_preload_present() -> bool:
+    """True when this process runs under rocprofv3 (its preload initialises the GPU in every child; with
+    --pmc a `#!/usr/bin/env python3` child such as rocm-smi is the exec of a GPU-initialised process that
+    takes a box of this pool down): no child process may be started then."""
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return True
+    return any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ)
+
+
+def rocm_smi_command(args):
+    """rocm-smi as `python3 <its script>` with the profiler's variables removed from the child's
+    environment — never through the `#!/usr/bin/env python3` shebang — or None under a profiler."""
+    if profiler_preload_present():
+        return None, None
+    script = "/opt/rocm/libexec/rocm_smi/rocm_smi.py"
+    if not os.path.exists(script):
+        return None, None
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
+    return [sys.executable, script] + list(args), env
+
+
 def gpu_sensors(torch, device_index: int):
     """Shader clock (MHz), socket power (W) and the busy percentage of the GPU this process steps on,
     read from sysfs (the amdgpu node whose PCI address is the torch device's), with `rocm-smi` as the
@@ -727,10 +748,12 @@ def gpu_sensors(torch, device_index: int):
             out["gpu_busy_percent"] = float(Path(pick, "gpu_busy_percent").read_text())
         except (OSError, ValueError):
             pass
-    if out["sclk_mhz"] is None and out["power_w"] is None:
+    cmd, child_env = rocm_smi_command(["-d", str(device_index), "--showclocks", "--showpower", "--showuse", "--json"])
+    if out["sclk_mhz"] is None and out["power_w"] is None and cmd is None:
+        out["source"] = out["source"] or "unreadable (sysfs silent; no child process under a profiler)"
+    elif out["sclk_mhz"] is None and out["power_w"] is None:
         try:
-            txt = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--showuse", "--json"],
-                                 capture_output=True, text=True, timeout=20).stdout
+            txt = subprocess.run(cmd, capture_output=True, text=True, timeout=20, env=child_env).stdout
             card = next(iter(json.loads(txt).values()))
             for k, v in card.items():
                 kl = k.lower()
@@ -784,8 +807,9 @@ def sustained_leg(gsa, torch, device, math_mode, n_local, min_seconds: float = 8
             try:
                 import subprocess
 
-                smi = subprocess.Popen(["rocm-smi", "--showuse", "--showpower", "--json"], stdout=subprocess.PIPE,
-                                       stderr=subprocess.DEVNULL, text=True)
+                cmd, child_env = rocm_smi_command(["--showuse", "--showpower", "--json"])
+                smi = None if cmd is None else subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                                                text=True, env=child_env)
             except OSError:
                 smi = None
         elif t == steps - steps // 8:
@@ -805,7 +829,7 @@ def sustained_leg(gsa, torch, device, math_mode, n_local, min_seconds: float = 8
             "episode_restarts_not_counted": restarts, "autoreset": "device",
             "sensors": sensors,
             "what": "continuous load for the driver's GPU-busy samples: the headline workload with device-side "
-                    "auto-reset for >= 2 s; beside `value` (the median 20-step window), never instead of it"}
+                    "auto-reset for >= 8 s; beside `value` (the median 20-step window), never instead of it"}
 
 
 def make_policy(torch, device, obs_dim: int, act_dim: int, amax: float, hidden: int = 64, seed: int = 0):
@@ -1251,7 +1275,7 @@ def main(argv=None, script=None) -> int:
     if (distributed and world > 1 and args.env == "SoftPendulum-v0" and hip and not args.no_sustained
             and not args.trial_child and args.math_mode == "fast" and args.scaling == "weak"
             and args.envs_per_gpu in (None, ENVS_PER_GPU) and args.n_elems is None):
-        # N > 1: EVERY rank keeps its GPU under continuous load for >= 2 s on a shard-sized batch of its own
+        # N > 1: EVERY rank keeps its GPU under continuous load for >= 8 s on a shard-sized batch of its own
         # (no exchange, no collective: a rank that fails here cannot block another), so that the driver's
         # GPU-busy samples see all N GPUs; rank 0's figure goes into the line, the others' to stderr
         mine = guarded(sustained_leg, gsa, torch, local_rank, math_mode, n_local)
@@ -1276,7 +1300,7 @@ def main(argv=None, script=None) -> int:
         else:
             line["cpu_baseline"] = None
         if full and not args.no_sustained:
-            # LAST: >= 2 s of continuous GPU work for the driver's GPU-busy samples (the timed windows
+            # LAST: >= 8 s of continuous GPU work for the driver's GPU-busy samples (the timed windows
             # above are ~30 ms in all)
             line["sustained"] = guarded(sustained_leg, gsa, torch, local_rank, math_mode, n_local)
             if "value" in line["sustained"]:

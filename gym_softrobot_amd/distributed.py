@@ -408,7 +408,8 @@ class ShardedVecEnv:
         """Make the outputs of the latest step() complete (overlap=True).  transport "p2p": a stream
         synchronise, a barrier of the group (all ranks call sync() at the same step indices) and a
         check of the generation words, from every rank, of every step launched since the previous
-        sync() whose buffer has not been reused since."""
+        sync() whose buffer has not been reused since, and a second barrier behind that check (no rank
+        starts overwriting buffers while another still reads their tags)."""
         if self.overlap:
             for w in self._works:
                 if w is not None:
@@ -419,13 +420,22 @@ class ShardedVecEnv:
                 written, self._since_sync = self._since_sync, []
                 if not written and self._last_k is not None:
                     written = [self._last_k]       # nothing new: the latest step's rows are checked again
+                bad = None
                 if self._verify:
                     for k in written:
                         tags = self._tags[k].cpu()
                         want = self._gen_of[k]
-                        if not bool((tags == want).all()):
-                            raise P2PError(f"rank {self.rank}: generation words {tags.tolist()} in buffer {k}, "
-                                           f"expected {want} from every rank (ranks out of step, or a stale read)")
+                        if bad is None and not bool((tags == want).all()):
+                            bad = (tags.tolist(), k, want)
+                    # Nobody leaves sync() before EVERY rank has read its generation words: a peer that
+                    # ran ahead after the first barrier would overwrite an older buffer (step t + depth
+                    # lands in buffer t mod depth) with a newer generation before this rank had read its
+                    # tag — a spurious P2PError in the latest-rows-only mode (s <= depth - 1 with
+                    # p2p_enforce_sync_interval = False).  All ranks reach this barrier whatever they found.
+                    dist.barrier(group=self.group)
+                if bad is not None:
+                    raise P2PError(f"rank {self.rank}: generation words {bad[0]} in buffer {bad[1]}, "
+                                   f"expected {bad[2]} from every rank (ranks out of step, or a stale read)")
 
     def close(self):
         try:

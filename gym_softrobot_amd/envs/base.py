@@ -133,6 +133,12 @@ class VecRodEnvBase:
         self.record_envs = (0,)
         self.recorder = None
 
+    spec = None      # set by gymnasium.make_vec (`env.unwrapped.spec = ...`)
+
+    @property
+    def unwrapped(self):
+        return self
+
     @property
     def queue_depth(self) -> int:
         """Unconsumed reset records the host keeps staged per env (device auto-reset).  May be
@@ -404,14 +410,21 @@ class VecRodEnvBase:
         by every replay (as `step` does).  The observation the policy reads is the one the previous step wrote —
         call `reset` BEFORE capturing.  Needs autoreset off or "device" (the host-driven NEXT_STEP mode reads flags
         back every step and cannot live in a graph); the queue top-ups of the device mode stay outside the graph
-        and run between replays.  Results are bit-identical to the eager loop (tests/test_gpu_policy_loop.py)."""
+        and run between replays.  Results are bit-identical to the eager loop (tests/test_gpu_policy_loop.py).
+        The kernel arguments (RodParams, array pointers) are baked into the graph BY VALUE at capture: after
+        anything that changes them (a radius profile, an action basis, enabling auto-reset) capture again.
+        Kernel timing (set_timing) is switched off by the capture and stays off."""
         import torch
 
         if self.autoreset:
             raise NotImplementedError("capture_policy_step needs autoreset=False or autoreset='device'")
+        if self.recorder is not None:
+            raise NotImplementedError("capture_policy_step with a diagnostics recorder: the per-step host tap "
+                                      "cannot live in a graph (config_generate_video=False)")
         be = self.backend
         if hasattr(be, "set_timing"):
-            be.set_timing(0)                      # event records around the kernel are not part of the graph
+            be.set_timing(0)                      # event records around the kernel are not part of the graph:
+                                                  # kernel timing is OFF from here on (call set_timing again to re-arm)
         side = torch.cuda.Stream(device=be.device)
         side.wait_stream(torch.cuda.current_stream(be.device))
         with torch.cuda.stream(side):             # warm-up off the capture: the POLICY only (lazy BLAS handles,
@@ -427,6 +440,8 @@ class VecRodEnvBase:
             graph.replay()
             if self.device_autoreset:
                 self._top_up_tick()
+            else:
+                self._steps += 1                  # what step() books: infos["time"] of a later eager step stays right
             return be.obs, be.reward, be.terminated.view(torch.bool), be.truncated.view(torch.bool)
 
         replay.graph = graph

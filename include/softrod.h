@@ -528,7 +528,7 @@ int softrod_last_kernel_ms(softrod_handle* h, float* ms);
 
 /* Which step-kernel tier softrod_step launches for this handle, as a short stable string: the
  * kernel template's name, its specialisation and the workgroup shape, e.g.
- * "softrod_step_fast_kernel<SoftPendulum,epl=1> planar" or "softrod_octo_step_kernel<zup,2 waves,4 envs/wg>".
+ * "softrod_step_fast_kernel<SoftPendulum,epl=1>" or "softrod_octo_step_kernel<zup,2 waves,4 envs/wg>".
  * The tier follows from softrod_config alone.  The A/B switches of the measurement builds
  * (SOFTROD_OCTO_ONE_WAVE, SOFTROD_OCTO_ONE_ENV_PER_BLOCK, SOFTROD_NO_WINDOW, SOFTROD_WINDOW_PAIRED,
  * SOFTROD_WINDOW_REFRESH) are honoured by softrod_create ONLY when SOFTROD_DEBUG_SWITCHES=1 is set as

@@ -29,4 +29,11 @@ def hip_lib():
         import __graft_entry__
 
         __graft_entry__.build()
-    return _capi.load_library()
+    lib = _capi.load_library()
+    # The .so is git-ignored and travels prebuilt to the GPU box: a binary older than csrc/ or
+    # include/ would be tested against the wrong kernels.  Fail loudly, here and on the GPU box.
+    built, disk = _capi.library_source_hash(), _capi.source_hash()
+    if built != disk:
+        pytest.fail(f"libsoftrod_hip.so was built from sources {built}, the tree holds {disk}: "
+                    "run `python __graft_entry__.py build`", pytrace=False)
+    return lib

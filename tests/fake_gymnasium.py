@@ -46,7 +46,8 @@ def make_vec(id, num_envs=1, vectorization_mode=None, vector_kwargs=None, **kw):
     if spec.vector_entry_point is None or vectorization_mode not in (None, "vector_entry_point"):
         raise NotImplementedError("the stand-in only knows vector_entry_point")
     env = spec.vector_entry_point(num_envs=num_envs, **{**spec.kwargs, **(vector_kwargs or {}), **kw})
-    env.spec = spec
+    env.unwrapped.spec = spec      # as upstream's make_vec ends (it also reads env.metadata)
+    _ = env.metadata
     return env
 
 

@@ -43,7 +43,13 @@ class OracleBackend:
             r.set_radius_profile(radius)
 
     def state(self):
-        return {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64), "control": self._ctrl}
+        st = {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64), "control": self._ctrl}
+        if not self.isocto:       # softrod_state_view.bc_targets: fixed_position[3], fixed_directors[9] per env
+            bc = np.stack([np.concatenate([r.get("fixed_pos"), r.get("fixed_dir").ravel()]) for r in self.rods], axis=1)
+            st["bc_targets"] = torch.from_numpy(bc)
+            if self.is3d:         # MovingBaseController position x, y; velocity x, y
+                st["control"] = torch.from_numpy(np.stack([r.get("control") for r in self.rods], axis=1))
+        return st
 
     def rod_snapshot(self, env_indices):
         rods = [self.rods[i] for i in env_indices]

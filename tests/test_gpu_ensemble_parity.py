@@ -11,8 +11,9 @@ the oracle's FMA build (B) run the same way as the calibration of every band
     target distance, fraction terminated; x0, v0, theta, reward, stretch for the pendulum):
     two-sample KS distance below the alpha = 0.001 critical value, ensemble means within four
     paired standard errors (the standard error of a difference of means once the ensembles have decorrelated);
-  * the PAIRED divergence |H - A| per env: its 50 / 90 / 99 % quantiles within 8 x the control's
-    |B - A| (or a few float32 ulps): the product leaves the oracle's trajectory no faster than another
+  * the PAIRED divergence |H - A| per env: its 50 / 90 / 99 % quantiles within the band times the control's
+    |B - A| (tools/ensemble_parity.py paired_factor: 4 x for OctoFlat, 16 x for the stabilised pendulum; or a
+    few float32 ulps): the product leaves the oracle's trajectory no faster than another
     rounding of the oracle does;
   * blow-up events (the explicit integrator loses a whipping rod, NaN follows some steps later): the
     same envs, within 3 env.steps; no env reported NaN while the oracle integrates it healthily.

@@ -924,10 +924,19 @@ def test_rod_recorder_on_gpu(torch_gpu, hip_lib, oracle_built):
         assert len(p["time"]) == 2 and p["time"][-1] == pytest.approx(0.08, rel=1e-9)
         np.testing.assert_array_equal(p["position"][-1], st["x"][i])
         np.testing.assert_array_equal(p["omega"][-1], st["w"][i])
-        rods[i].refresh_strains()
+        # the reference's RodCallBack copies the CACHED strain arrays (callback_func.py:31-41): those of the
+        # last force evaluation, i.e. the mid-substep configuration — the oracle's caches as they are, no refresh
         np.testing.assert_allclose(p["kappa"][-1], rods[i].get("kappa"), rtol=RTOL, atol=1e-7)
         np.testing.assert_allclose(p["sigma"][-1], rods[i].get("sigma"), rtol=RTOL, atol=1e-8)
         np.testing.assert_allclose(p["radius"][-1], rods[i].get("radius"), rtol=1e-9)
+        np.testing.assert_allclose(p["dilatation"][-1], rods[i].get("dilatation"), rtol=1e-9)
+        # the rebuilt mid-substep configuration IS the one the kernel evaluated its forces at: its tangents
+        # are the row the kernel cached there (softrod_state_view.tangents), to rounding
+        np.testing.assert_allclose(env.recorder.last_mid_tangents[k], st["tangents"][i], rtol=0, atol=1e-13)
+        # and the end-of-step strains are measurably different (the defect of round 5's taps)
+        end = rods[i].get("sigma").copy()
+        rods[i].refresh_strains()
+        assert np.abs(rods[i].get("sigma") - end).max() > 1e-9
     env.close()
 
 

@@ -9,7 +9,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # bench.py's own defaults (20 warm-up + 100 timed steps): the profile is of the SAME command
-ARGS="--no-cpu-baseline $*"
+# --no-sustained: the sustained leg starts rocm-smi as a child; no child process under a profiler preload
+ARGS="--no-cpu-baseline --no-sustained $*"
 
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- \
     python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
