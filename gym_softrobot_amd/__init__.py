@@ -2,18 +2,20 @@
 Gymnasium surface of gym-softrobot's SoftPendulum-v0 / SoftPendulum3D-v0."""
 from . import _capi
 from .envs import (
+    ArmPushEnv,
     ArmSingleEnv,
     FlatEnv,
     SoftArmTrackingEnv,
     SoftPendulum3DEnv,
     SoftPendulumEnv,
+    VecArmPushEnv,
     VecArmSingleEnv,
     VecOctoFlatEnv,
     VecSoftArmTrackingEnv,
     VecSoftPendulum3DEnv,
     VecSoftPendulumEnv,
 )
-from .registration import make, register, registered
+from .registration import make, parity_label, register, registered
 
 __version__ = "0.2.0"
 VERSION = __version__                       # gym_softrobot/version.py
@@ -31,6 +33,8 @@ _VEC = {
     "OctoFlat-v0": (VecOctoFlatEnv, {}),
     "OctoFlatLite-v0": (VecOctoFlatEnv, dict(n_arm=1, n_action=8)),   # gym_softrobot/__init__.py:11-15
     "SoftArmTracking-v0": (VecSoftArmTrackingEnv, {}),
+    "OctoArmPush-v0": (VecArmPushEnv, {}),                            # gym_softrobot/__init__.py:37-46
+    "OctoArmPush-v1": (VecArmPushEnv, dict(mode="continuous")),
 }
 
 # gym_softrobot/__init__.py:27-30,74-80
@@ -42,6 +46,12 @@ register(id="OctoFlat-v0", entry_point=FlatEnv, vector_entry_point=VecOctoFlatEn
 register(id="OctoFlatLite-v0", entry_point=FlatEnv, kwargs=dict(n_arm=1, n_action=8), vector_entry_point=VecOctoFlatEnv)
 # gym_softrobot/__init__.py:60-63
 register(id="SoftArmTracking-v0", entry_point=SoftArmTrackingEnv, vector_entry_point=VecSoftArmTrackingEnv)
+# gym_softrobot/__init__.py:37-46 — the COOMM muscle arm: registered WITH its caveat (envs/arm_push.py)
+from .envs.arm_push import PARITY_LABEL as _UNPINNED  # noqa: E402
+
+register(id="OctoArmPush-v0", entry_point=ArmPushEnv, vector_entry_point=VecArmPushEnv, label=_UNPINNED)
+register(id="OctoArmPush-v1", entry_point=ArmPushEnv, kwargs=dict(mode="continuous"), vector_entry_point=VecArmPushEnv,
+         label=_UNPINNED)
 
 
 def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
@@ -54,5 +64,5 @@ def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
 
 __all__ = [
     "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
-    "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv", "SoftArmTrackingEnv", "VecSoftArmTrackingEnv", "make", "make_vec", "register", "registered", "_capi",
+    "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv", "SoftArmTrackingEnv", "VecSoftArmTrackingEnv", "ArmPushEnv", "VecArmPushEnv", "parity_label", "make", "make_vec", "register", "registered", "_capi",
 ]

@@ -20,7 +20,8 @@ def main() -> None:
     args = ap.parse_args()
     if args.env is None:
         for i, name in enumerate(gsa.registered()):
-            print(f"{i:3d}  {name}")
+            label = gsa.parity_label(name)
+            print(f"{i:3d}  {name}" + (f"    [{label}]" if label else ""))
         return
     import torch
 

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # softrod_feature (include/softrod.h)
 FEAT_GRAVITY = 1 << 0
@@ -26,7 +26,11 @@ FEAT_REST_KAPPA_ACTION = 1 << 9
 FEAT_OCTO_HEAD = 1 << 10
 FEAT_SPLINE_MUSCLE_TORQUES = 1 << 11
 FEAT_SUCKER_CONSTRAINT = 1 << 12
+FEAT_COOMM_MUSCLES = 1 << 13
 MAX_SUCKERS = 4
+MAX_MUSCLES = 4
+MUSCLE_LONGITUDINAL = 0
+MUSCLE_TRANSVERSE = 1
 MATERIAL_ROWS = 16
 FEATURES_SOFTPENDULUM = (
     FEAT_GRAVITY | FEAT_POINT_FORCE_NODE0_X | FEAT_PENDULUM_BC | FEAT_ANALYTICAL_DAMPER
@@ -45,6 +49,8 @@ ENV_SOFTPENDULUM3D = 2
 ENV_ARM_SINGLE = 3
 ENV_OCTO_FLAT = 4
 ENV_SOFT_ARM = 5
+ENV_ARM_PUSH = 6
+FEATURES_ARM_PUSH = FEAT_ANALYTICAL_DAMPER | FEAT_SUCKER_CONSTRAINT | FEAT_COOMM_MUSCLES
 FEATURES_OCTO_FLAT = FEATURES_ARM_SINGLE | FEAT_OCTO_HEAD
 FEATURES_SOFT_ARM = FEAT_FIXED_BC | FEAT_ANALYTICAL_DAMPER | FEAT_SPLINE_MUSCLE_TORQUES
 
@@ -54,11 +60,11 @@ MATH_FAST = 1
 LANE_STRIDE = 64  # one wavefront row per rod (softrod_state_view.lane_stride)
 
 _ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2, ENV_ARM_SINGLE: 7, ENV_OCTO_FLAT: 24,
-               ENV_SOFT_ARM: 8}
+               ENV_SOFT_ARM: 8, ENV_ARM_PUSH: 2}
 _OBS_DIM = {ENV_NONE: 4, ENV_SOFTPENDULUM: 4, ENV_SOFTPENDULUM3D: 9, ENV_ARM_SINGLE: 25,
-            ENV_OCTO_FLAT: 8 * 56 + 13, ENV_SOFT_ARM: 14}
+            ENV_OCTO_FLAT: 8 * 56 + 13, ENV_SOFT_ARM: 14, ENV_ARM_PUSH: 84}
 _AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1, ENV_ARM_SINGLE: 0, ENV_OCTO_FLAT: 0,
-            ENV_SOFT_ARM: 0}
+            ENV_SOFT_ARM: 0, ENV_ARM_PUSH: 0}
 
 
 def action_dim(env_kind: int) -> int:
@@ -134,6 +140,15 @@ class SoftrodConfig(C.Structure):
         ("sucker_index", C.c_int32 * 4),
         ("reserved2", C.c_int32),
         ("sucker_reduction_ratio", C.c_double),
+        ("n_muscles", C.c_int32),
+        ("muscle_kind", C.c_int32 * 4),
+        ("muscle_fl_degree", C.c_int32),
+        ("muscle_equiv_load_form", C.c_int32),
+        ("muscle_position_current_radius", C.c_int32),
+        ("muscle_tm_length_law", C.c_int32),
+        ("arm_push_mode", C.c_int32),
+        ("reserved3", C.c_int32),
+        ("muscle_fl_coef", C.c_double * 8),
     ]
 
     def copy(self) -> "SoftrodConfig":
@@ -164,6 +179,8 @@ class SoftrodStateView(C.Structure):
         ("head", C.c_void_p),
         ("bc_targets", C.c_void_p),
         ("sucker_ratio", C.c_void_p),
+        ("muscle_activation", C.c_void_p),
+        ("sucker_index", C.c_void_p),
         ("material", C.c_void_p),
     ]
 
@@ -340,6 +357,96 @@ def soft_arm_config(n_envs: int = 1, *, n_elems: int = 40, math_mode: int = MATH
     return cfg
 
 
+# COOMM's force-length law as the paper prints it (Chang et al. 2023, section 2(c)):
+# f_l(l) = max{3.06 l^3 - 13.64 l^2 + 18.01 l - 6.44, 0}; ascending powers
+COOMM_FL_COEF = (-6.44, 18.01, -13.64, 3.06)
+
+
+def muscle_defaults(cfg: SoftrodConfig) -> None:
+    """The recalled COOMM details as softrod_config switches (include/softrod.h, PARITY UNPINNED) and the
+    three layers of create_es_muscle_layers (octopus/build.py:295-338): two longitudinal, one transverse."""
+    cfg.n_muscles = 3
+    cfg.muscle_kind[0], cfg.muscle_kind[1], cfg.muscle_kind[2] = MUSCLE_LONGITUDINAL, MUSCLE_LONGITUDINAL, MUSCLE_TRANSVERSE
+    cfg.muscle_fl_degree = len(COOMM_FL_COEF) - 1
+    for k, v in enumerate(COOMM_FL_COEF):
+        cfg.muscle_fl_coef[k] = v
+    cfg.muscle_equiv_load_form = 0
+    cfg.muscle_position_current_radius = 1
+    cfg.muscle_tm_length_law = 0
+
+
+def es_muscle_layers(radius_mean, radius_base: float, init_angle_rotates: bool = True, tm_sign: float = -1.0):
+    """(ratio_position [3][3][n], strength [3][n]) for softrod_set_muscle_layers: what
+    create_es_muscle_layers(radius_mean, radius_base) (octopus/build.py:295-338) hands to COOMM's constructors,
+      LongitudinalMuscle(muscle_init_angle=+pi/2, ratio_muscle_position=(0, -6/9, 0), rest_muscle_area=(r/r_base)^2, max_muscle_stress=0.5)
+      LongitudinalMuscle(muscle_init_angle=-pi/2, ...same...)
+      TransverseMuscle(rest_muscle_area=(r/r_base)^2, max_muscle_stress=1.0)
+    turned into the tables the kernels read.  RECALLED COOMM behaviour, each a keyword here:
+      init_angle_rotates  the longitudinal muscle's position is ratio_muscle_position turned about d3 by
+                          muscle_init_angle ((0, -2/3) -> (+2/3, 0) and (-2/3, 0): an antagonistic pair on d1);
+                          False: the array as given (both muscles at (0, -2/3, 0))
+      tm_sign             TransverseMuscle passes -max_muscle_stress: contraction of the radial fibres
+                          EXTENDS the arm (the force along the tangent is negative)."""
+    import numpy as np
+
+    r = np.asarray(radius_mean, np.float64)
+    n = r.size
+    area = (r / radius_base) ** 2
+    base = np.stack((np.zeros_like(r), -6 / 9 * np.ones_like(r), np.zeros_like(r)), axis=0)
+    ratio = np.zeros((3, 3, n))
+    for m, ang in enumerate((np.pi / 2, -np.pi / 2)):
+        if init_angle_rotates:
+            c, s = np.cos(ang), np.sin(ang)
+            ratio[m, 0] = c * base[0] - s * base[1]
+            ratio[m, 1] = s * base[0] + c * base[1]
+            ratio[m, 2] = base[2]
+        else:
+            ratio[m] = base
+    strength = np.stack((0.5 * area, 0.5 * area, tm_sign * 1.0 * area), axis=0)
+    return np.ascontiguousarray(ratio), np.ascontiguousarray(strength)
+
+
+def arm_push_radii(n_elems: int = 40, radius_base: float = 0.012, radius_tip: float = 0.001):
+    """radius_mean of ArmPushEnv._build (octopus/arm_push_env.py:160-165)."""
+    import numpy as np
+
+    radius = np.linspace(radius_base, radius_tip, n_elems + 1)
+    return (radius[:-1] + radius[1:]) / 2
+
+
+def arm_push_config(
+    n_envs: int = 1,
+    *,
+    final_time: float = 2.5,
+    time_step: float = 5.0e-5,
+    recording_fps: int = 40,
+    mode: str = "discrete",
+    math_mode: int = MATH_FAST,
+) -> SoftrodConfig:
+    """`softrod_config_arm_push`: ArmPushEnv.__init__ (octopus/arm_push_env.py:65-139) and `_build`
+    (:158-224): a 40-element arm of length 0.2, density 700, E = 1e4, G = E / 1.5, tapered 12:1
+    (arm_push_radii -> softrod_set_radius_profile), AnalyticalLinearDamper(0.05 * 2 * 1e2), one
+    ControllableFixConstraint at index 0 and ApplyMuscles over create_es_muscle_layers.  No gravity, no plane."""
+    if mode not in ("discrete", "continuous"):
+        raise NotImplementedError(f"The mode {mode} is not available.")            # arm_push_env.py:97
+    cfg = SoftrodConfig()
+    _common(cfg, n_envs, final_time, time_step, recording_fps, 40, math_mode)
+    cfg.features = FEATURES_ARM_PUSH
+    cfg.env_kind = ENV_ARM_PUSH
+    cfg.arm_push_mode = 0 if mode == "discrete" else 1
+    cfg.base_length = 0.2                           # L0, :160
+    cfg.base_radius = 0.012                         # radius_base (the profile overrides it per element)
+    cfg.density = 700.0                             # :174
+    cfg.youngs_modulus = 1e4                        # :175
+    cfg.shear_modulus = 1e4 / 1.5                   # :176
+    cfg.damping_constant = 0.05 * 2 * 1e2           # damp_coefficient * 1e2, :166,183
+    cfg.n_suckers = 1                               # :187-195
+    cfg.sucker_index[0] = 0
+    cfg.sucker_reduction_ratio = 1.0                # SuckerController default (controllable_constraint.py:11)
+    muscle_defaults(cfg)
+    return cfg
+
+
 def np_rint(x: float) -> float:
     import numpy as np
 
@@ -410,10 +517,14 @@ def octo_arm_frames(n_arm: int, head_radius: float):
 def config_action_dim(cfg: "SoftrodConfig") -> int:
     if int(cfg.env_kind) == ENV_OCTO_FLAT:
         return int(cfg.n_arm) * int(cfg.n_knots)
+    if int(cfg.env_kind) == ENV_ARM_PUSH:
+        return 1 if int(cfg.arm_push_mode) == 0 else 2      # Discrete(2) index / (location, activation)
     return action_dim(cfg.env_kind)
 
 
 def config_obs_dim(cfg: "SoftrodConfig") -> int:
+    if int(cfg.env_kind) == ENV_ARM_PUSH:
+        return 2 * (int(cfg.n_elem) + 1) + 2                # arm_push_env.py:104,118-120
     if int(cfg.env_kind) == ENV_OCTO_FLAT:
         n = int(cfg.n_elem)
         return int(cfg.n_arm) * ((n - 1) + 4 * (n + 1) + int(cfg.n_knots)) + 13
@@ -437,6 +548,8 @@ _EXPORTS = {
     "softrod_config_arm_single": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_octo_flat": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_soft_arm": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_config_arm_push": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.c_int]),
+    "softrod_set_muscle_layers": (C.c_int, [_VP, _VP, _VP]),
     "softrod_set_spline_table": (C.c_int, [_VP, _VP, _VP]),
     "softrod_config_action_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),
     "softrod_config_obs_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),

@@ -103,6 +103,15 @@ class HipRodBackend:
         check(self._lib.softrod_set_radius_profile(self._h, r.ctypes.data), self._h)
         self._tables["radius_profile"] = r.tobytes()
 
+    def set_muscle_layers(self, ratio_position, strength) -> None:
+        """The layers handed to COOMM's ApplyMuscles (softrod_set_muscle_layers): ratio_position
+        (n_muscles, 3, n_elem), strength = max_muscle_stress * rest_muscle_area (n_muscles, n_elem), signed."""
+        m, n = int(self.cfg.n_muscles), int(self.cfg.n_elem)
+        rp = np.ascontiguousarray(ratio_position, dtype=np.float64).reshape(m, 3, n)
+        st = np.ascontiguousarray(strength, dtype=np.float64).reshape(m, n)
+        check(self._lib.softrod_set_muscle_layers(self._h, rp.ctypes.data, st.ctypes.data), self._h)
+        self._tables["muscle_layers"] = rp.tobytes() + st.tobytes()
+
     def reset(self, theta0: np.ndarray, mask: Optional[np.ndarray] = None) -> None:
         th = np.ascontiguousarray(theta0, dtype=np.float64).reshape(self.n_envs)
         m = None
@@ -333,7 +342,14 @@ class HipRodBackend:
         def view(ptr, comps):
             return torch.as_tensor(_DevArray(ptr, (comps, n, s), "<f8", self), device=self.device)
 
+        extra = {}
+        if v.muscle_activation:
+            extra["muscle_activation"] = torch.as_tensor(
+                _DevArray(v.muscle_activation, (_capi.MAX_MUSCLES, n, s), "<f8", self), device=self.device)
         return {
+            **extra,
+            "sucker_index": torch.as_tensor(_DevArray(v.sucker_index, (_capi.MAX_SUCKERS, n), "<i4", self),
+                                            device=self.device),
             "position": view(v.position, 3),
             "velocity": view(v.velocity, 3),
             "director": view(v.director, 9),
@@ -354,7 +370,10 @@ class HipRodBackend:
         }
 
     _SNAPSHOT_KEYS = ("position", "velocity", "director", "omega", "tangents", "time", "control", "kappa",
-                      "rest_kappa", "env_memory", "prev_action", "head", "bc_targets", "sucker_ratio")
+                      "rest_kappa", "env_memory", "prev_action", "head", "bc_targets", "sucker_ratio", "sucker_index")
+
+    def _snapshot_keys(self):
+        return self._SNAPSHOT_KEYS + (("muscle_activation",) if self.cfg.features & _capi.FEAT_COOMM_MUSCLES else ())
 
     def config_fingerprint(self) -> bytes:
         """What a snapshot is only valid for: the ABI, every field of softrod_config except the
@@ -381,7 +400,7 @@ class HipRodBackend:
                                      "the pending-reset flags and the staged queue are not part of the state view")
         st = self.state()
         torch.cuda.synchronize(self.device)
-        snap = {k: st[k].cpu().clone() for k in self._SNAPSHOT_KEYS}
+        snap = {k: st[k].cpu().clone() for k in self._snapshot_keys()}
         snap["config_fingerprint"] = torch.frombuffer(bytearray(self.config_fingerprint()), dtype=torch.uint8).clone()
         return snap
 
@@ -395,7 +414,7 @@ class HipRodBackend:
                              "(dt, n_substeps, features, env_kind, material, radius profile, spline table, "
                              "action basis ...): refusing to load it")
         st = self.state()
-        for k in self._SNAPSHOT_KEYS:
+        for k in self._snapshot_keys():
             if tuple(snap[k].shape) != tuple(st[k].shape):
                 raise ValueError(f"snapshot field {k!r} has shape {tuple(snap[k].shape)}, expected {tuple(st[k].shape)}")
             st[k].copy_(snap[k].to(self.device))

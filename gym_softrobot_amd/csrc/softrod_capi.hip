@@ -43,6 +43,10 @@ struct softrod_handle {
     double* d_time_tab = nullptr;   // clock after k env.steps from a reset (clock_after, softrod_fast.hpp)
     double* d_mat = nullptr;        // [kMatRows][64] material table of a tapered rod
     double* d_sucker = nullptr;     // [SOFTROD_MAX_SUCKERS][N]
+    int* d_sucker_idx = nullptr;    // [SOFTROD_MAX_SUCKERS][N]
+    double* d_mact = nullptr;       // [SOFTROD_MAX_MUSCLES][N][64] muscle activations (SOFTROD_FEAT_COOMM_MUSCLES)
+    double* d_mtab = nullptr;       // [SOFTROD_MAX_MUSCLES][4][64] ratio_position x, y, z, strength
+    bool muscles_set = false;
     unsigned* d_ticket = nullptr;   // softrod_scatter_rows: blocks that have finished storing (tagged form)
     bool tapered = false;
     bool was_reset = false;
@@ -223,6 +227,16 @@ void fill_params(const softrod_config& c, RodParams& P) {
     for (int i = 0; i < 3; ++i) P.arm_target[i] = c.arm_target[i];
     P.n_suckers = c.n_suckers;
     for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) P.sucker_index[j] = c.sucker_index[j];
+    P.sucker_ratio0 = c.sucker_reduction_ratio;
+    // COOMM muscle layers
+    P.n_muscles = (c.features & SOFTROD_FEAT_COOMM_MUSCLES) ? c.n_muscles : 0;
+    for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) P.muscle_kind[m] = c.muscle_kind[m];
+    P.fl_degree = c.muscle_fl_degree;
+    for (int k = 0; k < SOFTROD_MAX_FL_COEF; ++k) P.fl_coef[k] = c.muscle_fl_coef[k];
+    P.muscle_form = c.muscle_equiv_load_form;
+    P.muscle_cur_radius = c.muscle_position_current_radius;
+    P.muscle_tm_law = c.muscle_tm_length_law;
+    P.push_mode = c.arm_push_mode;
 }
 
 bool is_octo(const softrod_handle* h) { return (h->cfg.features & SOFTROD_FEAT_OCTO_HEAD) != 0; }
@@ -242,6 +256,16 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
             hipLaunchKernelGGL(softrod_autoreset_kernel<1>, grid, block, 0, st, h->P, h->S, obs, reward, term,
                                trunc, aux, pack);
         SR_HIP(h, hipGetLastError());
+    }
+    if ((h->cfg.features & SOFTROD_FEAT_COOMM_MUSCLES) && h->cfg.math_mode == SOFTROD_MATH_FAST) {
+        // the fast kernel carries the muscle layers in two instantiations only (kMusclesCompiled): the tapered
+        // ArmPush arm and the uniform muscle rod; never let another one run a muscle handle without its muscles
+        const bool push = h->cfg.env_kind == SOFTROD_ENV_ARM_PUSH;
+        if (push && !h->tapered)
+            return fail(h, SOFTROD_EINVAL, "SOFTROD_ENV_ARM_PUSH (SOFTROD_MATH_FAST): call softrod_set_radius_profile first "
+                                           "(the reference's arm is tapered, arm_push_env.py:160-179)");
+        if (!push && h->tapered)
+            return fail(h, SOFTROD_EINVAL, "a tapered muscle rod outside SOFTROD_ENV_ARM_PUSH runs under SOFTROD_MATH_LIBM only");
     }
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
@@ -298,6 +322,8 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
                 SR_LAUNCH(SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup, SOFTROD_ENV_ARM_SINGLE, EPL); \
             else if (f == SOFTROD_FEATURES_SOFT_ARM && e == SOFTROD_ENV_SOFT_ARM)                   \
                 SR_LAUNCH(SOFTROD_FEATURES_SOFT_ARM, SOFTROD_ENV_SOFT_ARM, EPL);                    \
+            else if (f == kFeaturesMuscleRod && e == SOFTROD_ENV_NONE && EPL == 1)                  \
+                SR_LAUNCH(kFeaturesMuscleRod, SOFTROD_ENV_NONE, 1);                                 \
             else                                                                                    \
                 SR_LAUNCH(kRuntimeFeatures, kRuntimeEnv, EPL);                                      \
         } while (0)
@@ -313,6 +339,8 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
                 SR_LAUNCH_TAPER(SOFTROD_FEATURES_ARM_SINGLE | kFeatPlaneZup, SOFTROD_ENV_ARM_SINGLE);
             else if (f == kFeaturesTaperedSuckerArm && e == SOFTROD_ENV_NONE)
                 SR_LAUNCH_TAPER(kFeaturesTaperedSuckerArm, SOFTROD_ENV_NONE);
+            else if (f == SOFTROD_FEATURES_ARM_PUSH && e == SOFTROD_ENV_ARM_PUSH)     // OctoArmPush-v0 / -v1
+                SR_LAUNCH_TAPER(SOFTROD_FEATURES_ARM_PUSH, SOFTROD_ENV_ARM_PUSH);
             else
                 SR_LAUNCH_TAPER(kRuntimeFeatures, kRuntimeEnv);
 #undef SR_LAUNCH_TAPER
@@ -404,20 +432,24 @@ const char* softrod_source_hash(void) { return SOFTROD_SOURCE_HASH; }
 
 int softrod_action_dim(int env_kind) {
     return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 2 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 7
-         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 24 : env_kind == SOFTROD_ENV_SOFT_ARM ? 8 : 1;
+         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 24 : env_kind == SOFTROD_ENV_SOFT_ARM ? 8
+         : env_kind == SOFTROD_ENV_ARM_PUSH ? 2 : 1;
 }
 int softrod_obs_dim(int env_kind) {
     return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 9 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 25
-         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 8 * 56 + 13 : env_kind == SOFTROD_ENV_SOFT_ARM ? 14 : 4;
+         : env_kind == SOFTROD_ENV_OCTO_FLAT ? 8 * 56 + 13 : env_kind == SOFTROD_ENV_SOFT_ARM ? 14
+         : env_kind == SOFTROD_ENV_ARM_PUSH ? 84 : 4;
 }
 int softrod_config_action_dim(const softrod_config* cfg) {
     if (!cfg) return 0;
     if (cfg->env_kind == SOFTROD_ENV_SOFT_ARM) return 2 * cfg->n_ctrl;     // soft_arm_tracking.py:152-157
+    if (cfg->env_kind == SOFTROD_ENV_ARM_PUSH) return cfg->arm_push_mode == 0 ? 1 : 2;   // arm_push_env.py:100-118
     return cfg->env_kind == SOFTROD_ENV_OCTO_FLAT ? cfg->n_arm * cfg->n_knots : softrod_action_dim(cfg->env_kind);
 }
 int softrod_config_obs_dim(const softrod_config* cfg) {
     if (!cfg) return 0;
     if (cfg->env_kind == SOFTROD_ENV_SOFT_ARM) return 2 * cfg->n_ctrl + 6;  // :158-163
+    if (cfg->env_kind == SOFTROD_ENV_ARM_PUSH) return 2 * (cfg->n_elem + 1) + 2;          // arm_push_env.py:104,118-120
     if (cfg->env_kind != SOFTROD_ENV_OCTO_FLAT) return softrod_obs_dim(cfg->env_kind);
     return cfg->n_arm * ((cfg->n_elem - 1) + 4 * (cfg->n_elem + 1) + cfg->n_knots) + 13;
 }
@@ -534,6 +566,37 @@ int softrod_config_soft_arm(softrod_config* cfg, int n_envs) {
     return SOFTROD_OK;
 }
 
+int softrod_config_arm_push(softrod_config* cfg, int n_envs, int mode) {
+    if (!cfg || n_envs < 1 || (mode != 0 && mode != 1)) return fail(nullptr, SOFTROD_EINVAL, "bad argument");
+    config_common(cfg, n_envs);
+    cfg->features = SOFTROD_FEATURES_ARM_PUSH;
+    cfg->env_kind = SOFTROD_ENV_ARM_PUSH;
+    cfg->arm_push_mode = mode;                           // octopus/arm_push_env.py:90-97
+    cfg->n_elem = 40;                                    // :88
+    cfg->dt = 5.0e-5;                                    // :67
+    cfg->n_substeps = (int)(1.0 / (40 * cfg->dt));       // recording_fps = 40 (:68) -> 500 (:85)
+    cfg->final_time = 2.5;                               // :66
+    cfg->base_length = 0.2;                              // L0, :160
+    cfg->base_radius = 0.012;                            // radius_base, :161 (the taper: softrod_set_radius_profile)
+    cfg->density = 700.0;                                // :174
+    cfg->youngs_modulus = 1e4;                           // :175
+    cfg->shear_modulus = 1e4 / 1.5;                      // :176
+    cfg->damping_constant = 0.05 * 2 * 1e2;              // damp_coefficient * 1e2, :166,183
+    cfg->n_suckers = 1;                                  // :187-195
+    cfg->sucker_index[0] = 0;
+    cfg->sucker_reduction_ratio = 1.0;                   // controllable_constraint.py:11
+    cfg->n_muscles = 3;                                  // create_es_muscle_layers, octopus/build.py:295-338
+    cfg->muscle_kind[0] = SOFTROD_MUSCLE_LONGITUDINAL;
+    cfg->muscle_kind[1] = SOFTROD_MUSCLE_LONGITUDINAL;
+    cfg->muscle_kind[2] = SOFTROD_MUSCLE_TRANSVERSE;
+    cfg->muscle_fl_degree = 3;                           // Chang et al. 2023: max{3.06 l^3 - 13.64 l^2 + 18.01 l - 6.44, 0}
+    cfg->muscle_fl_coef[0] = -6.44; cfg->muscle_fl_coef[1] = 18.01; cfg->muscle_fl_coef[2] = -13.64; cfg->muscle_fl_coef[3] = 3.06;
+    cfg->muscle_equiv_load_form = 0;
+    cfg->muscle_position_current_radius = 1;
+    cfg->muscle_tm_length_law = 0;
+    return SOFTROD_OK;
+}
+
 int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) {
     if (!cfg || !out) return fail(nullptr, SOFTROD_EINVAL, "null argument");
     *out = nullptr;
@@ -548,8 +611,34 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "need n_substeps >= 0 and dt > 0");
     if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
-    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_SOFT_ARM)
+    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_ARM_PUSH)
         return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
+    if (cfg->features & SOFTROD_FEAT_COOMM_MUSCLES) {
+        if (cfg->n_muscles < 1 || cfg->n_muscles > SOFTROD_MAX_MUSCLES || cfg->muscle_fl_degree < 0 ||
+            cfg->muscle_fl_degree >= SOFTROD_MAX_FL_COEF || cfg->n_elem > kLanes - 1 ||
+            (cfg->features & SOFTROD_FEAT_OCTO_HEAD))
+            return fail(nullptr, SOFTROD_EINVAL,
+                        "COOMM muscles: 1 <= n_muscles <= 4, 0 <= muscle_fl_degree <= 7, one rod of up to 63 elements per env");
+        for (int m = 0; m < cfg->n_muscles; ++m)
+            if (cfg->muscle_kind[m] != SOFTROD_MUSCLE_LONGITUDINAL && cfg->muscle_kind[m] != SOFTROD_MUSCLE_TRANSVERSE)
+                return fail(nullptr, SOFTROD_EINVAL, "muscle_kind: SOFTROD_MUSCLE_LONGITUDINAL or SOFTROD_MUSCLE_TRANSVERSE");
+        if ((cfg->muscle_equiv_load_form | 1) != 1 || (cfg->muscle_position_current_radius | 1) != 1 ||
+            (cfg->muscle_tm_length_law | 1) != 1)
+            return fail(nullptr, SOFTROD_EINVAL, "muscle_equiv_load_form, muscle_position_current_radius, muscle_tm_length_law: 0 or 1");
+    }
+    if ((cfg->features & SOFTROD_FEAT_COOMM_MUSCLES) && cfg->math_mode == SOFTROD_MATH_FAST &&
+        !((cfg->features == SOFTROD_FEATURES_ARM_PUSH && cfg->env_kind == SOFTROD_ENV_ARM_PUSH) ||
+          (cfg->features == kFeaturesMuscleRod && cfg->env_kind == SOFTROD_ENV_NONE)))
+        return fail(nullptr, SOFTROD_EINVAL,
+                    "SOFTROD_MATH_FAST compiles the COOMM muscles for SOFTROD_FEATURES_ARM_PUSH with SOFTROD_ENV_ARM_PUSH "
+                    "(tapered) and for FIXED_BC | ANALYTICAL_DAMPER | COOMM_MUSCLES with SOFTROD_ENV_NONE (uniform rod); "
+                    "use SOFTROD_MATH_LIBM for any other mix");
+    if (cfg->env_kind == SOFTROD_ENV_ARM_PUSH) {
+        const unsigned need = SOFTROD_FEAT_COOMM_MUSCLES | SOFTROD_FEAT_SUCKER_CONSTRAINT;
+        if ((cfg->features & need) != need || cfg->n_muscles < 3 || (cfg->arm_push_mode != 0 && cfg->arm_push_mode != 1))
+            return fail(nullptr, SOFTROD_EINVAL,
+                        "SOFTROD_ENV_ARM_PUSH needs the sucker constraint, three muscle layers and arm_push_mode 0 or 1");
+    }
     if (cfg->damper_protocol != 0 && cfg->damper_protocol != 1)
         return fail(nullptr, SOFTROD_EINVAL, "damper_protocol: 0 (per unit mass) or 1 (uniform)");
     // The fast kernels expand theta / sin(theta + eps_sin) as (theta / sin theta)(1 - eps_sin cot theta)
@@ -703,6 +792,21 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     }
     alloc((void**)&h->d_sucker, (size_t)SOFTROD_MAX_SUCKERS * N * sizeof(double));
     h->S.sucker = h->d_sucker;
+    alloc((void**)&h->d_sucker_idx, (size_t)SOFTROD_MAX_SUCKERS * N * sizeof(int));
+    h->S.sucker_idx = h->d_sucker_idx;
+    if (rc == SOFTROD_OK) {
+        std::vector<int> idx((size_t)SOFTROD_MAX_SUCKERS * N, 0);
+        for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j)
+            for (size_t e = 0; e < N; ++e) idx[(size_t)j * N + e] = cfg->sucker_index[j];
+        if (hipMemcpy(h->d_sucker_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            rc = SOFTROD_EHIP;
+    }
+    if (cfg->features & SOFTROD_FEAT_COOMM_MUSCLES) {
+        alloc((void**)&h->d_mact, (size_t)SOFTROD_MAX_MUSCLES * rowb);
+        alloc((void**)&h->d_mtab, (size_t)SOFTROD_MAX_MUSCLES * 4 * kLanes * sizeof(double));
+        h->S.mact = h->d_mact;
+        h->S.mtab = h->d_mtab;
+    }
     if (rc == SOFTROD_OK && (cfg->features & SOFTROD_FEAT_SUCKER_CONSTRAINT)) {
         // the controllers are switched on after finalize (arm_push_env.py:222): effective ratio = the configured one
         std::vector<double> init((size_t)SOFTROD_MAX_SUCKERS * N, 0.0);
@@ -1121,6 +1225,29 @@ int softrod_set_radius_profile(softrod_handle* h, const double* radius) {
     return SOFTROD_OK;
 }
 
+int softrod_set_muscle_layers(softrod_handle* h, const double* ratio_position, const double* strength) {
+    if (!h || !ratio_position || !strength) return fail(h, SOFTROD_EINVAL, "null argument");
+    if (!(h->cfg.features & SOFTROD_FEAT_COOMM_MUSCLES)) return fail(h, SOFTROD_EINVAL, "this handle has no COOMM muscles");
+    const int n = h->cfg.n_elem, M = h->cfg.n_muscles;
+    constexpr int W = kLanes;
+    std::vector<double> T((size_t)SOFTROD_MAX_MUSCLES * 4 * W, 0.0);
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < n; ++k) {
+            for (int i = 0; i < 3; ++i) {
+                const double v = ratio_position[((size_t)m * 3 + i) * n + k];
+                if (!std::isfinite(v)) return fail(h, SOFTROD_EINVAL, "ratio_position must be finite");
+                T[((size_t)m * 4 + i) * W + k] = v;
+            }
+            const double st = strength[(size_t)m * n + k];
+            if (!std::isfinite(st)) return fail(h, SOFTROD_EINVAL, "strength must be finite");
+            T[((size_t)m * 4 + 3) * W + k] = st;
+        }
+    SR_ON_DEVICE(h);
+    SR_HIP(h, hipMemcpy(h->d_mtab, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->muscles_set = true;
+    return SOFTROD_OK;
+}
+
 int softrod_set_action_basis(softrod_handle* h, const double* basis) {
     if (!h || !basis) return fail(h, SOFTROD_EINVAL, "null argument");
     SR_ON_DEVICE(h);
@@ -1140,6 +1267,8 @@ int softrod_step(softrod_handle* h, const float* actions, float* obs, double* re
         return fail(h, SOFTROD_EINVAL, "softrod_set_spline_table must be called before softrod_step");
     if (h->cfg.env_kind == SOFTROD_ENV_NONE)
         return fail(h, SOFTROD_EINVAL, "env_kind NONE has no step epilogue; use softrod_substeps");
+    if ((h->cfg.features & SOFTROD_FEAT_COOMM_MUSCLES) && !h->muscles_set)
+        return fail(h, SOFTROD_EINVAL, "softrod_set_muscle_layers must be called before softrod_step");
     SR_ON_DEVICE(h);
     return launch_step(h, actions, obs, reward, terminated, truncated, aux, h->cfg.n_substeps, 1, 0,
                        (hipStream_t)stream);
@@ -1153,6 +1282,8 @@ int softrod_step_packed(softrod_handle* h, const float* actions, float* packed, 
         return fail(h, SOFTROD_EINVAL, "softrod_set_action_basis must be called before softrod_step");
     if ((h->cfg.features & SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) && !h->spline_set)
         return fail(h, SOFTROD_EINVAL, "softrod_set_spline_table must be called before softrod_step");
+    if ((h->cfg.features & SOFTROD_FEAT_COOMM_MUSCLES) && !h->muscles_set)
+        return fail(h, SOFTROD_EINVAL, "softrod_set_muscle_layers must be called before softrod_step");
     SR_ON_DEVICE(h);
     return launch_step(h, actions, packed, nullptr, nullptr, nullptr, aux, h->cfg.n_substeps, 1, 1,
                        (hipStream_t)stream);
@@ -1292,6 +1423,8 @@ int softrod_substeps(softrod_handle* h, const float* actions, int n, void* strea
     if (!h || n < 0) return fail(h, SOFTROD_EINVAL, "bad argument");
     if (actions && h->cfg.env_kind != SOFTROD_ENV_SOFTPENDULUM && h->cfg.env_kind != SOFTROD_ENV_NONE)
         return fail(h, SOFTROD_EINVAL, "softrod_substeps takes no actions for this env_kind");
+    if ((h->cfg.features & SOFTROD_FEAT_COOMM_MUSCLES) && !h->muscles_set)
+        return fail(h, SOFTROD_EINVAL, "softrod_set_muscle_layers must be called before softrod_substeps");
     SR_ON_DEVICE(h);
     return launch_step(h, actions, nullptr, nullptr, nullptr, nullptr, nullptr, n, 0, 0, (hipStream_t)stream);
 }
@@ -1334,6 +1467,8 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->head = h->S.head;
     out->bc_targets = h->S.bc;
     out->sucker_ratio = h->S.sucker;
+    out->muscle_activation = h->d_mact;
+    out->sucker_index = h->d_sucker_idx;
     out->material = h->d_mat;
     return SOFTROD_OK;
 }
@@ -1404,10 +1539,12 @@ const char* softrod_kernel_tier(softrod_handle* h) {
         if (h->tapered) {
             if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE && zup) spec = "ArmSingle";
             else if (f == kFeaturesTaperedSuckerArm && e == SOFTROD_ENV_NONE) spec = "damped sucker arm";
+            else if (f == SOFTROD_FEATURES_ARM_PUSH && e == SOFTROD_ENV_ARM_PUSH) spec = "ArmPush";
         } else if (f == SOFTROD_FEATURES_SOFTPENDULUM && e == SOFTROD_ENV_SOFTPENDULUM) spec = "SoftPendulum";
         else if (f == SOFTROD_FEATURES_SOFTPENDULUM3D && e == SOFTROD_ENV_SOFTPENDULUM3D) spec = "SoftPendulum3D";
         else if (f == SOFTROD_FEATURES_ARM_SINGLE && e == SOFTROD_ENV_ARM_SINGLE && zup) spec = "ArmSingle";
         else if (f == SOFTROD_FEATURES_SOFT_ARM && e == SOFTROD_ENV_SOFT_ARM) spec = "SoftArm";
+        else if (f == kFeaturesMuscleRod && e == SOFTROD_ENV_NONE) spec = "muscle rod";
         t = std::string("softrod_step_fast_kernel<") + spec + ",epl=" + std::to_string(h->tapered ? 1 : h->epl) +
             (h->tapered ? ",taper>" : ">");
     } else
@@ -1422,7 +1559,7 @@ int softrod_destroy(softrod_handle* h) {
     (void)hipDeviceSynchronize();
     autoreset_release(h);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_time_tab, h->d_mat, h->d_sucker, h->d_basis, h->d_spline, h->d_init, h->d_mask, h->d_ticket};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_time_tab, h->d_mat, h->d_sucker, h->d_sucker_idx, h->d_mact, h->d_mtab, h->d_basis, h->d_spline, h->d_init, h->d_mask, h->d_ticket};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

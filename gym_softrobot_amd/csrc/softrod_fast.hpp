@@ -293,6 +293,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
     }
     shift_next<EPL>(len, len_n);
     double up[EPL][3], um[EPL][3];
+    double kv[EPL][3], e3v[EPL];      // kappa (zero off the rod) and 1 / eps^3 for the muscle layers (dead otherwise)
 #pragma unroll
     for (int s = 0; s < EPL; ++s) {
         const bool vor_valid = slot_local<F>(P, lane * EPL + s) < n - 1;
@@ -314,6 +315,10 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         const double vd = (len_n[s] + len[s]) * (0.5 * P.inv_rest_vor);
         const double rvd = fast_rcp(vd);
         const double e3 = rvd * rvd * rvd;
+        if constexpr (kMusclesCompiled<F>) {
+            kv[s][0] = vor_valid ? k0 : 0.0; kv[s][1] = vor_valid ? k1 : 0.0; kv[s][2] = vor_valid ? k2 : 0.0;
+            e3v[s] = e3;
+        }
         if (F == kRuntimeFeatures || (F & (SOFTROD_FEAT_REST_KAPPA_ACTION | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))) {
             L.kap[s][0] = k0; L.kap[s][1] = k1; L.kap[s][2] = k2;
         }
@@ -369,6 +374,17 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         if (L.mflag & 3) spline_muscle_rebuild<EPL>(P, lane, len, L);
 #pragma unroll
         for (int s = 0; s < EPL; ++s) { tq[s][0] += L.rk[s][0]; tq[s][1] += L.rk[s][1]; }
+    }
+    // forcing: the COOMM muscle layers add their equivalent loads to external_forces / external_torques
+    // (ApplyMuscles, arm_push_env.py:208-212; softrod_muscle.hpp)
+    // Compiled into the instantiations FOR a muscle feature set only (kMusclesCompiled): inside the run-time-mask
+    // instantiation the block's live ranges tripled the scratch of every other feature mix (824 -> 2496 B per lane);
+    // softrod_create sends other mixes with muscles to the LIBM kernel.
+    if constexpr (kMusclesCompiled<F>) {
+        double r0s[EPL];
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) r0s[s] = TAPER ? C.r0s[s] : P.r0_sqrt_rest_len;
+        muscle_loads_n<EPL, true, true>(P, C, lane, L, e, il, qt, kv, e3v, r0s, f, tq);
     }
     connect(f, tq, L, xn);
     // plane contact
@@ -612,7 +628,8 @@ template <unsigned F, int EPL, bool TAPER>
 constexpr int fast_kernel_waves() {
     if (EPL > 1) return 1;
     if (F == kRuntimeFeatures) return SOFTROD_RUNTIME_WAVES;
-    if (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))
+    if (F & (SOFTROD_FEAT_PLANE_CONTACT_ANISO | SOFTROD_FEAT_LAPLACE_FILTER | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES |
+             SOFTROD_FEAT_COOMM_MUSCLES))
         return SOFTROD_CONTACT_WAVES;
     if (TAPER) return SOFTROD_CONTACT_WAVES;
     return F == SOFTROD_FEATURES_SOFTPENDULUM ? SOFTROD_PLANAR_WAVES : SOFTROD_FAST_WAVES;
@@ -644,6 +661,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     load_suckers<F>(P, S, N, rod, B);
     EnvAction A;
     set_action_n<F, E, EPL>(P, S, N, rod, lane, actions, A, B, L);
+    if (epilogue) push_store_prev_com<F, E, EPL>(P, S, N, rod, lane, L, n_sub);
     if (has<F>(P, SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES)) muscle_load<EPL>(P, S, rod, actions != nullptr, A, L);
     {
         BcTargets B0 = B;
@@ -656,6 +674,7 @@ softrod_step_fast_kernel(const RodParams P, const StatePtrs S, const float* __re
     double time = S.time[rod];
     ConstN<EPL> C;
     build_const<F, EPL, TAPER>(P, lane, A, C, S.mat);
+    if constexpr (kMusclesCompiled<F>) build_muscle_const<F, EPL, true>(P, S, N, rod, lane, A, C);
     RodParams Pk = P;
     if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
 

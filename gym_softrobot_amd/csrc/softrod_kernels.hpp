@@ -57,6 +57,12 @@ constexpr unsigned kFeaturesTaperedSuckerArm = SOFTROD_FEAT_ANALYTICAL_DAMPER | 
 // exactly e_z, set by the host in RodParams.features and in the template mask.
 constexpr unsigned kFeatPlaneZup = 1u << 30;
 constexpr int kRuntimeEnv = -1;
+// The fast kernel carries the COOMM muscle layers (softrod_muscle.hpp) in the instantiations compiled FOR a feature
+// set that has them: OctoArmPush (SOFTROD_FEATURES_ARM_PUSH) and the clamped / free muscle rod of the known-answer
+// tests; any other mix with muscles runs the LIBM kernel (softrod_create says so).
+constexpr unsigned kFeaturesMuscleRod = SOFTROD_FEAT_FIXED_BC | SOFTROD_FEAT_ANALYTICAL_DAMPER | SOFTROD_FEAT_COOMM_MUSCLES;
+template <unsigned F>
+constexpr bool kMusclesCompiled = F != kRuntimeFeatures && (F & SOFTROD_FEAT_COOMM_MUSCLES) != 0;
 
 // Wave-uniform parameters: passed by value, so they land in SGPRs (kernarg segment).
 struct RodParams {
@@ -97,9 +103,13 @@ struct RodParams {
     double joint_k, joint_nu, joint_kt;
     // ControllableFixConstraint (octopus/controllable_constraint.py:24-69)
     int n_suckers, sucker_index[SOFTROD_MAX_SUCKERS], pad2;
+    double sucker_ratio0;            // SuckerController.reduction_ratio as configured (a reset restores it for ArmPush)
     // clock table (StatePtrs.time_tab): entries, and 1 / (n_substeps dt) to find an env's entry
     int tab_len, tab_n_sub;
     double inv_step_time;
+    // SOFTROD_FEAT_COOMM_MUSCLES (softrod_muscle.hpp): layer kinds, the force-length polynomial, the recalled-detail switches
+    int n_muscles, muscle_kind[SOFTROD_MAX_MUSCLES], fl_degree, muscle_form, muscle_cur_radius, muscle_tm_law, push_mode, pad3;
+    double fl_coef[SOFTROD_MAX_FL_COEF];
 };
 
 // Rows of the per-lane material table of a TAPERED rod (softrod_set_radius_profile): what
@@ -138,6 +148,9 @@ struct StatePtrs {
                             // dt/2 per env.step, soft_pendulum.py:183-184); nullptr: none
     const double* mat;      // [kMatRows][64*EPL] material table of a tapered rod, or nullptr (uniform)
     double* sucker;         // [SOFTROD_MAX_SUCKERS][N] effective reduction ratio of each sucker
+    int* sucker_idx;        // [SOFTROD_MAX_SUCKERS][N] SuckerController.index of each sucker (Python indexing)
+    double* mact;           // [SOFTROD_MAX_MUSCLES][N][64*EPL] muscle activations per element, or nullptr
+    const double* mtab;     // [SOFTROD_MAX_MUSCLES][4][64*EPL] ratio_position x, y, z and strength per element, or nullptr
 };
 
 // ---------------------------------------------------------------------------------
@@ -230,6 +243,10 @@ struct ConstN {
     // tapered rods only (TAPER instantiations; dead otherwise): the constants a uniform rod
     // keeps in scalar registers (RodParams), per element
     double j01[EPL], j2[EPL], dlog0[EPL], dlog2[EPL], dr0[EPL], dr2[EPL], r0s[EPL], ir0s[EPL];
+    // SOFTROD_FEAT_COOMM_MUSCLES only (dead otherwise): the layers' position ratios and activation x strength
+    double mr[EPL][SOFTROD_MAX_MUSCLES][3], amp[EPL][SOFTROD_MAX_MUSCLES];
+    const double* mtab_lane;   // the same from memory (run-time-mask / LIBM kernels): StatePtrs.mtab / .mact at this lane's slot 0
+    const double* mact_lane;
 };
 
 // value of index+1 / index-1 for a per-slot array
@@ -297,12 +314,15 @@ struct BcTargets {
     double Q[9];
     double vel[3];      // imposed base velocity (moving base), else 0
     double keep[SOFTROD_MAX_SUCKERS];   // 1 - effective reduction ratio of each sucker (this env)
+    int snode[SOFTROD_MAX_SUCKERS], selem[SOFTROD_MAX_SUCKERS];   // the node / element each sucker holds (this env)
 };
 
 // Per-env action handling done once per env.step before the substeps.
 struct EnvAction {
     float a[8];         // raw action (float32), as many as the env has
     double force;       // SoftPendulum: point_force[0] (float32 value held in float64)
+    double mu[SOFTROD_MAX_MUSCLES];   // ArmPush: the activations set_action applied (uniform over the elements)
+    bool mu_set;
 };
 
 __device__ __forceinline__ void load_bc(const StatePtrs& S, size_t N, int rod, BcTargets& B) {
@@ -312,7 +332,14 @@ __device__ __forceinline__ void load_bc(const StatePtrs& S, size_t N, int rod, B
     for (int i = 0; i < 9; ++i) B.Q[i] = S.bc[(size_t)(3 + i) * N + rod];
     B.vel[0] = B.vel[1] = B.vel[2] = 0.0;
 #pragma unroll
-    for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) B.keep[j] = 1.0;
+    for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) { B.keep[j] = 1.0; B.snode[j] = -1; B.selem[j] = -1; }
+}
+
+// SuckerController.index with Python indexing: i >= 0 holds node i and element i; i < 0 counts from the end of
+// each array, velocity_collection has n + 1 columns and omega_collection n (arm_push_env.py:262: index = -1)
+__device__ __forceinline__ void sucker_targets(const RodParams& P, int index, int& node, int& elem) {
+    node = index >= 0 ? index : P.n_elem + 1 + index;
+    elem = index >= 0 ? index : P.n_elem + index;
 }
 
 // ControllableFixConstraint.constrain_rates (octopus/controllable_constraint.py:45-69):
@@ -323,8 +350,10 @@ template <unsigned F>
 __device__ __forceinline__ void load_suckers(const RodParams& P, const StatePtrs& S, size_t N, int rod, BcTargets& B) {
     if (has<F>(P, SOFTROD_FEAT_SUCKER_CONSTRAINT)) {
 #pragma unroll
-        for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j)
+        for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) {
             B.keep[j] = (j < P.n_suckers) ? 1.0 - S.sucker[(size_t)j * N + rod] : 1.0;
+            if (j < P.n_suckers) sucker_targets(P, S.sucker_idx[(size_t)j * N + rod], B.snode[j], B.selem[j]);
+        }
     }
 }
 template <unsigned F, int EPL>
@@ -335,10 +364,10 @@ __device__ __forceinline__ void sucker_rates_n(const RodParams& P, const BcTarge
             if (j >= P.n_suckers) continue;
 #pragma unroll
             for (int s = 0; s < EPL; ++s) {
-                const bool here = (lane * EPL + s) == P.sucker_index[j];
-                const double k = here ? B.keep[j] : 1.0;
+                const double kn = (lane * EPL + s) == B.snode[j] ? B.keep[j] : 1.0;
+                const double ke = (lane * EPL + s) == B.selem[j] ? B.keep[j] : 1.0;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { L.v[s][c] *= k; L.w[s][c] *= k; }
+                for (int c = 0; c < 3; ++c) { L.v[s][c] *= kn; L.w[s][c] *= ke; }
             }
         }
     }
@@ -626,6 +655,7 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 
 }  // namespace softrod
 #include "softrod_contact.hpp"
+#include "softrod_muscle.hpp"
 namespace softrod {
 
 // The OctoFlat kernel runs out of scalar registers (some 40 wave-uniform doubles live in its loop
@@ -849,7 +879,36 @@ __device__ __forceinline__ double tilt_n(const RodParams& P, int lane, const Lan
 // observation width of the single-rod envs (softrod_obs_dim)
 __device__ __forceinline__ int env_obs_dim(const RodParams& P) {
     return (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 9 : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 25
-         : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 2 * P.n_ctrl + 6 : 4;
+         : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 2 * P.n_ctrl + 6
+         : (P.env_kind == SOFTROD_ENV_ARM_PUSH) ? 2 * (P.n_elem + 1) + 2 : 4;
+}
+
+// ArmPushEnv.get_state (octopus/arm_push_env.py:225-245): position_collection[0], velocity_collection[0], then
+// np.eye(2)[previous_action] (discrete) or the previous action (continuous); float32.  Every lane writes its own
+// node's two entries.  -> does any entry hold a NaN (`np.any(np.isnan(states))`, :335)?  `fix`: np.nan_to_num.
+template <int EPL>
+__device__ __forceinline__ bool push_get_state_n(const RodParams& P, int lane, const LaneN<EPL>& L, const float* pa,
+                                                 float* __restrict__ o, bool fix) {
+    const int n = P.n_elem;
+    float tail[2];
+    if (P.push_mode == 0) { const int a = (int)pa[0]; tail[0] = a == 0 ? 1.0f : 0.0f; tail[1] = a == 0 ? 0.0f : 1.0f; }
+    else { tail[0] = pa[0]; tail[1] = pa[1]; }
+    bool bad = isnan(tail[0]) || isnan(tail[1]);
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+        bad = bad || ((lane * EPL + s) <= n && (isnan(L.x[s][0]) || isnan(L.v[s][0])));
+    bad = __any(bad);
+    auto clean = [&](float v) {
+        if (!(fix && bad)) return v;
+        return isnan(v) ? 0.0f : (isinf(v) ? copysignf(3.4028234663852886e38f, v) : v);
+    };
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int idx = lane * EPL + s;
+        if (idx <= n) { o[idx] = clean((float)L.x[s][0]); o[n + 1 + idx] = clean((float)L.v[s][0]); }
+    }
+    if (lane == 0) { o[2 * n + 2] = clean(tail[0]); o[2 * n + 3] = clean(tail[1]); }
+    return bad;
 }
 
 template <int E, int EPL>
@@ -873,6 +932,8 @@ __device__ __forceinline__ void env_observe_n(const RodParams& P, const StatePtr
         soft_arm_get_state_n<EPL>(P, S, N, rod, lane, L, st);
         if (lane == 0)
             for (int i = 0; i < 2 * P.n_ctrl + 6; ++i) o[i] = (float)st[i];
+    } else if (env == SOFTROD_ENV_ARM_PUSH) {
+        (void)push_get_state_n<EPL>(P, lane, L, pa, o, false);
     } else {
         const double th = theta_n<EPL>(P, lane, L);
         if (lane == 0) {
@@ -950,6 +1011,37 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
                 if (nan) v = isnan(v) ? 0.0 : (isinf(v) ? copysign(1.7976931348623157e308, v) : v);   // np.nan_to_num
                 o[i] = (float)v;
             }
+        }
+    } else if (env == SOFTROD_ENV_ARM_PUSH) {
+        // ArmPushEnv.step after the loop (octopus/arm_push_env.py:288-347).  _isnan_check covers position,
+        // velocity, director, alpha, omega and the centre of mass (:298-309; alpha = J^-1 tau e of the last substep
+        // is NaN only where omega became NaN in that substep)
+        bool qbad = false;
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            bool q = false;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q = q || isnan(L.w[s][c]);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) q = q || isnan(L.Q[s][c]);
+            qbad = qbad || ((lane * EPL + s) < P.n_elem && q);
+        }
+        double com[2];
+        com_xy_n<EPL>(P, C, lane, L, com);
+        const bool nan_state = invalid || __any(qbad) || isnan(com[0]) || isnan(com[1]);
+        const int od = 2 * (P.n_elem + 1) + 2;
+        float* o = out_row(obs, rod, od, pack);
+        const bool nan_obs = push_get_state_n<EPL>(P, lane, L, A.a, o, true);
+        if (lane == 0) {
+            const double p0 = S.ctrl[(size_t)0 * N + rod], p1 = S.ctrl[(size_t)1 * N + rod];   // prev_cm_pos (prologue)
+            double forward = 0.0, survive = 0.0;
+            bool term = false;
+            if (nan_state) { term = true; survive = -20.0; }
+            else forward = sqrt(com[0] * com[0] + com[1] * com[1]) - sqrt(p0 * p0 + p1 * p1);
+            double rw = forward + survive;
+            if (isnan(rw)) { term = true; rw = -20.0; }
+            if (nan_obs) { term = true; rw = -20.0; }
+            emit_scalars(o, od, pack, rod, rw, term, time > P.final_time, reward, terminated, truncated, S.needs_reset);
         }
     } else if (env == SOFTROD_ENV_ARM_SINGLE) {
         double pw = 0.0;
@@ -1073,8 +1165,48 @@ __device__ __forceinline__ void set_action_n(const RodParams& P, const StatePtrs
 #pragma unroll
     for (int i = 0; i < 8; ++i) A.a[i] = 0.0f;
     A.force = 0.0;
+#pragma unroll
+    for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) A.mu[m] = 0.0;
+    A.mu_set = false;
     const int env = env_of<E>(P);
-    if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
+    if (env == SOFTROD_ENV_ARM_PUSH) {
+        // ArmPushEnv.set_action (octopus/arm_push_env.py:247-274): the sucker's index and the layers' activations
+        if (actions) {
+            int index;
+            if (P.push_mode == 0) {
+                A.a[0] = actions[rod];
+                const bool hold_base = (int)A.a[0] == 0;
+                index = hold_base ? 0 : -1;                              // :257,262
+                A.mu[0] = hold_base ? -0.0 * 1.0 : 0.0;                  // :258-260, :263-265
+                A.mu[1] = 0.0;
+                A.mu[2] = hold_base ? 0.5 * 1.0 : 0.0;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    if (m >= P.n_muscles || !S.mact) continue;
+#pragma unroll
+                    for (int s = 0; s < EPL; ++s) S.mact[((size_t)m * N + rod) * W + lane * EPL + s] = A.mu[m];
+                }
+            } else {
+                A.a[0] = actions[2 * (size_t)rod]; A.a[1] = actions[2 * (size_t)rod + 1];
+                // int(np.clip(location * self.n_elem, 0, self.n_elem - 1)): np.float32 * int stays float32 (:270)
+                const float loc = fminf(fmaxf(A.a[0] * (float)P.n_elem, 0.0f), (float)(P.n_elem - 1));
+                index = (int)loc;
+                // only the transverse layer is written (:271); the others keep what they hold (zeros after a reset)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    if (m >= P.n_muscles || !S.mact) continue;
+                    A.mu[m] = (m == 2) ? (double)A.a[1] : S.mact[((size_t)m * N + rod) * W];
+                }
+                if (P.n_muscles > 2 && S.mact) {
+#pragma unroll
+                    for (int s = 0; s < EPL; ++s) S.mact[((size_t)2 * N + rod) * W + lane * EPL + s] = A.mu[2];
+                }
+            }
+            A.mu_set = true;
+            sucker_targets(P, index, B.snode[0], B.selem[0]);
+            if (lane == 0) S.sucker_idx[rod] = index;
+        }
+    } else if (env == SOFTROD_ENV_SOFTPENDULUM3D) {
         if (actions) { A.a[0] = actions[2 * rod]; A.a[1] = actions[2 * rod + 1]; }
         if (has<F>(P, SOFTROD_FEAT_MOVING_BASE_BC)) {
 #pragma unroll
@@ -1124,6 +1256,27 @@ __device__ __forceinline__ void set_action_n(const RodParams& P, const StatePtrs
         if (actions) A.a[0] = actions[rod];
         A.force = (double)A.a[0];
     }
+}
+
+// ArmPushEnv.step: `prev_cm_pos = self.shearable_rod.compute_position_center_of_mass()[:2]` before the loop
+// (octopus/arm_push_env.py:280), kept in the control rows [0..1] for the epilogue's reward.  Only when the
+// launch integrates (n_sub > 0): with n_substeps = 0 the step is the epilogue alone on the resident state and
+// prev_cm_pos is whatever the control rows hold (fixture replay, tests/test_gpu_muscle_fixtures.py).
+template <unsigned F, int E, int EPL>
+__device__ __forceinline__ void push_store_prev_com(const RodParams& P, const StatePtrs& S, size_t N, int rod, int lane,
+                                                    const LaneN<EPL>& L, int n_sub) {
+    if (env_of<E>(P) != SOFTROD_ENV_ARM_PUSH || n_sub <= 0) return;
+    ConstN<EPL> C0;
+    EnvAction A0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A0.a[i] = 0.0f;
+    A0.force = 0.0;
+    A0.mu_set = false;
+    if (S.mat) build_const<F, EPL, true>(P, lane, A0, C0, S.mat);
+    else build_const<F, EPL>(P, lane, A0, C0);
+    double com[2];
+    com_xy_n<EPL>(P, C0, lane, L, com);
+    if (lane == 0) { S.ctrl[(size_t)0 * N + rod] = com[0]; S.ctrl[(size_t)1 * N + rod] = com[1]; }
 }
 
 // ---- SoftArmTracking: MuscleTorquesWithVaryingBetaSplines x 2 --------------------------------
@@ -1291,8 +1444,9 @@ __device__ __forceinline__ void libm_material(const RodParams& P, const double* 
 
 // Internal forces/torques + forcing + dynamic update + dampers + rate constraints:
 // steps (3)-(6) of the substep (DESIGN.md "substep order").
-__device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const LibmMat& M, const BcTargets& B, int lane,
-                                                  double action, double mass, LaneN<1>& L) {
+__device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const LibmMat& M, const ConstN<1>& CM,
+                                                  const BcTargets& B, int lane, double action, double mass,
+                                                  LaneN<1>& L) {
     const int n = P.n_elem;
     const bool node_valid = lane <= n;
     const bool elem_valid = lane < n;
@@ -1406,6 +1560,15 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const Libm
         fe1 += tip ? P.tip_force[1] : 0.0;
         fe2 += tip ? P.tip_force[2] : 0.0;
     }
+    if (P.features & SOFTROD_FEAT_COOMM_MUSCLES) {       // ApplyMuscles: sqrt and divisions as written (FASTM = false)
+        const double ea[1] = {e}, ila[1] = {1.0 / len}, qta[1][3] = {{qt0, qt1, qt2}};
+        const double kva[1][3] = {{vor_valid ? k0 : 0.0, vor_valid ? k1 : 0.0, vor_valid ? k2 : 0.0}};
+        const double e3a[1] = {e3}, r0a[1] = {M.r0s};
+        double fm[1][3] = {{0.0, 0.0, 0.0}}, tm[1][3] = {{0.0, 0.0, 0.0}};
+        muscle_loads_n<1, false, false>(P, CM, lane, L, ea, ila, qta, kva, e3a, r0a, fm, tm);
+        fe0 += fm[0][0]; fe1 += fm[0][1]; fe2 += fm[0][2];
+        tq0 += tm[0][0]; tq1 += tm[0][1]; tq2 += tm[0][2];
+    }
     if (has_contact && !P.contact_before_forcing) {
         const double F[1][3] = {{f0 + (node_valid ? fe0 : 0.0), f1 + (node_valid ? fe1 : 0.0),
                                  f2 + (node_valid ? fe2 : 0.0)}};
@@ -1467,9 +1630,11 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
     load_suckers<kRuntimeFeatures>(P, S, N, rod, B);
     EnvAction A;
     set_action_n<kRuntimeFeatures, kRuntimeEnv, 1>(P, S, N, rod, lane, actions, A, B, L);
+    if (epilogue) push_store_prev_com<kRuntimeFeatures, kRuntimeEnv, 1>(P, S, N, rod, lane, L, n_sub);
     ConstN<1> C;
     if (S.mat) build_const<kRuntimeFeatures, 1, true>(P, lane, A, C, S.mat);
     else build_const<kRuntimeFeatures, 1>(P, lane, A, C);
+    build_muscle_const<kRuntimeFeatures, 1, false>(P, S, N, rod, lane, A, C);
     LibmMat M;
     libm_material(P, S.mat, lane, M);
 
@@ -1480,7 +1645,7 @@ softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __re
         libm_kinematic_step(P, P.half_dt, L);
         if (P.time_two_half_adds) time += P.half_dt;
         constrain_values_n<kRuntimeFeatures, 1>(P, B, lane, L);
-        libm_dynamic_step(P, M, B, lane, A.force, mass, L);
+        libm_dynamic_step(P, M, C, B, lane, A.force, mass, L);
         libm_kinematic_step(P, P.half_dt, L);
         time += P.time_two_half_adds ? P.half_dt : P.dt;
         constrain_values_n<kRuntimeFeatures, 1>(P, B, lane, L);
@@ -1514,11 +1679,13 @@ softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __rest
 #pragma unroll
     for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
     A.force = 0.0;
+    A.mu_set = false;
     ConstN<EPL> C;
     if (S.mat) build_const<kRuntimeFeatures, EPL, true>(P, lane, A, C, S.mat);
     else build_const<kRuntimeFeatures, EPL>(P, lane, A, C);
     const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2
-                   : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 0 : 1;
+                   : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 0
+                   : (P.env_kind == SOFTROD_ENV_ARM_PUSH) ? (P.push_mode == 0 ? 1 : 2) : 1;
     float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = 0; i < adim; ++i)
         pa[i] = prev_action ? prev_action[adim * (size_t)rod + i] : S.prev_action[7 * (size_t)rod + i];
@@ -1579,6 +1746,20 @@ __device__ __forceinline__ void reset_rod(const RodParams& P, const StatePtrs& S
         if (S.mat) build_const<kRuntimeFeatures, EPL, true>(P, lane, A0, C, S.mat);
         else build_const<kRuntimeFeatures, EPL>(P, lane, A0, C);
         com_xy_n<EPL>(P, C, lane, L, com);
+    }
+    if (P.features & SOFTROD_FEAT_COOMM_MUSCLES) {
+        // a reset builds fresh muscle objects (activation zero) and, for ArmPush, a fresh SuckerController(index=0)
+        // that is switched on after finalize (arm_push_env.py:187-195,205,222)
+        if (S.mact) {
+#pragma unroll
+            for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m)
+#pragma unroll
+                for (int s = 0; s < EPL; ++s) S.mact[((size_t)m * N + rod) * W + (size_t)lane * EPL + s] = 0.0;
+        }
+    }
+    if (lane == 0 && P.env_kind == SOFTROD_ENV_ARM_PUSH) {
+        S.sucker_idx[rod] = P.sucker_index[0];
+        S.sucker[rod] = P.sucker_ratio0;
     }
     if (lane == 0) {
         S.time[rod] = 0.0;
@@ -1651,6 +1832,7 @@ softrod_autoreset_kernel(const RodParams P, const StatePtrs S, float* __restrict
 #pragma unroll
     for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
     A.force = 0.0;
+    A.mu_set = false;
     ConstN<EPL> C;
     if (S.mat) build_const<kRuntimeFeatures, EPL, true>(P, lane, A, C, S.mat);
     else build_const<kRuntimeFeatures, EPL>(P, lane, A, C);

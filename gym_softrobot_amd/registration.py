@@ -17,10 +17,14 @@ except ImportError:
     _gymnasium = None
 
 
-def register(id: str, entry_point: Callable, kwargs=None, vector_entry_point: Callable = None) -> None:  # noqa: A002
+def register(id: str, entry_point: Callable, kwargs=None, vector_entry_point: Callable = None,  # noqa: A002
+             label: str = None) -> None:
     """`vector_entry_point`: the batched (N envs on one GPU) class of the id — what Gymnasium 1.0's
-    `gymnasium.make_vec(id, num_envs=N, vectorization_mode="vector_entry_point")` instantiates."""
-    _REGISTRY[id] = {"entry_point": entry_point, "kwargs": dict(kwargs or {}), "vector_entry_point": vector_entry_point}
+    `gymnasium.make_vec(id, num_envs=N, vectorization_mode="vector_entry_point")` instantiates.
+    `label`: a parity caveat that travels with the id (`parity_label(id)`, `python -m gym_softrobot_amd`,
+    bench.py): the COOMM muscle envs carry "parity-unpinned (...)"."""
+    _REGISTRY[id] = {"entry_point": entry_point, "kwargs": dict(kwargs or {}), "vector_entry_point": vector_entry_point,
+                     "label": label}
     if _gymnasium is not None:
         gid = f"{NAMESPACE}/{id}"
         if gid not in _gymnasium.registry:
@@ -44,3 +48,9 @@ def make(id: str, **kwargs):  # noqa: A002
 
 def registered() -> list:
     return sorted(_REGISTRY)
+
+
+def parity_label(id: str):  # noqa: A002
+    """None for an env whose whole path is restated from PyElastica's published algorithm and the reference's
+    on-disk code; otherwise what is NOT pinned (the COOMM muscle envs)."""
+    return _REGISTRY[id].get("label")

@@ -6,10 +6,51 @@ from __future__ import annotations
 import numpy as np
 
 try:  # pragma: no cover - gymnasium is not installed in the build image
-    from gymnasium.spaces import Box, Dict  # type: ignore
+    from gymnasium.spaces import Box, Dict, Discrete  # type: ignore
     HAVE_GYMNASIUM = True
 except Exception:  # noqa: BLE001
     HAVE_GYMNASIUM = False
+
+    class Discrete:  # type: ignore[no-redef]
+        """Subset of gymnasium.spaces.Discrete used by ArmPushEnv (octopus/arm_push_env.py:101):
+        {0, ..., n - 1}, shape (), dtype int64."""
+
+        def __init__(self, n, seed=None, start=0):
+            self.n, self.start = int(n), int(start)
+            self.shape, self.dtype = (), np.dtype(np.int64)
+            self._np_random = None
+            if seed is not None:
+                self.seed(seed)
+
+        @property
+        def np_random(self):
+            if self._np_random is None:
+                self.seed()
+            return self._np_random
+
+        def seed(self, seed=None):
+            from .seeding import np_random
+
+            self._np_random, s = np_random(seed)
+            return s
+
+        def sample(self):
+            return np.int64(self.start + self.np_random.integers(self.n))
+
+        def contains(self, x) -> bool:
+            if isinstance(x, (int, np.integer)):
+                v = int(x)
+            elif isinstance(x, np.ndarray) and x.shape == () and np.issubdtype(x.dtype, np.integer):
+                v = int(x)
+            else:
+                return False
+            return self.start <= v < self.start + self.n
+
+        def __contains__(self, x):
+            return self.contains(x)
+
+        def __repr__(self):
+            return f"Discrete({self.n})"
 
     class Dict:  # type: ignore[no-redef]
         """Subset of gymnasium.spaces.Dict used by FlatEnv (octopus/flat_env.py:100-109)."""

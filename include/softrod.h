@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define SOFTROD_ABI_VERSION 15
+#define SOFTROD_ABI_VERSION 16
 
 /* error codes */
 #define SOFTROD_OK 0
@@ -106,7 +106,32 @@ enum softrod_feature {
      *   crawl_env.py:148-161.  Up to SOFTROD_MAX_SUCKERS per rod (softrod_config.sucker_index);
      *   the per-env effective ratio lives in softrod_state_view.sucker_ratio.                */
     SOFTROD_FEAT_SUCKER_CONSTRAINT = 1u << 12,
+    /* ApplyMuscles(muscles=[LongitudinalMuscle, ..., TransverseMuscle]) of COOMM, registered as a forcing at
+     *   octopus/arm_push_env.py:197-212,596-604, build_muscle_octopus.py:160-172,270-282 with the layers of
+     *   create_es_muscle_layers (octopus/build.py:295-338).
+     * COOMM (git pin uv.lock:173-175, branch refactor-numba-hotloops) is NOT on disk and not installable:
+     * what this bit computes restates the published model (Chang, Halder, Gribkova, Tekinalp, Naughton,
+     * Gazzola, Mehta: "Energy-shaping control of a muscular octopus arm moving in three dimensions",
+     * Proc. R. Soc. A 479:20220593, 2023, section 2(c)) in the operation order recalled from
+     * coomm/actuations/muscles/muscle.py — PARITY UNPINNED.  Per substep, per muscle m, per element:
+     *   x_m   = radius * ratio_position_m                  muscle position in the material frame
+     *   nu_m  = (sigma + e_3) + average(kappa) x x_m       muscle strain; l_m = |nu_m|, t_m = nu_m / l_m
+     *   F_m   = activation_m * strength_m * max(fl(l_m), 0)   strength = max_muscle_stress * rest_muscle_area
+     *   f     = sum F_m t_m ;  c = sum x_m x (F_m t_m)     internal force / couple of the actuation
+     * and the equivalent external loads  F_ext += D^h(Q^T f),  tau_ext += D^h(c_v) + A^h(kappa x c_v D^) +
+     * (e Q t) x f l^  with c_v the element couples averaged onto the Voronoi vertices.  The force-length law
+     * fl, the layer geometry and strengths are DATA (softrod_config.muscle_fl_coef, softrod_set_muscle_layers);
+     * every other recalled detail is a named switch of softrod_config (muscle_*).  Activations live in
+     * softrod_state_view.muscle_activation (apply_activation, arm_push_env.py:257-271).                       */
+    SOFTROD_FEAT_COOMM_MUSCLES = 1u << 13,
 };
+#define SOFTROD_MAX_MUSCLES 4
+#define SOFTROD_MUSCLE_LONGITUDINAL 0 /* l_m = |nu_m|                                             */
+#define SOFTROD_MUSCLE_TRANSVERSE 1   /* on the axis; l_m follows softrod_config.muscle_tm_length_law */
+#define SOFTROD_MAX_FL_COEF 8
+/* arm_push_env.py:160-196: the damped tapered arm with one sucker and the three muscle layers */
+#define SOFTROD_FEATURES_ARM_PUSH                                                 \
+    (SOFTROD_FEAT_ANALYTICAL_DAMPER | SOFTROD_FEAT_SUCKER_CONSTRAINT | SOFTROD_FEAT_COOMM_MUSCLES)
 
 #define SOFTROD_FEATURES_SOFTPENDULUM                                             \
     (SOFTROD_FEAT_GRAVITY | SOFTROD_FEAT_POINT_FORCE_NODE0_X |                   \
@@ -131,6 +156,7 @@ enum softrod_feature {
 #define SOFTROD_ENV_ARM_SINGLE 3     /* octopus/arm_single_env.py:186-316           */
 #define SOFTROD_ENV_OCTO_FLAT 4      /* octopus/flat_env.py:231-408                 */
 #define SOFTROD_ENV_SOFT_ARM 5       /* soft_arm/soft_arm_tracking.py:160-259       */
+#define SOFTROD_ENV_ARM_PUSH 6       /* octopus/arm_push_env.py:225-347 (OctoArmPush-v0 / -v1; parity unpinned: COOMM) */
 
 /* math_mode (HIP library only; the oracle always uses libm). */
 #define SOFTROD_MATH_LIBM 0 /* sqrt/sin/cos/acos/pow evaluated as written   */
@@ -226,6 +252,25 @@ typedef struct softrod_config {
     int32_t reserved2;
     double sucker_reduction_ratio; /* initial reduction_ratio of every sucker (1.0, :11); the
                                  controllers are on after finalize (arm_push_env.py:222)  */
+    /* ---- SOFTROD_FEAT_COOMM_MUSCLES (octopus/build.py:295-338; COOMM itself NOT on disk: every field below
+     *      restates a recalled detail and is a switch for the day the muscle-env fixtures exist) ---- */
+    int32_t n_muscles;        /* layers of create_es_muscle_layers: 3 (two longitudinal, one transverse)   */
+    int32_t muscle_kind[4];   /* SOFTROD_MUSCLE_* of each layer                                            */
+    int32_t muscle_fl_degree; /* degree of the force-length polynomial (3)                                 */
+    int32_t muscle_equiv_load_form; /* internal load -> equivalent external load: 0 (default) = the physical form,
+                                 F = D^h(Q^T f), tau = D^h(c) + A^h(kappa x c D^) + (e Q t) x f l^;
+                                 1 = PyElastica's own internal-load form applied to (f, c): Q^T f / e, c / eps^3,
+                                 (Q t) x f l^                                                               */
+    int32_t muscle_position_current_radius; /* 1 (default): x_m = rod.radius * ratio, the CURRENT (volume-preserving)
+                                 radius; 0: the rest radius                                               */
+    int32_t muscle_tm_length_law; /* TransverseMuscle's normalised length: 0 (default) = 1 / sqrt(|nu_m|)
+                                 (incompressible cross-section: the radial fibre shortens as the arm extends);
+                                 1 = |nu_m| like a longitudinal muscle                                      */
+    int32_t arm_push_mode;    /* ArmPushEnv(mode=...): 0 "discrete" (OctoArmPush-v0), 1 "continuous" (-v1)
+                                 arm_push_env.py:90-130                                                    */
+    int32_t reserved3;
+    double muscle_fl_coef[8]; /* fl(l) = sum_k coef[k] l^k, clipped at 0 from below; the cubic of the paper,
+                                 max{3.06 l^3 - 13.64 l^2 + 18.01 l - 6.44, 0}: (-6.44, 18.01, -13.64, 3.06)      */
 } softrod_config;
 
 #define SOFTROD_MAX_SUCKERS 4
@@ -233,13 +278,14 @@ typedef struct softrod_config {
 #define SOFTROD_MAX_SPLINE_PIECES 8
 
 /* Per-env I/O widths implied by env_kind (OctoFlat: at the reference's n_arm = 8,
- * n_elem = 10, n_knots = 3). */
-int softrod_action_dim(int env_kind); /* 1, 2, 7, 24, 8                     */
-int softrod_obs_dim(int env_kind);    /* 4, 9, 25, 8*56 + 13 = 461, 14      */
+ * n_elem = 10, n_knots = 3; ArmPush: continuous mode at n_elem = 40). */
+int softrod_action_dim(int env_kind); /* 1, 2, 7, 24, 8, 2                  */
+int softrod_obs_dim(int env_kind);    /* 4, 9, 25, 8*56 + 13 = 461, 14, 84  */
 int softrod_aux_dim(int env_kind);    /* 0, 1 (info["tilt"], float64), 0    */
 /* The same for a given configuration: OctoFlat widths follow n_arm, n_elem and n_knots
  * (flat_env.py:112-141): action n_arm*n_knots; obs n_arm*((n-1) + 4(n+1) + n_knots) + 13,
- * the "individual" rows followed by "shared" (flat_env.py:231-286). */
+ * the "individual" rows followed by "shared" (flat_env.py:231-286).  ArmPush (arm_push_env.py:100-130): action 1
+ * (discrete: the index 0 / 1 as a float32) or 2 (continuous); obs 2 (n_elem + 1) + 2. */
 int softrod_config_action_dim(const softrod_config* cfg);
 int softrod_config_obs_dim(const softrod_config* cfg);
 
@@ -299,6 +345,17 @@ typedef struct softrod_state_view {
                          ControllableFixConstraint: SuckerController.reduction_ratio while its
                          flag is on, 0 while it is off (x * (1 - 0) is x).  Written by the
                          caller between steps (arm_two_env.py:228 sets it from the action) */
+    double* muscle_activation; /* [SOFTROD_MAX_MUSCLES][n_envs][lane_stride]  MuscleForce.activation of each layer, per
+                         element (apply_activation broadcasts a scalar, arm_push_env.py:257-271, or takes an
+                         array, arm_two_env.py:246-248, reach_env.py:176-179).  Written by the ArmPush prologue
+                         from the action; with env_kind NONE by the caller between steps.  NULL without
+                         SOFTROD_FEAT_COOMM_MUSCLES                                                          */
+    int32_t* sucker_index; /* [SOFTROD_MAX_SUCKERS][n_envs]  SuckerController.index of each sucker of each env,
+                         Python indexing: i >= 0 holds node i and element i; i < 0 holds node n_elem + 1 + i and
+                         element n_elem + i (`velocity_collection[..., -1]` is the LAST NODE, `omega_collection
+                         [..., -1]` the LAST ELEMENT: arm_push_env.py:262, controllable_constraint.py:66-69).
+                         Starts as softrod_config.sucker_index; the ArmPush prologue rewrites row 0 from the
+                         action (arm_push_env.py:257,262,270; crawl_env.py:236-238 does the same)              */
     double* material; /* [SOFTROD_MATERIAL_ROWS][lane_stride]  per-node / per-element constants of
                          a TAPERED rod (softrod_set_radius_profile), shared by all envs; NULL
                          for a uniform rod.  Read-only for the caller.                     */
@@ -345,6 +402,24 @@ int softrod_set_spline_table(softrod_handle* h, const double* breaks, const doub
  * 63 elements; not with SOFTROD_FEAT_OCTO_HEAD.                                            */
 #define SOFTROD_MATERIAL_ROWS 16
 int softrod_set_radius_profile(softrod_handle* h, const double* radius);
+
+/* Replaces: the geometry and strength of the muscle layers handed to ApplyMuscles — for the reference's
+ * create_es_muscle_layers(radius_mean, radius_base) (octopus/build.py:295-338):
+ *   LongitudinalMuscle(muscle_init_angle = +-pi/2, ratio_muscle_position = (0, -6/9, 0) per element,
+ *                      rest_muscle_area = (radius_mean / radius_base)^2, max_muscle_stress = 0.5)  x 2
+ *   TransverseMuscle(rest_muscle_area = (radius_mean / radius_base)^2, max_muscle_stress = 1.0)
+ * ratio_position: host [n_muscles][3][n_elem] float64, the muscle's position in the material frame in units of
+ *                 the element radius (how muscle_init_angle enters it is the caller's: _capi.es_muscle_layers);
+ * strength:       host [n_muscles][n_elem] float64 = max_muscle_stress * rest_muscle_area, SIGNED (a transverse
+ *                 muscle extends the arm: negative).
+ * Needed before the first softrod_step / softrod_substeps of a handle with SOFTROD_FEAT_COOMM_MUSCLES; rods of
+ * up to 63 elements, one rod per env.                                                                     */
+int softrod_set_muscle_layers(softrod_handle* h, const double* ratio_position, const double* strength);
+
+/* Same as softrod_config_arm_single for ArmPushEnv (octopus/arm_push_env.py:65-224): the 40-element arm tapered
+ * 12:1 (the radii themselves go through softrod_set_radius_profile), damper, one sucker, three muscle layers
+ * (softrod_set_muscle_layers); mode 0 = "discrete" (OctoArmPush-v0), 1 = "continuous" (OctoArmPush-v1).      */
+int softrod_config_arm_push(softrod_config* cfg, int n_envs, int mode);
 
 /* Replaces the constant part of set_action's
  *   interp1d(linspace(0,1,n_action), action, kind="cubic")(linspace(0,1,n_seg))

@@ -93,6 +93,12 @@ def _load(omp) -> C.CDLL:
     lib.oracle_set_run_substeps.argtypes = [C.c_void_p, C.c_int]
     lib.oracle_set_round_state_f32.argtypes = [C.c_void_p, C.c_int]
     lib.oracle_forcing_probe.argtypes = [C.c_void_p, C.c_double]
+    lib.oracle_set_muscle_layers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_apply_activation.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.oracle_muscle_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_observe_push.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_reset_push.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_env_step_push.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     lib.oracle_get.restype = C.c_int
     lib.oracle_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.oracle_set.restype = C.c_int
@@ -115,7 +121,9 @@ _SHAPES = {
     "f_ext": lambda n: (3, n + 1), "t_ext": lambda n: (3, n), "time": lambda n: (1,),
     "prev_kappa": lambda n: (n - 1,), "prev_com": lambda n: (2,), "prev_action7": lambda n: (7,),
     "prev_action2": lambda n: (2,), "prev_action": lambda n: (1,), "fixed_pos": lambda n: (3,),
-    "fixed_dir": lambda n: (3, 3),
+    "fixed_dir": lambda n: (3, 3), "voronoi_dilatation": lambda n: (n - 1,),
+    "muscle_force": lambda n: (4, n), "muscle_length": lambda n: (4, n), "muscle_activation": lambda n: (4, n),
+    "sucker_index": lambda n: (4,),
 }
 
 
@@ -297,6 +305,45 @@ class OracleRod:
         trunc = np.empty(1, np.uint8)
         self._lib.oracle_env_step_soft_arm(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data,
                                            term.ctypes.data, trunc.ctypes.data)
+        return obs, float(rew[0]), bool(term[0]), bool(trunc[0])
+
+    # -- COOMM muscle layers / OctoArmPush-v0, -v1 -------------------------------------------------
+    def set_muscle_layers(self, ratio_position, strength) -> None:
+        m = int(self.cfg.n_muscles)
+        rp = np.ascontiguousarray(ratio_position, np.float64).reshape(m, 3, self.n)
+        st = np.ascontiguousarray(strength, np.float64).reshape(m, self.n)
+        self._lib.oracle_set_muscle_layers(self._h, rp.ctypes.data, st.ctypes.data)
+
+    def apply_activation(self, m: int, activation: float) -> None:
+        self._lib.oracle_apply_activation(self._h, int(m), float(activation))
+
+    def muscle_probe(self):
+        """ApplyMuscles on the current caches -> (external force (3, n+1), external couple (3, n))."""
+        f = np.empty((3, self.n + 1), np.float64)
+        c = np.empty((3, self.n), np.float64)
+        self._lib.oracle_muscle_probe(self._h, f.ctypes.data, c.ctypes.data)
+        return f, c
+
+    def reset_push(self) -> np.ndarray:
+        obs = np.empty(2 * self.n + 4, np.float32)
+        self._lib.oracle_reset_push(self._h, obs.ctypes.data)
+        return obs
+
+    def observe_push(self) -> np.ndarray:
+        obs = np.empty(2 * self.n + 4, np.float32)
+        self._lib.oracle_observe_push(self._h, obs.ctypes.data)
+        return obs
+
+    def env_step_push(self, action):
+        a = np.zeros(2, np.float32)
+        act = np.atleast_1d(np.asarray(action, np.float32)).ravel()
+        a[: act.size] = act
+        obs = np.empty(2 * self.n + 4, np.float32)
+        rew = np.empty(1, np.float64)
+        term = np.empty(1, np.uint8)
+        trunc = np.empty(1, np.uint8)
+        self._lib.oracle_env_step_push(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data,
+                                       term.ctypes.data, trunc.ctypes.data)
         return obs, float(rew[0]), bool(term[0]), bool(trunc[0])
 
     def get(self, name: str) -> np.ndarray:

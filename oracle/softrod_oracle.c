@@ -91,6 +91,13 @@ typedef struct oracle_rod {
     /* ControllableFixConstraint: effective reduction ratio of each sucker (controller.flag ?
      * controller.reduction_ratio : 0), octopus/controllable_constraint.py:45-69 */
     double sucker_ratio[SOFTROD_MAX_SUCKERS];
+    int sucker_index[SOFTROD_MAX_SUCKERS];   /* SuckerController.index (Python indexing; set_action rewrites it) */
+    /* COOMM muscle layers (ApplyMuscles; octopus/build.py:295-338): geometry / strength tables, the
+     * activations apply_activation wrote, and the per-substep work arrays of coomm's Muscle objects */
+    double m_ratio[SOFTROD_MAX_MUSCLES][3][NMAX], m_strength[SOFTROD_MAX_MUSCLES][NMAX];
+    double m_act[SOFTROD_MAX_MUSCLES][NMAX];
+    double m_force[SOFTROD_MAX_MUSCLES][NMAX], m_length[SOFTROD_MAX_MUSCLES][NMAX];   /* diagnostics */
+    float prev_action_push[2];   /* ArmPushEnv._prev_action (discrete: the index in [0]) */
     int round_state_f32;   /* diagnostic (tools/episode_parity.py --fp32-proxy): the dynamic state is
                               rounded to float32 after every substep — float32 STORAGE with float64
                               arithmetic, a lower bound on what a float32 stepper loses */
@@ -193,8 +200,10 @@ static void straight_rod(oracle_rod* r, const double start[3],
     r->point_force = 0.0;
     for (int i = 0; i < 3; ++i) { r->ctrl_pos[i] = 0.0; r->ctrl_vel[i] = 0.0; }
     /* SuckerController: reduction_ratio as configured, switched on after finalize (arm_push_env.py:188,222) */
-    for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j)
+    for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) {
         r->sucker_ratio[j] = (j < c->n_suckers) ? c->sucker_reduction_ratio : 0.0;
+        r->sucker_index[j] = c->sucker_index[j];
+    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -427,9 +436,12 @@ static void constrain_rates(oracle_rod* r)
      * (a controller that is off is an effective ratio of 0: x * (1 - 0) = x) */
     if (r->cfg.features & SOFTROD_FEAT_SUCKER_CONSTRAINT)
         for (int j = 0; j < r->cfg.n_suckers; ++j) {
-            const int idx = r->cfg.sucker_index[j];
+            /* velocity_collection[..., index] has n + 1 columns, omega_collection[..., index] n: a negative
+             * index counts from each array's own end (arm_push_env.py:262 sets index = -1) */
+            const int idx = r->sucker_index[j];
+            const int node = idx >= 0 ? idx : r->n + 1 + idx, elem = idx >= 0 ? idx : r->n + idx;
             const double keep = 1.0 - r->sucker_ratio[j];
-            for (int i = 0; i < 3; ++i) { r->v[i][idx] *= keep; r->w[i][idx] *= keep; }
+            for (int i = 0; i < 3; ++i) { r->v[i][node] *= keep; r->w[i][elem] *= keep; }
         }
 }
 
@@ -664,6 +676,113 @@ static void spline_muscle_torques(oracle_rod* r)
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* coomm.actuations.muscles.muscle.ApplyMuscles.apply_torques (COOMM, git pin   */
+/* uv.lock:173-175, NOT on disk): RECALLED from coomm/actuations/muscles/        */
+/* muscle.py (Muscle.__call__, MuscleForce, LongitudinalMuscle, TransverseMuscle) */
+/* and coomm/actuations/actuation.py (ContinuousActuation, ApplyActuations,      */
+/* internal_load_to_equivalent_external_load), anchored on the published model   */
+/* (Chang et al., Proc. R. Soc. A 479:20220593, 2023, section 2(c): muscle force  */
+/* F = u sigma_max A f_l(l), f_l(l) = max{3.06 l^3 - 13.64 l^2 + 18.01 l - 6.44,   */
+/* 0}, applied along the muscle tangent at the offset x_m) and on the reference's */
+/* call sites octopus/build.py:295-338, arm_push_env.py:197-212,247-274.          */
+/* PARITY UNPINNED: every recalled detail is a switch of softrod_config.          */
+/* ------------------------------------------------------------------------- */
+static void apply_muscles(oracle_rod* r)
+{
+    const softrod_config* c = &r->cfg;
+    const int n = r->n;
+    double kav[3][NMAX];            /* average2D(kappa): Voronoi -> elements, half weights at both ends */
+    double fi[3][NMAX], ce[3][NMAX];   /* internal force (local frame, elements), x_m x force (elements) */
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < n; ++k) {
+            kav[i][k] = 0.0;
+            fi[i][k] = 0.0;
+            ce[i][k] = 0.0;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < n - 1; ++k) {
+            kav[i][k] += 0.5 * r->kappa[i][k];
+            kav[i][k + 1] += 0.5 * r->kappa[i][k];
+        }
+    for (int m = 0; m < c->n_muscles; ++m) {
+        for (int k = 0; k < n; ++k) {
+            /* Muscle.__call__: position, strain, tangent, length */
+            const double rad = c->muscle_position_current_radius ? r->radius[k]
+                             : sqrt(r->volume[k] / r->rest_len[k] / M_PI);
+            double pos[3], nu[3];
+            for (int i = 0; i < 3; ++i) pos[i] = rad * r->m_ratio[m][i][k];
+            const double sh[3] = { r->sigma[0][k], r->sigma[1][k], r->sigma[2][k] + 1.0 };
+            nu[0] = sh[0] + (kav[1][k] * pos[2] - kav[2][k] * pos[1]);
+            nu[1] = sh[1] + (kav[2][k] * pos[0] - kav[0][k] * pos[2]);
+            nu[2] = sh[2] + (kav[0][k] * pos[1] - kav[1][k] * pos[0]);
+            const double nrm = sqrt(nu[0] * nu[0] + nu[1] * nu[1] + nu[2] * nu[2]);
+            const double tg[3] = { nu[0] / nrm, nu[1] / nrm, nu[2] / nrm };
+            double len = nrm;       /* muscle_rest_length = 1: the normalised length is the length */
+            if (c->muscle_kind[m] == SOFTROD_MUSCLE_TRANSVERSE && c->muscle_tm_length_law == 0)
+                len = 1.0 / sqrt(nrm);
+            /* MuscleForce: force-length weight (clipped at zero), force */
+            double w = 0.0;
+            for (int p = c->muscle_fl_degree; p >= 0; --p) w = w * len + c->muscle_fl_coef[p];
+            if (w < 0.0) w = 0.0;
+            const double F = r->m_act[m][k] * r->m_strength[m][k] * w;
+            r->m_force[m][k] = F;
+            r->m_length[m][k] = len;
+            /* ContinuousActuation: internal force along the muscle tangent, couple x_m x force */
+            const double fm[3] = { F * tg[0], F * tg[1], F * tg[2] };
+            for (int i = 0; i < 3; ++i) fi[i][k] += fm[i];
+            ce[0][k] += pos[1] * fm[2] - pos[2] * fm[1];
+            ce[1][k] += pos[2] * fm[0] - pos[0] * fm[2];
+            ce[2][k] += pos[0] * fm[1] - pos[1] * fm[0];
+        }
+    }
+    /* force_induced_couple: quadrature_kernel(x_m x f)[:, 1:-1] — element values averaged onto the Voronoi vertices */
+    double cv[3][NMAX];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < n - 1; ++k) cv[i][k] = 0.5 * (ce[i][k] + ce[i][k + 1]);
+    /* internal_load_to_equivalent_external_load */
+    const int pyel = c->muscle_equiv_load_form == 1;
+    double cs[3][NMAX];
+    for (int k = 0; k < n; ++k)
+        for (int i = 0; i < 3; ++i) {
+            double q = 0.0;
+            for (int j = 0; j < 3; ++j) q += r->Q[j][i][k] * fi[j][k];
+            cs[i][k] = pyel ? q / r->dil[k] : q;
+        }
+    for (int i = 0; i < 3; ++i) {                      /* difference_kernel */
+        r->f_ext[i][0] += cs[i][0];
+        for (int k = 1; k < n; ++k) r->f_ext[i][k] += cs[i][k] - cs[i][k - 1];
+        r->f_ext[i][n] += -cs[i][n - 1];
+    }
+    double c2[3][NMAX], c3[3][NMAX];
+    for (int k = 0; k < n - 1; ++k) {
+        const double e3 = pyel ? 1.0 / (r->vdil[k] * r->vdil[k] * r->vdil[k]) : 1.0;
+        for (int i = 0; i < 3; ++i) c2[i][k] = cv[i][k] * e3;
+        c3[0][k] = (r->kappa[1][k] * cv[2][k] - r->kappa[2][k] * cv[1][k]) * r->rest_vor[k] * e3;
+        c3[1][k] = (r->kappa[2][k] * cv[0][k] - r->kappa[0][k] * cv[2][k]) * r->rest_vor[k] * e3;
+        c3[2][k] = (r->kappa[0][k] * cv[1][k] - r->kappa[1][k] * cv[0][k]) * r->rest_vor[k] * e3;
+    }
+    for (int k = 0; k < n; ++k) {
+        double qt[3];
+        for (int i = 0; i < 3; ++i) {
+            double q = r->Q[i][0][k] * r->tang[0][k];
+            q += r->Q[i][1][k] * r->tang[1][k];
+            q += r->Q[i][2][k] * r->tang[2][k];
+            qt[i] = pyel ? q : q * r->dil[k];
+        }
+        const double sc[3] = { (qt[1] * fi[2][k] - qt[2] * fi[1][k]) * r->rest_len[k],
+                               (qt[2] * fi[0][k] - qt[0] * fi[2][k]) * r->rest_len[k],
+                               (qt[0] * fi[1][k] - qt[1] * fi[0][k]) * r->rest_len[k] };
+        for (int i = 0; i < 3; ++i) {
+            double d2, d3;                             /* difference / quadrature kernels, Voronoi -> elements */
+            if (k == 0) { d2 = c2[i][0]; d3 = 0.5 * c3[i][0]; }
+            else if (k == n - 1) { d2 = -c2[i][n - 2]; d3 = 0.5 * c3[i][n - 2]; }
+            else { d2 = c2[i][k] - c2[i][k - 1]; d3 = 0.5 * (c3[i][k] + c3[i][k - 1]); }
+            r->t_ext[i][k] += d2 + d3 + sc[i];
+        }
+    }
+}
+
 static void apply_forcing(oracle_rod* r)
 {
     const int n = r->n;
@@ -674,6 +793,7 @@ static void apply_forcing(oracle_rod* r)
     if (r->cfg.features & SOFTROD_FEAT_TIP_FORCE)
         for (int i = 0; i < 3; ++i) r->f_ext[i][n] += r->cfg.tip_force[i];
     if (r->cfg.features & SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES) spline_muscle_torques(r);
+    if (r->cfg.features & SOFTROD_FEAT_COOMM_MUSCLES) apply_muscles(r);
 }
 
 /* _update_accelerations + overload_operator_dynamic_numba (v += dt*a) */
@@ -1115,6 +1235,11 @@ int oracle_get(const oracle_rod* r, const char* name, double* out)
     if (!strcmp(name, "dilatation")) { for (int k = 0; k < n; ++k) out[k] = r->dil[k]; return n; }
     if (!strcmp(name, "rest_lengths")) { for (int k = 0; k < n; ++k) out[k] = r->rest_len[k]; return n; }
     if (!strcmp(name, "damp_t")) { out[0] = r->damp_t; return 1; }
+    if (!strcmp(name, "voronoi_dilatation")) { for (int k = 0; k < n - 1; ++k) out[k] = r->vdil[k]; return n - 1; }
+    if (!strcmp(name, "muscle_force")) { for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) for (int k = 0; k < n; ++k) out[m * n + k] = r->m_force[m][k]; return SOFTROD_MAX_MUSCLES * n; }
+    if (!strcmp(name, "muscle_length")) { for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) for (int k = 0; k < n; ++k) out[m * n + k] = r->m_length[m][k]; return SOFTROD_MAX_MUSCLES * n; }
+    if (!strcmp(name, "muscle_activation")) { for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) for (int k = 0; k < n; ++k) out[m * n + k] = r->m_act[m][k]; return SOFTROD_MAX_MUSCLES * n; }
+    if (!strcmp(name, "sucker_index")) { for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) out[j] = (double)r->sucker_index[j]; return SOFTROD_MAX_SUCKERS; }
     if (!strcmp(name, "rest_kappa")) COPY3X(rest_kappa, n - 1);
     if (!strcmp(name, "radius")) { for (int k = 0; k < n; ++k) out[k] = r->radius[k]; return n; }
     if (!strcmp(name, "f_ext")) COPY3X(f_ext, n + 1);
@@ -1139,6 +1264,8 @@ int oracle_get(const oracle_rod* r, const char* name, double* out)
 int oracle_set(oracle_rod* r, const char* name, const double* in)
 {
     const int n = r->n;
+#define SET3X(arr, cnt) do { for (int i = 0; i < 3; ++i) for (int k = 0; k < (cnt); ++k) \
+        r->arr[i][k] = in[i * (cnt) + k]; return 0; } while (0)
 #define SET3(arr, cnt) do { for (int i = 0; i < 3; ++i) for (int k = 0; k < (cnt); ++k) \
         r->arr[i][k] = in[i * (cnt) + k]; return 0; } while (0)
     if (!strcmp(name, "x")) SET3(x, n + 1);
@@ -1155,6 +1282,9 @@ int oracle_set(oracle_rod* r, const char* name, const double* in)
     if (!strcmp(name, "damp_r")) SET3(damp_r, n);
 #undef SET3
     if (!strcmp(name, "damp_t")) { r->damp_t = in[0]; return 0; }
+    if (!strcmp(name, "sigma")) SET3X(sigma, n);
+    if (!strcmp(name, "muscle_activation")) { for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) for (int k = 0; k < n; ++k) r->m_act[m][k] = in[m * n + k]; return 0; }
+    if (!strcmp(name, "sucker_index")) { for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) r->sucker_index[j] = (int)in[j]; return 0; }
     if (!strcmp(name, "time")) { r->time = in[0]; return 0; }
     if (!strcmp(name, "prev_kappa")) { for (int k = 0; k < n - 1; ++k) r->prev_kappa[k] = in[k]; return 0; }
     if (!strcmp(name, "prev_com")) { r->prev_com[0] = in[0]; r->prev_com[1] = in[1]; return 0; }
@@ -1291,6 +1421,138 @@ void oracle_env_step_soft_arm(oracle_rod* r, const float* action, double* obs, d
         *terminated = 1;
     }
     *truncated = ((double)r->tick * c->dt >= c->final_time) ? 1 : 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* COOMM muscle layers + ArmPushEnv (octopus/arm_push_env.py)                  */
+/* ------------------------------------------------------------------------- */
+void oracle_set_muscle_layers(oracle_rod* r, const double* ratio_position, const double* strength)
+{
+    const int n = r->n;
+    for (int m = 0; m < r->cfg.n_muscles; ++m)
+        for (int k = 0; k < n; ++k) {
+            for (int i = 0; i < 3; ++i) r->m_ratio[m][i][k] = ratio_position[(m * 3 + i) * n + k];
+            r->m_strength[m][k] = strength[m * n + k];
+        }
+}
+
+/* MuscleForce.apply_activation(activation): a scalar is broadcast over the elements */
+void oracle_apply_activation(oracle_rod* r, int m, double activation)
+{
+    for (int k = 0; k < r->n; ++k) r->m_act[m][k] = activation;
+}
+
+/* test probe: ApplyMuscles on the current caches (sigma, kappa, radius, tangents, dilatations as last
+ * evaluated or injected) -> the equivalent external force [3][n+1] and couple [3][n] */
+void oracle_muscle_probe(oracle_rod* r, double* force, double* couple)
+{
+    const int n = r->n;
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k <= n; ++k) r->f_ext[i][k] = 0.0;
+        for (int k = 0; k < n; ++k) r->t_ext[i][k] = 0.0;
+    }
+    apply_muscles(r);
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k <= n; ++k) { force[i * (n + 1) + k] = r->f_ext[i][k]; r->f_ext[i][k] = 0.0; }
+        for (int k = 0; k < n; ++k) { couple[i * n + k] = r->t_ext[i][k]; r->t_ext[i][k] = 0.0; }
+    }
+}
+
+/* get_state, arm_push_env.py:225-245: x-positions, x-velocities, then np.eye(2)[previous_action]
+ * (discrete) or the previous action (continuous) */
+static void get_state_push(const oracle_rod* r, float* obs)
+{
+    const int n = r->n;
+    for (int k = 0; k <= n; ++k) { obs[k] = (float)r->x[0][k]; obs[n + 1 + k] = (float)r->v[0][k]; }
+    if (r->cfg.arm_push_mode == 0) {
+        const int a = (int)r->prev_action_push[0];
+        obs[2 * n + 2] = a == 0 ? 1.0f : 0.0f;
+        obs[2 * n + 3] = a == 0 ? 0.0f : 1.0f;
+    } else {
+        obs[2 * n + 2] = r->prev_action_push[0];
+        obs[2 * n + 3] = r->prev_action_push[1];
+    }
+}
+
+void oracle_observe_push(const oracle_rod* r, float* obs) { get_state_push(r, obs); }
+
+/* ArmPushEnv.reset -> _build, arm_push_env.py:141-224 (the radii and the muscle layers were handed over
+ * with oracle_set_radius_profile / oracle_set_muscle_layers, as _build computes them with NumPy) */
+void oracle_reset_push(oracle_rod* r, float* obs)
+{
+    const double start[3] = { 0.0, 0.0, 0.0 }, direction[3] = { 1.0, 0.0, 0.0 }, normal[3] = { 0.0, 1.0, -0.0 };
+    oracle_reset_straight(r, start, direction, normal);
+    for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) oracle_apply_activation(r, m, 0.0);   /* fresh muscle objects */
+    get_state_push(r, obs);
+}
+
+/* ArmPushEnv.step, arm_push_env.py:247-347.  action: the index (discrete, 0 / 1, as a float) or
+ * (location, activation) in float32 (continuous). */
+void oracle_env_step_push(oracle_rod* r, const float* action, float* obs, double* reward,
+                          uint8_t* terminated, uint8_t* truncated)
+{
+    const softrod_config* c = &r->cfg;
+    const int n = r->n;
+    /* set_action, :247-274 */
+    if (c->arm_push_mode == 0) {
+        if ((int)action[0] == 0) {
+            r->sucker_index[0] = 0;
+            oracle_apply_activation(r, 0, -0.0 * 1.0);
+            oracle_apply_activation(r, 1, 0.0 * 1.0);
+            oracle_apply_activation(r, 2, 0.5 * 1.0);
+        } else {
+            r->sucker_index[0] = -1;
+            oracle_apply_activation(r, 0, 0.0);
+            oracle_apply_activation(r, 1, 0.0);
+            oracle_apply_activation(r, 2, 0.0);
+        }
+        r->prev_action_push[0] = action[0];
+        r->prev_action_push[1] = 0.0f;
+    } else {
+        /* int(np.clip(location * self.n_elem, 0, self.n_elem - 1)): np.float32 * int stays float32 */
+        float loc = action[0] * (float)n;
+        if (loc < 0.0f) loc = 0.0f;
+        if (loc > (float)(n - 1)) loc = (float)(n - 1);
+        r->sucker_index[0] = (int)loc;
+        oracle_apply_activation(r, 2, (double)action[1]);
+        r->prev_action_push[0] = action[0];
+        r->prev_action_push[1] = action[1];
+    }
+    /* prev_cm_pos (:280).  run_substeps = 0 (fixture replay: the epilogue alone on an injected state): it is what
+     * oracle_set("prev_com") put there */
+    double prev_cm[3], cm[3];
+    if (substeps_to_run(r) > 0) { center_of_mass(r, prev_cm); r->prev_com[0] = prev_cm[0]; r->prev_com[1] = prev_cm[1]; }
+    else { prev_cm[0] = r->prev_com[0]; prev_cm[1] = r->prev_com[1]; prev_cm[2] = 0.0; }
+    for (int s = 0; s < substeps_to_run(r); ++s) position_verlet_step(r);
+    center_of_mass(r, cm);
+    /* _isnan_check over position, velocity, director, alpha, omega, cm_pos (:298-309); alpha = J^-1 tau e of the
+     * last substep is NaN only where omega became NaN in that substep, so omega covers it */
+    int invalid = 0;
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k <= n; ++k) if (isnan(r->x[i][k]) || isnan(r->v[i][k])) invalid = 1;
+        for (int k = 0; k < n; ++k) {
+            if (isnan(r->w[i][k])) invalid = 1;
+            for (int j = 0; j < 3; ++j) if (isnan(r->Q[i][j][k])) invalid = 1;
+        }
+    }
+    if (isnan(cm[0]) || isnan(cm[1])) invalid = 1;
+    double survive = 0.0, forward = 0.0;
+    *terminated = 0;
+    *truncated = 0;
+    if (invalid) { *terminated = 1; survive = -20.0; }
+    else forward = sqrt(cm[0] * cm[0] + cm[1] * cm[1]) - sqrt(prev_cm[0] * prev_cm[0] + prev_cm[1] * prev_cm[1]);
+    if (r->time > c->final_time) *truncated = 1;
+    *reward = forward + survive;
+    if (isnan(*reward)) { *terminated = 1; *reward = -20.0; }
+    get_state_push(r, obs);
+    int bad = 0;
+    for (int i = 0; i < 2 * n + 4; ++i) bad = bad || isnan(obs[i]);
+    if (bad) {
+        *terminated = 1;
+        *reward = -20.0;
+        for (int i = 0; i < 2 * n + 4; ++i)        /* np.nan_to_num on float32 */
+            obs[i] = isnan(obs[i]) ? 0.0f : (isinf(obs[i]) ? copysignf(3.4028234663852886e38f, obs[i]) : obs[i]);
+    }
 }
 
 size_t oracle_config_size(void) { return sizeof(softrod_config); }

@@ -153,6 +153,22 @@ class Box(Space):
                     and np.all(x >= self.low) and np.all(x <= self.high))
 
 
+class Discrete(Space):
+    """gymnasium.spaces.Discrete: {start, ..., start + n - 1}, shape (), int64."""
+
+    def __init__(self, n, seed=None, start=0):
+        super().__init__((), np.int64, seed)
+        self.n, self.start = int(n), int(start)
+
+    def sample(self):
+        return np.int64(self.start + self.np_random.integers(self.n))
+
+    def contains(self, x):
+        if isinstance(x, (int, np.integer)) or (isinstance(x, np.ndarray) and x.shape == () and np.issubdtype(x.dtype, np.integer)):
+            return self.start <= int(x) < self.start + self.n
+        return False
+
+
 class Dict(Space):
     def __init__(self, spaces=None, seed=None, **kw):
         super().__init__(None, None, None)
@@ -180,7 +196,7 @@ def install():
     g.__version__ = "1.0.0-standin"
     g.registry, g.register, g.make, g.make_vec, g.Env, g.EnvSpec = registry, register, make, make_vec, Env, EnvSpec
     sp = types.ModuleType("gymnasium.spaces")
-    sp.Space, sp.Box, sp.Dict = Space, Box, Dict
+    sp.Space, sp.Box, sp.Dict, sp.Discrete = Space, Box, Dict, Discrete
     g.spaces = sp
     envs = types.ModuleType("gymnasium.envs")
     reg = types.ModuleType("gymnasium.envs.registration")

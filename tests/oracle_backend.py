@@ -21,6 +21,7 @@ class OracleBackend:
         self.isarm = cfg.env_kind == _capi.ENV_ARM_SINGLE
         self.isocto = cfg.env_kind == _capi.ENV_OCTO_FLAT
         self.issoftarm = cfg.env_kind == _capi.ENV_SOFT_ARM
+        self.ispush = cfg.env_kind == _capi.ENV_ARM_PUSH
         # softrod_state_view.control: SoftArmTracking keeps tick and the target there
         self._ctrl = torch.zeros((4, int(cfg.n_envs)), dtype=torch.float64)
         self.action_dim = _capi.config_action_dim(cfg)
@@ -41,6 +42,10 @@ class OracleBackend:
     def set_radius_profile(self, radius):
         for r in self.rods:
             r.set_radius_profile(radius)
+
+    def set_muscle_layers(self, ratio_position, strength):
+        for r in self.rods:
+            r.set_muscle_layers(ratio_position, strength)
 
     def state(self):
         st = {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64), "control": self._ctrl}
@@ -69,7 +74,9 @@ class OracleBackend:
             if mask is None or mask[i]:
                 if self.is3d:
                     self._prev[i] = 0.0   # SoftPendulum3DEnv.reset clears _prev_action
-                if self.isarm:
+                if self.ispush:
+                    r.reset_push()
+                elif self.isarm:
                     r.reset_arm()   # also re-arms prev_kappa_state / prev_com_state
                 elif self.issoftarm:
                     r.reset_soft_arm()
@@ -179,6 +186,9 @@ class OracleBackend:
         if prev_action is not None:
             pa = torch.as_tensor(prev_action).reshape(self.n_envs, self.action_dim).numpy()
         for i, r in enumerate(self.rods):
+            if self.ispush:
+                self.obs[i] = torch.from_numpy(r.observe_push())   # the oracle keeps _prev_action itself
+                continue
             if self.is3d:
                 o = r.observe3d()
                 o[6:8] = pa[i]   # the env owns _prev_action; the rod only sees it at step time
@@ -219,6 +229,8 @@ class OracleBackend:
                 self.aux[i, 0] = tilt
             elif self.isarm:
                 o, rw, te, tr = r.env_step_arm(a[i])
+            elif self.ispush:
+                o, rw, te, tr = r.env_step_push(a[i])
             elif self.issoftarm:
                 r.set_arm_target(self._ctrl[1:4, i].numpy())
                 o, rw, te, tr = r.env_step_soft_arm(a[i])
