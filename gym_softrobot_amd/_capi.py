@@ -443,6 +443,9 @@ def arm_push_config(
     cfg.n_suckers = 1                               # :187-195
     cfg.sucker_index[0] = 0
     cfg.sucker_reduction_ratio = 1.0                # SuckerController default (controllable_constraint.py:11)
+    # _build registers dampen() BEFORE constrain() (:180-195; tests/golden/ref_muscle_build_records.json "order"):
+    # under the registration-order rule the damper runs first here (the other builds register constrain() first)
+    cfg.damp_before_constrain = 1
     muscle_defaults(cfg)
     return cfg
 

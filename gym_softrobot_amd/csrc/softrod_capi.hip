@@ -585,6 +585,7 @@ int softrod_config_arm_push(softrod_config* cfg, int n_envs, int mode) {
     cfg->n_suckers = 1;                                  // :187-195
     cfg->sucker_index[0] = 0;
     cfg->sucker_reduction_ratio = 1.0;                   // controllable_constraint.py:11
+    cfg->damp_before_constrain = 1;                      // _build registers dampen() before constrain() (:180-195)
     cfg->n_muscles = 3;                                  // create_es_muscle_layers, octopus/build.py:295-338
     cfg->muscle_kind[0] = SOFTROD_MUSCLE_LONGITUDINAL;
     cfg->muscle_kind[1] = SOFTROD_MUSCLE_LONGITUDINAL;

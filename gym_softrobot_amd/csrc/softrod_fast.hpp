@@ -422,8 +422,15 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
             // c_r^e = c_r * c_r^(e-1): the strain e-1 is small, so the exponent stays in the
             // polynomial's range also where log c_r is not (octopus arms: log c_r = -0.057)
             const double em1 = e[s] - 1.0;
-            exp_pair(em1 * (TAPER ? C.dlog0[s] : P.damp_logr[0]), em1 * (TAPER ? C.dlog2[s] : P.damp_logr[2]),
-                     elem_valid, ex0, ex2);
+            double x0 = em1 * (TAPER ? C.dlog0[s] : P.damp_logr[0]), x2 = em1 * (TAPER ? C.dlog2[s] : P.damp_logr[2]);
+            if constexpr (TAPER) {
+                // The thin end of a tapered arm has log c_r = -nu dt m / J of -2000 and less (c_r underflows to 0: the
+                // damper annihilates omega there, pow(0, e) = 0 in the reference's arithmetic); a COMPRESSED element
+                // (e < 1) then asks for exp(+1000) = inf, and inf * 0 is NaN.  Capped where exp is still finite:
+                // the product with c_r = 0 stays the 0 it is.
+                x0 = fmin(x0, 700.0); x2 = fmin(x2, 700.0);
+            }
+            exp_pair(x0, x2, elem_valid, ex0, ex2);
             ex0 *= TAPER ? C.dr0[s] : P.damp_r[0]; ex2 *= TAPER ? C.dr2[s] : P.damp_r[2];
             w0 *= ex0; w1 *= ex0; w2 *= ex2;
         }

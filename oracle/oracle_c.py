@@ -123,7 +123,7 @@ _SHAPES = {
     "prev_action2": lambda n: (2,), "prev_action": lambda n: (1,), "fixed_pos": lambda n: (3,),
     "fixed_dir": lambda n: (3, 3), "voronoi_dilatation": lambda n: (n - 1,),
     "muscle_force": lambda n: (4, n), "muscle_length": lambda n: (4, n), "muscle_activation": lambda n: (4, n),
-    "sucker_index": lambda n: (4,),
+    "sucker_index": lambda n: (4,), "prev_action_push": lambda n: (2,),
 }
 
 

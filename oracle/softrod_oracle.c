@@ -1285,6 +1285,7 @@ int oracle_set(oracle_rod* r, const char* name, const double* in)
     if (!strcmp(name, "sigma")) SET3X(sigma, n);
     if (!strcmp(name, "muscle_activation")) { for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) for (int k = 0; k < n; ++k) r->m_act[m][k] = in[m * n + k]; return 0; }
     if (!strcmp(name, "sucker_index")) { for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) r->sucker_index[j] = (int)in[j]; return 0; }
+    if (!strcmp(name, "prev_action_push")) { r->prev_action_push[0] = (float)in[0]; r->prev_action_push[1] = (float)in[1]; return 0; }
     if (!strcmp(name, "time")) { r->time = in[0]; return 0; }
     if (!strcmp(name, "prev_kappa")) { for (int k = 0; k < n - 1; ++k) r->prev_kappa[k] = in[k]; return 0; }
     if (!strcmp(name, "prev_com")) { r->prev_com[0] = in[0]; r->prev_com[1] = in[1]; return 0; }

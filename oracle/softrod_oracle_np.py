@@ -582,3 +582,66 @@ class NumpyOctopus:
         for rod in self.arms:
             rod.zero_external()
         self.head.zero_external()
+
+
+# =================================================================================================
+# COOMM muscle layers (SOFTROD_FEAT_COOMM_MUSCLES) — second transcription, in COOMM's own whole-array
+# style as recalled (coomm/actuations/muscles/muscle.py: Muscle.__call__, MuscleForce, TransverseMuscle;
+# coomm/actuations/actuation.py: ContinuousActuation, internal_load_to_equivalent_external_load;
+# coomm/_rod_tool.py: average2D, sigma_to_shear).  COOMM (git pin /root/reference/uv.lock:173-175) is NOT on disk:
+# PARITY UNPINNED, like softrod_oracle.c's apply_muscles, which tests/test_muscles.py holds against this to 1e-12.
+# Call sites in the reference: gym_softrobot/envs/octopus/build.py:295-338, arm_push_env.py:197-212,247-274.
+# =================================================================================================
+def average2D(vector_collection):
+    """Voronoi (3, n-1) -> elements (3, n): each Voronoi value goes half to each neighbouring element."""
+    out = np.zeros((3, vector_collection.shape[1] + 1))
+    out[:, :-1] += 0.5 * vector_collection
+    out[:, 1:] += 0.5 * vector_collection
+    return out
+
+
+def force_length_weight_poly(muscle_length, coef):
+    """sum_k coef[k] l^k, clipped at zero from below (Chang et al. 2023: max{3.06 l^3 - 13.64 l^2 + 18.01 l - 6.44, 0})."""
+    w = np.zeros_like(muscle_length)
+    for power, c in enumerate(coef):
+        w += c * muscle_length ** power
+    return np.where(w < 0.0, 0.0, w)
+
+
+def muscle_equivalent_loads(Q, sigma, kappa, tangents, radius, rest_radius, rest_lengths, rest_voronoi_lengths,
+                            dilatation, voronoi_dilatation, layers, fl_coef, form=0, current_radius=True, tm_law=0):
+    """ApplyMuscles for one rod.  layers: list of dicts {kind: 0 longitudinal / 1 transverse, ratio (3, n),
+    strength (n,), activation (n,)}.  -> (external force (3, n+1), external couple (3, n), per-layer force (m, n))."""
+    n = sigma.shape[1]
+    shear = sigma + np.array([[0.0], [0.0], [1.0]])                      # sigma_to_shear
+    kappa_e = average2D(kappa)
+    internal_force = np.zeros((3, n))
+    couple_e = np.zeros((3, n))
+    forces = []
+    for layer in layers:
+        muscle_position = (radius if current_radius else rest_radius) * layer["ratio"]
+        muscle_strain = shear + _cross(kappa_e, muscle_position)
+        norm = _norm(muscle_strain)
+        muscle_tangent = muscle_strain / norm
+        muscle_length = norm
+        if layer["kind"] == 1 and tm_law == 0:
+            muscle_length = 1.0 / np.sqrt(norm)
+        weight = force_length_weight_poly(muscle_length, fl_coef)
+        muscle_force = layer["activation"] * layer["strength"] * weight
+        forces.append(muscle_force)
+        f = muscle_force * muscle_tangent
+        internal_force += f
+        couple_e += _cross(muscle_position, f)
+    internal_couple = 0.5 * (couple_e[:, :-1] + couple_e[:, 1:])       # quadrature_kernel(...)[:, 1:-1]
+    QT = np.transpose(Q, (1, 0, 2))
+    if form == 0:       # F = D^h(Q^T f); tau = D^h(c) + A^h(kappa x c D^) + (e Q t) x f l^
+        ext_force = _difference(_matvec(QT, internal_force))
+        ext_couple = (_difference(internal_couple) + _trapezoidal(_cross(kappa, internal_couple) * rest_voronoi_lengths)
+                      + _cross(_matvec(Q, tangents * dilatation), internal_force) * rest_lengths)
+    else:               # PyElastica's own internal-load form applied to (f, c)
+        e3 = 1.0 / voronoi_dilatation ** 3
+        ext_force = _difference(_matvec(QT, internal_force) / dilatation)
+        ext_couple = (_difference(internal_couple * e3)
+                      + _trapezoidal(_cross(kappa, internal_couple) * rest_voronoi_lengths * e3)
+                      + _cross(_matvec(Q, tangents), internal_force) * rest_lengths)
+    return ext_force, ext_couple, np.array(forces)

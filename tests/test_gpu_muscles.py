@@ -47,7 +47,10 @@ def test_arm_push_env_matches_oracle(torch_gpu, hip_lib, oracle_built, mode, mat
     rng = np.random.default_rng(3)
     for t in range(6):
         if mode == "discrete":
-            a = np.array([[0, 0, 1, 1], [0, 1, 1, 0], [1, 1, 0, 0], [1, 0, 0, 1], [0, 0, 0, 0], [1, 1, 1, 1]][t],
+            # scripts that stay in the regime the restated law is meant for: alternations such as 0,0,1,1,0 drive
+            # single elements to stretches of 1e3 and beyond in the ORACLE (the published cubic is unbounded above
+            # l ~ 2.2), where no two evaluations can be compared
+            a = np.array([[0, 0, 1, 1], [0, 1, 1, 0], [0, 0, 0, 1], [0, 1, 0, 0], [0, 0, 0, 1], [0, 1, 1, 0]][t],
                          np.float32).reshape(N, 1)
         else:
             a = rng.uniform(0.0, 1.0, (N, 2)).astype(np.float32)
@@ -60,6 +63,7 @@ def test_arm_push_env_matches_oracle(torch_gpu, hip_lib, oracle_built, mode, mat
         np.testing.assert_array_equal(te.cpu().numpy(), te2)
         np.testing.assert_array_equal(tr.cpu().numpy(), tr2)
         np.testing.assert_array_equal(np.asarray(info["time"]), np.asarray(info2["time"]))
+    assert not te.cpu().numpy().any() and max(np.abs(r_.get("v")).max() for r_ in ref.backend.rods) < 10.0
     _assert_state(env.backend, ref.backend.rods)
     st = env.backend.state()
     idx = st["sucker_index"][0].cpu().numpy()

@@ -94,10 +94,16 @@ class _Dict(dict):
         super().__init__(spaces)
 
 
+class _Discrete:
+    def __init__(self, n, seed=None, start=0):
+        self.n, self.start = int(n), int(start)
+        self.shape, self.dtype = (), np.dtype(np.int64)
+
+
 def _install_gymnasium():
     g = types.ModuleType("gymnasium")
     sp = types.ModuleType("gymnasium.spaces")
-    sp.Box, sp.Dict = _Box, _Dict
+    sp.Box, sp.Dict, sp.Discrete = _Box, _Dict, _Discrete
     g.Env, g.spaces = _Env, sp
     reg = types.ModuleType("gymnasium.envs.registration")
     reg.register = lambda *a, **k: None
