@@ -104,7 +104,21 @@ CYCLES_PER_FP64_WAVE_INSTR = 4.0   # wave64 fp64 op: 16 lanes per clock per SIMD
 VALU_PEAK_GINSTR = N_SIMD * CLOCK_HZ / CYCLES_PER_FP64_WAVE_INSTR / 1e9   # 614.4
 METHODOLOGY_VERSION = 5
 AMAX = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
-        "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0}
+        "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0, "OctoArmPush-v0": 1.0, "OctoArmPush-v1": 1.0}
+
+
+def random_actions(np, env_id: str, shape, amax: float, seed: int = 1):
+    """Synthetic actions of the env's own action space: uniform in [-amax, amax]; OctoArmPush-v1: uniform in [0, 1]
+    (Box(0, 1), arm_push_env.py:113-115); OctoArmPush-v0: 0 / 1 (Discrete(2), :101) held for four env.steps each (an
+    inchworm stroke lasts several steps; flipping every step drives the restated muscle law out of its range)."""
+    rng = np.random.default_rng(seed)
+    if env_id == "OctoArmPush-v1":
+        return (rng.uniform(0.0, 1.0, shape) * (1.0 if amax else 0.0)).astype(np.float32)
+    if env_id == "OctoArmPush-v0":
+        T = shape[0]
+        strokes = rng.integers(0, 2, ((T + 3) // 4,) + tuple(shape[1:]))
+        return (np.repeat(strokes, 4, axis=0)[:T] * (1 if amax else 0)).astype(np.float32)
+    return rng.uniform(-amax, amax, shape).astype(np.float32)
 TAPER_RATIO = 12.0           # base : tip radius of the tapered arm (octopus/arm_push_env.py:160-165: 0.012 : 0.001)
 
 
@@ -239,7 +253,8 @@ def parse_args(argv=None):
                     help=f"default {ENVS_PER_GPU}; OctoFlat-v0: 1024 (BASELINE configs[4]: 8192 envs on 8 GPUs)")
     ap.add_argument("--math-mode", choices=["fast", "libm"], default="fast")
     ap.add_argument("--env", default="SoftPendulum-v0",
-                    choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0", "OctoFlat-v0", "SoftArmTracking-v0"],
+                    choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0", "OctoFlat-v0", "SoftArmTracking-v0",
+                             "OctoArmPush-v0", "OctoArmPush-v1"],
                     help="headline metric is SoftPendulum-v0; the others are the widened §8 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -485,13 +500,16 @@ def taper_profile(base_radius: float, n_elem: int):
 
 def workload_name(env_id: str, cfg, n_local: int, world: int = 1, taper: bool = False) -> str:
     octo = env_id == "OctoFlat-v0"
+    taper = taper or env_id.startswith("OctoArmPush")          # the muscle arm is tapered 12:1 by construction
     return (f"{env_id}, {n_local} envs x " + (f"{int(cfg.n_arm)} arms x " if octo else "")
             + f"{int(cfg.n_elem)} elements per GPU " + ("tapered " if taper else "")
+            + ("+ COOMM muscle layers, PARITY UNPINNED " if env_id.startswith("OctoArmPush") else "")
             + (f"(BASELINE configs[1]; x{world} GPUs)" if env_id == "SoftPendulum-v0"
                else "(widened row of SURVEY §8; not the headline metric)"))
 
 
 def profile_key(env_id: str, n_elem: int, taper: bool = False) -> str:
+    taper = taper or env_id.startswith("OctoArmPush")      # (workload_name says "tapered": tools/update_profile_tables.py keys on it)
     return f"{env_id}|n_elem={n_elem}" + ("|taper" if taper else "")
 
 
@@ -549,7 +567,7 @@ def roofline_block(env_id, cfg, n_local, kernel_ms, math_mode, lib_hash, hip, ba
         "kernel": "softrod_octo_step_kernel" if octo else
                   "softrod_step_window_kernel + softrod_step_fast_kernel (epilogue only)"
                   if (env_id == "OctoArmSingle-v0" and 64 <= int(cfg.n_elem) <= 102 and math_mode == "fast") else
-                  (("softrod_step_fast_kernel" + (" (TAPER instantiation)" if taper else ""))
+                  (("softrod_step_fast_kernel" + (" (TAPER instantiation)" if taper or env_id.startswith("OctoArmPush") else ""))
                    if math_mode == "fast" else "softrod_step_libm_kernel"),
         "kernel_ms_avg": kernel_ms,
         "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz / {CYCLES_PER_FP64_WAVE_INSTR:g} cycles per "
@@ -596,6 +614,10 @@ SECONDARY = (
     # sin / cos / acos / exp, IEEE division, no planar specialisation): what the fast-math reformulations buy
     dict(env_id="SoftPendulum-v0", n_local=ENVS_PER_GPU, extra={}, force_math_mode="libm",
          baseline="configs[1] in math_mode libm (the reference-literal arithmetic; not the headline)"),
+    # the COOMM muscle arm (arm_push_env.py), continuous mode, 40 elements tapered 12:1, 500 substeps
+    dict(env_id="OctoArmPush-v1", n_local=ENVS_PER_GPU, extra={},
+         baseline="none: BASELINE configs[2]'s `+ muscle actuation` taken literally (the reference's COOMM muscle arm); "
+                  "PARITY UNPINNED - the muscle law restates the published model, COOMM is not on disk"),
 )
 
 
@@ -611,7 +633,7 @@ def secondary_workload(gsa, _capi, torch, device, math_mode, lib_hash, env_id, n
     env = gsa.make_vec(env_id, n_local, device=device, math_mode=math_mode, **extra)
     env.reset(seed=0)
     adim = env.backend.action_dim
-    acts = np.random.default_rng(1).uniform(-AMAX[env_id], AMAX[env_id], (warmup + steps, n_local, adim)).astype(np.float32)
+    acts = random_actions(np, env_id, (warmup + steps, n_local, adim), AMAX[env_id])
     acts_dev = torch.from_numpy(acts).to(env.backend.device)
     env.backend.set_timing(warmup + steps)
     for t in range(warmup):
@@ -629,6 +651,7 @@ def secondary_workload(gsa, _capi, torch, device, math_mode, lib_hash, env_id, n
     out = {
         "workload": workload_name(env_id, cfg, n_local),
         "baseline_config": baseline,
+        "parity_label": gsa.parity_label(env_id),        # None, or what is NOT pinned (the COOMM muscle envs)
         "math_mode": "fast" if math_mode == _capi.MATH_FAST else "libm",
         "value": n_local * steps / elapsed, "unit": "env-steps/s",
         "steps": steps, "warmup": warmup,
@@ -1093,7 +1116,7 @@ def main(argv=None, script=None) -> int:
         amax = 0.0
     # the truncation flag of SoftPendulum first fires on env.step #126; the default window
     # (120 steps) stays inside one episode
-    acts = np.random.default_rng(1).uniform(-amax, amax, (T, n_total, adim)).astype(np.float32)
+    acts = random_actions(np, args.env, (T, n_total, adim), amax)
     acts_dev = torch.from_numpy(acts[:, lo:hi].copy()).to(local.backend.device)
 
     timed = hasattr(local.backend, "set_timing")

@@ -292,3 +292,36 @@ def test_arm_push_env_host_logic_on_the_oracle_backend(oracle_built):
         trunc_seen += int(tr.sum())
     assert trunc_seen >= 2 and o.shape == (2, 84)
     vec.close()
+
+
+# ---- the one-command pin, extended to the muscle arm ----------------------------------------------------------------
+def test_pin_tooling_covers_the_muscle_envs(tmp_path, oracle_built):
+    """tools/make_pyelastica_golden.py --muscle-envs records OctoArmPush-v0 / -v1 where pyelastica AND coomm import;
+    here the same record / replay code runs on oracle-made fixtures: exact self-replay, and a flipped recalled detail
+    is not matched — for the three switches this env can decide (it never activates a longitudinal layer, so the two
+    longitudinal-geometry details are invisible to it: OctoArmTwo / OctoReach fixtures decide those)."""
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import make_pyelastica_golden as gen
+    import pyelastica_pin as pin
+
+    with pytest.raises(SystemExit, match="import (elastica|coomm)"):
+        gen.main(["--muscle-envs", "--out", str(tmp_path / "never")])
+    assert gen.main(["--source", "oracle", "--out", str(tmp_path), "--envs", "--muscle-envs", "--seeds", "42", "--steps", "3"]) == 0
+    files = pin.fixture_files(tmp_path, "oracle")
+    assert [f.name for f in files] == ["oracle_OctoArmPush-v0_seed42.npz", "oracle_OctoArmPush-v1_seed42.npz"]
+    for f in files:
+        fx = dict(np.load(f, allow_pickle=False))
+        env_id = str(fx["env_id"])
+        assert "sub1_x" not in fx and "step3_x" in fx            # no raw-substep records for the unactuated arm
+        drv = pin.OracleDriver(env_id, None)
+        assert pin.worst(pin.compare_case(drv, fx)) == 0.0
+        drv.close()
+        decided = {}
+        for k, cands in pin.MUSCLE_SWITCHES.items():
+            drv = pin.OracleDriver(env_id, {k: cands[1]})
+            decided[k] = pin.worst(pin.compare_case(drv, fx)) > 1e-3
+            drv.close()
+        assert decided == {"muscle_equiv_load_form": True, "muscle_position_current_radius": False,
+                           "muscle_tm_length_law": True, "muscle_init_angle_rotates": False, "muscle_tm_sign": True}

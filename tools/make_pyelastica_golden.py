@@ -5,7 +5,8 @@
                                                       # (uv sync --frozen in the reference; Python >= 3.12)
 
 imports the REFERENCE (`/root/reference/gym_softrobot`, pyelastica 1.0.0, uv.lock:845-860), runs
-SoftPendulum-v0, SoftPendulum3D-v0, OctoArmSingle-v0 and OctoFlat-v0 for seeds {0, 1, 42, 123} under a
+SoftPendulum-v0, SoftPendulum3D-v0, OctoArmSingle-v0 and OctoFlat-v0 (with --muscle-envs also the COOMM muscle arm,
+OctoArmPush-v0 / -v1: SURVEY 8(f) N3) for seeds {0, 1, 42, 123} under a
 fixed action script (the shape of the reference's tests/envs/test_determinism.py:12-54: reset(seed),
 then env.step over a sampled action list) and writes tests/golden/pyelastica_<env>_seed<k>.npz:
 rod state after 1 / 10 / 100 raw substeps, obs / reward / flags / time after every env.step, full rod
@@ -65,10 +66,21 @@ def main(argv=None) -> int:
     ap.add_argument("--out", default=str(ROOT / "tests" / "golden"))
     ap.add_argument("--prefix", default=None, help="file prefix (default: pyelastica for the reference, oracle otherwise)")
     ap.add_argument("--envs", nargs="*", default=list(pin.ENVS))
+    ap.add_argument("--muscle-envs", action="store_true",
+                    help="also the COOMM muscle arm, OctoArmPush-v0 / -v1 (SURVEY 8(f) N3; needs `import coomm` as well: "
+                         "uv.lock:173-175).  Their fixtures are what decides pyelastica_pin.MUSCLE_SWITCHES")
     ap.add_argument("--seeds", nargs="*", type=int, default=list(pin.SEEDS))
     ap.add_argument("--steps", type=int, default=None, help="env.steps per case (default: the schedule's)")
     ap.add_argument("--flip", action="append", help="--source oracle only: name=value of a recalled detail")
     args = ap.parse_args(argv)
+    if args.muscle_envs:
+        args.envs = list(args.envs) + [e for e in pin.MUSCLE_ENVS if e not in args.envs]
+        if args.source == "pyelastica":
+            try:
+                import coomm  # noqa: F401
+            except ImportError as exc:
+                raise SystemExit(f"`import coomm` failed ({exc}): the muscle envs need COOMM at the reference's git pin "
+                                 "(uv.lock:173-175).  Nothing was written.")
     prefix = args.prefix or ("pyelastica" if args.source == "pyelastica" else "oracle")
     out = Path(args.out)
     if args.source != "pyelastica" and prefix == "pyelastica" and out.resolve() == (ROOT / "tests" / "golden").resolve():
