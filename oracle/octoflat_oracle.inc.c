@@ -376,6 +376,22 @@ void oracle_octo_env_step(oracle_octo* o, const float* action, const double* res
     octo_epilogue(o, before, individual, shared, reward, terminated, truncated);
 }
 
+/* batched driver (OpenMP over envs when built with it): full-batch parity at BASELINE configs[4]'s per-GPU share.
+ * obs rows: the n_arm "individual" rows, then "shared" (13). */
+void oracle_octo_env_step_batch(oracle_octo** envs, int n_envs, const float* actions, const double* rest_kappa0,
+                                float* obs, double* reward, uint8_t* terminated, uint8_t* truncated)
+{
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int e = 0; e < n_envs; ++e) {
+        oracle_octo* o = envs[e];
+        const int na = o->n_arm, n = o->arm[0]->n, nk = o->cfg.n_knots;
+        const int wi = (n - 1) + 4 * (n + 1) + nk, w = na * wi + 13;
+        oracle_octo_env_step(o, actions + (size_t)na * nk * e, rest_kappa0 + (size_t)na * (n - 1) * e,
+                             obs + (size_t)w * e, obs + (size_t)w * e + (size_t)na * wi, reward + e, terminated + e,
+                             truncated + e);
+    }
+}
+
 /* The epilogue alone, on whatever state the arms / head / clock hold now, with the
  * pre-loop head position given: replays the fixtures recorded from the reference's own
  * FlatEnv.step (tests/golden/ref_octoflat.npz). */

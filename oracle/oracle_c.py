@@ -56,6 +56,8 @@ def _load(omp) -> C.CDLL:
     lib.oracle_substeps.argtypes = [C.c_void_p, C.c_float, C.c_int]
     lib.oracle_env_step.argtypes = [C.c_void_p, C.c_float] + [C.c_void_p] * 4
     lib.oracle_env_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    lib.oracle_env_step_arm_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    lib.oracle_octo_env_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
     lib.oracle_reset_pendulum3d.argtypes = [C.c_void_p, C.c_double]
     lib.oracle_observe3d.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_clear_prev_action3d.argtypes = [C.c_void_p]
@@ -516,4 +518,67 @@ class OracleBatch:
             self._ptrs, self.n_rods, a.ctypes.data, obs.ctypes.data, rew.ctypes.data,
             term.ctypes.data, trunc.ctypes.data,
         )
+        return obs, rew, term.astype(bool), trunc.astype(bool)
+
+
+class OracleArmBatch:
+    """N independent OctoArmSingle arms; env_step runs them with OpenMP (full-batch parity at BASELINE sizes)."""
+
+    def __init__(self, cfg: SoftrodConfig, n_rods: int, omp: bool = True):
+        self._lib = _load(omp)
+        c1 = cfg.copy()
+        c1.n_envs = 1
+        self.rods = [OracleRod(c1, omp=omp) for _ in range(n_rods)]
+        self._ptrs = (C.c_void_p * n_rods)(*[r._h for r in self.rods])
+        self.n_rods, self.n = n_rods, int(cfg.n_elem)
+
+    def reset(self) -> None:
+        for r in self.rods:
+            r.reset_arm()
+
+    def env_step(self, actions):
+        from scipy.interpolate import interp1d
+
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_rods, 7)
+        rk = interp1d(np.linspace(0, 1, 7), a, kind="cubic", axis=-1)(np.linspace(0, 1, self.n - 1))
+        rk = np.ascontiguousarray(rk, dtype=np.float64)
+        obs = np.empty((self.n_rods, 25), np.float32)
+        rew = np.empty(self.n_rods, np.float64)
+        term = np.empty(self.n_rods, np.uint8)
+        trunc = np.empty(self.n_rods, np.uint8)
+        self._lib.oracle_env_step_arm_batch(self._ptrs, self.n_rods, a.ctypes.data, rk.ctypes.data, obs.ctypes.data,
+                                            rew.ctypes.data, term.ctypes.data, trunc.ctypes.data)
+        return obs, rew, term.astype(bool), trunc.astype(bool)
+
+
+class OracleOctoBatch:
+    """N independent OctoFlat envs; env_step runs them with OpenMP."""
+
+    def __init__(self, cfg: SoftrodConfig, n_envs: int, omp: bool = True):
+        self._lib = _load(omp)
+        c1 = cfg.copy()
+        c1.n_envs = 1
+        self.envs = [OracleOcto(c1, variant=omp) for _ in range(n_envs)]
+        self._ptrs = (C.c_void_p * n_envs)(*[e._h for e in self.envs])
+        self.n_envs, self.n_arm, self.n, self.nk = n_envs, int(cfg.n_arm), int(cfg.n_elem), int(cfg.n_knots)
+        self.width = self.n_arm * self.envs[0].width + 13
+
+    def reset(self, targets) -> None:
+        for e, t in zip(self.envs, targets):
+            e.reset(t)
+
+    def env_step(self, actions):
+        from scipy.interpolate import interp1d
+
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.n_envs, self.n_arm * self.nk)
+        k = a.reshape(self.n_envs, self.n_arm, self.nk)
+        k = np.concatenate([np.zeros((self.n_envs, self.n_arm, 1)), k, np.zeros((self.n_envs, self.n_arm, 1))], axis=-1)
+        rk = interp1d(np.linspace(0, 1, self.nk + 2), k, kind="cubic", axis=-1)(np.linspace(0, 1, self.n - 1))
+        rk = np.ascontiguousarray(rk, dtype=np.float64)
+        obs = np.empty((self.n_envs, self.width), np.float32)
+        rew = np.empty(self.n_envs, np.float64)
+        term = np.empty(self.n_envs, np.uint8)
+        trunc = np.empty(self.n_envs, np.uint8)
+        self._lib.oracle_octo_env_step_batch(self._ptrs, self.n_envs, a.ctypes.data, rk.ctypes.data, obs.ctypes.data,
+                                             rew.ctypes.data, term.ctypes.data, trunc.ctypes.data)
         return obs, rew, term.astype(bool), trunc.astype(bool)

@@ -1202,6 +1202,16 @@ void oracle_env_step_batch(oracle_rod** rods, int n_rods, const float* actions, 
                         truncated + e);
 }
 
+/* the same for OctoArmSingle (rest_kappa0: [n_rods][n_elem - 1], the interp1d output per rod) */
+void oracle_env_step_arm_batch(oracle_rod** rods, int n_rods, const float* actions, const double* rest_kappa0,
+                               float* obs, double* reward, uint8_t* terminated, uint8_t* truncated)
+{
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int e = 0; e < n_rods; ++e)
+        oracle_env_step_arm(rods[e], actions + 7 * e, rest_kappa0 + (size_t)(rods[e]->n - 1) * e, obs + 25 * e,
+                            reward + e, terminated + e, truncated + e);
+}
+
 #define COPY3X(arr, cnt) do { for (int i = 0; i < 3; ++i) for (int k = 0; k < (cnt); ++k) \
         out[i * (cnt) + k] = r->arr[i][k]; return 3 * (cnt); } while (0)
 /* field access for tests: name in {x,v,Q,w,tangents,kappa,sigma,mass,f_int,t_int,...} */

@@ -1,0 +1,127 @@
+"""EVERY env of the BASELINE-size batches against the oracle (VERDICT r5 "next" #2), not a handful of spot envs:
+
+    configs[1]        SoftPendulum-v0, 4096 envs x 50 elements, 3 env.steps            (soft_pendulum.py:176-251)
+    configs[2]        OctoArmSingle-style reach, 4096 envs x 100 elements, 1 env.step  (octopus/arm_single_env.py:237-316)
+    configs[4] share  OctoFlat-v0, 1024 envs x 8 arms x 10 elements, 1 env.step        (octopus/flat_env.py:315-408)
+
+The reference's own shape for this is tests/envs/test_determinism.py:46-54 (reset(seed), sampled actions, three
+steps, arrays compared) — here on a population, HIP against the C oracle stepping the SAME envs with OpenMP over
+rods (oracle_env_step_batch / _arm_batch / oracle_octo_env_step_batch: the driver of bench.py's cpu_baseline leg;
+1-7 s per env.step of a whole batch on the GPU box's 16 cores).  rtol 1e-5 (north_star), with the absolute floors
+the spot tests use.  The worst env of each batch and where it sits — workgroup, wave, XCD (workgroups are dealt
+round-robin over the 8 XCDs) — goes into gpurun_out/full_batch_parity.json: a mapping bug (a wave that reads its
+neighbour's row, an XCD-specific cache effect) would show up as a position pattern, not as noise.
+OctoFlat beyond its first whole step is the ensemble tests' regime."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def torch_gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch
+
+
+def _report(name, got, want, atol, envs_per_wg=1, waves_per_env=1, extra=None):
+    """Per-env worst deviation relative to the tolerance band (<= 1 passes); the record of the worst env."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    band = atol + RTOL * np.abs(want)
+    ratio = (np.abs(got - want) / band).reshape(got.shape[0], -1)
+    per_env = ratio.max(axis=1)
+    i = int(per_env.argmax())
+    rec = {"batch": name, "envs": int(got.shape[0]), "rtol": RTOL, "atol": atol,
+           "worst_env": i, "worst_over_band": float(per_env[i]), "worst_entry": int(ratio[i].argmax()),
+           "worst_abs_diff": float(np.abs(got - want).reshape(got.shape[0], -1)[i].max()),
+           "median_env_over_band": float(np.median(per_env)), "envs_over_half_band": int((per_env > 0.5).sum()),
+           "position_of_worst": {"workgroup": i // envs_per_wg, "slot_in_workgroup": i % envs_per_wg,
+                                 "waves_per_env": waves_per_env, "xcd": (i // envs_per_wg) % 8},
+           # worst env per XCD: a position pattern would show here
+           "worst_over_band_by_xcd": [float(per_env[np.arange(got.shape[0]) // envs_per_wg % 8 == x].max()) for x in range(8)]}
+    rec.update(extra or {})
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    f = out / "full_batch_parity.json"
+    doc = json.loads(f.read_text()) if f.exists() else {}
+    doc[name] = rec
+    f.write_text(json.dumps(doc, indent=1) + "\n")
+    return rec
+
+
+def test_config2_every_one_of_4096_pendulums_three_steps(torch_gpu, hip_lib, oracle_built):
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd.seeding import initial_angle, np_random
+
+    n, T = 4096, 3
+    env = gsa.make_vec("SoftPendulum-v0", n)
+    env.reset(seed=0)
+    ref = oracle_built.OracleBatch(env.cfg, n, omp=True)
+    ref.reset([initial_angle(np_random(i)[0]) for i in range(n)])
+    acts = np.random.default_rng(1).uniform(-22, 22, (T, n)).astype(np.float32)
+    for t in range(T):
+        o, r, te, tr, _ = env.step(acts[t])
+        o2, r2, te2, tr2 = ref.env_step(acts[t])
+        torch_gpu.cuda.synchronize()
+        ro = _report(f"configs[1] SoftPendulum-v0 4096x50 step {t + 1} obs", o.cpu().numpy(), o2, 1e-7)
+        rr = _report(f"configs[1] SoftPendulum-v0 4096x50 step {t + 1} reward", r.cpu().numpy(), r2, 1e-9)
+        assert ro["worst_over_band"] <= 1.0 and rr["worst_over_band"] <= 1.0, (ro, rr)
+        np.testing.assert_array_equal(te.cpu().numpy(), te2)
+        np.testing.assert_array_equal(tr.cpu().numpy(), tr2)
+    st = env.backend.state_numpy()
+    x = np.stack([r_.get("x") for r_ in ref.rods])
+    rx = _report("configs[1] SoftPendulum-v0 4096x50 step 3 positions", st["x"], x, 1e-9)
+    assert rx["worst_over_band"] <= 1.0, rx
+    env.close()
+
+
+def test_config3_every_one_of_4096_arms_of_100_elements(torch_gpu, hip_lib, oracle_built):
+    import gym_softrobot_amd as gsa
+
+    n = 4096
+    env = gsa.make_vec("OctoArmSingle-v0", n, n_elems=100)
+    assert "window" in env.backend.kernel_tier()
+    env.reset(seed=0)
+    ref = oracle_built.OracleArmBatch(gsa._capi.arm_single_config(1, n_elems=100), n, omp=True)
+    ref.reset()
+    acts = np.random.default_rng(2).uniform(-6, 6, (n, 7)).astype(np.float32)
+    o, r, te, tr, _ = env.step(acts)
+    o2, r2, te2, tr2 = ref.env_step(acts)
+    torch_gpu.cuda.synchronize()
+    ro = _report("configs[2] OctoArmSingle-v0 4096x100 step 1 obs", o.cpu().numpy(), o2, 2e-6, envs_per_wg=4, waves_per_env=2)
+    rr = _report("configs[2] OctoArmSingle-v0 4096x100 step 1 reward", r.cpu().numpy(), r2, 1e-7, envs_per_wg=4, waves_per_env=2)
+    st = env.backend.state_numpy()
+    rx = _report("configs[2] OctoArmSingle-v0 4096x100 step 1 positions", st["x"], np.stack([q.get("x") for q in ref.rods]),
+                 1e-8, envs_per_wg=4, waves_per_env=2)
+    assert ro["worst_over_band"] <= 1.0 and rr["worst_over_band"] <= 1.0 and rx["worst_over_band"] <= 1.0, (ro, rr, rx)
+    np.testing.assert_array_equal(te.cpu().numpy(), te2)
+    np.testing.assert_array_equal(tr.cpu().numpy(), tr2)
+    env.close()
+
+
+def test_config5_share_every_one_of_1024_octoflat_envs(torch_gpu, hip_lib, oracle_built):
+    import gym_softrobot_amd as gsa
+
+    n = 1024
+    env = gsa.make_vec("OctoFlat-v0", n, numpy_output=True)
+    assert env.backend.kernel_tier() == "softrod_octo_step_kernel<zup,2 waves,4 envs/wg>"
+    env.reset(seed=0)
+    ref = oracle_built.OracleOctoBatch(gsa._capi.octo_flat_config(1), n, omp=True)
+    ref.reset(env.targets)
+    acts = np.random.default_rng(3).uniform(-22, 22, (n, 24)).astype(np.float32)
+    o, r, te, tr, _ = env.step(acts)
+    o2, r2, te2, tr2 = ref.env_step(acts)
+    ro = _report("configs[4] share OctoFlat-v0 1024x8x10 step 1 obs", o, o2, 2e-6, envs_per_wg=4, waves_per_env=2)
+    rr = _report("configs[4] share OctoFlat-v0 1024x8x10 step 1 reward", r, r2, 1e-6, envs_per_wg=4, waves_per_env=2,
+                 extra={"crossing_counts_equal": None})
+    assert ro["worst_over_band"] <= 1.0 and rr["worst_over_band"] <= 1.0, (ro, rr)
+    np.testing.assert_array_equal(te, te2)
+    np.testing.assert_array_equal(tr, tr2)
+    env.close()

@@ -1,9 +1,9 @@
 """BASELINE.json configs[2] and the per-GPU share of configs[4] at their FULL sizes (config[1] at
 4096 envs is tests/test_gpu_parity.py::test_full_size_batch_properties): size-independent
 properties of the whole batch — finite, bitwise repeatable, independent of the batch an env sits
-in — plus spot parity of a few envs against the oracle.  The oracle cannot step thousands of
-envs in a test; a handful spread over the batch (first, last, across wave / workgroup / XCD
-boundaries) is what it checks."""
+in — plus spot parity of a few envs against the oracle over SEVERAL steps.  EVERY env of these
+batches against the oracle (stepped with OpenMP over rods) for the first step(s) is
+tests/test_gpu_full_batch_parity.py."""
 import numpy as np
 import pytest
 
