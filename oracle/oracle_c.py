@@ -32,16 +32,22 @@ def build_fma() -> None:
     subprocess.run(["make", "-C", str(_DIR), "fma"], check=True, capture_output=True)
 
 
+def build_jitter() -> None:
+    """The same source with the transcendental functions' results moved by one ulp in half of the calls: the
+    second rounding control ("another libm"; softrod_oracle.c ORACLE_LIBM_JITTER)."""
+    subprocess.run(["make", "-C", str(_DIR), "jitter"], check=True, capture_output=True)
+
+
 def _load(omp) -> C.CDLL:
     key = omp if isinstance(omp, str) else ("omp" if omp else "st")
     if key in _libs:
         return _libs[key]
     path = _DIR / {"omp": "libsoftrod_oracle_omp.so", "st": "libsoftrod_oracle.so",
-                   "fma": "libsoftrod_oracle_fma.so"}[key]
+                   "fma": "libsoftrod_oracle_fma.so", "jitter": "libsoftrod_oracle_jitter.so"}[key]
     if key == "st" and os.environ.get("SOFTROD_ORACLE_LIB"):      # e.g. the ASan/UBSan build (oracle/Makefile: asan)
         path = Path(os.environ["SOFTROD_ORACLE_LIB"])
     if not path.exists():
-        build_fma() if key == "fma" else build()
+        build_fma() if key == "fma" else (build_jitter() if key == "jitter" else build())
     lib = C.CDLL(str(path))
     lib.oracle_create.restype = C.c_void_p
     lib.oracle_create.argtypes = [C.POINTER(SoftrodConfig)]

@@ -39,6 +39,31 @@
 
 #include "../include/softrod.h"
 
+#ifdef ORACLE_LIBM_JITTER
+/* CONTROL BUILD (oracle/Makefile: jitter): the results of libm's transcendental functions — sin, cos, acos, pow,
+ * exp, the calls PyElastica's substep makes through NumPy / Numba — are moved by one unit in the last place in half
+ * of the calls (deterministically, by a hash of the result).  A second, equally valid evaluation of the same algorithm
+ * under ANOTHER libm: glibc, Numba's LLVM intrinsics and the GPU's device library round these functions differently
+ * in the last bit, which the FMA control (same glibc, contraction only) does not show.  tools/ensemble_parity.py
+ * calibrates its paired-divergence band on the larger of the two controls. */
+static inline double oracle_ulp_jitter(double x)
+{
+    uint64_t u;
+    if (!(x == x) || x == 0.0) return x;
+    memcpy(&u, &x, 8);
+    const uint64_t h = (u ^ (u >> 29)) * 0x9E3779B97F4A7C15ull;
+    if ((h >> 62) == 0) u += 1;
+    else if ((h >> 62) == 1) u -= 1;
+    memcpy(&x, &u, 8);
+    return x;
+}
+#define sin(x) oracle_ulp_jitter((sin)(x))
+#define cos(x) oracle_ulp_jitter((cos)(x))
+#define acos(x) oracle_ulp_jitter((acos)(x))
+#define pow(x, y) oracle_ulp_jitter((pow)(x, y))
+#define exp(x) oracle_ulp_jitter((exp)(x))
+#endif
+
 #define NMAX 256 /* max elements per rod the oracle supports */
 
 typedef struct oracle_rod {
