@@ -520,19 +520,19 @@ def taper_profile(base_radius: float, n_elem: int):
     return (edge[:-1] + edge[1:]) / 2
 
 
-def workload_name(env_id: str, cfg, n_local: int, world: int = 1, taper: bool = False) -> str:
+def workload_name(env_id: str, cfg, n_local: int, world: int = 1, taper: bool = False, libm: bool = False) -> str:
     octo = env_id == "OctoFlat-v0"
     taper = taper or env_id.startswith("OctoArmPush")          # the muscle arm is tapered 12:1 by construction
     return (f"{env_id}, {n_local} envs x " + (f"{int(cfg.n_arm)} arms x " if octo else "")
-            + f"{int(cfg.n_elem)} elements per GPU " + ("tapered " if taper else "")
+            + f"{int(cfg.n_elem)} elements per GPU " + ("tapered " if taper else "") + ("libm kernel " if libm else "")
             + ("+ COOMM muscle layers, PARITY UNPINNED " if env_id.startswith("OctoArmPush") else "")
             + (f"(BASELINE configs[1]; x{world} GPUs)" if env_id == "SoftPendulum-v0"
                else "(widened row of SURVEY §8; not the headline metric)"))
 
 
-def profile_key(env_id: str, n_elem: int, taper: bool = False) -> str:
+def profile_key(env_id: str, n_elem: int, taper: bool = False, libm: bool = False) -> str:
     taper = taper or env_id.startswith("OctoArmPush")      # (workload_name says "tapered": tools/update_profile_tables.py keys on it)
-    return f"{env_id}|n_elem={n_elem}" + ("|taper" if taper else "")
+    return f"{env_id}|n_elem={n_elem}" + ("|taper" if taper else "") + ("|libm" if libm else "")
 
 
 def roofline_block(env_id, cfg, n_local, kernel_ms, math_mode, lib_hash, hip, backend, taper=False):
@@ -546,12 +546,10 @@ def roofline_block(env_id, cfg, n_local, kernel_ms, math_mode, lib_hash, hip, ba
     bytes_per_launch = n_local * nsub * (rods_per_env * algorithmic_bytes_per_rod_substep(int(cfg.n_elem))
                                          + (2 * 18 * 8 if octo else 0))
     kernel_s = kernel_ms * 1e-3
-    key = profile_key(env_id, int(cfg.n_elem), taper)
+    key = profile_key(env_id, int(cfg.n_elem), taper, math_mode != "fast")
     traffic_rec, traffic_why = fresh_or_none(load_profile_table("hbm_traffic.json", f"{key}|envs={n_local}"), lib_hash)
     traffic = (traffic_rec or {}).get("hbm_bytes_per_launch")
-    valu_rec, valu_why = (None, "valu_counts.json holds the fast-math kernels only")
-    if math_mode == "fast":
-        valu_rec, valu_why = fresh_or_none(load_profile_table("valu_counts.json", key), lib_hash)
+    valu_rec, valu_why = fresh_or_none(load_profile_table("valu_counts.json", key), lib_hash)
     valu_per = (valu_rec or {}).get("valu_instr_per_rod_substep")
     achieved = None if valu_per is None else valu_per * rod_substeps / kernel_s / 1e9
     frac = None if achieved is None else achieved / VALU_PEAK_GINSTR
@@ -671,7 +669,7 @@ def secondary_workload(gsa, _capi, torch, device, math_mode, lib_hash, env_id, n
     kernel_ms = float(np.sum(kt[per_step * warmup:])) / steps
     cfg = env.cfg
     out = {
-        "workload": workload_name(env_id, cfg, n_local),
+        "workload": workload_name(env_id, cfg, n_local, libm=math_mode != _capi.MATH_FAST),
         "baseline_config": baseline,
         "parity_label": gsa.parity_label(env_id),        # None, or what is NOT pinned (the COOMM muscle envs)
         "math_mode": "fast" if math_mode == _capi.MATH_FAST else "libm",
@@ -1257,7 +1255,7 @@ def main(argv=None, script=None) -> int:
             "data": "synthetic" if hip else "TEST-DOUBLE (not a measurement)",
             "methodology_version": METHODOLOGY_VERSION,
             "config": {
-                "workload": workload_name(args.env, cfg, n_local, world, args.taper),
+                "workload": workload_name(args.env, cfg, n_local, world, args.taper, args.math_mode != "fast"),
                 "envs_total": n_total,
                 "substeps_per_env_step": nsub,
                 "math_mode": args.math_mode,

@@ -15,9 +15,10 @@
 //     by a previous step are handled exactly like the reference;
 //   * sin/cos of the Rodrigues angle, theta/sin(theta) of _inv_rotate and the damper's
 //     pow() are short polynomials in their (tiny) arguments with wave-uniform range
-//     checks (one s_cbranch on the fast path); outside the range the argument is halved
-//     until it fits and the result rebuilt with double-angle / squaring identities (no libm
-//     calls, which keeps the register budget small enough for several waves per SIMD);
+//     checks (one s_cbranch on the fast path); outside the range the trigonometric arguments are
+//     halved until they fit and the result rebuilt with double-angle identities, the exponential is
+//     reduced by powers of two (exp_wide) — no libm calls, which keeps the register budget small
+//     enough for several waves per SIMD;
 //     the damper's c_r^e is evaluated as c_r * c_r^(e-1) so that only the strain e-1, not
 //     log c_r, has to be small;
 //   * divisions become one Newton-refined v_rcp_f64 / v_rsq_f64 each; circular cross
@@ -155,8 +156,35 @@ __device__ __forceinline__ double eps_sin_factor(double y, double eps_sin) {
     return fma(fma(y, eps_sin, -0.5 * eps_sin), rho, 1.0);
 }
 
-// exp(x) for the damper: |x| < 1e-3 -> degree-4 Taylor (remainder x^5/120 < 1e-17);
-// larger |x| (strong damping constants) are halved k times and squared back.
+// exp(x) for any x: exp(x) = 2^n exp(r), n = rint(x log2 e), r = x - n ln 2 with ln 2 in two parts (fdlibm's split: n ln2_hi is
+// exact for |n| < 2^20), |r| <= ln 2 / 2 = 0.347, degree-13 Taylor (remainder r^14 / 14! < 5e-18), v_ldexp_f64.  ~21 VALU
+// instructions, no loop, relative error ~1e-16 plus the argument's own rounding.
+__device__ __forceinline__ double exp_wide(double x) {
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)fmin(fmax(n, -1100.0), 1100.0));
+}
+
+// exp(x) for the damper: |x| < 1e-3 -> degree-4 Taylor (remainder x^5/120 < 1e-17), one s_cbranch on the fast path;
+// larger |x| — strong damping constants, and above all the thin end of a TAPERED arm, whose log c_r = -nu dt m / J
+// reaches -1500: (e - 1) log c_r is 10 .. 700 in every substep of a stretched arm — take exp_wide.  (Until round 6 this
+// tier halved the argument until it fitted and squared the result back: up to 21 wave-uniform loop trips and a
+// dependent chain of 42 multiplications per substep, 2.7 of the 4.5 ms of an OctoArmPush-v0 env.step.)
 __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid_lane, double& e0, double& e2) {
     const unsigned long long valid = __builtin_amdgcn_ballot_w64(valid_lane);
     if (!wave_any_of(valid, !(fmax(fabs(x0), fabs(x2)) < 1.0e-3))) {
@@ -164,13 +192,8 @@ __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid_lane, 
         e2 = fma(x2, fma(x2, fma(x2, horner(1.0 / 24.0, x2, 1.0 / 6.0), 0.5), 1.0), 1.0);
         return;
     }
-    int k = 0;   // 2^24 * 1e-3 > 16000: exp underflows long before
-    while (wave_any_of(valid, !(fmax(fabs(x0), fabs(x2)) < 1.0e-3)) && k < 24) {
-        x0 *= 0.5; x2 *= 0.5; ++k;
-    }
-    e0 = fma(x0, fma(x0, fma(x0, fma(x0, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
-    e2 = fma(x2, fma(x2, fma(x2, fma(x2, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0), 1.0);
-    for (; k > 0; --k) { e0 *= e0; e2 *= e2; }
+    e0 = exp_wide(x0);
+    e2 = exp_wide(x2);
 }
 
 }  // namespace softrod

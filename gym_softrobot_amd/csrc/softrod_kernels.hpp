@@ -1610,7 +1610,12 @@ __device__ __forceinline__ void libm_dynamic_step(const RodParams& P, const Libm
 // LIBM kernel: one env.step (or `n_sub` bare substeps) for every rod of the shard.
 // grid = n_envs blocks of one wavefront; one node per lane (n_elem <= 63).
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kLanes)
+// SOFTROD_LIBM_WAVES: waves per SIMD the register allocator leaves room for.  1: the kernel takes the ~390 registers
+// it asks for (256 VGPRs + 138 AGPRs, no scratch); 2: capped at 256, the rest spills (measured: profiles/README.md r6).
+#ifndef SOFTROD_LIBM_WAVES
+#define SOFTROD_LIBM_WAVES 1
+#endif
+__global__ void __launch_bounds__(kLanes, SOFTROD_LIBM_WAVES)
 softrod_step_libm_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,

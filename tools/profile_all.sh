@@ -19,9 +19,10 @@ declare -A ARGS=(
   [OctoArmSingle-v0_taper]="--env OctoArmSingle-v0 --taper"
   [SoftArmTracking-v0]="--env SoftArmTracking-v0"
   [OctoArmPush-v1]="--env OctoArmPush-v1"
+  [SoftPendulum-v0_libm]="--math-mode libm"
   [OctoArmPush-v0]="--env OctoArmPush-v0"
 )
-NAMES=${*:-SoftPendulum-v0 SoftPendulum3D-v0 OctoArmSingle-v0 OctoArmSingle-v0_n100 OctoArmSingle-v0_taper OctoFlat-v0 SoftArmTracking-v0 OctoArmPush-v1}
+NAMES=${*:-SoftPendulum-v0 SoftPendulum3D-v0 OctoArmSingle-v0 OctoArmSingle-v0_n100 OctoArmSingle-v0_taper OctoFlat-v0 SoftArmTracking-v0 OctoArmPush-v1 SoftPendulum-v0_libm}
 for NAME in $NAMES; do
   A="--no-cpu-baseline --no-secondary ${ARGS[$NAME]}"
   OUT=$ROOT/gpurun_out/prof_${TAG}_$NAME

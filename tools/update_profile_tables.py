@@ -28,9 +28,9 @@ for f in sys.argv[1:]:
     h = d.get("library_source_hash")
     if not h:
         sys.exit(f"{f}: passes ran on different builds of the library (or no bench line): refused")
-    m = re.match(r"(\S+), (\d+) envs x (?:\d+ arms x )?(\d+) elements per GPU (tapered )?", d["workload"])
+    m = re.match(r"(\S+), (\d+) envs x (?:\d+ arms x )?(\d+) elements per GPU (tapered )?(libm kernel )?", d["workload"])
     env, envs, n_elem = m.group(1), int(m.group(2)), int(m.group(3))
-    key = f"{env}|n_elem={n_elem}" + ("|taper" if m.group(4) else "")      # bench.py profile_key()
+    key = f"{env}|n_elem={n_elem}" + ("|taper" if m.group(4) else "") + ("|libm" if m.group(5) else "")      # bench.py profile_key()
     src = f"profiles/{f.name} ({d.get('command', 'tools/profile_all.sh')})"
     if "pmc3" in d:
         p = d["pmc3"]
