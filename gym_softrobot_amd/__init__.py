@@ -2,12 +2,14 @@
 Gymnasium surface of gym-softrobot's SoftPendulum-v0 / SoftPendulum3D-v0."""
 from . import _capi
 from .envs import (
+    ArmPullWeightEnv,
     ArmPushEnv,
     ArmSingleEnv,
     FlatEnv,
     SoftArmTrackingEnv,
     SoftPendulum3DEnv,
     SoftPendulumEnv,
+    VecArmPullWeightEnv,
     VecArmPushEnv,
     VecArmSingleEnv,
     VecOctoFlatEnv,
@@ -35,6 +37,7 @@ _VEC = {
     "SoftArmTracking-v0": (VecSoftArmTrackingEnv, {}),
     "OctoArmPush-v0": (VecArmPushEnv, {}),                            # gym_softrobot/__init__.py:37-46
     "OctoArmPush-v1": (VecArmPushEnv, dict(mode="continuous")),
+    "OctoArmPullWeight-v0": (VecArmPullWeightEnv, dict(mode="continuous")),   # gym_softrobot/__init__.py:48-52
 }
 
 # gym_softrobot/__init__.py:27-30,74-80
@@ -52,6 +55,9 @@ from .envs.arm_push import PARITY_LABEL as _UNPINNED  # noqa: E402
 register(id="OctoArmPush-v0", entry_point=ArmPushEnv, vector_entry_point=VecArmPushEnv, label=_UNPINNED)
 register(id="OctoArmPush-v1", entry_point=ArmPushEnv, kwargs=dict(mode="continuous"), vector_entry_point=VecArmPushEnv,
          label=_UNPINNED)
+# gym_softrobot/__init__.py:48-52
+register(id="OctoArmPullWeight-v0", entry_point=ArmPullWeightEnv, kwargs=dict(mode="continuous"),
+         vector_entry_point=VecArmPullWeightEnv, label=_UNPINNED)
 
 
 def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
@@ -64,5 +70,5 @@ def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
 
 __all__ = [
     "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
-    "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv", "SoftArmTrackingEnv", "VecSoftArmTrackingEnv", "ArmPushEnv", "VecArmPushEnv", "parity_label", "make", "make_vec", "register", "registered", "_capi",
+    "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv", "SoftArmTrackingEnv", "VecSoftArmTrackingEnv", "ArmPushEnv", "VecArmPushEnv", "ArmPullWeightEnv", "VecArmPullWeightEnv", "parity_label", "make", "make_vec", "register", "registered", "_capi",
 ]

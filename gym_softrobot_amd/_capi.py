@@ -50,7 +50,9 @@ ENV_ARM_SINGLE = 3
 ENV_OCTO_FLAT = 4
 ENV_SOFT_ARM = 5
 ENV_ARM_PUSH = 6
+ENV_ARM_PULL_WEIGHT = 7
 FEATURES_ARM_PUSH = FEAT_ANALYTICAL_DAMPER | FEAT_SUCKER_CONSTRAINT | FEAT_COOMM_MUSCLES
+FEATURES_ARM_PULL_WEIGHT = FEATURES_ARM_PUSH | FEAT_OCTO_HEAD
 FEATURES_OCTO_FLAT = FEATURES_ARM_SINGLE | FEAT_OCTO_HEAD
 FEATURES_SOFT_ARM = FEAT_FIXED_BC | FEAT_ANALYTICAL_DAMPER | FEAT_SPLINE_MUSCLE_TORQUES
 
@@ -60,11 +62,11 @@ MATH_FAST = 1
 LANE_STRIDE = 64  # one wavefront row per rod (softrod_state_view.lane_stride)
 
 _ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2, ENV_ARM_SINGLE: 7, ENV_OCTO_FLAT: 24,
-               ENV_SOFT_ARM: 8, ENV_ARM_PUSH: 2}
+               ENV_SOFT_ARM: 8, ENV_ARM_PUSH: 2, ENV_ARM_PULL_WEIGHT: 2}
 _OBS_DIM = {ENV_NONE: 4, ENV_SOFTPENDULUM: 4, ENV_SOFTPENDULUM3D: 9, ENV_ARM_SINGLE: 25,
-            ENV_OCTO_FLAT: 8 * 56 + 13, ENV_SOFT_ARM: 14, ENV_ARM_PUSH: 84}
+            ENV_OCTO_FLAT: 8 * 56 + 13, ENV_SOFT_ARM: 14, ENV_ARM_PUSH: 84, ENV_ARM_PULL_WEIGHT: 84}
 _AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1, ENV_ARM_SINGLE: 0, ENV_OCTO_FLAT: 0,
-            ENV_SOFT_ARM: 0, ENV_ARM_PUSH: 0}
+            ENV_SOFT_ARM: 0, ENV_ARM_PUSH: 0, ENV_ARM_PULL_WEIGHT: 0}
 
 
 def action_dim(env_kind: int) -> int:
@@ -149,6 +151,10 @@ class SoftrodConfig(C.Structure):
         ("arm_push_mode", C.c_int32),
         ("reserved3", C.c_int32),
         ("muscle_fl_coef", C.c_double * 8),
+        ("head_center", C.c_double * 3),
+        ("head_length", C.c_double),
+        ("joint_angle0", C.c_double),
+        ("joint_angle_step", C.c_double),
     ]
 
     def copy(self) -> "SoftrodConfig":
@@ -329,6 +335,11 @@ def octo_flat_config(
     cfg.joint_k = 1e6
     cfg.joint_nu = 1e-3
     cfg.joint_kt = 1e0
+    # Cylinder(start = (0, 0, -r0), direction = e_z, normal = e_y, base_length = 2 r0) and the joints' angles
+    # 360 / n_arm * arm_i (octopus/build.py:73-74,95-105,117-132)
+    cfg.head_center[0], cfg.head_center[1], cfg.head_center[2] = 0.0, 0.0, -cfg.base_radius + 2.0 * cfg.base_radius / 2
+    cfg.head_length = 2.0 * cfg.base_radius
+    cfg.joint_angle0, cfg.joint_angle_step = 0.0, 360 / int(n_arm)
     return cfg
 
 
@@ -450,6 +461,36 @@ def arm_push_config(
     return cfg
 
 
+def arm_pull_weight_config(
+    n_envs: int = 1,
+    *,
+    final_time: float = 2.5,
+    recording_fps: int = 40,
+    mode: str = "continuous",
+    math_mode: int = MATH_FAST,
+) -> SoftrodConfig:
+    """`softrod_config_arm_pull_weight`: ArmPullWeightEnv (octopus/arm_push_env.py:516-618) — ArmPushEnv with
+    time_step 2.5e-5 (:518), damper 0.05 * 2 * 5e2 (:549), a rigid Cylinder "weight" (:552-567) held by
+    BodyBoundaryCondition (:569-575) and joined to the arm's node 0 by FixedJoint2Rigid(k=1e6, nu=1e-2, kt=1, angle=0,
+    radius=0.015) (:577-589), the sucker at reduction_ratio 0.9 (:591-599)."""
+    cfg = arm_push_config(n_envs, final_time=final_time, time_step=2.5e-5, recording_fps=recording_fps, mode=mode,
+                          math_mode=math_mode)
+    cfg.features = FEATURES_ARM_PULL_WEIGHT
+    cfg.env_kind = ENV_ARM_PULL_WEIGHT
+    cfg.damping_constant = 0.05 * 2 * 5e2
+    cfg.sucker_reduction_ratio = 0.9
+    cfg.n_arm, cfg.n_knots = 1, 1
+    rigid_rod_radius, radius_base = 0.015, 0.012
+    cfg.head_radius = rigid_rod_radius
+    cfg.head_density = 700 * 1.0
+    cfg.head_length = radius_base * 2
+    # start = (-0.9 * radius, 0, -2 * radius_base), direction e_z: centre = start + direction * length / 2
+    cfg.head_center[0], cfg.head_center[1], cfg.head_center[2] = -rigid_rod_radius * 0.9, 0.0, -2 * radius_base + radius_base * 2 / 2
+    cfg.joint_k, cfg.joint_nu, cfg.joint_kt = 1e6, 1e-2, 1e0
+    cfg.joint_angle0, cfg.joint_angle_step = 0.0, 0.0
+    return cfg
+
+
 def np_rint(x: float) -> float:
     import numpy as np
 
@@ -520,13 +561,13 @@ def octo_arm_frames(n_arm: int, head_radius: float):
 def config_action_dim(cfg: "SoftrodConfig") -> int:
     if int(cfg.env_kind) == ENV_OCTO_FLAT:
         return int(cfg.n_arm) * int(cfg.n_knots)
-    if int(cfg.env_kind) == ENV_ARM_PUSH:
+    if int(cfg.env_kind) in (ENV_ARM_PUSH, ENV_ARM_PULL_WEIGHT):
         return 1 if int(cfg.arm_push_mode) == 0 else 2      # Discrete(2) index / (location, activation)
     return action_dim(cfg.env_kind)
 
 
 def config_obs_dim(cfg: "SoftrodConfig") -> int:
-    if int(cfg.env_kind) == ENV_ARM_PUSH:
+    if int(cfg.env_kind) in (ENV_ARM_PUSH, ENV_ARM_PULL_WEIGHT):
         return 2 * (int(cfg.n_elem) + 1) + 2                # arm_push_env.py:104,118-120
     if int(cfg.env_kind) == ENV_OCTO_FLAT:
         n = int(cfg.n_elem)
@@ -552,6 +593,7 @@ _EXPORTS = {
     "softrod_config_octo_flat": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_soft_arm": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_arm_push": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.c_int]),
+    "softrod_config_arm_pull_weight": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_set_muscle_layers": (C.c_int, [_VP, _VP, _VP]),
     "softrod_set_spline_table": (C.c_int, [_VP, _VP, _VP]),
     "softrod_config_action_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),

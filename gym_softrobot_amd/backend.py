@@ -41,7 +41,9 @@ class HipRodBackend:
         self.n_envs = int(cfg.n_envs)
         self.action_dim = _capi.config_action_dim(cfg)
         self.obs_dim = _capi.config_obs_dim(cfg)
-        self.is_octo = bool(cfg.features & _capi.FEAT_OCTO_HEAD)
+        # FlatEnv's host API (reset_octo, Dict observations); the muscle arm with a weight (ENV_ARM_PULL_WEIGHT) has a
+        # rigid body too but resets and observes like any single rod
+        self.is_octo = bool(cfg.features & _capi.FEAT_OCTO_HEAD) and int(cfg.env_kind) == _capi.ENV_OCTO_FLAT
         self.aux_dim = _capi.aux_dim(cfg.env_kind)
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)

@@ -205,7 +205,11 @@ void fill_params(const softrod_config& c, RodParams& P) {
         P.seg = 1 << P.seg_shift;
         P.n_arm = c.n_arm;
         P.n_action = c.n_knots;
-        const double hl = 2.0 * c.base_radius, hr = c.head_radius;
+        if (c.features & SOFTROD_FEAT_COOMM_MUSCLES) P.seg_shift = 6, P.seg = 64;    // the muscle arm: one arm per wave
+        const double hl = c.head_length > 0.0 ? c.head_length : 2.0 * c.base_radius, hr = c.head_radius;
+        for (int i = 0; i < 3; ++i) P.head_center[i] = c.head_length > 0.0 ? c.head_center[i] : 0.0;
+        P.joint_angle0 = c.head_length > 0.0 ? c.joint_angle0 : 0.0;
+        P.joint_angle_step = c.head_length > 0.0 ? c.joint_angle_step : 360 / (double)c.n_arm;
         const double harea = M_PI * hr * hr;
         P.head_mass = (M_PI * hr * hr * hl) * c.head_density;
         const double s1 = harea * harea / (4.0 * M_PI);
@@ -240,6 +244,10 @@ void fill_params(const softrod_config& c, RodParams& P) {
 }
 
 bool is_octo(const softrod_handle* h) { return (h->cfg.features & SOFTROD_FEAT_OCTO_HEAD) != 0; }
+// the rigid-body set whose host API is FlatEnv's (softrod_reset_octo, softrod_queue_push_octo); the muscle arm with a
+// weight (SOFTROD_ENV_ARM_PULL_WEIGHT) runs the same kernels but resets like any single rod (softrod_reset_straight)
+bool is_flat(const softrod_handle* h) { return h->cfg.env_kind == SOFTROD_ENV_OCTO_FLAT; }
+bool is_pull(const softrod_handle* h) { return h->cfg.env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT; }
 
 int launch_step(softrod_handle* h, const float* actions, float* obs, double* reward,
                 uint8_t* term, uint8_t* trunc, double* aux, int n_sub, int epilogue, int pack,
@@ -260,7 +268,7 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     if ((h->cfg.features & SOFTROD_FEAT_COOMM_MUSCLES) && h->cfg.math_mode == SOFTROD_MATH_FAST) {
         // the fast kernel carries the muscle layers in two instantiations only (kMusclesCompiled): the tapered
         // ArmPush arm and the uniform muscle rod; never let another one run a muscle handle without its muscles
-        const bool push = h->cfg.env_kind == SOFTROD_ENV_ARM_PUSH;
+        const bool push = h->cfg.env_kind == SOFTROD_ENV_ARM_PUSH || is_pull(h);
         if (push && !h->tapered)
             return fail(h, SOFTROD_EINVAL, "SOFTROD_ENV_ARM_PUSH (SOFTROD_MATH_FAST): call softrod_set_radius_profile first "
                                            "(the reference's arm is tapered, arm_push_env.py:160-179)");
@@ -270,7 +278,10 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     const bool timing = h->timed < (int)h->ev_start.size();
     if (timing) SR_HIP(h, hipEventRecord(h->ev_start[h->timed], st));
     const bool zup = (h->P.features & kFeatPlaneZup) != 0;
-    if (is_octo(h)) {
+    if (is_octo(h) && is_pull(h)) {
+        hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_ARM_PULL_WEIGHT, 2, 1>), grid, block, 0, st, h->P, h->S,
+                           actions, obs, reward, term, trunc, n_sub, epilogue, pack);
+    } else if (is_octo(h)) {
 #define SR_OCTO(FEATS, MAXW)                                                                        \
         hipLaunchKernelGGL((softrod_octo_step_kernel<FEATS, MAXW>), grid, block, 0, st, h->P, h->S,     \
                            actions, obs, reward, term, trunc, n_sub, epilogue, pack)
@@ -540,6 +551,11 @@ int softrod_config_octo_flat(softrod_config* cfg, int n_envs) {
     cfg->joint_k = 1e6;                                  // :117-132
     cfg->joint_nu = 1e-3;
     cfg->joint_kt = 1e0;
+    cfg->head_center[0] = 0.0; cfg->head_center[1] = 0.0;          // Cylinder(start = (0, 0, -r0), e_z, e_y, 2 r0), :95-105
+    cfg->head_center[2] = -cfg->base_radius + 2.0 * cfg->base_radius / 2;
+    cfg->head_length = 2.0 * cfg->base_radius;
+    cfg->joint_angle0 = 0.0;
+    cfg->joint_angle_step = 360 / (double)cfg->n_arm;    // :73-74
     return SOFTROD_OK;
 }
 
@@ -598,6 +614,28 @@ int softrod_config_arm_push(softrod_config* cfg, int n_envs, int mode) {
     return SOFTROD_OK;
 }
 
+int softrod_config_arm_pull_weight(softrod_config* cfg, int n_envs) {
+    const int rc = softrod_config_arm_push(cfg, n_envs, 1);      // registered with mode "continuous" (gym_softrobot/__init__.py:48-52)
+    if (rc != SOFTROD_OK) return rc;
+    cfg->features = SOFTROD_FEATURES_ARM_PULL_WEIGHT;
+    cfg->env_kind = SOFTROD_ENV_ARM_PULL_WEIGHT;
+    cfg->dt = 2.5e-5;                                    // octopus/arm_push_env.py:518
+    cfg->n_substeps = (int)(1.0 / (40 * cfg->dt));       // 1000
+    cfg->damping_constant = 0.05 * 2 * 5e2;              // :549
+    cfg->sucker_reduction_ratio = 0.9;                   // :591-599
+    cfg->n_arm = 1; cfg->n_knots = 1;
+    const double rigid_rod_radius = 0.015, radius_base = 0.012;     // :524,554
+    cfg->head_radius = rigid_rod_radius;
+    cfg->head_density = 700 * 1.0;                       // :565
+    cfg->head_length = radius_base * 2;                  // :553
+    cfg->head_center[0] = -rigid_rod_radius * 0.9;       // start (:555-558) + direction * length / 2
+    cfg->head_center[1] = 0.0;
+    cfg->head_center[2] = -2 * radius_base + radius_base * 2 / 2;
+    cfg->joint_k = 1e6; cfg->joint_nu = 1e-2; cfg->joint_kt = 1e0;   // :577-589
+    cfg->joint_angle0 = 0.0; cfg->joint_angle_step = 0.0;
+    return SOFTROD_OK;
+}
+
 int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) {
     if (!cfg || !out) return fail(nullptr, SOFTROD_EINVAL, "null argument");
     *out = nullptr;
@@ -612,12 +650,12 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "need n_substeps >= 0 and dt > 0");
     if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
-    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_ARM_PUSH)
+    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_ARM_PULL_WEIGHT)
         return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
     if (cfg->features & SOFTROD_FEAT_COOMM_MUSCLES) {
         if (cfg->n_muscles < 1 || cfg->n_muscles > SOFTROD_MAX_MUSCLES || cfg->muscle_fl_degree < 0 ||
             cfg->muscle_fl_degree >= SOFTROD_MAX_FL_COEF || cfg->n_elem > kLanes - 1 ||
-            (cfg->features & SOFTROD_FEAT_OCTO_HEAD))
+            ((cfg->features & SOFTROD_FEAT_OCTO_HEAD) && cfg->env_kind != SOFTROD_ENV_ARM_PULL_WEIGHT))
             return fail(nullptr, SOFTROD_EINVAL,
                         "COOMM muscles: 1 <= n_muscles <= 4, 0 <= muscle_fl_degree <= 7, one rod of up to 63 elements per env");
         for (int m = 0; m < cfg->n_muscles; ++m)
@@ -629,12 +667,18 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     }
     if ((cfg->features & SOFTROD_FEAT_COOMM_MUSCLES) && cfg->math_mode == SOFTROD_MATH_FAST &&
         !((cfg->features == SOFTROD_FEATURES_ARM_PUSH && cfg->env_kind == SOFTROD_ENV_ARM_PUSH) ||
+          (cfg->features == SOFTROD_FEATURES_ARM_PULL_WEIGHT && cfg->env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT) ||
           (cfg->features == kFeaturesMuscleRod && cfg->env_kind == SOFTROD_ENV_NONE)))
         return fail(nullptr, SOFTROD_EINVAL,
                     "SOFTROD_MATH_FAST compiles the COOMM muscles for SOFTROD_FEATURES_ARM_PUSH with SOFTROD_ENV_ARM_PUSH "
                     "(tapered) and for FIXED_BC | ANALYTICAL_DAMPER | COOMM_MUSCLES with SOFTROD_ENV_NONE (uniform rod); "
                     "use SOFTROD_MATH_LIBM for any other mix");
-    if (cfg->env_kind == SOFTROD_ENV_ARM_PUSH) {
+    if (cfg->env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT &&
+        (cfg->features != SOFTROD_FEATURES_ARM_PULL_WEIGHT || cfg->math_mode != SOFTROD_MATH_FAST || cfg->n_arm != 1 ||
+         !(cfg->head_length > 0.0) || !(cfg->head_radius > 0.0) || !(cfg->head_density > 0.0)))
+        return fail(nullptr, SOFTROD_EINVAL, "SOFTROD_ENV_ARM_PULL_WEIGHT: SOFTROD_FEATURES_ARM_PULL_WEIGHT, SOFTROD_MATH_FAST, n_arm = 1, "
+                                             "head_length / head_radius / head_density > 0");
+    if (cfg->env_kind == SOFTROD_ENV_ARM_PUSH || cfg->env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT) {
         const unsigned need = SOFTROD_FEAT_COOMM_MUSCLES | SOFTROD_FEAT_SUCKER_CONSTRAINT;
         if ((cfg->features & need) != need || cfg->n_muscles < 3 || (cfg->arm_push_mode != 0 && cfg->arm_push_mode != 1))
             return fail(nullptr, SOFTROD_EINVAL,
@@ -667,9 +711,10 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
                         "max_activation_rate > 0");
     }
     const bool octo = (cfg->features & SOFTROD_FEAT_OCTO_HEAD) != 0;
-    if (octo != (cfg->env_kind == SOFTROD_ENV_OCTO_FLAT))
-        return fail(nullptr, SOFTROD_EINVAL, "SOFTROD_FEAT_OCTO_HEAD and SOFTROD_ENV_OCTO_FLAT go together");
-    if (octo) {
+    const bool pull = cfg->env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT;
+    if (octo != (cfg->env_kind == SOFTROD_ENV_OCTO_FLAT || pull))
+        return fail(nullptr, SOFTROD_EINVAL, "SOFTROD_FEAT_OCTO_HEAD goes with SOFTROD_ENV_OCTO_FLAT or SOFTROD_ENV_ARM_PULL_WEIGHT");
+    if (octo && !pull) {
         if (cfg->features != SOFTROD_FEATURES_OCTO_FLAT || cfg->math_mode != SOFTROD_MATH_FAST)
             return fail(nullptr, SOFTROD_EINVAL,
                         "OctoFlat exists for SOFTROD_FEATURES_OCTO_FLAT and SOFTROD_MATH_FAST only");
@@ -683,7 +728,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
             return fail(nullptr, SOFTROD_EINVAL, "OctoFlat needs head_radius > 0 and head_density > 0");
     }
     if (cfg->features & SOFTROD_FEAT_SUCKER_CONSTRAINT) {
-        if (octo || cfg->n_suckers < 1 || cfg->n_suckers > SOFTROD_MAX_SUCKERS)
+        if ((octo && !pull) || cfg->n_suckers < 1 || cfg->n_suckers > SOFTROD_MAX_SUCKERS)
             return fail(nullptr, SOFTROD_EINVAL, "ControllableFixConstraint: 1 <= n_suckers <= 4, not with OctoFlat");
         for (int j = 0; j < cfg->n_suckers; ++j)
             if (cfg->sucker_index[j] < 0 || cfg->sucker_index[j] >= cfg->n_elem)
@@ -837,7 +882,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
 int softrod_reset_octo(softrod_handle* h, const double* arm_start, const double* arm_direction,
                        const double* target, const uint8_t* mask, void* stream) {
     if (!h || !arm_start || !arm_direction || !target) return fail(h, SOFTROD_EINVAL, "null argument");
-    if (!is_octo(h)) return fail(h, SOFTROD_EINVAL, "softrod_reset_octo is for SOFTROD_ENV_OCTO_FLAT");
+    if (!is_flat(h)) return fail(h, SOFTROD_EINVAL, "softrod_reset_octo is for SOFTROD_ENV_OCTO_FLAT");
     SR_ON_DEVICE(h);
     SR_HIP(h, hipEventSynchronize(h->ev_reset));
     const int N = h->cfg.n_envs, na = h->cfg.n_arm;
@@ -996,7 +1041,7 @@ int queue_commit(softrod_handle* h, hipStream_t st) {
 int softrod_queue_push(softrod_handle* h, const double* theta0, const int32_t* counts, int max_count,
                        void* stream) {
     if (!h || !theta0) return fail(h, SOFTROD_EINVAL, "null argument");
-    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat stages resets through softrod_queue_push_octo");
+    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "rigid-body envs stage resets through softrod_queue_push_octo / _straight");
     SR_ON_DEVICE(h);
     const int rc = queue_begin(h, counts, max_count);
     if (rc != SOFTROD_OK) return rc;
@@ -1014,14 +1059,16 @@ int softrod_queue_push(softrod_handle* h, const double* theta0, const int32_t* c
 int softrod_queue_push_straight(softrod_handle* h, const double* start, const double* direction,
                                 const double* normal, const int32_t* counts, int max_count, void* stream) {
     if (!h || !start || !direction || !normal) return fail(h, SOFTROD_EINVAL, "null argument");
-    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat stages resets through softrod_queue_push_octo");
+    if (is_flat(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat stages resets through softrod_queue_push_octo");
     SR_ON_DEVICE(h);
     const int rc = queue_begin(h, counts, max_count);
     if (rc != SOFTROD_OK) return rc;
     for (int e = 0; e < h->cfg.n_envs; ++e)
         for (int j = 0; j < counts[e]; ++j) {
             const size_t k = ((size_t)e * max_count + j) * 3;
-            straight_init(h->cfg, start + k, direction + k, normal + k, queue_slot(h, e, h->h_produced[e]++));
+            double* rec = queue_slot(h, e, h->h_produced[e]++);
+            straight_init(h->cfg, start + k, direction + k, normal + k, rec);
+            if (is_pull(h)) { rec[18] = 0.0; rec[19] = 0.0; }      // the rigid-body record's target slot: unused
         }
     return queue_commit(h, (hipStream_t)stream);
 }
@@ -1029,7 +1076,7 @@ int softrod_queue_push_straight(softrod_handle* h, const double* start, const do
 int softrod_queue_push_octo(softrod_handle* h, const double* arm_start, const double* arm_direction,
                             const double* target, const int32_t* counts, int max_count, void* stream) {
     if (!h || !arm_start || !arm_direction || !target) return fail(h, SOFTROD_EINVAL, "null argument");
-    if (!is_octo(h)) return fail(h, SOFTROD_EINVAL, "softrod_queue_push_octo is for SOFTROD_ENV_OCTO_FLAT");
+    if (!is_flat(h)) return fail(h, SOFTROD_EINVAL, "softrod_queue_push_octo is for SOFTROD_ENV_OCTO_FLAT");
     SR_ON_DEVICE(h);
     const int rc = queue_begin(h, counts, max_count);
     if (rc != SOFTROD_OK) return rc;
@@ -1113,7 +1160,7 @@ int softrod_queue_advance(softrod_handle* h, const int32_t* by, void* stream) {
 
 int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask, void* stream) {
     if (!h || !theta0) return fail(h, SOFTROD_EINVAL, "null argument");
-    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat resets through softrod_reset_octo");
+    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "rigid-body envs reset through softrod_reset_octo / softrod_reset_straight");
     SR_ON_DEVICE(h);
     SR_HIP(h, hipEventSynchronize(h->ev_reset));  // previous upload out of the pinned buffers
     const int N = h->cfg.n_envs;
@@ -1133,14 +1180,17 @@ int softrod_reset(softrod_handle* h, const double* theta0, const uint8_t* mask, 
 int softrod_reset_straight(softrod_handle* h, const double* start, const double* direction,
                            const double* normal, const uint8_t* mask, void* stream) {
     if (!h || !start || !direction || !normal) return fail(h, SOFTROD_EINVAL, "null argument");
-    if (is_octo(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat resets through softrod_reset_octo");
+    if (is_flat(h)) return fail(h, SOFTROD_EINVAL, "OctoFlat resets through softrod_reset_octo");
     SR_ON_DEVICE(h);
     SR_HIP(h, hipEventSynchronize(h->ev_reset));
     const int N = h->cfg.n_envs;
+    // ArmPullWeightEnv: the one arm's record where the rigid-body reset kernel expects the arms', a zero target behind them
+    double* tgt = h->h_init + (size_t)N * 18;
     for (int e = 0; e < N; ++e) {
         if (mask) h->h_mask[e] = mask[e];
         if (mask && !mask[e]) continue;
         straight_init(h->cfg, start + 3 * e, direction + 3 * e, normal + 3 * e, h->h_init + (size_t)e * 18);
+        if (is_pull(h)) { tgt[2 * (size_t)e] = 0.0; tgt[2 * (size_t)e + 1] = 0.0; }
     }
     return upload_and_reset(h, (hipStream_t)stream, mask != nullptr);
 }
@@ -1166,7 +1216,7 @@ int softrod_set_spline_table(softrod_handle* h, const double* breaks, const doub
 // kernels' per-lane material table.  Mirrors straight_rod() of oracle/softrod_oracle.c.
 int softrod_set_radius_profile(softrod_handle* h, const double* radius) {
     if (!h || !radius) return fail(h, SOFTROD_EINVAL, "null argument");
-    if (is_octo(h) || h->epl != 1 || h->window_refresh > 0)
+    if ((is_octo(h) && !is_pull(h)) || h->epl != 1 || h->window_refresh > 0)
         return fail(h, SOFTROD_EINVAL, "tapered rods: one rod of up to 63 elements per env");
     if (h->was_reset) return fail(h, SOFTROD_EINVAL, "softrod_set_radius_profile must precede the first reset");
     const softrod_config& c = h->cfg;
@@ -1435,7 +1485,7 @@ int softrod_observe(softrod_handle* h, const float* prev_action, float* obs, voi
     if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no observation");
     SR_ON_DEVICE(h);
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
-    if (is_octo(h))
+    if (is_octo(h) && !is_pull(h))
         hipLaunchKernelGGL(softrod_octo_observe_kernel, grid, dim3(kLanes * h->nw), 0, (hipStream_t)stream,
                            h->P, h->S, prev_action, obs);
     else if (h->epl == 2)
@@ -1453,7 +1503,7 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->n_envs = h->cfg.n_envs;
     out->n_elem = h->cfg.n_elem;
     out->lane_stride = kLanes * h->epl * h->nw;
-    out->arm_stride = is_octo(h) ? h->P.seg : 0;
+    out->arm_stride = is_flat(h) ? h->P.seg : 0;
     out->position = h->S.pos;
     out->velocity = h->S.vel;
     out->director = h->S.dir;
@@ -1524,7 +1574,9 @@ const char* softrod_kernel_tier(softrod_handle* h) {
     const unsigned f = h->cfg.features;
     const int e = h->cfg.env_kind;
     std::string t;
-    if (is_octo(h)) {
+    if (is_octo(h) && is_pull(h)) {
+        t = "softrod_octo_step_kernel<ArmPullWeight,1 wave,1 env/wg,taper>";
+    } else if (is_octo(h)) {
         if (zup && h->nw == 2 && h->octo_one_wave && h->P.n_arm * h->P.seg == 2 * kLanes && !(h->P.seg & 1))
             t = "softrod_octo1w_step_kernel<zup,1 wave,1 env/wg>";
         else if (zup && h->nw == 2 && !h->octo_one_env_per_block)

@@ -96,6 +96,7 @@ struct RodParams {
     // OctoFlat-v0: n_arm rods per wave, `seg` slots apart (0 = one rod per wave), + rigid head
     int seg, n_arm, seg_shift, pad1;
     double head_mass, head_invJ[3], head_radius;   // the planar head only ever turns about d3
+    double head_center[3], joint_angle0, joint_angle_step;   // Cylinder centre at reset; FixedJoint2Rigid angle of arm a (degrees)
     // SoftArmTracking: the two spline muscles (muscle_torques_with_bspline.py:98-126)
     int n_ctrl, n_pieces;
     double muscle_scale, max_rate, base_length, arm_target[3];
@@ -198,6 +199,8 @@ __device__ __forceinline__ int env_of(const RodParams& P) {
     if constexpr (E == kRuntimeEnv) return P.env_kind;
     else return E;
 }
+// ArmPullWeightEnv IS ArmPushEnv with another _build (octopus/arm_push_env.py:516-618): same set_action, step, get_state
+__device__ __forceinline__ bool is_push_env(int env) { return env == SOFTROD_ENV_ARM_PUSH || env == SOFTROD_ENV_ARM_PULL_WEIGHT; }
 // Index of a slot inside its rod.  One rod per wave: the slot index itself.  OctoFlat packs
 // n_arm rods `seg` slots apart (seg a power of two; the slots between an arm's last node and
 // the next arm's first are ghosts with zero stiffness — PyElastica's own memory-block idea;
@@ -880,7 +883,7 @@ __device__ __forceinline__ double tilt_n(const RodParams& P, int lane, const Lan
 __device__ __forceinline__ int env_obs_dim(const RodParams& P) {
     return (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 9 : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 25
          : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 2 * P.n_ctrl + 6
-         : (P.env_kind == SOFTROD_ENV_ARM_PUSH) ? 2 * (P.n_elem + 1) + 2 : 4;
+         : is_push_env(P.env_kind) ? 2 * (P.n_elem + 1) + 2 : 4;
 }
 
 // ArmPushEnv.get_state (octopus/arm_push_env.py:225-245): position_collection[0], velocity_collection[0], then
@@ -932,7 +935,7 @@ __device__ __forceinline__ void env_observe_n(const RodParams& P, const StatePtr
         soft_arm_get_state_n<EPL>(P, S, N, rod, lane, L, st);
         if (lane == 0)
             for (int i = 0; i < 2 * P.n_ctrl + 6; ++i) o[i] = (float)st[i];
-    } else if (env == SOFTROD_ENV_ARM_PUSH) {
+    } else if (is_push_env(env)) {
         (void)push_get_state_n<EPL>(P, lane, L, pa, o, false);
     } else {
         const double th = theta_n<EPL>(P, lane, L);
@@ -1012,7 +1015,7 @@ __device__ __forceinline__ void env_epilogue_n(const RodParams& P, const StatePt
                 o[i] = (float)v;
             }
         }
-    } else if (env == SOFTROD_ENV_ARM_PUSH) {
+    } else if (is_push_env(env)) {
         // ArmPushEnv.step after the loop (octopus/arm_push_env.py:288-347).  _isnan_check covers position,
         // velocity, director, alpha, omega and the centre of mass (:298-309; alpha = J^-1 tau e of the last substep
         // is NaN only where omega became NaN in that substep)
@@ -1169,7 +1172,7 @@ __device__ __forceinline__ void set_action_n(const RodParams& P, const StatePtrs
     for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) A.mu[m] = 0.0;
     A.mu_set = false;
     const int env = env_of<E>(P);
-    if (env == SOFTROD_ENV_ARM_PUSH) {
+    if (is_push_env(env)) {
         // ArmPushEnv.set_action (octopus/arm_push_env.py:247-274): the sucker's index and the layers' activations
         if (actions) {
             int index;
@@ -1265,7 +1268,7 @@ __device__ __forceinline__ void set_action_n(const RodParams& P, const StatePtrs
 template <unsigned F, int E, int EPL>
 __device__ __forceinline__ void push_store_prev_com(const RodParams& P, const StatePtrs& S, size_t N, int rod, int lane,
                                                     const LaneN<EPL>& L, int n_sub) {
-    if (env_of<E>(P) != SOFTROD_ENV_ARM_PUSH || n_sub <= 0) return;
+    if (!is_push_env(env_of<E>(P)) || n_sub <= 0) return;
     ConstN<EPL> C0;
     EnvAction A0;
 #pragma unroll
@@ -1690,7 +1693,7 @@ softrod_observe_kernel(const RodParams P, const StatePtrs S, const float* __rest
     else build_const<kRuntimeFeatures, EPL>(P, lane, A, C);
     const int adim = (P.env_kind == SOFTROD_ENV_SOFTPENDULUM3D) ? 2
                    : (P.env_kind == SOFTROD_ENV_ARM_SINGLE) ? 7 : (P.env_kind == SOFTROD_ENV_SOFT_ARM) ? 0
-                   : (P.env_kind == SOFTROD_ENV_ARM_PUSH) ? (P.push_mode == 0 ? 1 : 2) : 1;
+                   : is_push_env(P.env_kind) ? (P.push_mode == 0 ? 1 : 2) : 1;
     float pa[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = 0; i < adim; ++i)
         pa[i] = prev_action ? prev_action[adim * (size_t)rod + i] : S.prev_action[7 * (size_t)rod + i];
@@ -1762,7 +1765,7 @@ __device__ __forceinline__ void reset_rod(const RodParams& P, const StatePtrs& S
                 for (int s = 0; s < EPL; ++s) S.mact[((size_t)m * N + rod) * W + (size_t)lane * EPL + s] = 0.0;
         }
     }
-    if (lane == 0 && P.env_kind == SOFTROD_ENV_ARM_PUSH) {
+    if (lane == 0 && is_push_env(P.env_kind)) {
         S.sucker_idx[rod] = P.sucker_index[0];
         S.sucker[rod] = P.sucker_ratio0;
     }

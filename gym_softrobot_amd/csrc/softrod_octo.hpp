@@ -261,7 +261,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
 
     // set_action (flat_env.py:288-311): rest_kappa[0,:] = zero-padded cubic interp1d of the
     // arm's knots = basis @ knots
-    if (actions && live) {
+    if (has<F>(P, SOFTROD_FEAT_REST_KAPPA_ACTION) && actions && live) {
         double rk0 = 0.0;
         if (arm_ok && r < n - 1) {
             const float* a = actions + (size_t)env * (P.n_arm * nk) + arm * nk;
@@ -273,20 +273,36 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
 
     // joint frame of this arm: z_rotation(head d2, 360/n_arm * arm degrees), joint.py:66-71
     const bool base = arm_ok && r == 0;
-    const double ang = (360.0 / (double)P.n_arm * (double)arm) / 180.0 * M_PI;
+    // FixedJoint2Rigid(angle = ...): 360 / n_arm * arm_i in FlatEnv (octopus/build.py:73-74,117-132), 0 for the weight
+    // of ArmPullWeightEnv (arm_push_env.py:585-587); the host's product, so that it is the reference's float64
+    const double ang = (P.joint_angle0 + P.joint_angle_step * (double)arm) / 180.0 * M_PI;
     const double ct = cos(ang), st = sin(ang);
 
+    // The muscle arm joined to a rigid body (ArmPullWeightEnv): tapered, COOMM layers, a sucker; ArmPushEnv's
+    // set_action / step / get_state (softrod_kernels.hpp).  One wave per env (n_arm * seg <= 64).
+    constexpr bool kMuscleArm = kMusclesCompiled<F>;
     EnvAction A;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) A.a[i] = 0.0f;
+    for (int i = 0; i < 8; ++i) A.a[i] = 0.0f;
     A.force = 0.0;
-    ConstN<1> C;
-    build_const<F, 1>(P, tid, A, C);
+    A.mu_set = false;
     BcTargets B;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { B.pos[i] = 0.0; B.vel[i] = 0.0; }
 #pragma unroll
     for (int i = 0; i < 9; ++i) B.Q[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) { B.keep[j] = 1.0; B.snode[j] = -1; B.selem[j] = -1; }
+    if constexpr (kMuscleArm) {
+        load_suckers<F>(P, S, N, env, B);
+        if (live) {
+            set_action_n<F, kRuntimeEnv, 1>(P, S, NR, row, lane, actions, A, B, L);
+            if (epilogue) push_store_prev_com<F, kRuntimeEnv, 1>(P, S, NR, row, lane, L, n_sub);
+        }
+    }
+    ConstN<1> C;
+    build_const<F, 1, kMuscleArm>(P, tid, A, C, S.mat);
+    if constexpr (kMuscleArm) build_muscle_const<F, 1, true>(P, S, NR, row, lane, A, C);
     RodParams Pk = P;
     if (!has<F>(P, SOFTROD_FEAT_ANALYTICAL_DAMPER)) Pk.damp_t = 1.0;
     const double head_inv_mass = 1.0 / P.head_mass;
@@ -474,7 +490,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
 #if SOFTROD_OCTO_PRIO
             if constexpr (EPB > 1) __builtin_amdgcn_s_setprio(SOFTROD_OCTO_PRIO);
 #endif
-            dynamic_n<F, 1>(Pk, C, B, tid, L, joints);
+            dynamic_n<F, 1, kMusclesCompiled<F>>(Pk, C, B, tid, L, joints);
             const bool last = (s == n_sub - 1);
             const double h = last ? P.half_dt : P.dt;
             kinematic_n<1>(h, C, L);
@@ -500,6 +516,12 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         }
     }
     if (!epilogue) return;
+    if constexpr (kMusclesCompiled<F>) {
+        // ArmPullWeightEnv.step = ArmPushEnv.step after the loop (arm_push_env.py:288-347) on the arm alone
+        if (live)
+            env_epilogue_n<kRuntimeEnv, 1>(P, S, NR, row, lane, C, L, time, A, obs, reward, terminated, truncated, nullptr, pack);
+        return;
+    }
 
     // ---- FlatEnv.step epilogue, flat_env.py:330-408 ----
     const int adim = P.n_arm * nk;
@@ -627,7 +649,17 @@ __device__ __forceinline__ void octo_reset_env(const RodParams& P, const StatePt
     for (int c = 0; c < 3; ++c) S.rkap[c * NR * kLanes + m] = 0.0;
     S.envmem[m] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { H.x[i] = 0.0; H.v[i] = 0.0; H.w[i] = 0.0; }
+    for (int i = 0; i < 3; ++i) { H.x[i] = P.head_center[i]; H.v[i] = 0.0; H.w[i] = 0.0; }
+    if (P.features & SOFTROD_FEAT_COOMM_MUSCLES) {     // fresh muscle objects and SuckerController (reset_rod says why)
+        if (S.mact) {
+#pragma unroll
+            for (int mm = 0; mm < SOFTROD_MAX_MUSCLES; ++mm) S.mact[((size_t)mm * NR + row) * kLanes + lane] = 0.0;
+        }
+        if (tid == 0 && is_push_env(P.env_kind)) {
+            S.sucker_idx[env] = P.sucker_index[0];
+            S.sucker[env] = P.sucker_ratio0;
+        }
+    }
     const double Q0[9] = {0.0, 1.0, 0.0, -1.0, 0.0, 0.0, 0.0, 0.0, 1.0};
 #pragma unroll
     for (int i = 0; i < 9; ++i) H.Q[i] = Q0[i];
@@ -669,9 +701,14 @@ softrod_octo_autoreset_kernel(const RodParams P, const StatePtrs S, float* __res
     LaneN<1> L;
     HeadState H;
     octo_reset_env(P, S, env, in, tgt, L, H);
-    const int od = octo_obs_dim(P);
+    const bool push = is_push_env(P.env_kind);
+    const int od = push ? env_obs_dim(P) : octo_obs_dim(P);
     float* o = out_row(obs, env, od, pack);
-    octo_write_obs(P, tid, L, H, tgt, S.prev_action + (size_t)env * (P.n_arm * P.n_action), o);
+    if (push) {
+        float pa[2] = {S.prev_action[7 * (size_t)env], S.prev_action[7 * (size_t)env + 1]};
+        (void)push_get_state_n<1>(P, tid & 63, L, pa, o, false);
+    } else
+        octo_write_obs(P, tid, L, H, tgt, S.prev_action + (size_t)env * (P.n_arm * P.n_action), o);
     __syncthreads();                           // every thread has read needs_reset / q_consumed
     if (tid == 0) {
         emit_scalars(o, od, pack, env, 0.0, false, false, reward, terminated, truncated, S.needs_reset);

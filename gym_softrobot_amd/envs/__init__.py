@@ -1,4 +1,4 @@
-from .arm_push import ArmPushEnv, VecArmPushEnv
+from .arm_push import ArmPullWeightEnv, ArmPushEnv, VecArmPullWeightEnv, VecArmPushEnv
 from .arm_single import ArmSingleEnv, VecArmSingleEnv
 from .octo_flat import FlatEnv, VecOctoFlatEnv
 from .soft_arm import SoftArmTrackingEnv, VecSoftArmTrackingEnv
@@ -8,5 +8,5 @@ from .soft_pendulum_3d import SoftPendulum3DEnv, VecSoftPendulum3DEnv
 __all__ = [
     "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
     "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv",
-    "SoftArmTrackingEnv", "VecSoftArmTrackingEnv", "ArmPushEnv", "VecArmPushEnv",
+    "SoftArmTrackingEnv", "VecSoftArmTrackingEnv", "ArmPushEnv", "VecArmPushEnv", "ArmPullWeightEnv", "VecArmPullWeightEnv",
 ]

@@ -61,8 +61,8 @@ class VecArmPushEnv(VecRodEnvBase):
         if config_early_termination:
             raise NotImplementedError("config_early_termination (the Hamiltonian cut-off of arm_push_env.py:311-314, "
                                       "389-404) is not built: the default (False) only")
-        cfg = _capi.arm_push_config(num_envs, final_time=final_time, time_step=time_step,
-                                    recording_fps=recording_fps, mode=mode, math_mode=math_mode)
+        cfg = self._config(num_envs, final_time=final_time, time_step=time_step,
+                           recording_fps=recording_fps, mode=mode, math_mode=math_mode)
         super().__init__(num_envs, cfg, render_mode=render_mode, config_generate_video=config_generate_video,
                          device=device, numpy_output=numpy_output, autoreset=autoreset, backend=backend)
         self.final_time = final_time
@@ -79,6 +79,10 @@ class VecArmPushEnv(VecRodEnvBase):
         self.backend.set_radius_profile(radius_mean)
         ratio, strength = _capi.es_muscle_layers(radius_mean, 0.012, **(muscle_kwargs or {}))
         self.backend.set_muscle_layers(ratio, strength)
+
+    @staticmethod
+    def _config(num_envs, **kw):
+        return _capi.arm_push_config(num_envs, **kw)
 
     def _validate_actions(self, actions) -> None:
         if self.mode == 0:
@@ -102,6 +106,22 @@ class VecArmPushEnv(VecRodEnvBase):
 
     def _reset_backend(self, mask, use_mask, draws=None):
         self.backend.reset_straight(*self._frames((self.num_envs,)), mask.astype(np.uint8) if use_mask else None)
+
+
+class VecArmPullWeightEnv(VecArmPushEnv):
+    """N parallel OctoArmPullWeight-v0 envs: `ArmPullWeightEnv(ArmPushEnv)` (octopus/arm_push_env.py:516-618) — the same
+    arm and step(), time_step 2.5e-5, joined at node 0 to a rigid Cylinder "weight" (FixedJoint2Rigid, held upright by
+    BodyBoundaryCondition), the sucker at reduction_ratio 0.9.  PARITY UNPINNED like OctoArmPush."""
+
+    def __init__(self, num_envs: int, **kwargs):
+        if "time_step" in kwargs:        # `super().__init__(time_step=2.5e-5, **kwargs)` (:518) would raise the same
+            raise TypeError("__init__() got multiple values for keyword argument 'time_step'")
+        super().__init__(num_envs, time_step=2.5e-5, **kwargs)
+
+    @staticmethod
+    def _config(num_envs, *, time_step, **kw):
+        assert time_step == 2.5e-5
+        return _capi.arm_pull_weight_config(num_envs, **kw)
 
 
 class ArmPushEnv(_GymEnv):
@@ -129,9 +149,8 @@ class ArmPushEnv(_GymEnv):
         if render_mode not in {None, *self.metadata["render_modes"]}:
             raise ValueError(f"Unsupported render mode: {render_mode}")
         self.render_mode = render_mode
-        self._vec = VecArmPushEnv(1, final_time, time_step, recording_fps, mode, config_generate_video,
-                                  config_early_termination, None, device=device, math_mode=math_mode,
-                                  numpy_output=True, backend=backend)
+        self._vec = self._make_vec(final_time, time_step, recording_fps, mode, config_generate_video,
+                                   config_early_termination, device, math_mode, backend)
         self.final_time = final_time
         self.time_step = time_step
         self.total_steps = self._vec.total_steps
@@ -150,6 +169,13 @@ class ArmPushEnv(_GymEnv):
         self.config_generate_video = config_generate_video
         self.config_early_termination = config_early_termination
         self.time = np.float64(0.0)
+
+    @staticmethod
+    def _make_vec(final_time, time_step, recording_fps, mode, config_generate_video, config_early_termination,
+                  device, math_mode, backend):
+        return VecArmPushEnv(1, final_time, time_step, recording_fps, mode, config_generate_video,
+                             config_early_termination, None, device=device, math_mode=math_mode,
+                             numpy_output=True, backend=backend)
 
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
         super().reset(seed=seed)
@@ -189,3 +215,20 @@ class ArmPushEnv(_GymEnv):
 
         close_env(self)
         self._vec.close()
+
+
+class ArmPullWeightEnv(ArmPushEnv):
+    """Drop-in for gym_softrobot's ArmPullWeightEnv (octopus/arm_push_env.py:516-618), N = 1.  PARITY UNPINNED."""
+
+    def __init__(self, **kwargs):
+        if "time_step" in kwargs:
+            raise TypeError("__init__() got multiple values for keyword argument 'time_step'")
+        super().__init__(time_step=2.5e-5, **kwargs)        # :518
+
+    @staticmethod
+    def _make_vec(final_time, time_step, recording_fps, mode, config_generate_video, config_early_termination,
+                  device, math_mode, backend):
+        return VecArmPullWeightEnv(1, final_time=final_time, recording_fps=recording_fps, mode=mode,
+                                   config_generate_video=config_generate_video,
+                                   config_early_termination=config_early_termination, render_mode=None, device=device,
+                                   math_mode=math_mode, numpy_output=True, backend=backend)

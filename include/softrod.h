@@ -132,6 +132,8 @@ enum softrod_feature {
 /* arm_push_env.py:160-196: the damped tapered arm with one sucker and the three muscle layers */
 #define SOFTROD_FEATURES_ARM_PUSH                                                 \
     (SOFTROD_FEAT_ANALYTICAL_DAMPER | SOFTROD_FEAT_SUCKER_CONSTRAINT | SOFTROD_FEAT_COOMM_MUSCLES)
+/* arm_push_env.py:520-618: the same arm + Cylinder + BodyBoundaryCondition + FixedJoint2Rigid (n_arm = 1) */
+#define SOFTROD_FEATURES_ARM_PULL_WEIGHT (SOFTROD_FEATURES_ARM_PUSH | SOFTROD_FEAT_OCTO_HEAD)
 
 #define SOFTROD_FEATURES_SOFTPENDULUM                                             \
     (SOFTROD_FEAT_GRAVITY | SOFTROD_FEAT_POINT_FORCE_NODE0_X |                   \
@@ -157,6 +159,9 @@ enum softrod_feature {
 #define SOFTROD_ENV_OCTO_FLAT 4      /* octopus/flat_env.py:231-408                 */
 #define SOFTROD_ENV_SOFT_ARM 5       /* soft_arm/soft_arm_tracking.py:160-259       */
 #define SOFTROD_ENV_ARM_PUSH 6       /* octopus/arm_push_env.py:225-347 (OctoArmPush-v0 / -v1; parity unpinned: COOMM) */
+#define SOFTROD_ENV_ARM_PULL_WEIGHT 7 /* octopus/arm_push_env.py:516-618 ArmPullWeightEnv (OctoArmPullWeight-v0): the same
+                                        arm and step(), joined to a rigid Cylinder "weight" by FixedJoint2Rigid; with
+                                        SOFTROD_FEATURES_ARM_PULL_WEIGHT (parity unpinned: COOMM)                     */
 
 /* math_mode (HIP library only; the oracle always uses libm). */
 #define SOFTROD_MATH_LIBM 0 /* sqrt/sin/cos/acos/pow evaluated as written   */
@@ -271,6 +276,14 @@ typedef struct softrod_config {
     int32_t reserved3;
     double muscle_fl_coef[8]; /* fl(l) = sum_k coef[k] l^k, clipped at 0 from below; the cubic of the paper,
                                  max{3.06 l^3 - 13.64 l^2 + 18.01 l - 6.44, 0}: (-6.44, 18.01, -13.64, 3.06)      */
+    /* ---- the rigid body of the SOFTROD_FEAT_OCTO_HEAD sets, as Cylinder(start, direction = e_z, normal = e_y,
+     *      base_length, base_radius = head_radius, density = head_density) allocates it, and its joints ---- */
+    double head_center[3];    /* start + direction * base_length / 2.  FlatEnv: (0, 0, 0) (octopus/build.py:95-105);
+                                 ArmPullWeightEnv: (-0.9 * 0.015, 0, -0.012) (arm_push_env.py:553-566)            */
+    double head_length;       /* Cylinder base_length.  FlatEnv: 2 r0; ArmPullWeightEnv: 2 * radius_base = 0.024  */
+    double joint_angle0;      /* FixedJoint2Rigid(angle=...) of arm a, degrees: joint_angle0 + a * joint_angle_step. */
+    double joint_angle_step;  /* FlatEnv: 0, 360 / n_arm (octopus/build.py:73-74,117-132); ArmPullWeightEnv: 0, 0
+                                 (arm_push_env.py:585-587)                                                         */
 } softrod_config;
 
 #define SOFTROD_MAX_SUCKERS 4
@@ -415,6 +428,12 @@ int softrod_set_radius_profile(softrod_handle* h, const double* radius);
  * Needed before the first softrod_step / softrod_substeps of a handle with SOFTROD_FEAT_COOMM_MUSCLES; rods of
  * up to 63 elements, one rod per env.                                                                     */
 int softrod_set_muscle_layers(softrod_handle* h, const double* ratio_position, const double* strength);
+
+/* Same for ArmPullWeightEnv (octopus/arm_push_env.py:516-618; registered as OctoArmPullWeight-v0 with mode
+ * "continuous", gym_softrobot/__init__.py:48-52): time_step 2.5e-5 (1000 substeps per env.step), damper 0.05 * 2 * 5e2,
+ * the sucker at reduction_ratio 0.9, a Cylinder of radius 0.015 / length 0.024 / density 700 joined to node 0 by
+ * FixedJoint2Rigid(k = 1e6, nu = 1e-2, kt = 1, angle = 0, radius = 0.015) and held by BodyBoundaryCondition.      */
+int softrod_config_arm_pull_weight(softrod_config* cfg, int n_envs);
 
 /* Same as softrod_config_arm_single for ArmPushEnv (octopus/arm_push_env.py:65-224): the 40-element arm tapered
  * 12:1 (the radii themselves go through softrod_set_radius_profile), damper, one sucker, three muscle layers

@@ -189,7 +189,12 @@ static void octo_substep(oracle_octo* o)
     for (int a = 0; a < na; ++a) dynamic_step(o->arm[a], dt);
     head_dynamic(&o->head, dt);
     head_constrain_rates(&o->head);
-    for (int a = 0; a < na; ++a) dampen_rates(o->arm[a]);
+    /* the arms' own constraints (ControllableFixConstraint of the muscle arms, arm_push_env.py:591-599; none in
+     * FlatEnv) and dampers, in registration order (damp_before_constrain: dampen() is registered first there) */
+    for (int a = 0; a < na; ++a) {
+        if (o->cfg.damp_before_constrain) { dampen_rates(o->arm[a]); constrain_rates(o->arm[a]); }
+        else { constrain_rates(o->arm[a]); dampen_rates(o->arm[a]); }
+    }
     for (int a = 0; a < na; ++a) kinematic_step(o->arm[a], 0.5 * dt);
     head_kinematic(&o->head, 0.5 * dt, o->cfg.eps_rot_axis);
     o->time += o->cfg.time_two_half_adds ? 0.5 * dt : dt;
@@ -453,4 +458,46 @@ void oracle_octo_head(const oracle_octo* o, double* out)
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out[6 + 3 * i + j] = o->head.Q[i][j];
     out[18] = o->head.mass;
     for (int i = 0; i < 3; ++i) out[19 + i] = o->head.J[i];
+}
+
+
+/* ------------------------------------------------------------------------- */
+/* ArmPullWeightEnv (octopus/arm_push_env.py:516-618, OctoArmPullWeight-v0):    */
+/* ArmPushEnv's arm and step() with a rigid Cylinder joined to node 0.          */
+/* PARITY UNPINNED (the COOMM muscle law; softrod_oracle.c apply_muscles).      */
+/* ------------------------------------------------------------------------- */
+/* reset -> _build (:520-618): the arm as ArmPushEnv's; Cylinder(start, e_z, e_y, 2 radius_base, 0.015, 700) (:552-567);
+ * BodyBoundaryCondition on it (:569-575); FixedJoint2Rigid(head idx -1, arm idx 0, angle 0) (:577-589) */
+void oracle_pull_reset(oracle_octo* o, float* obs)
+{
+    const softrod_config* c = &o->cfg;
+    const double start[3] = { 0.0, 0.0, 0.0 }, direction[3] = { 1.0, 0.0, 0.0 }, normal[3] = { 0.0, 1.0, -0.0 };
+    oracle_rod* r = o->arm[0];
+    oracle_reset_straight(r, start, direction, normal);
+    for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) oracle_apply_activation(r, m, 0.0);
+    o->angle[0] = c->joint_angle0;
+    const double hd[3] = { 0.0, 0.0, 1.0 }, hn[3] = { 0.0, 1.0, 0.0 };
+    const double hs[3] = { c->head_center[0] - hd[0] * c->head_length / 2, c->head_center[1] - hd[1] * c->head_length / 2,
+                           c->head_center[2] - hd[2] * c->head_length / 2 };
+    cylinder_init(&o->head, hs, hd, hn, c->head_length, c->head_radius, c->head_density);
+    head_constrain_values(&o->head);
+    head_constrain_rates(&o->head);
+    o->time = 0.0;
+    r->time = 0.0;
+    get_state_push(r, obs);
+}
+
+void oracle_pull_observe(const oracle_octo* o, float* obs) { get_state_push(o->arm[0], obs); }
+
+/* ArmPullWeightEnv.step = ArmPushEnv.step (:276-347) over the two-body simulator */
+void oracle_env_step_pull(oracle_octo* o, const float* action, float* obs, double* reward,
+                          uint8_t* terminated, uint8_t* truncated)
+{
+    oracle_rod* r = o->arm[0];
+    push_set_action(r, action);
+    double prev_cm[3];
+    center_of_mass(r, prev_cm);
+    for (int s = 0; s < o->cfg.n_substeps; ++s) octo_substep(o);
+    r->time = o->time;
+    push_epilogue(r, prev_cm, obs, reward, terminated, truncated);
 }

@@ -64,6 +64,9 @@ def _load(omp) -> C.CDLL:
     lib.oracle_env_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     lib.oracle_env_step_arm_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
     lib.oracle_octo_env_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    lib.oracle_pull_reset.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_pull_observe.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_env_step_pull.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     lib.oracle_reset_pendulum3d.argtypes = [C.c_void_p, C.c_double]
     lib.oracle_observe3d.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_clear_prev_action3d.argtypes = [C.c_void_p]
@@ -438,6 +441,46 @@ class OracleOcto:
 
     def substeps(self, n: int) -> None:
         self._lib.oracle_octo_substeps(self._h, int(n))
+
+    # -- OctoArmPullWeight-v0 (one tapered muscle arm joined to a rigid weight) --------------------
+    def _arm_rod(self) -> "OracleRod":
+        """Arm 0 through OracleRod's interface (a borrowed handle: never destroyed from here)."""
+        r = OracleRod.__new__(OracleRod)
+        r._lib, r.cfg, r.n = self._lib, self.cfg, self.n
+        r._h = None
+        object.__setattr__(r, "_borrowed", self._lib.oracle_octo_arm(self._h, 0))
+        return r
+
+    def pull_setup(self, radius, ratio_position, strength) -> None:
+        a = np.ascontiguousarray(radius, np.float64).reshape(self.n)
+        arm = self._lib.oracle_octo_arm(self._h, 0)
+        self._lib.oracle_set_radius_profile(arm, a.ctypes.data)
+        m = int(self.cfg.n_muscles)
+        rp = np.ascontiguousarray(ratio_position, np.float64).reshape(m, 3, self.n)
+        st = np.ascontiguousarray(strength, np.float64).reshape(m, self.n)
+        self._lib.oracle_set_muscle_layers(arm, rp.ctypes.data, st.ctypes.data)
+
+    def reset_pull(self) -> np.ndarray:
+        obs = np.empty(2 * self.n + 4, np.float32)
+        self._lib.oracle_pull_reset(self._h, obs.ctypes.data)
+        return obs
+
+    def observe_pull(self) -> np.ndarray:
+        obs = np.empty(2 * self.n + 4, np.float32)
+        self._lib.oracle_pull_observe(self._h, obs.ctypes.data)
+        return obs
+
+    def env_step_pull(self, action):
+        a = np.zeros(2, np.float32)
+        act = np.atleast_1d(np.asarray(action, np.float32)).ravel()
+        a[: act.size] = act
+        obs = np.empty(2 * self.n + 4, np.float32)
+        rew = np.empty(1, np.float64)
+        term = np.empty(1, np.uint8)
+        trunc = np.empty(1, np.uint8)
+        self._lib.oracle_env_step_pull(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
+                                       trunc.ctypes.data)
+        return obs, float(rew[0]), bool(term[0]), bool(trunc[0])
 
     def set_target(self, target) -> None:
         t = np.ascontiguousarray(target, np.float64).reshape(2)

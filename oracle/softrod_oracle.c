@@ -1522,14 +1522,12 @@ void oracle_reset_push(oracle_rod* r, float* obs)
     get_state_push(r, obs);
 }
 
-/* ArmPushEnv.step, arm_push_env.py:247-347.  action: the index (discrete, 0 / 1, as a float) or
+/* ArmPushEnv.set_action, arm_push_env.py:247-274.  action: the index (discrete, 0 / 1, as a float) or
  * (location, activation) in float32 (continuous). */
-void oracle_env_step_push(oracle_rod* r, const float* action, float* obs, double* reward,
-                          uint8_t* terminated, uint8_t* truncated)
+static void push_set_action(oracle_rod* r, const float* action)
 {
     const softrod_config* c = &r->cfg;
     const int n = r->n;
-    /* set_action, :247-274 */
     if (c->arm_push_mode == 0) {
         if ((int)action[0] == 0) {
             r->sucker_index[0] = 0;
@@ -1554,12 +1552,15 @@ void oracle_env_step_push(oracle_rod* r, const float* action, float* obs, double
         r->prev_action_push[0] = action[0];
         r->prev_action_push[1] = action[1];
     }
-    /* prev_cm_pos (:280).  run_substeps = 0 (fixture replay: the epilogue alone on an injected state): it is what
-     * oracle_set("prev_com") put there */
-    double prev_cm[3], cm[3];
-    if (substeps_to_run(r) > 0) { center_of_mass(r, prev_cm); r->prev_com[0] = prev_cm[0]; r->prev_com[1] = prev_cm[1]; }
-    else { prev_cm[0] = r->prev_com[0]; prev_cm[1] = r->prev_com[1]; prev_cm[2] = 0.0; }
-    for (int s = 0; s < substeps_to_run(r); ++s) position_verlet_step(r);
+}
+
+/* ArmPushEnv.step after the loop, arm_push_env.py:288-347; prev_cm = prev_cm_pos (:280) */
+static void push_epilogue(oracle_rod* r, const double prev_cm[3], float* obs, double* reward,
+                          uint8_t* terminated, uint8_t* truncated)
+{
+    const softrod_config* c = &r->cfg;
+    const int n = r->n;
+    double cm[3];
     center_of_mass(r, cm);
     /* _isnan_check over position, velocity, director, alpha, omega, cm_pos (:298-309); alpha = J^-1 tau e of the
      * last substep is NaN only where omega became NaN in that substep, so omega covers it */
@@ -1589,6 +1590,20 @@ void oracle_env_step_push(oracle_rod* r, const float* action, float* obs, double
         for (int i = 0; i < 2 * n + 4; ++i)        /* np.nan_to_num on float32 */
             obs[i] = isnan(obs[i]) ? 0.0f : (isinf(obs[i]) ? copysignf(3.4028234663852886e38f, obs[i]) : obs[i]);
     }
+}
+
+/* ArmPushEnv.step, arm_push_env.py:276-347 */
+void oracle_env_step_push(oracle_rod* r, const float* action, float* obs, double* reward,
+                          uint8_t* terminated, uint8_t* truncated)
+{
+    push_set_action(r, action);
+    /* prev_cm_pos (:280).  run_substeps = 0 (fixture replay: the epilogue alone on an injected state): it is what
+     * oracle_set("prev_com") put there */
+    double prev_cm[3];
+    if (substeps_to_run(r) > 0) { center_of_mass(r, prev_cm); r->prev_com[0] = prev_cm[0]; r->prev_com[1] = prev_cm[1]; }
+    else { prev_cm[0] = r->prev_com[0]; prev_cm[1] = r->prev_com[1]; prev_cm[2] = 0.0; }
+    for (int s = 0; s < substeps_to_run(r); ++s) position_verlet_step(r);
+    push_epilogue(r, prev_cm, obs, reward, terminated, truncated);
 }
 
 size_t oracle_config_size(void) { return sizeof(softrod_config); }

@@ -22,11 +22,12 @@ class OracleBackend:
         self.isocto = cfg.env_kind == _capi.ENV_OCTO_FLAT
         self.issoftarm = cfg.env_kind == _capi.ENV_SOFT_ARM
         self.ispush = cfg.env_kind == _capi.ENV_ARM_PUSH
+        self.ispull = cfg.env_kind == _capi.ENV_ARM_PULL_WEIGHT
         # softrod_state_view.control: SoftArmTracking keeps tick and the target there
         self._ctrl = torch.zeros((4, int(cfg.n_envs)), dtype=torch.float64)
         self.action_dim = _capi.config_action_dim(cfg)
         self.obs_dim = _capi.config_obs_dim(cfg)
-        if self.isocto:
+        if self.isocto or self.ispull:
             self.rods = [oracle_c.OracleOcto(self.cfg) for _ in range(self.n_envs)]
             self._octo_obs = [None] * self.n_envs
         else:
@@ -40,12 +41,18 @@ class OracleBackend:
         self._queue = None          # device-side auto-reset emulation (softrod_queue_*)
 
     def set_radius_profile(self, radius):
+        self._radius = np.asarray(radius, np.float64).copy()
+        if self.ispull:
+            return                      # handed over together with the layers (OracleOcto.pull_setup)
         for r in self.rods:
             r.set_radius_profile(radius)
 
     def set_muscle_layers(self, ratio_position, strength):
         for r in self.rods:
-            r.set_muscle_layers(ratio_position, strength)
+            if self.ispull:
+                r.pull_setup(self._radius, ratio_position, strength)
+            else:
+                r.set_muscle_layers(ratio_position, strength)
 
     def state(self):
         st = {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64), "control": self._ctrl}
@@ -74,7 +81,9 @@ class OracleBackend:
             if mask is None or mask[i]:
                 if self.is3d:
                     self._prev[i] = 0.0   # SoftPendulum3DEnv.reset clears _prev_action
-                if self.ispush:
+                if self.ispull:
+                    r.reset_pull()
+                elif self.ispush:
                     r.reset_push()
                 elif self.isarm:
                     r.reset_arm()   # also re-arms prev_kappa_state / prev_com_state
@@ -186,8 +195,8 @@ class OracleBackend:
         if prev_action is not None:
             pa = torch.as_tensor(prev_action).reshape(self.n_envs, self.action_dim).numpy()
         for i, r in enumerate(self.rods):
-            if self.ispush:
-                self.obs[i] = torch.from_numpy(r.observe_push())   # the oracle keeps _prev_action itself
+            if self.ispush or self.ispull:
+                self.obs[i] = torch.from_numpy(r.observe_pull() if self.ispull else r.observe_push())   # the oracle keeps _prev_action itself
                 continue
             if self.is3d:
                 o = r.observe3d()
@@ -229,6 +238,8 @@ class OracleBackend:
                 self.aux[i, 0] = tilt
             elif self.isarm:
                 o, rw, te, tr = r.env_step_arm(a[i])
+            elif self.ispull:
+                o, rw, te, tr = r.env_step_pull(a[i])
             elif self.ispush:
                 o, rw, te, tr = r.env_step_push(a[i])
             elif self.issoftarm:

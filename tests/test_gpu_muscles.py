@@ -291,3 +291,44 @@ def test_hip_replays_muscle_env_fixtures_of_the_pin_tooling(tmp_path, hip_lib, o
         dev = pin.compare_case(drv, fx)
         drv.close()
         assert pin.strict_worst(dev, str(fx["env_id"])) <= 1e-5, (f.name, max(dev, key=dev.get), max(dev.values()))
+
+
+def test_arm_pull_weight_env_matches_oracle(torch_gpu, hip_lib, oracle_built):
+    """OctoArmPullWeight-v0 (ArmPullWeightEnv, arm_push_env.py:516-618): the muscle arm joined to a rigid Cylinder by
+    FixedJoint2Rigid, one wave per env on the rigid-body kernel (softrod_octo.hpp) with the tapered material table, the
+    COOMM layers and the sucker: four env.steps of 1000 substeps against the oracle's two-body stepper — observations,
+    rewards, flags, the arm's state and the weight's."""
+    import gym_softrobot_amd as gsa
+    from tests.oracle_backend import OracleBackend
+
+    N = 3
+    env = gsa.make_vec("OctoArmPullWeight-v0", N)
+    assert "ArmPullWeight" in env.backend.kernel_tier()
+    ref = gsa.make_vec("OctoArmPullWeight-v0", N, backend=OracleBackend(gsa._capi.arm_pull_weight_config(N)), numpy_output=True)
+    o, _ = env.reset(seed=0)
+    o2, _ = ref.reset(seed=0)
+    np.testing.assert_array_equal(o.cpu().numpy(), o2)
+    acts = np.array([[[0.0, 0.6], [0.3, 0.2], [0.0, 0.0]], [[0.0, 0.6], [0.3, 0.9], [0.5, 0.4]],
+                     [[0.95, 0.0], [1.0, 0.1], [0.5, 0.0]], [[0.95, 0.0], [0.0, 0.5], [0.2, 0.3]]], np.float32)
+    for t in range(4):
+        o, r, te, tr, info = env.step(acts[t])
+        o2, r2, te2, tr2, info2 = ref.step(acts[t])
+        torch_gpu.cuda.synchronize()
+        np.testing.assert_allclose(o.cpu().numpy(), o2, rtol=RTOL, atol=2e-7, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(r.cpu().numpy(), r2, rtol=RTOL, atol=1e-9, err_msg=f"reward step {t}")
+        np.testing.assert_array_equal(te.cpu().numpy(), te2)
+        np.testing.assert_array_equal(tr.cpu().numpy(), tr2)
+    st = env.backend.state_numpy()
+    head = env.backend.state()["head"].cpu().numpy()            # [20][N]: x 0..2, v 3..5, Q 6..14, w 15..17
+    for i, q in enumerate(ref.backend.rods):
+        arm = q.arm(0)
+        for name in ("x", "v", "w", "Q"):
+            np.testing.assert_allclose(st[name][i], arm.get(name), rtol=RTOL, atol=1e-9, err_msg=f"{name} env {i}")
+        h = q.head()
+        np.testing.assert_allclose(head[0:3, i], h["x"], rtol=RTOL, atol=1e-10)
+        np.testing.assert_allclose(head[3:6, i], h["v"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(head[6:15, i].reshape(3, 3), h["Q"], rtol=RTOL, atol=1e-10)
+        np.testing.assert_allclose(head[15:18, i], h["w"], rtol=RTOL, atol=1e-7)
+    assert head[0, 0] > -0.0135 + 3e-3          # env 0 dragged its weight forward
+    env.close()
+    ref.close()

@@ -325,3 +325,62 @@ def test_pin_tooling_covers_the_muscle_envs(tmp_path, oracle_built):
             drv.close()
         assert decided == {"muscle_equiv_load_form": True, "muscle_position_current_radius": False,
                            "muscle_tm_length_law": True, "muscle_init_angle_rotates": False, "muscle_tm_sign": True}
+
+
+def test_pull_weight_build_matches_the_executed_reference(oracle_built):
+    """ArmPullWeightEnv._build executed from the reference's file (arm_push_env.py:520-618): the Cylinder, the
+    BodyBoundaryCondition, the FixedJoint2Rigid, the damper, the sucker — against _capi.arm_pull_weight_config and what
+    the oracle allocates from it."""
+    r = json.loads((GOLD / "ref_muscle_build_records.json").read_text())["OctoArmPullWeight"]
+    cfg = _capi.arm_pull_weight_config(1)
+    init = r["init"]
+    assert (init["step_skip"], init["time_step"], init["final_time"], init["mode"]) == (cfg.n_substeps, cfg.dt, cfg.final_time, cfg.arm_push_mode)
+    assert init["obs_shape"] == [_capi.config_obs_dim(cfg)]
+    cyl = r["cylinder"]
+    assert (cyl["base_length"], cyl["base_radius"], cyl["density"]) == (cfg.head_length, cfg.head_radius, cfg.head_density)
+    assert cyl["direction"] == [0.0, 0.0, 1.0] and cyl["normal"] == [0.0, 1.0, 0.0]
+    np.testing.assert_allclose(np.asarray(cyl["start"]) + np.asarray(cyl["direction"]) * cyl["base_length"] / 2,
+                               [cfg.head_center[i] for i in range(3)], rtol=0, atol=1e-18)
+    assert r["order"] == ["append:FakeRod[0]", "damping:AnalyticalLinearDamper[0]", "append:Cylinder[1]",
+                          "constrain:BodyBoundaryCondition[1]", "connect:FixedJoint2Rigid[1,0]",
+                          "constrain:ControllableFixConstraint[0]", "forcing:ApplyMuscles[0]"]
+    ops = {o["cls"]: o for o in r["ops"]}
+    assert ops["AnalyticalLinearDamper"]["kwargs"] == {"damping_constant": cfg.damping_constant, "time_step": cfg.dt}
+    j = ops["FixedJoint2Rigid"]["kwargs"]
+    assert (j["k"], j["nu"], j["kt"], j["angle"], j["radius"]) == (cfg.joint_k, cfg.joint_nu, cfg.joint_kt, cfg.joint_angle0, cfg.head_radius)
+    assert r["connect_indices"] == [-1, 0] and cfg.joint_angle_step == 0.0 and cfg.n_arm == 1
+    assert ops["ControllableFixConstraint"]["kwargs"] == {"index": 0, "reduction_ratio": cfg.sucker_reduction_ratio}
+    assert r["sucker"] == {"index": 0, "flag": True, "reduction_ratio": 0.9}
+    assert r["time_step_kwarg"].startswith("TypeError")          # the subclass passes time_step itself (:518)
+    rod = r["straight_rod"]
+    assert (rod["density"], rod["youngs_modulus"], rod["shear_modulus"], rod["base_length"]) == (cfg.density, cfg.youngs_modulus, cfg.shear_modulus, cfg.base_length)
+    np.testing.assert_array_equal(rod["base_radius"], _capi.arm_push_radii(N_ELEM))
+    # the oracle's allocation from that config: Cylinder mass = rho pi r^2 L, reset observation = the reference's
+    o = oracle_built.OracleOcto(cfg)
+    radii = _capi.arm_push_radii(N_ELEM)
+    o.pull_setup(radii, *_capi.es_muscle_layers(radii, 0.012))
+    obs = o.reset_pull()
+    np.testing.assert_array_equal(obs, np.load(GOLD / "ref_armpush.npz")["w_reset_obs"])
+    h = o.head()
+    np.testing.assert_allclose(h["mass"], 700.0 * np.pi * 0.015 ** 2 * 0.024, rtol=1e-15)
+    np.testing.assert_allclose(h["x"], [-0.0135, 0.0, -0.012], rtol=0, atol=1e-18)
+
+
+def test_pull_weight_env_drags_the_weight(oracle_built):
+    """Host logic over the CPU test double: extend with the base held, then hold the tip and relax — the joint drags
+    the rigid weight along; a `time_step` keyword raises like the reference's subclass does."""
+    import gym_softrobot_amd as gsa
+    from tests.oracle_backend import OracleBackend
+
+    be = OracleBackend(_capi.arm_pull_weight_config(1))
+    env = gsa.make_vec("OctoArmPullWeight-v0", 1, backend=be, numpy_output=True)
+    assert env.cfg.n_substeps == 1000 and gsa.parity_label("OctoArmPullWeight-v0") is not None
+    env.reset(seed=0)
+    x0 = be.rods[0].head()["x"][0]
+    for a in ([0.0, 0.6], [0.0, 0.6], [0.95, 0.0], [0.95, 0.0]):
+        o, r, te, tr, _ = env.step(np.array([a], np.float32))
+        assert not te[0] and not tr[0]
+    assert be.rods[0].head()["x"][0] > x0 + 5e-3
+    with pytest.raises(TypeError, match="time_step"):
+        gsa.make_vec("OctoArmPullWeight-v0", 1, time_step=1e-5, backend=be)
+    env.close()

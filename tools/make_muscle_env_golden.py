@@ -254,6 +254,32 @@ def main():
             ref_step(a_last, base, st, t_end, f"shifted{k}")
         out.update(S.arrays(tag + "step_"))
 
+    # ---- ArmPullWeightEnv._build (arm_push_env.py:520-618): what it hands to Cylinder, BodyBoundaryCondition,
+    #      FixedJoint2Rigid, the damper and the sucker; its step() is ArmPushEnv's (inherited) -------------------------
+    env = mod.ArmPullWeightEnv(mode="continuous")
+    obs0, _ = env.reset(seed=0)
+    ops = []
+    for op in env.simulator._ops:
+        kw = {k: jsonable(v) for k, v in op["kwargs"].items() if k not in ("controller", "muscles", "callback_params_list")}
+        ops.append({"kind": op["kind"], "cls": op["cls"].__name__, "kwargs": kw,
+                    "targets": [env.simulator._systems.index(t) for t in op["targets"] if t in env.simulator._systems]})
+    records["OctoArmPullWeight"] = {
+        "init": {"step_skip": env.step_skip, "final_time": env.final_time, "time_step": env.time_step, "n_elem": env.n_elem,
+                 "mode": env.mode, "obs_shape": env.observation_space.shape},
+        "straight_rod": {k: jsonable(v) for k, v in env.shearable_rod.recorded.items()},
+        "cylinder": {k: jsonable(v) for k, v in env.rigid_rod.recorded.items()},
+        "order": env.simulator.order(), "ops": ops,
+        "connect_indices": list(getattr(env.simulator, "_last_connect_idx", ())),
+        "muscle_layers": [{"kind": m.kind, **{k: jsonable(v) for k, v in m.kwargs.items()}} for m in env.muscle_layers],
+        "sucker": {"index": env.BC.index, "flag": bool(env.BC.flag), "reduction_ratio": env.BC.reduction_ratio},
+    }
+    out["w_reset_obs"] = np.asarray(obs0)
+    try:
+        mod.ArmPullWeightEnv(time_step=1e-5)
+        records["OctoArmPullWeight"]["time_step_kwarg"] = "accepted"
+    except TypeError as exc:
+        records["OctoArmPullWeight"]["time_step_kwarg"] = "TypeError: " + str(exc)
+
     # ---- ControllableFixConstraint with the indices set_action produces (0, -1, 39) -----------------------------
     cc = refshim.load("gym_softrobot.envs.octopus.controllable_constraint")
     C = Stack()
