@@ -104,7 +104,8 @@ CYCLES_PER_FP64_WAVE_INSTR = 4.0   # wave64 fp64 op: 16 lanes per clock per SIMD
 VALU_PEAK_GINSTR = N_SIMD * CLOCK_HZ / CYCLES_PER_FP64_WAVE_INSTR / 1e9   # 614.4
 METHODOLOGY_VERSION = 5
 AMAX = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
-        "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0, "OctoArmPush-v0": 1.0, "OctoArmPush-v1": 1.0}
+        "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0, "OctoArmPush-v0": 1.0, "OctoArmPush-v1": 1.0, "OctoArmPullWeight-v0": 1.0}
+MUSCLE_ENVS = ("OctoArmPush-v0", "OctoArmPush-v1", "OctoArmPullWeight-v0")      # COOMM muscle arms: parity unpinned
 
 
 def random_actions(np, env_id: str, shape, amax: float, seed: int = 1):
@@ -112,7 +113,7 @@ def random_actions(np, env_id: str, shape, amax: float, seed: int = 1):
     (Box(0, 1), arm_push_env.py:113-115); OctoArmPush-v0: 0 / 1 (Discrete(2), :101) held for four env.steps each (an
     inchworm stroke lasts several steps; flipping every step drives the restated muscle law out of its range)."""
     rng = np.random.default_rng(seed)
-    if env_id == "OctoArmPush-v1":
+    if env_id in ("OctoArmPush-v1", "OctoArmPullWeight-v0"):
         return (rng.uniform(0.0, 1.0, shape) * (1.0 if amax else 0.0)).astype(np.float32)
     if env_id == "OctoArmPush-v0":
         T = shape[0]
@@ -276,7 +277,7 @@ def parse_args(argv=None):
     ap.add_argument("--math-mode", choices=["fast", "libm"], default="fast")
     ap.add_argument("--env", default="SoftPendulum-v0",
                     choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0", "OctoFlat-v0", "SoftArmTracking-v0",
-                             "OctoArmPush-v0", "OctoArmPush-v1"],
+                             "OctoArmPush-v0", "OctoArmPush-v1", "OctoArmPullWeight-v0"],
                     help="headline metric is SoftPendulum-v0; the others are the widened §8 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -522,16 +523,16 @@ def taper_profile(base_radius: float, n_elem: int):
 
 def workload_name(env_id: str, cfg, n_local: int, world: int = 1, taper: bool = False, libm: bool = False) -> str:
     octo = env_id == "OctoFlat-v0"
-    taper = taper or env_id.startswith("OctoArmPush")          # the muscle arm is tapered 12:1 by construction
+    taper = taper or env_id in MUSCLE_ENVS          # the muscle arm is tapered 12:1 by construction
     return (f"{env_id}, {n_local} envs x " + (f"{int(cfg.n_arm)} arms x " if octo else "")
             + f"{int(cfg.n_elem)} elements per GPU " + ("tapered " if taper else "") + ("libm kernel " if libm else "")
-            + ("+ COOMM muscle layers, PARITY UNPINNED " if env_id.startswith("OctoArmPush") else "")
+            + ("+ COOMM muscle layers, PARITY UNPINNED " if env_id in MUSCLE_ENVS else "")
             + (f"(BASELINE configs[1]; x{world} GPUs)" if env_id == "SoftPendulum-v0"
                else "(widened row of SURVEY §8; not the headline metric)"))
 
 
 def profile_key(env_id: str, n_elem: int, taper: bool = False, libm: bool = False) -> str:
-    taper = taper or env_id.startswith("OctoArmPush")      # (workload_name says "tapered": tools/update_profile_tables.py keys on it)
+    taper = taper or env_id in MUSCLE_ENVS      # (workload_name says "tapered": tools/update_profile_tables.py keys on it)
     return f"{env_id}|n_elem={n_elem}" + ("|taper" if taper else "") + ("|libm" if libm else "")
 
 
@@ -585,9 +586,11 @@ def roofline_block(env_id, cfg, n_local, kernel_ms, math_mode, lib_hash, hip, ba
         "useful_lane_frac": lanes,
         "frac_of_lane_slots": None if frac is None else frac * lanes,
         "kernel": "softrod_octo_step_kernel" if octo else
+                  "softrod_octo_step_kernel (ArmPullWeight instantiation: one arm wave + the rigid weight)"
+                  if env_id == "OctoArmPullWeight-v0" else
                   "softrod_step_window_kernel + softrod_step_fast_kernel (epilogue only)"
                   if (env_id == "OctoArmSingle-v0" and 64 <= int(cfg.n_elem) <= 102 and math_mode == "fast") else
-                  (("softrod_step_fast_kernel" + (" (TAPER instantiation)" if taper or env_id.startswith("OctoArmPush") else ""))
+                  (("softrod_step_fast_kernel" + (" (TAPER instantiation)" if taper or env_id in MUSCLE_ENVS else ""))
                    if math_mode == "fast" else "softrod_step_libm_kernel"),
         "kernel_ms_avg": kernel_ms,
         "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz / {CYCLES_PER_FP64_WAVE_INSTR:g} cycles per "

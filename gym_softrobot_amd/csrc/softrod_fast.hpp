@@ -17,7 +17,7 @@
 //     pow() are short polynomials in their (tiny) arguments with wave-uniform range
 //     checks (one s_cbranch on the fast path); outside the range the trigonometric arguments are
 //     halved until they fit and the result rebuilt with double-angle identities, the exponential is
-//     reduced by powers of two (exp_wide) — no libm calls, which keeps the register budget small
+//     reduced by powers of two (exp_wide_pair) — no libm calls, which keeps the register budget small
 //     enough for several waves per SIMD;
 //     the damper's c_r^e is evaluated as c_r * c_r^(e-1) so that only the strain e-1, not
 //     log c_r, has to be small;
@@ -104,8 +104,8 @@ __device__ __forceinline__ void sinc_cosc(double t, double& sc, double& cc) {
 //   y < 2.5e-3 (neighbouring elements < 0.1 rad apart, a 50-element rod at rest):  6 terms
 //   y < 0.04   (< 0.40 rad: the falling / whipping pendulum):                      12 terms
 //   y < 0.15   (< 0.79 rad: 10-element octopus arms at full curl):                 20 terms
-// Beyond that the half-angle recursion y' = y / (2 (1 + sqrt(1-y))) is applied until the last
-// tier fits and theta/sin(theta) = 2^k (phi/sin phi) sin(phi)/sin(theta).
+// Beyond that two half-angle steps y' = (1 - sqrt(1-y)) / 2 bring any y <= 1 into the last tier and
+// theta/sin(theta) = (phi/sin phi) / (cos(theta/2) cos(theta/4)).
 template <int K>
 __device__ __forceinline__ double theta_over_sin_series(double y) {
     // c_k by the recurrence, folded at compile time
@@ -119,25 +119,58 @@ __device__ __forceinline__ double theta_over_sin_series(double y) {
     return fma(g, y, 1.0);       // c[0] = 1 is an inline constant
 }
 
+// BATCHED: the three range tests are issued together and branched on afterwards — one VALU -> SALU round trip instead of three on
+// the way to the last tier, two compares more on the way to the first.  The rigid-body kernel's arms (ten elements curled to
+// 0.8-1.8 rad per joint under the benchmark's actions) take the last tier in 90 % of their substeps: -1.0 % of the OctoFlat
+// env.step (profiles/r6_octo_ab.txt, "cmp3"); the one-rod kernels live in the first tier and keep the sequential tests.
+template <bool BATCHED = false>
 __device__ __forceinline__ double theta_over_sin(double y, bool valid_lane) {
     const unsigned long long valid = __builtin_amdgcn_ballot_w64(valid_lane);     // (loop-invariant: two scalar registers)
-    if (!wave_any_of(valid, !(y < 2.5e-3))) return theta_over_sin_series<6>(y);
-    if (!wave_any_of(valid, !(y < 0.04))) return theta_over_sin_series<12>(y);
-    const double y0 = y;
-    int k = 0;
-    while (wave_any_of(valid, !(y < 0.15)) && k < 12) {
-        const double om = fmax(1.0 - y, 1.0e-300);
-        y = 0.5 * y * fast_rcp(1.0 + om * fast_rsqrt(om));
-        ++k;
+    if constexpr (BATCHED) {
+        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(!(y < 2.5e-3)) & valid;
+        const unsigned long long m2 = __builtin_amdgcn_ballot_w64(!(y < 0.04)) & valid;
+        const unsigned long long m3 = __builtin_amdgcn_ballot_w64(!(y < 0.15)) & valid;
+        if (m1 == 0) return theta_over_sin_series<6>(y);
+        if (m2 == 0) return theta_over_sin_series<12>(y);
+        if (m3 == 0) return theta_over_sin_series<20>(y);
+    } else {
+        if (!wave_any_of(valid, !(y < 2.5e-3))) return theta_over_sin_series<6>(y);
+        if (!wave_any_of(valid, !(y < 0.04))) return theta_over_sin_series<12>(y);
+#ifdef SOFTROD_DIAG_THETA_LOOP      // round 5's tier, for the A/B of tools/octo_ab.sh (variant "thetaloop")
+        {
+            const double y0 = y;
+            int k = 0;
+            while (wave_any_of(valid, !(y < 0.15)) && k < 12) {
+                const double om = fmax(1.0 - y, 1.0e-300);
+                y = 0.5 * y * fast_rcp(1.0 + om * fast_rsqrt(om));
+                ++k;
+            }
+            double g = theta_over_sin_series<20>(y);
+            if (k > 0) {
+                const double a = fmax(y * (1.0 - y), 1.0e-300), b = fmax(y0 * (1.0 - y0), 1.0e-300);
+                g *= (double)(1 << k) * (a * fast_rsqrt(a)) * fast_rsqrt(b);
+                g = (y0 < 1.0e-30) ? 1.0 : g;
+            }
+            return g;
+        }
+#endif
+        if (!wave_any_of(valid, !(y < 0.15))) return theta_over_sin_series<20>(y);
     }
-    double g = theta_over_sin_series<20>(y);
-    if (k > 0) {
-        // sin(phi) = 2 sqrt(y(1-y)) at both levels
-        const double a = fmax(y * (1.0 - y), 1.0e-300), b = fmax(y0 * (1.0 - y0), 1.0e-300);
-        g *= (double)(1 << k) * (a * fast_rsqrt(a)) * fast_rsqrt(b);
-        g = (y0 < 1.0e-30) ? 1.0 : g;     // a straight joint in a wave that had to halve
-    }
-    return g;
+    // Beyond: two half-angle steps, unconditionally — y <= 1 means sin^2(theta/8) <= sin^2(pi/8) = 0.1465 < 0.15, so two always
+    // suffice and no wave-uniform loop (a VALU -> SALU round trip per test) is needed.
+    //   cos(theta/2) = sqrt(1 - y),  sin^2(theta/4) = (1 - cos(theta/2)) / 2,
+    //   theta/sin(theta) = (phi/sin(phi)) / (cos(theta/2) cos(theta/4)),  phi = theta/4.
+    // The subtraction cancels for a straight joint in a wave that has a curled one, harmlessly: the series is 1 + (2/3) y' + ...,
+    // so an ABSOLUTE error of 1e-16 in y' is a relative 1e-16 in the result; the two cosines enter as the refined 1/sqrt the
+    // half-angle steps compute anyway.  (Until round 6: a ballot loop of up to 12 trips with a division per trip and two more
+    // square roots to rebuild sin(phi)/sin(theta) — twice the instructions, in one dependent chain; OctoFlat 9.39 -> 8.84 ms.)
+    const double om0 = fmax(1.0 - y, 1.0e-300);
+    const double r0 = fast_rsqrt(om0);
+    const double y1 = fma(-0.5 * om0, r0, 0.5);
+    const double om1 = 1.0 - y1;                       // >= 1/2
+    const double r1 = fast_rsqrt(om1);
+    const double y2 = fma(-0.5 * om1, r1, 0.5);
+    return theta_over_sin_series<20>(y2) * (r0 * r1);
 }
 
 // The reference divides by sin(theta + 1e-14) (PyElastica _inv_rotate; softrod_config.eps_sin):
@@ -156,33 +189,66 @@ __device__ __forceinline__ double eps_sin_factor(double y, double eps_sin) {
     return fma(fma(y, eps_sin, -0.5 * eps_sin), rho, 1.0);
 }
 
-// exp(x) for any x: exp(x) = 2^n exp(r), n = rint(x log2 e), r = x - n ln 2 with ln 2 in two parts (fdlibm's split: n ln2_hi is
-// exact for |n| < 2^20), |r| <= ln 2 / 2 = 0.347, degree-13 Taylor (remainder r^14 / 14! < 5e-18), v_ldexp_f64.  ~21 VALU
-// instructions, no loop, relative error ~1e-16 plus the argument's own rounding.
-__device__ __forceinline__ double exp_wide(double x) {
-    const double n = rint(x * 1.4426950408889634);
-    double r = fma(-n, 6.93147180369123816490e-01, x);
-    r = fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)fmin(fmax(n, -1100.0), 1100.0));
+// A double literal that is materialised WHERE IT IS USED: two s_mov_b32 in a volatile asm.  The out-of-range tiers sit inside the
+// substep loops; left to the compiler, their sixteen 64-bit literals are hoisted in front of the loop as scalar register
+// pairs, stay live across it, and the allocator spills the HOT path's scalars instead (round 6: 32 v_readlane_b32 per
+// planar substep, 99 -> 131 VALU, caught by tests/test_codegen.py).  A volatile asm cannot be hoisted.
+template <unsigned long long BITS>
+__device__ __forceinline__ double cold_literal() {
+    int lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3"
+                 : "=s"(lo), "=s"(hi)
+                 : "i"((int)(unsigned)(BITS & 0xffffffffull)), "i"((int)(unsigned)(BITS >> 32)));
+    return __hiloint2double(hi, lo);
+}
+#ifdef SOFTROD_DIAG_HOIST_LITERALS      // A/B (tools/octo_ab.sh "hoistlit"): plain literals, the compiler's placement
+#define SOFTROD_COLD_LIT(x) ((double)(x))
+#else
+#define SOFTROD_COLD_LIT(x) cold_literal<__builtin_bit_cast(unsigned long long, (double)(x))>()
+#endif
+
+// exp(x0), exp(x2) for any x: exp(x) = 2^n exp(r), n = rint(x log2 e), r = x - n ln 2 with ln 2 in two parts (fdlibm's split:
+// n ln2_hi is exact for |n| < 2^20), |r| <= ln 2 / 2 = 0.347, degree-13 Taylor (remainder r^14 / 14! < 5e-18), v_ldexp_f64.
+// ~21 VALU instructions each, no loop, relative error ~1e-16 plus the argument's own rounding; the two chains share every
+// literal (one scalar pair live at a time) and interleave.
+__device__ __forceinline__ void exp_wide_pair(double x0, double x2, double& e0, double& e2) {
+    double c = SOFTROD_COLD_LIT(1.4426950408889634);
+    const double n0 = rint(x0 * c), n2 = rint(x2 * c);
+    c = SOFTROD_COLD_LIT(6.93147180369123816490e-01);
+    double r0 = fma(-n0, c, x0), r2 = fma(-n2, c, x2);
+    c = SOFTROD_COLD_LIT(1.90821492927058770002e-10);
+    r0 = fma(-n0, c, r0);
+    r2 = fma(-n2, c, r2);
+    double p0 = SOFTROD_COLD_LIT(1.0 / 6227020800.0), p2 = p0;
+#define SOFTROD_EXP_TERM(k)                                   \
+    c = SOFTROD_COLD_LIT(1.0 / (k));                          \
+    p0 = fma(p0, r0, c);                                      \
+    p2 = fma(p2, r2, c);
+    SOFTROD_EXP_TERM(479001600.0)
+    SOFTROD_EXP_TERM(39916800.0)
+    SOFTROD_EXP_TERM(3628800.0)
+    SOFTROD_EXP_TERM(362880.0)
+    SOFTROD_EXP_TERM(40320.0)
+    SOFTROD_EXP_TERM(5040.0)
+    SOFTROD_EXP_TERM(720.0)
+    SOFTROD_EXP_TERM(120.0)
+    SOFTROD_EXP_TERM(24.0)
+    SOFTROD_EXP_TERM(6.0)
+#undef SOFTROD_EXP_TERM
+    p0 = fma(p0, r0, 0.5);
+    p2 = fma(p2, r2, 0.5);
+    p0 = fma(p0, r0, 1.0);
+    p2 = fma(p2, r2, 1.0);
+    p0 = fma(p0, r0, 1.0);
+    p2 = fma(p2, r2, 1.0);
+    c = SOFTROD_COLD_LIT(1100.0);
+    e0 = ldexp(p0, (int)fmin(fmax(n0, -c), c));
+    e2 = ldexp(p2, (int)fmin(fmax(n2, -c), c));
 }
 
 // exp(x) for the damper: |x| < 1e-3 -> degree-4 Taylor (remainder x^5/120 < 1e-17), one s_cbranch on the fast path;
 // larger |x| — strong damping constants, and above all the thin end of a TAPERED arm, whose log c_r = -nu dt m / J
-// reaches -1500: (e - 1) log c_r is 10 .. 700 in every substep of a stretched arm — take exp_wide.  (Until round 6 this
+// reaches -1500: (e - 1) log c_r is 10 .. 700 in every substep of a stretched arm — take exp_wide_pair.  (Until round 6 this
 // tier halved the argument until it fitted and squared the result back: up to 21 wave-uniform loop trips and a
 // dependent chain of 42 multiplications per substep, 2.7 of the 4.5 ms of an OctoArmPush-v0 env.step.)
 __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid_lane, double& e0, double& e2) {
@@ -192,8 +258,7 @@ __device__ __forceinline__ void exp_pair(double x0, double x2, bool valid_lane, 
         e2 = fma(x2, fma(x2, fma(x2, horner(1.0 / 24.0, x2, 1.0 / 6.0), 0.5), 1.0), 1.0);
         return;
     }
-    e0 = exp_wide(x0);
-    e2 = exp_wide(x2);
+    exp_wide_pair(x0, x2, e0, e2);
 }
 
 }  // namespace softrod
@@ -333,7 +398,7 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
 #undef SR_RD
 #undef SR_RD_SUB
         const double y = fma(-0.25, trace, 0.75 + 0.5 * P.acos_shift);
-        const double gk = theta_over_sin(y, vor_valid) * eps_sin_factor(y, P.eps_sin) * (-0.5 * P.inv_rest_vor);
+        const double gk = theta_over_sin<(F != kRuntimeFeatures && (F & SOFTROD_FEAT_OCTO_HEAD) != 0)>(y, vor_valid) * eps_sin_factor(y, P.eps_sin) * (-0.5 * P.inv_rest_vor);
         const double k0 = vec0 * gk, k1 = vec1 * gk, k2 = vec2 * gk;
         const double vd = (len_n[s] + len[s]) * (0.5 * P.inv_rest_vor);
         const double rvd = fast_rcp(vd);

@@ -4,7 +4,9 @@
 #   tools/octo_ab.sh build                      (here: hipcc cross-compiles)
 #   tools/octo_ab.sh run <tag>                  (on the box, via gpurun) -> gpurun_out/octo_ab_<tag>.txt
 # Variants: r4 = the shipped kernel, basemask = joints and head step under the base-lane EXEC mask,
-# diagN = SOFTROD_OCTO_DIAG=N (timing only: results are wrong by construction).  Every run is bounded by
+# diagN = SOFTROD_OCTO_DIAG=N (timing only: results are wrong by construction); round 6: r6 = the shipped kernel,
+# thetaloop = round 5's large-angle tier of theta/sin(theta), waves3 = the kernel capped at 168 registers (what a ninth,
+# coupling wave per workgroup would leave each arm wave: three waves on one SIMD).  Every run is bounded by
 # `timeout`: a diagnostic build that breaks the rendezvous must not hold the box.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -22,6 +24,10 @@ declare -A FLAGS=(
   [nomaskbase]="-DSOFTROD_OCTO_BASE_MASK=0"
   [maskjoints]="-DSOFTROD_OCTO_BASE_MASK=1"
   [maskhead]="-DSOFTROD_OCTO_BASE_MASK=2"
+  [r6]=""
+  [thetaloop]="-DSOFTROD_DIAG_THETA_LOOP"
+  [waves3]="-DSOFTROD_OCTO_WAVES=3"
+  [hoistlit]="-DSOFTROD_DIAG_HOIST_LITERALS"
 )
 NAMES=${OCTO_AB_VARIANTS:-r4 basemask diag4 diag8 diag12 diag1 diag2 diag7}
 if [ "${1:-}" = build ]; then
