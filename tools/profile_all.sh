@@ -21,6 +21,7 @@ declare -A ARGS=(
   [OctoArmPush-v1]="--env OctoArmPush-v1"
   [SoftPendulum-v0_libm]="--math-mode libm"
   [OctoArmPush-v0]="--env OctoArmPush-v0"
+  [OctoArmPullWeight-v0]="--env OctoArmPullWeight-v0"
 )
 NAMES=${*:-SoftPendulum-v0 SoftPendulum3D-v0 OctoArmSingle-v0 OctoArmSingle-v0_n100 OctoArmSingle-v0_taper OctoFlat-v0 SoftArmTracking-v0 OctoArmPush-v1 SoftPendulum-v0_libm}
 for NAME in $NAMES; do
