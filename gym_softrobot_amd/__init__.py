@@ -5,14 +5,20 @@ from .envs import (
     ArmPullWeightEnv,
     ArmPushEnv,
     ArmSingleEnv,
+    ArmTwoEnv,
+    CrawlEnv,
     FlatEnv,
+    ReachEnv,
     SoftArmTrackingEnv,
     SoftPendulum3DEnv,
     SoftPendulumEnv,
     VecArmPullWeightEnv,
     VecArmPushEnv,
     VecArmSingleEnv,
+    VecArmTwoEnv,
+    VecCrawlEnv,
     VecOctoFlatEnv,
+    VecReachEnv,
     VecSoftArmTrackingEnv,
     VecSoftPendulum3DEnv,
     VecSoftPendulumEnv,
@@ -38,6 +44,9 @@ _VEC = {
     "OctoArmPush-v0": (VecArmPushEnv, {}),                            # gym_softrobot/__init__.py:37-46
     "OctoArmPush-v1": (VecArmPushEnv, dict(mode="continuous")),
     "OctoArmPullWeight-v0": (VecArmPullWeightEnv, dict(mode="continuous")),   # gym_softrobot/__init__.py:48-52
+    "OctoCrawl-v0": (VecCrawlEnv, {}),                                # gym_softrobot/__init__.py:17-25
+    "OctoReach-v0": (VecReachEnv, {}),
+    "OctoArmTwo-v0": (VecArmTwoEnv, {}),                              # gym_softrobot/__init__.py:32-35
 }
 
 # gym_softrobot/__init__.py:27-30,74-80
@@ -58,6 +67,10 @@ register(id="OctoArmPush-v1", entry_point=ArmPushEnv, kwargs=dict(mode="continuo
 # gym_softrobot/__init__.py:48-52
 register(id="OctoArmPullWeight-v0", entry_point=ArmPullWeightEnv, kwargs=dict(mode="continuous"),
          vector_entry_point=VecArmPullWeightEnv, label=_UNPINNED)
+# gym_softrobot/__init__.py:17-25,32-35 — the muscle octopus (octopus/build_muscle_octopus.py): the same caveat
+register(id="OctoCrawl-v0", entry_point=CrawlEnv, vector_entry_point=VecCrawlEnv, label=_UNPINNED)
+register(id="OctoReach-v0", entry_point=ReachEnv, vector_entry_point=VecReachEnv, label=_UNPINNED)
+register(id="OctoArmTwo-v0", entry_point=ArmTwoEnv, vector_entry_point=VecArmTwoEnv, label=_UNPINNED)
 
 
 def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
@@ -70,5 +83,5 @@ def make_vec(id: str, num_envs: int, **kwargs):  # noqa: A002
 
 __all__ = [
     "SoftPendulumEnv", "VecSoftPendulumEnv", "SoftPendulum3DEnv", "VecSoftPendulum3DEnv",
-    "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv", "SoftArmTrackingEnv", "VecSoftArmTrackingEnv", "ArmPushEnv", "VecArmPushEnv", "ArmPullWeightEnv", "VecArmPullWeightEnv", "parity_label", "make", "make_vec", "register", "registered", "_capi",
+    "ArmSingleEnv", "VecArmSingleEnv", "FlatEnv", "VecOctoFlatEnv", "SoftArmTrackingEnv", "VecSoftArmTrackingEnv", "ArmPushEnv", "VecArmPushEnv", "ArmPullWeightEnv", "VecArmPullWeightEnv", "CrawlEnv", "VecCrawlEnv", "ArmTwoEnv", "VecArmTwoEnv", "ReachEnv", "VecReachEnv", "parity_label", "make", "make_vec", "register", "registered", "_capi",
 ]

@@ -51,6 +51,10 @@ ENV_OCTO_FLAT = 4
 ENV_SOFT_ARM = 5
 ENV_ARM_PUSH = 6
 ENV_ARM_PULL_WEIGHT = 7
+ENV_CRAWL = 8
+ENV_ARM_TWO = 9
+ENV_REACH = 10
+MUSCLE_OCTOPUS_ENVS = (ENV_CRAWL, ENV_ARM_TWO, ENV_REACH)
 FEATURES_ARM_PUSH = FEAT_ANALYTICAL_DAMPER | FEAT_SUCKER_CONSTRAINT | FEAT_COOMM_MUSCLES
 FEATURES_ARM_PULL_WEIGHT = FEATURES_ARM_PUSH | FEAT_OCTO_HEAD
 FEATURES_OCTO_FLAT = FEATURES_ARM_SINGLE | FEAT_OCTO_HEAD
@@ -62,11 +66,12 @@ MATH_FAST = 1
 LANE_STRIDE = 64  # one wavefront row per rod (softrod_state_view.lane_stride)
 
 _ACTION_DIM = {ENV_NONE: 1, ENV_SOFTPENDULUM: 1, ENV_SOFTPENDULUM3D: 2, ENV_ARM_SINGLE: 7, ENV_OCTO_FLAT: 24,
-               ENV_SOFT_ARM: 8, ENV_ARM_PUSH: 2, ENV_ARM_PULL_WEIGHT: 2}
+               ENV_SOFT_ARM: 8, ENV_ARM_PUSH: 2, ENV_ARM_PULL_WEIGHT: 2, 8: 24, 9: 18, 10: 480}
 _OBS_DIM = {ENV_NONE: 4, ENV_SOFTPENDULUM: 4, ENV_SOFTPENDULUM3D: 9, ENV_ARM_SINGLE: 25,
-            ENV_OCTO_FLAT: 8 * 56 + 13, ENV_SOFT_ARM: 14, ENV_ARM_PUSH: 84, ENV_ARM_PULL_WEIGHT: 84}
+            ENV_OCTO_FLAT: 8 * 56 + 13, ENV_SOFT_ARM: 14, ENV_ARM_PUSH: 84, ENV_ARM_PULL_WEIGHT: 84,
+            8: 8 * 131, 9: 2 * 52, 10: 8 * 189}          # CrawlEnv / ArmTwoEnv / ReachEnv at their registered sizes
 _AUX_DIM = {ENV_NONE: 0, ENV_SOFTPENDULUM: 0, ENV_SOFTPENDULUM3D: 1, ENV_ARM_SINGLE: 0, ENV_OCTO_FLAT: 0,
-            ENV_SOFT_ARM: 0, ENV_ARM_PUSH: 0, ENV_ARM_PULL_WEIGHT: 0}
+            ENV_SOFT_ARM: 0, ENV_ARM_PUSH: 0, ENV_ARM_PULL_WEIGHT: 0, 8: 0, 9: 0, 10: 0}
 
 
 def action_dim(env_kind: int) -> int:
@@ -149,12 +154,13 @@ class SoftrodConfig(C.Structure):
         ("muscle_position_current_radius", C.c_int32),
         ("muscle_tm_length_law", C.c_int32),
         ("arm_push_mode", C.c_int32),
-        ("reserved3", C.c_int32),
+        ("head_fixed", C.c_int32),
         ("muscle_fl_coef", C.c_double * 8),
         ("head_center", C.c_double * 3),
         ("head_length", C.c_double),
         ("joint_angle0", C.c_double),
         ("joint_angle_step", C.c_double),
+        ("damper_time_step", C.c_double),
     ]
 
     def copy(self) -> "SoftrodConfig":
@@ -188,6 +194,8 @@ class SoftrodStateView(C.Structure):
         ("muscle_activation", C.c_void_p),
         ("sucker_index", C.c_void_p),
         ("material", C.c_void_p),
+        ("env_aux", C.c_void_p),
+        ("prev_kappa", C.c_void_p),
     ]
 
 
@@ -491,6 +499,128 @@ def arm_pull_weight_config(
     return cfg
 
 
+MUSCLE_OCTOPUS = {
+    # build_muscle_octopus.py:26-47 ARM_MATERIAL / DEFAULT_SCALE_LENGTH / HEAD_PROPERTIES
+    "density": 1000.0, "youngs_modulus": 1.5e4, "shear_modulus": 1.5e4 / (1.0 + 0.5), "damping_constant": 0.20,
+    "nu_scale": 1e-2, "base_length": 0.25, "base_radius": 0.013, "tip_radius": 0.0042, "head_radius": 0.04,
+    "head_density": 50.0, "body_arm_k": 1e6, "body_arm_kt": 1e2, "body_arm_nu": 1e-3, "damper_time_step": 7e-5,
+}
+
+
+def muscle_octopus_radii(n_elem: int = 20):
+    """build_arm's `base_radius=np.linspace(base_radius, tip_radius, n_elem)` (build_muscle_octopus.py:60-62): one value
+    PER ELEMENT (ArmPushEnv averages n + 1 node values instead)."""
+    import numpy as np
+
+    return np.linspace(MUSCLE_OCTOPUS["base_radius"], MUSCLE_OCTOPUS["tip_radius"], n_elem)
+
+
+def muscle_octopus_arm_frames(env_kind: int, head_radius: float = 0.04):
+    """Arm start points, directions and joint angles of build_octopus_muscles (8 arms at 22.5 + 45 i degrees,
+    build_muscle_octopus.py:83-93) / build_two_arms (2 arms at 90 + 180 i, :200-210)."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation as Rot
+
+    if int(env_kind) == ENV_ARM_TWO:
+        angles = [90.0 + 180.0 * arm_i for arm_i in range(2)]
+    else:
+        angles = [45.0 / 2 + 45 * arm_i for arm_i in range(8)]
+    pos, dirs = [], []
+    for angle in angles:
+        rot = Rot.from_euler("z", angle, degrees=True)
+        pos.append(rot.apply([head_radius, 0.0, 0.0]))
+        dirs.append(rot.apply([1.0, 0.0, 0.0]))
+    return np.ascontiguousarray(pos, np.float64), np.ascontiguousarray(dirs, np.float64), angles
+
+
+def muscle_octopus_rest_length_sum(n_elem: int = 20, head_radius: float = 0.04) -> float:
+    """`sum(self.shearable_rods[0].rest_lengths)` of ReachEnv.reset (reach_env.py:141-143) as straight_rod computes the
+    rest lengths of arm 0: per-coordinate linspace from start to start + direction * base_length, norms of the differences
+    (sum of the three squares in order), added up by Python's sum()."""
+    import numpy as np
+
+    pos, dirs, _ = muscle_octopus_arm_frames(ENV_REACH, head_radius)
+    start = pos[0]
+    end = start + dirs[0] * MUSCLE_OCTOPUS["base_length"]
+    position = np.zeros((3, n_elem + 1))
+    for i in range(3):
+        position[i, ...] = np.linspace(start[i], end[i], n_elem + 1)
+    d = position[..., 1:] - position[..., :-1]
+    rest = np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+    return sum(rest)
+
+
+def arm_two_activation_basis(n_elems: int = 20, n_sucker: int = 3):
+    """W [n_elems][n_sucker] with apply_X = W @ activation: ArmTwoEnv.set_action's
+    `interp1d(control_location, [0] + list(activation) + [0], kind="cubic")(range(n_elems))` (arm_two_env.py:237-245)
+    applied to unit vectors; control_location = [0] + sucker_location + [n_elems - 1] (:77-81)."""
+    import numpy as np
+    from scipy.interpolate import interp1d
+
+    sucker_location = [n_elems // (n_sucker * 2) * (2 * i + 1) for i in range(n_sucker)]
+    control_location = [0] + sucker_location + [n_elems - 1]
+    cols = [interp1d(control_location, [0] + list(np.eye(n_sucker)[j]) + [0], kind="cubic")(range(n_elems)) for j in range(n_sucker)]
+    return np.ascontiguousarray(np.stack(cols, axis=1), np.float64), sucker_location
+
+
+def muscle_octopus_config(
+    env_kind: int,
+    n_envs: int = 1,
+    *,
+    final_time: float = None,
+    time_step: float = 5.0e-5,
+    recording_fps: int = 25,
+    n_elems: int = 20,
+    math_mode: int = MATH_FAST,
+) -> SoftrodConfig:
+    """`softrod_config_muscle_octopus`: CrawlEnv / ArmTwoEnv / ReachEnv.__init__ (crawl_env.py:61-125,
+    arm_two_env.py:55-113, reach_env.py:53-106) over build_octopus_muscles / build_two_arms
+    (build_muscle_octopus.py:66-179,182-291).  No gravity, no plane: the arms float, held by their suckers."""
+    env_kind = int(env_kind)
+    if env_kind not in MUSCLE_OCTOPUS_ENVS:
+        raise ValueError("env_kind must be ENV_CRAWL, ENV_ARM_TWO or ENV_REACH")
+    if final_time is None:
+        final_time = {ENV_CRAWL: 10.0, ENV_ARM_TWO: 5.0, ENV_REACH: 5.0}[env_kind]
+    m = MUSCLE_OCTOPUS
+    cfg = SoftrodConfig()
+    _common(cfg, n_envs, final_time, time_step, recording_fps, n_elems, math_mode)
+    cfg.features = FEATURES_ARM_PULL_WEIGHT
+    cfg.env_kind = env_kind
+    cfg.arm_push_mode = 1
+    cfg.base_length = m["base_length"]
+    cfg.base_radius = m["base_radius"]                       # r0: the head's geometry; the arms' radii are a profile
+    cfg.density = m["density"]
+    cfg.youngs_modulus = m["youngs_modulus"]
+    cfg.shear_modulus = m["shear_modulus"]
+    cfg.damping_constant = m["damping_constant"] * m["nu_scale"]
+    cfg.damper_time_step = m["damper_time_step"]
+    cfg.n_arm = 2 if env_kind == ENV_ARM_TWO else 8
+    cfg.n_knots = {ENV_CRAWL: 3, ENV_ARM_TWO: 9, ENV_REACH: 3 * int(n_elems)}[env_kind]       # actions per arm
+    cfg.head_radius = m["head_radius"]
+    cfg.head_density = m["head_density"]
+    r0 = m["base_radius"]
+    cfg.head_length = r0 * 2
+    cfg.head_center[0], cfg.head_center[1], cfg.head_center[2] = 0.0, 0.0, -r0 * 2 + r0 * 2 / 2
+    cfg.head_fixed = 1 if env_kind == ENV_REACH else 0
+    cfg.joint_k, cfg.joint_nu, cfg.joint_kt = m["body_arm_k"], m["body_arm_nu"], m["body_arm_kt"]
+    if env_kind == ENV_ARM_TWO:
+        cfg.joint_angle0, cfg.joint_angle_step = 90.0, 180.0
+        cfg.n_suckers = 3
+        _, loc = arm_two_activation_basis(int(n_elems), 3)
+        for j in range(3):
+            cfg.sucker_index[j] = loc[j]
+    else:
+        cfg.joint_angle0, cfg.joint_angle_step = 45.0 / 2, 45.0
+        cfg.n_suckers = 1 if env_kind == ENV_CRAWL else 0
+        cfg.sucker_index[0] = 0
+    cfg.sucker_reduction_ratio = 1.0
+    # builds register dampen() first, the envs constrain() the arms afterwards (build_muscle_octopus.py:101-106 before
+    # crawl_env.py:148-155)
+    cfg.damp_before_constrain = 1
+    muscle_defaults(cfg)
+    return cfg
+
+
 def np_rint(x: float) -> float:
     import numpy as np
 
@@ -563,6 +693,8 @@ def config_action_dim(cfg: "SoftrodConfig") -> int:
         return int(cfg.n_arm) * int(cfg.n_knots)
     if int(cfg.env_kind) in (ENV_ARM_PUSH, ENV_ARM_PULL_WEIGHT):
         return 1 if int(cfg.arm_push_mode) == 0 else 2      # Discrete(2) index / (location, activation)
+    if int(cfg.env_kind) in MUSCLE_OCTOPUS_ENVS:
+        return int(cfg.n_arm) * int(cfg.n_knots)
     return action_dim(cfg.env_kind)
 
 
@@ -572,6 +704,12 @@ def config_obs_dim(cfg: "SoftrodConfig") -> int:
     if int(cfg.env_kind) == ENV_OCTO_FLAT:
         n = int(cfg.n_elem)
         return int(cfg.n_arm) * ((n - 1) + 4 * (n + 1) + int(cfg.n_knots)) + 13
+    if int(cfg.env_kind) in MUSCLE_OCTOPUS_ENVS:
+        n, na, nk = int(cfg.n_elem), int(cfg.n_arm), int(cfg.n_knots)
+        if int(cfg.env_kind) == ENV_ARM_TWO:
+            return na * ((n - 1) * 2 + nk + na + 3)                    # arm_two_env.py:92-95
+        shared = 17 if int(cfg.env_kind) == ENV_CRAWL else 18          # crawl_env.py:91-101, reach_env.py:87-91
+        return na * ((n - 1) + (n + 1) * 4 + nk + na + shared)
     return obs_dim(cfg.env_kind)
 
 
@@ -594,6 +732,7 @@ _EXPORTS = {
     "softrod_config_soft_arm": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
     "softrod_config_arm_push": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.c_int]),
     "softrod_config_arm_pull_weight": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int]),
+    "softrod_config_muscle_octopus": (C.c_int, [C.POINTER(SoftrodConfig), C.c_int, C.c_int]),
     "softrod_set_muscle_layers": (C.c_int, [_VP, _VP, _VP]),
     "softrod_set_spline_table": (C.c_int, [_VP, _VP, _VP]),
     "softrod_config_action_dim": (C.c_int, [C.POINTER(SoftrodConfig)]),

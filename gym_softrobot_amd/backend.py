@@ -44,6 +44,9 @@ class HipRodBackend:
         # FlatEnv's host API (reset_octo, Dict observations); the muscle arm with a weight (ENV_ARM_PULL_WEIGHT) has a
         # rigid body too but resets and observes like any single rod
         self.is_octo = bool(cfg.features & _capi.FEAT_OCTO_HEAD) and int(cfg.env_kind) == _capi.ENV_OCTO_FLAT
+        # the muscle octopus envs (CrawlEnv / ArmTwoEnv / ReachEnv): FlatEnv's reset API with their own arm frames,
+        # three numbers per target
+        self.is_mocto = int(cfg.env_kind) in _capi.MUSCLE_OCTOPUS_ENVS
         self.aux_dim = _capi.aux_dim(cfg.env_kind)
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
@@ -57,6 +60,10 @@ class HipRodBackend:
                 basis = _capi.octo_action_basis(int(cfg.n_elem), int(cfg.n_knots))
             else:
                 basis = _capi.action_basis(int(cfg.n_elem), self.action_dim)
+            check(self._lib.softrod_set_action_basis(self._h, basis.ctypes.data), self._h)
+            self._tables["action_basis"] = basis.tobytes()
+        if int(cfg.env_kind) == _capi.ENV_ARM_TWO:
+            basis, _ = _capi.arm_two_activation_basis(int(cfg.n_elem), 3)
             check(self._lib.softrod_set_action_basis(self._h, basis.ctypes.data), self._h)
             self._tables["action_basis"] = basis.tobytes()
         if self.cfg.features & _capi.FEAT_SPLINE_MUSCLE_TORQUES:
@@ -142,13 +149,20 @@ class HipRodBackend:
             self._h,
         )
 
+    def _arm_frames(self):
+        if self.is_mocto:
+            pos, dirs, _ = _capi.muscle_octopus_arm_frames(int(self.cfg.env_kind), float(self.cfg.head_radius))
+            return pos, dirs
+        return _capi.octo_arm_frames(int(self.cfg.n_arm), float(self.cfg.head_radius))
+
     def reset_octo(self, targets, mask: Optional[np.ndarray] = None) -> None:
-        """FlatEnv.reset: targets (n_envs, 2); the arm frames are build_octopus's."""
+        """FlatEnv.reset: targets (n_envs, 2); the arm frames are build_octopus's.  The muscle octopus envs: targets
+        (n_envs, 3), the frames of build_octopus_muscles / build_two_arms."""
         na = int(self.cfg.n_arm)
-        pos, dirs = _capi.octo_arm_frames(na, float(self.cfg.head_radius))
+        pos, dirs = self._arm_frames()
         pos = np.ascontiguousarray(np.broadcast_to(pos, (self.n_envs, na, 3)))
         dirs = np.ascontiguousarray(np.broadcast_to(dirs, (self.n_envs, na, 3)))
-        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, 2)
+        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, 3 if self.is_mocto else 2)
         m = None
         if mask is not None:
             m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.n_envs)
@@ -185,9 +199,9 @@ class HipRodBackend:
 
     def queue_push_octo(self, targets, counts) -> None:
         na = int(self.cfg.n_arm)
-        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, -1, 2)
+        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, -1, 3 if self.is_mocto else 2)
         m = tg.shape[1]
-        pos, dirs = _capi.octo_arm_frames(na, float(self.cfg.head_radius))
+        pos, dirs = self._arm_frames()
         pos = np.ascontiguousarray(np.broadcast_to(pos, (self.n_envs, m, na, 3)))
         dirs = np.ascontiguousarray(np.broadcast_to(dirs, (self.n_envs, m, na, 3)))
         c = self._counts(counts, self.n_envs)
@@ -331,7 +345,7 @@ class HipRodBackend:
         """Writable (n_envs, action_dim) view of the resident `_prev_action`."""
         if getattr(self, "_prev_rows", None) is None:
             self._prev_rows = self.state()["prev_action"]
-            if not self.is_octo:
+            if not self.is_octo and not self.is_mocto:
                 self._prev_rows = self._prev_rows[:, : self.action_dim]
         return self._prev_rows
 
@@ -345,12 +359,17 @@ class HipRodBackend:
             return torch.as_tensor(_DevArray(ptr, (comps, n, s), "<f8", self), device=self.device)
 
         extra = {}
+        ns = n * (int(self.cfg.n_arm) if self.is_mocto else 1)      # SuckerControllers: per env, per arm of the muscle octopus
+        if v.env_aux:
+            extra["env_aux"] = torch.as_tensor(_DevArray(v.env_aux, (8, n), "<f8", self), device=self.device)
+            extra["prev_kappa"] = torch.as_tensor(
+                _DevArray(v.prev_kappa, (n, int(self.cfg.n_arm) * (int(self.cfg.n_elem) - 1)), "<f4", self), device=self.device)
         if v.muscle_activation:
             extra["muscle_activation"] = torch.as_tensor(
                 _DevArray(v.muscle_activation, (_capi.MAX_MUSCLES, n, s), "<f8", self), device=self.device)
         return {
             **extra,
-            "sucker_index": torch.as_tensor(_DevArray(v.sucker_index, (_capi.MAX_SUCKERS, n), "<i4", self),
+            "sucker_index": torch.as_tensor(_DevArray(v.sucker_index, (_capi.MAX_SUCKERS, ns), "<i4", self),
                                             device=self.device),
             "position": view(v.position, 3),
             "velocity": view(v.velocity, 3),
@@ -366,7 +385,7 @@ class HipRodBackend:
                                            device=self.device),
             "head": torch.as_tensor(_DevArray(v.head, (20, n), "<f8", self), device=self.device),
             "bc_targets": torch.as_tensor(_DevArray(v.bc_targets, (12, n), "<f8", self), device=self.device),
-            "sucker_ratio": torch.as_tensor(_DevArray(v.sucker_ratio, (_capi.MAX_SUCKERS, n), "<f8", self),
+            "sucker_ratio": torch.as_tensor(_DevArray(v.sucker_ratio, (_capi.MAX_SUCKERS, ns), "<f8", self),
                                             device=self.device),
             "arm_stride": int(v.arm_stride),
         }
@@ -375,7 +394,8 @@ class HipRodBackend:
                       "rest_kappa", "env_memory", "prev_action", "head", "bc_targets", "sucker_ratio", "sucker_index")
 
     def _snapshot_keys(self):
-        return self._SNAPSHOT_KEYS + (("muscle_activation",) if self.cfg.features & _capi.FEAT_COOMM_MUSCLES else ())
+        return (self._SNAPSHOT_KEYS + (("muscle_activation",) if self.cfg.features & _capi.FEAT_COOMM_MUSCLES else ())
+                + (("env_aux", "prev_kappa") if self.is_mocto else ()))
 
     def config_fingerprint(self) -> bytes:
         """What a snapshot is only valid for: the ABI, every field of softrod_config except the

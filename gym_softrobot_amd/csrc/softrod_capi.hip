@@ -44,6 +44,8 @@ struct softrod_handle {
     double* d_mat = nullptr;        // [kMatRows][64] material table of a tapered rod
     double* d_sucker = nullptr;     // [SOFTROD_MAX_SUCKERS][N]
     int* d_sucker_idx = nullptr;    // [SOFTROD_MAX_SUCKERS][N]
+    double* d_aux = nullptr;        // [8][N] the muscle octopus envs' target and xposbefore
+    float* d_prev_kappa = nullptr;  // [N][n_arm * (n_elem - 1)] ArmTwoEnv._prev_kappa
     double* d_mact = nullptr;       // [SOFTROD_MAX_MUSCLES][N][64] muscle activations (SOFTROD_FEAT_COOMM_MUSCLES)
     double* d_mtab = nullptr;       // [SOFTROD_MAX_MUSCLES][4][64] ratio_position x, y, z, strength
     bool muscles_set = false;
@@ -153,12 +155,15 @@ void fill_params(const softrod_config& c, RodParams& P) {
     const double volume = M_PI * (r * r) * rest_len;
     P.mass_node = c.density * volume;  // two half-element contributions
     for (int i = 0; i < 3; ++i) { P.gravity[i] = c.gravity[i]; P.tip_force[i] = c.tip_force[i]; }
-    P.damp_t = std::exp(-c.damping_constant * c.dt);
+    // AnalyticalLinearDamper(time_step=...): the stepper's dt unless the build hands it another one
+    // (build_muscle_octopus.py:101-106: 7e-5 under a stepper run at 5e-5)
+    const double ddt = c.damper_time_step > 0.0 ? c.damper_time_step : c.dt;
+    P.damp_t = std::exp(-c.damping_constant * ddt);
     // element mass seen by the damper: 0.5(m_k+m_{k+1}), ends augmented by half their
     // outer node -> rho*V for every element of a uniform rod
     const double me = P.mass_node;
     for (int i = 0; i < 3; ++i) {      // (damper_protocol 1: the uniform protocol, the same exp(-nu dt) on every rate)
-        P.damp_logr[i] = c.damper_protocol == 1 ? -c.damping_constant * c.dt : -c.damping_constant * c.dt * me * P.invJ[i];
+        P.damp_logr[i] = c.damper_protocol == 1 ? -c.damping_constant * ddt : -c.damping_constant * ddt * me * P.invJ[i];
         P.damp_r[i] = std::exp(P.damp_logr[i]);
     }
     P.eps_length = c.eps_length;
@@ -205,7 +210,8 @@ void fill_params(const softrod_config& c, RodParams& P) {
         P.seg = 1 << P.seg_shift;
         P.n_arm = c.n_arm;
         P.n_action = c.n_knots;
-        if (c.features & SOFTROD_FEAT_COOMM_MUSCLES) P.seg_shift = 6, P.seg = 64;    // the muscle arm: one arm per wave
+        if (c.env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT) P.seg_shift = 6, P.seg = 64;    // the muscle arm with a weight: one arm, one wave
+        P.head_fixed = c.head_fixed;
         const double hl = c.head_length > 0.0 ? c.head_length : 2.0 * c.base_radius, hr = c.head_radius;
         for (int i = 0; i < 3; ++i) P.head_center[i] = c.head_length > 0.0 ? c.head_center[i] : 0.0;
         P.joint_angle0 = c.head_length > 0.0 ? c.joint_angle0 : 0.0;
@@ -248,6 +254,9 @@ bool is_octo(const softrod_handle* h) { return (h->cfg.features & SOFTROD_FEAT_O
 // weight (SOFTROD_ENV_ARM_PULL_WEIGHT) runs the same kernels but resets like any single rod (softrod_reset_straight)
 bool is_flat(const softrod_handle* h) { return h->cfg.env_kind == SOFTROD_ENV_OCTO_FLAT; }
 bool is_pull(const softrod_handle* h) { return h->cfg.env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT; }
+// the muscle octopus envs (softrod_mocto.hpp): FlatEnv's host API (arm frames + target), the muscle arm's tables
+bool mocto_kind(int e) { return e == SOFTROD_ENV_CRAWL || e == SOFTROD_ENV_ARM_TWO || e == SOFTROD_ENV_REACH; }
+bool is_mocto(const softrod_handle* h) { return mocto_kind(h->cfg.env_kind); }
 
 int launch_step(softrod_handle* h, const float* actions, float* obs, double* reward,
                 uint8_t* term, uint8_t* trunc, double* aux, int n_sub, int epilogue, int pack,
@@ -268,7 +277,10 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     if ((h->cfg.features & SOFTROD_FEAT_COOMM_MUSCLES) && h->cfg.math_mode == SOFTROD_MATH_FAST) {
         // the fast kernel carries the muscle layers in two instantiations only (kMusclesCompiled): the tapered
         // ArmPush arm and the uniform muscle rod; never let another one run a muscle handle without its muscles
-        const bool push = h->cfg.env_kind == SOFTROD_ENV_ARM_PUSH || is_pull(h);
+        const bool push = h->cfg.env_kind == SOFTROD_ENV_ARM_PUSH || is_pull(h) || is_mocto(h);
+        if (is_mocto(h) && (!h->tapered || !h->muscles_set || (h->cfg.env_kind == SOFTROD_ENV_ARM_TWO && !h->basis_set)))
+            return fail(h, SOFTROD_EINVAL, "the muscle octopus needs softrod_set_radius_profile and softrod_set_muscle_layers "
+                                           "(and SOFTROD_ENV_ARM_TWO softrod_set_action_basis) before it steps");
         if (push && !h->tapered)
             return fail(h, SOFTROD_EINVAL, "SOFTROD_ENV_ARM_PUSH (SOFTROD_MATH_FAST): call softrod_set_radius_profile first "
                                            "(the reference's arm is tapered, arm_push_env.py:160-179)");
@@ -281,6 +293,14 @@ int launch_step(softrod_handle* h, const float* actions, float* obs, double* rew
     if (is_octo(h) && is_pull(h)) {
         hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_ARM_PULL_WEIGHT, 2, 1>), grid, block, 0, st, h->P, h->S,
                            actions, obs, reward, term, trunc, n_sub, epilogue, pack);
+    } else if (is_mocto(h)) {
+        // set_action | the body's substeps | get_state + reward (softrod_mocto.hpp); the timing events bracket all three
+        if (epilogue && actions)
+            hipLaunchKernelGGL(softrod_mocto_action_kernel, grid, block, 0, st, h->P, h->S, actions, n_sub);
+        hipLaunchKernelGGL((softrod_octo_step_kernel<SOFTROD_FEATURES_ARM_PULL_WEIGHT, 4, 1>), grid, block, 0, st, h->P, h->S,
+                           actions, obs, reward, term, trunc, n_sub, epilogue, pack);
+        if (epilogue)
+            hipLaunchKernelGGL(softrod_mocto_epilogue_kernel, grid, block, 0, st, h->P, h->S, obs, reward, term, trunc, 1, pack);
     } else if (is_octo(h)) {
 #define SR_OCTO(FEATS, MAXW)                                                                        \
         hipLaunchKernelGGL((softrod_octo_step_kernel<FEATS, MAXW>), grid, block, 0, st, h->P, h->S,     \
@@ -376,7 +396,7 @@ int upload_and_reset(softrod_handle* h, hipStream_t st, bool use_mask) {
         SR_HIP(h, hipMemcpyAsync(h->d_mask, h->h_mask, N, hipMemcpyHostToDevice, st));
     ResetArgs A{h->d_init, use_mask ? h->d_mask : nullptr};
     if (is_octo(h)) {
-        OctoResetArgs OA{h->d_init, h->d_init + N * (size_t)h->cfg.n_arm * 18, use_mask ? h->d_mask : nullptr};
+        OctoResetArgs OA{h->d_init, h->d_init + N * (size_t)h->cfg.n_arm * 18, use_mask ? h->d_mask : nullptr};   // (targets: 2 per env, 3 for the muscle octopus)
         hipLaunchKernelGGL(softrod_octo_reset_kernel, dim3((unsigned)N), dim3(kLanes * h->nw), 0, st, h->P, h->S, OA);
     } else if (h->epl == 2)
         hipLaunchKernelGGL(softrod_reset_kernel<2>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
@@ -444,23 +464,33 @@ const char* softrod_source_hash(void) { return SOFTROD_SOURCE_HASH; }
 int softrod_action_dim(int env_kind) {
     return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 2 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 7
          : env_kind == SOFTROD_ENV_OCTO_FLAT ? 24 : env_kind == SOFTROD_ENV_SOFT_ARM ? 8
-         : env_kind == SOFTROD_ENV_ARM_PUSH ? 2 : 1;
+         : (env_kind == SOFTROD_ENV_ARM_PUSH || env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT) ? 2
+         : env_kind == SOFTROD_ENV_CRAWL ? 24 : env_kind == SOFTROD_ENV_ARM_TWO ? 18 : env_kind == SOFTROD_ENV_REACH ? 480 : 1;
 }
 int softrod_obs_dim(int env_kind) {
     return env_kind == SOFTROD_ENV_SOFTPENDULUM3D ? 9 : env_kind == SOFTROD_ENV_ARM_SINGLE ? 25
          : env_kind == SOFTROD_ENV_OCTO_FLAT ? 8 * 56 + 13 : env_kind == SOFTROD_ENV_SOFT_ARM ? 14
-         : env_kind == SOFTROD_ENV_ARM_PUSH ? 84 : 4;
+         : (env_kind == SOFTROD_ENV_ARM_PUSH || env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT) ? 84
+         : env_kind == SOFTROD_ENV_CRAWL ? 8 * 131 : env_kind == SOFTROD_ENV_ARM_TWO ? 2 * 52 : env_kind == SOFTROD_ENV_REACH ? 8 * 189 : 4;
 }
 int softrod_config_action_dim(const softrod_config* cfg) {
     if (!cfg) return 0;
     if (cfg->env_kind == SOFTROD_ENV_SOFT_ARM) return 2 * cfg->n_ctrl;     // soft_arm_tracking.py:152-157
-    if (cfg->env_kind == SOFTROD_ENV_ARM_PUSH) return cfg->arm_push_mode == 0 ? 1 : 2;   // arm_push_env.py:100-118
+    if (cfg->env_kind == SOFTROD_ENV_ARM_PUSH || cfg->env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT)
+        return cfg->arm_push_mode == 0 ? 1 : 2;                             // arm_push_env.py:100-118
+    if (mocto_kind(cfg->env_kind)) return cfg->n_arm * cfg->n_knots;        // crawl_env.py:84-88, arm_two_env.py:84-89, reach_env.py:79-84
     return cfg->env_kind == SOFTROD_ENV_OCTO_FLAT ? cfg->n_arm * cfg->n_knots : softrod_action_dim(cfg->env_kind);
 }
 int softrod_config_obs_dim(const softrod_config* cfg) {
     if (!cfg) return 0;
     if (cfg->env_kind == SOFTROD_ENV_SOFT_ARM) return 2 * cfg->n_ctrl + 6;  // :158-163
-    if (cfg->env_kind == SOFTROD_ENV_ARM_PUSH) return 2 * (cfg->n_elem + 1) + 2;          // arm_push_env.py:104,118-120
+    if (cfg->env_kind == SOFTROD_ENV_ARM_PUSH || cfg->env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT)
+        return 2 * (cfg->n_elem + 1) + 2;                                   // arm_push_env.py:104,118-120
+    if (mocto_kind(cfg->env_kind)) {
+        const int n = cfg->n_elem, na = cfg->n_arm, nk = cfg->n_knots;
+        if (cfg->env_kind == SOFTROD_ENV_ARM_TWO) return na * ((n - 1) * 2 + nk + na + 3);          // arm_two_env.py:92-95
+        return na * ((n - 1) + (n + 1) * 4 + nk + na + (cfg->env_kind == SOFTROD_ENV_CRAWL ? 17 : 18));   // crawl_env.py:91-101, reach_env.py:87-91
+    }
     if (cfg->env_kind != SOFTROD_ENV_OCTO_FLAT) return softrod_obs_dim(cfg->env_kind);
     return cfg->n_arm * ((cfg->n_elem - 1) + 4 * (cfg->n_elem + 1) + cfg->n_knots) + 13;
 }
@@ -636,6 +666,46 @@ int softrod_config_arm_pull_weight(softrod_config* cfg, int n_envs) {
     return SOFTROD_OK;
 }
 
+int softrod_config_muscle_octopus(softrod_config* cfg, int n_envs, int env_kind) {
+    if (!cfg || n_envs < 1 || !mocto_kind(env_kind)) return fail(nullptr, SOFTROD_EINVAL, "bad argument");
+    const int rc = softrod_config_arm_push(cfg, n_envs, 1);      // the three layers and the recalled COOMM switches
+    if (rc != SOFTROD_OK) return rc;
+    cfg->features = SOFTROD_FEATURES_ARM_PULL_WEIGHT;
+    cfg->env_kind = env_kind;
+    cfg->n_elem = 20;                                    // crawl_env.py:65, arm_two_env.py:59, reach_env.py:57
+    cfg->dt = 5.0e-5;                                    // :63 / :57 / :55
+    cfg->n_substeps = (int)(1.0 / (25 * cfg->dt));       // recording_fps 25 -> 800
+    cfg->final_time = env_kind == SOFTROD_ENV_CRAWL ? 10.0 : 5.0;
+    // build_muscle_octopus.py:26-47 ARM_MATERIAL / DEFAULT_SCALE_LENGTH / HEAD_PROPERTIES
+    cfg->base_length = 0.25;
+    cfg->base_radius = 0.013;                            // r0; the arms' radii: linspace(0.013, 0.0042, n) through softrod_set_radius_profile
+    cfg->density = 1000.0;
+    cfg->youngs_modulus = 1.5e4;
+    cfg->shear_modulus = 1.5e4 / (1.0 + 0.5);
+    cfg->damping_constant = 0.20 * 1e-2;                 // damping_constant * nu_scale (:101-106)
+    cfg->damper_time_step = 7e-5;                        // the dampers' own time_step (:105)
+    cfg->n_arm = env_kind == SOFTROD_ENV_ARM_TWO ? 2 : 8;
+    cfg->n_knots = env_kind == SOFTROD_ENV_CRAWL ? 3 : (env_kind == SOFTROD_ENV_ARM_TWO ? 9 : 3 * cfg->n_elem);
+    cfg->head_radius = 0.04;
+    cfg->head_density = 50.0;
+    cfg->head_length = 0.013 * 2;                        // Cylinder(start (0, 0, -2 r0), e_z, e_y, 2 r0, head_radius, density) (:108-114)
+    cfg->head_center[0] = 0.0; cfg->head_center[1] = 0.0; cfg->head_center[2] = -0.013 * 2 + 0.013 * 2 / 2;
+    cfg->head_fixed = env_kind == SOFTROD_ENV_REACH ? 1 : 0;      // OneEndFixedBC on the head (reach_env.py:126-130)
+    cfg->joint_k = 1e6; cfg->joint_kt = 1e2; cfg->joint_nu = 1e-3;
+    if (env_kind == SOFTROD_ENV_ARM_TWO) {               // build_two_arms (:200-203); three suckers per arm (arm_two_env.py:76-80,126-139)
+        cfg->joint_angle0 = 90.0; cfg->joint_angle_step = 180.0;
+        cfg->n_suckers = 3;
+        for (int j = 0; j < 3; ++j) cfg->sucker_index[j] = cfg->n_elem / (3 * 2) * (2 * j + 1);
+    } else {                                             // build_octopus_muscles (:83-86); CrawlEnv: one sucker per arm (crawl_env.py:146-155)
+        cfg->joint_angle0 = 45.0 / 2; cfg->joint_angle_step = 45.0;
+        cfg->n_suckers = env_kind == SOFTROD_ENV_CRAWL ? 1 : 0;
+        cfg->sucker_index[0] = 0;
+    }
+    cfg->sucker_reduction_ratio = 1.0;
+    cfg->damp_before_constrain = 1;                      // the builds dampen(), the envs constrain() afterwards
+    return SOFTROD_OK;
+}
+
 int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) {
     if (!cfg || !out) return fail(nullptr, SOFTROD_EINVAL, "null argument");
     *out = nullptr;
@@ -650,12 +720,12 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         return fail(nullptr, SOFTROD_EINVAL, "need n_substeps >= 0 and dt > 0");
     if (cfg->math_mode != SOFTROD_MATH_LIBM && cfg->math_mode != SOFTROD_MATH_FAST)
         return fail(nullptr, SOFTROD_EINVAL, "unknown math_mode");
-    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_ARM_PULL_WEIGHT)
+    if (cfg->env_kind < SOFTROD_ENV_NONE || cfg->env_kind > SOFTROD_ENV_REACH)
         return fail(nullptr, SOFTROD_EINVAL, "unknown env_kind");
     if (cfg->features & SOFTROD_FEAT_COOMM_MUSCLES) {
         if (cfg->n_muscles < 1 || cfg->n_muscles > SOFTROD_MAX_MUSCLES || cfg->muscle_fl_degree < 0 ||
             cfg->muscle_fl_degree >= SOFTROD_MAX_FL_COEF || cfg->n_elem > kLanes - 1 ||
-            ((cfg->features & SOFTROD_FEAT_OCTO_HEAD) && cfg->env_kind != SOFTROD_ENV_ARM_PULL_WEIGHT))
+            ((cfg->features & SOFTROD_FEAT_OCTO_HEAD) && cfg->env_kind != SOFTROD_ENV_ARM_PULL_WEIGHT && !mocto_kind(cfg->env_kind)))
             return fail(nullptr, SOFTROD_EINVAL,
                         "COOMM muscles: 1 <= n_muscles <= 4, 0 <= muscle_fl_degree <= 7, one rod of up to 63 elements per env");
         for (int m = 0; m < cfg->n_muscles; ++m)
@@ -667,7 +737,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     }
     if ((cfg->features & SOFTROD_FEAT_COOMM_MUSCLES) && cfg->math_mode == SOFTROD_MATH_FAST &&
         !((cfg->features == SOFTROD_FEATURES_ARM_PUSH && cfg->env_kind == SOFTROD_ENV_ARM_PUSH) ||
-          (cfg->features == SOFTROD_FEATURES_ARM_PULL_WEIGHT && cfg->env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT) ||
+          (cfg->features == SOFTROD_FEATURES_ARM_PULL_WEIGHT && (cfg->env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT || mocto_kind(cfg->env_kind))) ||
           (cfg->features == kFeaturesMuscleRod && cfg->env_kind == SOFTROD_ENV_NONE)))
         return fail(nullptr, SOFTROD_EINVAL,
                     "SOFTROD_MATH_FAST compiles the COOMM muscles for SOFTROD_FEATURES_ARM_PUSH with SOFTROD_ENV_ARM_PUSH "
@@ -712,9 +782,25 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     }
     const bool octo = (cfg->features & SOFTROD_FEAT_OCTO_HEAD) != 0;
     const bool pull = cfg->env_kind == SOFTROD_ENV_ARM_PULL_WEIGHT;
-    if (octo != (cfg->env_kind == SOFTROD_ENV_OCTO_FLAT || pull))
-        return fail(nullptr, SOFTROD_EINVAL, "SOFTROD_FEAT_OCTO_HEAD goes with SOFTROD_ENV_OCTO_FLAT or SOFTROD_ENV_ARM_PULL_WEIGHT");
-    if (octo && !pull) {
+    const bool mocto = mocto_kind(cfg->env_kind);
+    if (octo != (cfg->env_kind == SOFTROD_ENV_OCTO_FLAT || pull || mocto))
+        return fail(nullptr, SOFTROD_EINVAL, "SOFTROD_FEAT_OCTO_HEAD goes with SOFTROD_ENV_OCTO_FLAT, SOFTROD_ENV_ARM_PULL_WEIGHT "
+                                             "or the muscle octopus envs");
+    if (mocto) {
+        // n_arm * 32 slots = 1 or 4 whole waves, so that every slot of the block belongs to an arm
+        if (cfg->features != SOFTROD_FEATURES_ARM_PULL_WEIGHT || cfg->math_mode != SOFTROD_MATH_FAST)
+            return fail(nullptr, SOFTROD_EINVAL, "the muscle octopus exists for SOFTROD_FEATURES_ARM_PULL_WEIGHT and SOFTROD_MATH_FAST only");
+        if (cfg->n_elem < 16 || cfg->n_elem > 31 || (cfg->n_arm != 2 && cfg->n_arm != 8) || cfg->n_muscles != 3)
+            return fail(nullptr, SOFTROD_EINVAL, "the muscle octopus needs 16 <= n_elem <= 31, n_arm = 2 or 8, three muscle layers");
+        const int nk = cfg->env_kind == SOFTROD_ENV_CRAWL ? 3 : (cfg->env_kind == SOFTROD_ENV_ARM_TWO ? 9 : 3 * cfg->n_elem);
+        if (cfg->n_knots != nk || (cfg->env_kind == SOFTROD_ENV_ARM_TWO && cfg->n_suckers != 3) ||
+            (cfg->env_kind == SOFTROD_ENV_CRAWL && cfg->n_suckers != 1) || (cfg->env_kind == SOFTROD_ENV_REACH && cfg->n_suckers != 0))
+            return fail(nullptr, SOFTROD_EINVAL, "the muscle octopus: n_knots (actions per arm) 3 / 9 / 3 n_elem and n_suckers 1 / 3 / 0 "
+                                                 "for CRAWL / ARM_TWO / REACH");
+        if (!(cfg->head_radius > 0.0) || !(cfg->head_density > 0.0) || !(cfg->head_length > 0.0))
+            return fail(nullptr, SOFTROD_EINVAL, "the muscle octopus needs head_radius, head_density, head_length > 0");
+    }
+    if (octo && !pull && !mocto) {
         if (cfg->features != SOFTROD_FEATURES_OCTO_FLAT || cfg->math_mode != SOFTROD_MATH_FAST)
             return fail(nullptr, SOFTROD_EINVAL,
                         "OctoFlat exists for SOFTROD_FEATURES_OCTO_FLAT and SOFTROD_MATH_FAST only");
@@ -728,7 +814,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
             return fail(nullptr, SOFTROD_EINVAL, "OctoFlat needs head_radius > 0 and head_density > 0");
     }
     if (cfg->features & SOFTROD_FEAT_SUCKER_CONSTRAINT) {
-        if ((octo && !pull) || cfg->n_suckers < 1 || cfg->n_suckers > SOFTROD_MAX_SUCKERS)
+        if ((octo && !pull && !mocto) || cfg->n_suckers < (mocto ? 0 : 1) || cfg->n_suckers > SOFTROD_MAX_SUCKERS)
             return fail(nullptr, SOFTROD_EINVAL, "ControllableFixConstraint: 1 <= n_suckers <= 4, not with OctoFlat");
         for (int j = 0; j < cfg->n_suckers; ++j)
             if (cfg->sucker_index[j] < 0 || cfg->sucker_index[j] >= cfg->n_elem)
@@ -757,7 +843,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     const size_t N = (size_t)cfg->n_envs;
     if (octo) {
         h->nw = (cfg->n_arm * h->P.seg + kLanes - 1) / kLanes;
-        h->init_stride = (size_t)cfg->n_arm * 18 + 2;
+        h->init_stride = (size_t)cfg->n_arm * 18 + (mocto ? 3 : 2);
     }
     // A/B switches for profiling and tests.  A product library must not change its kernel tier because of a
     // stray environment variable: they are read only when SOFTROD_DEBUG_SWITCHES=1 is set as well
@@ -836,14 +922,21 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
         if (rc == SOFTROD_OK && hipMemcpy(h->d_params, &h->P, sizeof(RodParams), hipMemcpyHostToDevice) != hipSuccess)
             rc = SOFTROD_EHIP;
     }
-    alloc((void**)&h->d_sucker, (size_t)SOFTROD_MAX_SUCKERS * N * sizeof(double));
+    const size_t NS = N * (size_t)(mocto ? cfg->n_arm : 1);      // SuckerControllers: per env, per ARM of the muscle octopus
+    alloc((void**)&h->d_sucker, (size_t)SOFTROD_MAX_SUCKERS * NS * sizeof(double));
     h->S.sucker = h->d_sucker;
-    alloc((void**)&h->d_sucker_idx, (size_t)SOFTROD_MAX_SUCKERS * N * sizeof(int));
+    alloc((void**)&h->d_sucker_idx, (size_t)SOFTROD_MAX_SUCKERS * NS * sizeof(int));
     h->S.sucker_idx = h->d_sucker_idx;
+    if (mocto) {
+        alloc((void**)&h->d_aux, (size_t)8 * N * sizeof(double));
+        alloc((void**)&h->d_prev_kappa, N * (size_t)cfg->n_arm * (size_t)(cfg->n_elem - 1) * sizeof(float));
+        h->S.aux = h->d_aux;
+        h->S.prev_kappa = h->d_prev_kappa;
+    }
     if (rc == SOFTROD_OK) {
-        std::vector<int> idx((size_t)SOFTROD_MAX_SUCKERS * N, 0);
+        std::vector<int> idx((size_t)SOFTROD_MAX_SUCKERS * NS, 0);
         for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j)
-            for (size_t e = 0; e < N; ++e) idx[(size_t)j * N + e] = cfg->sucker_index[j];
+            for (size_t e = 0; e < NS; ++e) idx[(size_t)j * NS + e] = cfg->sucker_index[j];
         if (hipMemcpy(h->d_sucker_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
             rc = SOFTROD_EHIP;
     }
@@ -855,9 +948,9 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     }
     if (rc == SOFTROD_OK && (cfg->features & SOFTROD_FEAT_SUCKER_CONSTRAINT)) {
         // the controllers are switched on after finalize (arm_push_env.py:222): effective ratio = the configured one
-        std::vector<double> init((size_t)SOFTROD_MAX_SUCKERS * N, 0.0);
+        std::vector<double> init((size_t)SOFTROD_MAX_SUCKERS * NS, 0.0);
         for (int j = 0; j < cfg->n_suckers; ++j)
-            for (size_t e = 0; e < N; ++e) init[(size_t)j * N + e] = cfg->sucker_reduction_ratio;
+            for (size_t e = 0; e < NS; ++e) init[(size_t)j * NS + e] = cfg->sucker_reduction_ratio;
         if (hipMemcpy(h->d_sucker, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
             rc = SOFTROD_EHIP;
     }
@@ -882,12 +975,13 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
 int softrod_reset_octo(softrod_handle* h, const double* arm_start, const double* arm_direction,
                        const double* target, const uint8_t* mask, void* stream) {
     if (!h || !arm_start || !arm_direction || !target) return fail(h, SOFTROD_EINVAL, "null argument");
-    if (!is_flat(h)) return fail(h, SOFTROD_EINVAL, "softrod_reset_octo is for SOFTROD_ENV_OCTO_FLAT");
+    if (!is_flat(h) && !is_mocto(h)) return fail(h, SOFTROD_EINVAL, "softrod_reset_octo is for SOFTROD_ENV_OCTO_FLAT and the muscle octopus envs");
     SR_ON_DEVICE(h);
     SR_HIP(h, hipEventSynchronize(h->ev_reset));
     const int N = h->cfg.n_envs, na = h->cfg.n_arm;
-    const double normal[3] = {0.0, 0.0, 1.0};             // octopus/build.py:82
+    const double normal[3] = {0.0, 0.0, 1.0};             // octopus/build.py:82, build_muscle_octopus.py:92
     double* tgt = h->h_init + (size_t)N * na * 18;
+    const size_t td = is_mocto(h) ? 3 : 2;                // the muscle octopus: three numbers per target
     for (int e = 0; e < N; ++e) {
         if (mask) h->h_mask[e] = mask[e];
         if (mask && !mask[e]) continue;
@@ -895,8 +989,7 @@ int softrod_reset_octo(softrod_handle* h, const double* arm_start, const double*
             const size_t k = (size_t)e * na + a;
             straight_init(h->cfg, arm_start + 3 * k, arm_direction + 3 * k, normal, h->h_init + k * 18);
         }
-        tgt[2 * (size_t)e] = target[2 * (size_t)e];
-        tgt[2 * (size_t)e + 1] = target[2 * (size_t)e + 1];
+        for (size_t i = 0; i < td; ++i) tgt[td * (size_t)e + i] = target[td * (size_t)e + i];
     }
     return upload_and_reset(h, (hipStream_t)stream, mask != nullptr);
 }
@@ -1076,7 +1169,7 @@ int softrod_queue_push_straight(softrod_handle* h, const double* start, const do
 int softrod_queue_push_octo(softrod_handle* h, const double* arm_start, const double* arm_direction,
                             const double* target, const int32_t* counts, int max_count, void* stream) {
     if (!h || !arm_start || !arm_direction || !target) return fail(h, SOFTROD_EINVAL, "null argument");
-    if (!is_flat(h)) return fail(h, SOFTROD_EINVAL, "softrod_queue_push_octo is for SOFTROD_ENV_OCTO_FLAT");
+    if (!is_flat(h) && !is_mocto(h)) return fail(h, SOFTROD_EINVAL, "softrod_queue_push_octo is for SOFTROD_ENV_OCTO_FLAT and the muscle octopus envs");
     SR_ON_DEVICE(h);
     const int rc = queue_begin(h, counts, max_count);
     if (rc != SOFTROD_OK) return rc;
@@ -1089,8 +1182,8 @@ int softrod_queue_push_octo(softrod_handle* h, const double* arm_start, const do
             for (int a = 0; a < na; ++a)
                 straight_init(h->cfg, arm_start + (k * na + a) * 3, arm_direction + (k * na + a) * 3, normal,
                               rec + (size_t)a * 18);
-            rec[(size_t)na * 18] = target[2 * k];
-            rec[(size_t)na * 18 + 1] = target[2 * k + 1];
+            const size_t td = is_mocto(h) ? 3 : 2;
+            for (size_t i = 0; i < td; ++i) rec[(size_t)na * 18 + i] = target[td * k + i];
         }
     return queue_commit(h, (hipStream_t)stream);
 }
@@ -1216,8 +1309,8 @@ int softrod_set_spline_table(softrod_handle* h, const double* breaks, const doub
 // kernels' per-lane material table.  Mirrors straight_rod() of oracle/softrod_oracle.c.
 int softrod_set_radius_profile(softrod_handle* h, const double* radius) {
     if (!h || !radius) return fail(h, SOFTROD_EINVAL, "null argument");
-    if ((is_octo(h) && !is_pull(h)) || h->epl != 1 || h->window_refresh > 0)
-        return fail(h, SOFTROD_EINVAL, "tapered rods: one rod of up to 63 elements per env");
+    if ((is_octo(h) && !is_pull(h) && !is_mocto(h)) || h->epl != 1 || h->window_refresh > 0)
+        return fail(h, SOFTROD_EINVAL, "tapered rods: one rod of up to 63 elements per env, or the muscle octopus' arms");
     if (h->was_reset) return fail(h, SOFTROD_EINVAL, "softrod_set_radius_profile must precede the first reset");
     const softrod_config& c = h->cfg;
     const int n = c.n_elem;
@@ -1225,6 +1318,9 @@ int softrod_set_radius_profile(softrod_handle* h, const double* radius) {
         if (!(radius[k] > 0.0)) return fail(h, SOFTROD_EINVAL, "radii must be positive");
     SR_ON_DEVICE(h);
     constexpr int W = kLanes;
+    // the muscle octopus: every arm is this rod, `seg` slots apart — the table is built for one arm's slots and repeated
+    const int period = is_mocto(h) ? h->P.seg : W;
+    const double ddt = c.damper_time_step > 0.0 ? c.damper_time_step : c.dt;
     std::vector<double> T((size_t)kMatRows * W, 0.0);
     const double rest_len = c.base_length / (double)n;
     std::vector<double> mass((size_t)n + 1, 0.0), bend01((size_t)n), bend2((size_t)n);
@@ -1251,21 +1347,23 @@ int softrod_set_radius_profile(softrod_handle* h, const double* radius) {
     }
     double ms = 0.0;
     for (int k = 0; k <= n; ++k) { T[(size_t)kMatMass * W + k] = mass[(size_t)k]; ms += mass[(size_t)k]; }
-    for (int k = n + 1; k < W; ++k) T[(size_t)kMatMass * W + k] = 1.0;     // finite filler past the rod
+    for (int k = n + 1; k < period; ++k) T[(size_t)kMatMass * W + k] = 1.0;     // finite filler past the rod
     for (int k = 0; k < n; ++k) {          // AnalyticalLinearDamper's per-element coefficients
         double me = 0.5 * (mass[(size_t)k + 1] + mass[(size_t)k]);
         if (k == 0) me += 0.5 * mass[0];
         if (k == n - 1) me += 0.5 * mass[(size_t)n];
-        const double l0 = c.damper_protocol == 1 ? -c.damping_constant * c.dt : -c.damping_constant * c.dt * me * T[(size_t)kMatInvJ0 * W + k];
-        const double l2 = c.damper_protocol == 1 ? -c.damping_constant * c.dt : -c.damping_constant * c.dt * me * T[(size_t)kMatInvJ2 * W + k];
+        const double l0 = c.damper_protocol == 1 ? -c.damping_constant * ddt : -c.damping_constant * ddt * me * T[(size_t)kMatInvJ0 * W + k];
+        const double l2 = c.damper_protocol == 1 ? -c.damping_constant * ddt : -c.damping_constant * ddt * me * T[(size_t)kMatInvJ2 * W + k];
         T[(size_t)kMatDampLog0 * W + k] = l0; T[(size_t)kMatDampLog2 * W + k] = l2;
         T[(size_t)kMatDampR0 * W + k] = std::exp(l0); T[(size_t)kMatDampR2 * W + k] = std::exp(l2);
     }
-    for (int k = n; k < W; ++k) {           // slots past the last element: harmless finite values
+    for (int k = n; k < period; ++k) {      // slots past the last element: harmless finite values
         T[(size_t)kMatInvJ0 * W + k] = 0.0; T[(size_t)kMatInvJ2 * W + k] = 0.0;
         T[(size_t)kMatDampR0 * W + k] = 1.0; T[(size_t)kMatDampR2 * W + k] = 1.0;
         T[(size_t)kMatR0s * W + k] = 1.0; T[(size_t)kMatInvR0s * W + k] = 1.0;
     }
+    for (int row = 0; row < kMatRows; ++row)
+        for (int k = period; k < W; ++k) T[(size_t)row * W + k] = T[(size_t)row * W + (k % period)];
     if (!h->d_mat) SR_HIP(h, hipMalloc((void**)&h->d_mat, T.size() * sizeof(double)));
     SR_HIP(h, hipMemcpy(h->d_mat, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice));
     h->S.mat = h->d_mat;
@@ -1293,6 +1391,9 @@ int softrod_set_muscle_layers(softrod_handle* h, const double* ratio_position, c
             if (!std::isfinite(st)) return fail(h, SOFTROD_EINVAL, "strength must be finite");
             T[((size_t)m * 4 + 3) * W + k] = st;
         }
+    if (is_mocto(h))                        // every arm carries the same layers, `seg` slots apart
+        for (int row = 0; row < SOFTROD_MAX_MUSCLES * 4; ++row)
+            for (int k = h->P.seg; k < W; ++k) T[(size_t)row * W + k] = T[(size_t)row * W + (k % h->P.seg)];
     SR_ON_DEVICE(h);
     SR_HIP(h, hipMemcpy(h->d_mtab, T.data(), T.size() * sizeof(double), hipMemcpyHostToDevice));
     h->muscles_set = true;
@@ -1302,7 +1403,10 @@ int softrod_set_muscle_layers(softrod_handle* h, const double* ratio_position, c
 int softrod_set_action_basis(softrod_handle* h, const double* basis) {
     if (!h || !basis) return fail(h, SOFTROD_EINVAL, "null argument");
     SR_ON_DEVICE(h);
-    const size_t bytes = (size_t)(h->cfg.n_elem - 1) * (is_octo(h) ? h->cfg.n_knots : 7) * sizeof(double);
+    // SOFTROD_ENV_ARM_TWO: [n_elem][3], apply_X = basis @ activation (arm_two_env.py:237-245)
+    if (is_mocto(h) && h->cfg.env_kind != SOFTROD_ENV_ARM_TWO) return fail(h, SOFTROD_EINVAL, "this env interpolates nothing");
+    const size_t bytes = is_mocto(h) ? (size_t)h->cfg.n_elem * 3 * sizeof(double)
+                                     : (size_t)(h->cfg.n_elem - 1) * (is_octo(h) ? h->cfg.n_knots : 7) * sizeof(double);
     SR_HIP(h, hipMemcpy(h->d_basis, basis, bytes, hipMemcpyHostToDevice));
     h->basis_set = true;
     return SOFTROD_OK;
@@ -1485,7 +1589,12 @@ int softrod_observe(softrod_handle* h, const float* prev_action, float* obs, voi
     if (h->cfg.env_kind == SOFTROD_ENV_NONE) return fail(h, SOFTROD_EINVAL, "env_kind NONE has no observation");
     SR_ON_DEVICE(h);
     const dim3 grid((unsigned)h->cfg.n_envs), block(kLanes);
-    if (is_octo(h) && !is_pull(h))
+    if (is_mocto(h)) {
+        // get_state on the resident state (prev_action: the resident copy); like the reference's it moves ArmTwoEnv's _prev_kappa
+        if (prev_action) return fail(h, SOFTROD_EINVAL, "the muscle octopus envs observe with their resident prev_action (pass NULL)");
+        hipLaunchKernelGGL(softrod_mocto_epilogue_kernel, grid, dim3(kLanes * h->nw), 0, (hipStream_t)stream, h->P, h->S, obs,
+                           nullptr, nullptr, nullptr, 0, 0);
+    } else if (is_octo(h) && !is_pull(h))
         hipLaunchKernelGGL(softrod_octo_observe_kernel, grid, dim3(kLanes * h->nw), 0, (hipStream_t)stream,
                            h->P, h->S, prev_action, obs);
     else if (h->epl == 2)
@@ -1503,7 +1612,7 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->n_envs = h->cfg.n_envs;
     out->n_elem = h->cfg.n_elem;
     out->lane_stride = kLanes * h->epl * h->nw;
-    out->arm_stride = is_flat(h) ? h->P.seg : 0;
+    out->arm_stride = (is_flat(h) || is_mocto(h)) ? h->P.seg : 0;
     out->position = h->S.pos;
     out->velocity = h->S.vel;
     out->director = h->S.dir;
@@ -1521,6 +1630,8 @@ int softrod_state_view_get(softrod_handle* h, softrod_state_view* out) {
     out->muscle_activation = h->d_mact;
     out->sucker_index = h->d_sucker_idx;
     out->material = h->d_mat;
+    out->env_aux = h->d_aux;
+    out->prev_kappa = h->d_prev_kappa;
     return SOFTROD_OK;
 }
 
@@ -1574,7 +1685,10 @@ const char* softrod_kernel_tier(softrod_handle* h) {
     const unsigned f = h->cfg.features;
     const int e = h->cfg.env_kind;
     std::string t;
-    if (is_octo(h) && is_pull(h)) {
+    if (is_mocto(h)) {
+        t = std::string("softrod_mocto_action_kernel | softrod_octo_step_kernel<muscle arms,") + std::to_string(h->nw) +
+            (h->nw == 1 ? " wave" : " waves") + ",1 env/wg,taper> | softrod_mocto_epilogue_kernel";
+    } else if (is_octo(h) && is_pull(h)) {
         t = "softrod_octo_step_kernel<ArmPullWeight,1 wave,1 env/wg,taper>";
     } else if (is_octo(h)) {
         if (zup && h->nw == 2 && h->octo_one_wave && h->P.n_arm * h->P.seg == 2 * kLanes && !(h->P.seg & 1))
@@ -1612,7 +1726,7 @@ int softrod_destroy(softrod_handle* h) {
     (void)hipDeviceSynchronize();
     autoreset_release(h);
     void* bufs[] = {h->S.pos, h->S.vel, h->S.dir, h->S.omg, h->S.tan, h->S.time, h->S.bc,
-                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_time_tab, h->d_mat, h->d_sucker, h->d_sucker_idx, h->d_mact, h->d_mtab, h->d_basis, h->d_spline, h->d_init, h->d_mask, h->d_ticket};
+                    h->S.ctrl, h->S.kap, h->S.rkap, h->S.envmem, h->S.prev_action, h->S.head, h->d_params, h->d_state, h->d_time_tab, h->d_mat, h->d_sucker, h->d_sucker_idx, h->d_aux, h->d_prev_kappa, h->d_mact, h->d_mtab, h->d_basis, h->d_spline, h->d_init, h->d_mask, h->d_ticket};
     for (void* p : bufs) (void)hipFree(p);
     if (h->h_init) (void)hipHostFree(h->h_init);
     if (h->h_mask) (void)hipHostFree(h->h_mask);

@@ -409,6 +409,8 @@ __device__ __forceinline__ void dynamic_n(const RodParams& P, const ConstN<EPL>&
         }
         if (F == kRuntimeFeatures || (F & (SOFTROD_FEAT_REST_KAPPA_ACTION | SOFTROD_FEAT_SPLINE_MUSCLE_TORQUES))) {
             L.kap[s][0] = k0; L.kap[s][1] = k1; L.kap[s][2] = k2;
+        } else if constexpr (kMusclesCompiled<F> && (F & SOFTROD_FEAT_OCTO_HEAD) != 0) {
+            L.kap[s][0] = k0;        // rod.kappa[0]: what the muscle octopus envs' get_state reads (softrod_mocto.hpp)
         }
         if (has<F>(P, SOFTROD_FEAT_REST_KAPPA_ACTION)) {
             const double m0 = C.b01[s] * (k0 - L.rk[s][0]), m1 = C.b01[s] * (k1 - L.rk[s][1]),

@@ -94,7 +94,7 @@ struct RodParams {
     double kin_mu[3], stat_mu[3];
     double r0_sqrt_rest_len;         // radius_k = r0 sqrt(l_rest / l_k)  (volume preserving)
     // OctoFlat-v0: n_arm rods per wave, `seg` slots apart (0 = one rod per wave), + rigid head
-    int seg, n_arm, seg_shift, pad1;
+    int seg, n_arm, seg_shift, head_fixed;     // head_fixed: OneEndFixedBC on the rigid body too (reach_env.py:126-130)
     double head_mass, head_invJ[3], head_radius;   // the planar head only ever turns about d3
     double head_center[3], joint_angle0, joint_angle_step;   // Cylinder centre at reset; FixedJoint2Rigid angle of arm a (degrees)
     // SoftArmTracking: the two spline muscles (muscle_torques_with_bspline.py:98-126)
@@ -152,6 +152,9 @@ struct StatePtrs {
     int* sucker_idx;        // [SOFTROD_MAX_SUCKERS][N] SuckerController.index of each sucker (Python indexing)
     double* mact;           // [SOFTROD_MAX_MUSCLES][N][64*EPL] muscle activations per element, or nullptr
     const double* mtab;     // [SOFTROD_MAX_MUSCLES][4][64*EPL] ratio_position x, y, z and strength per element, or nullptr
+    // the muscle octopus envs (softrod_mocto.hpp): `sucker` / `sucker_idx` are [SOFTROD_MAX_SUCKERS][N * n_arm] there
+    double* aux;            // [8][N] target x, y, z; the head's x, y before the step
+    float* prev_kappa;      // [N][n_arm * (n_elem - 1)] ArmTwoEnv._prev_kappa
 };
 
 // ---------------------------------------------------------------------------------
@@ -1114,6 +1117,9 @@ __device__ __forceinline__ void build_const(const RodParams& P, int lane, const 
         double shear01 = P.shear[0], shear2 = P.shear[2], bend01 = P.bend[0], bend2 = P.bend[2];
         double invJ0 = P.invJ[0], invJ2 = P.invJ[2];
         if constexpr (TAPER) {      // CosseratRod.straight_rod with an array of radii: per-element constants
+            // (the table is one wave wide; the arms of a multi-wave env repeat it: softrod_set_radius_profile)
+            const int wide = raw;
+            const int raw = wide & (W - 1);
             const int nx = raw + 1 < W ? raw + 1 : raw;
             mass = node_valid ? mat[kMatMass * W + raw] : 1.0;
             mass_next = (idx + 1 <= n) ? mat[kMatMass * W + nx] : 1.0;

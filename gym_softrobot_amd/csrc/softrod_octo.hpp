@@ -54,6 +54,10 @@ __device__ __forceinline__ void store_head(const StatePtrs& S, size_t N, int env
     for (int i = 0; i < 9; ++i) S.head[(size_t)(6 + i) * N + env] = H.Q[i];
 }
 
+}  // namespace softrod
+#include "softrod_mocto.hpp"
+namespace softrod {
+
 // Kinematic half/full step of the rigid body followed by
 // BodyBoundaryCondition.compute_contrain_values (constraint.py:41-58): z held, d3 = e_z,
 // d1 and d2 renormalised in the plane.  compute_constrain_rates (constraint.py:60-85) keeps
@@ -237,10 +241,12 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
         }
     };
     bool live = active;
+    // the muscle octopus envs (softrod_mocto.hpp): this kernel steps the body only; set_action has run, get_state / reward follow
+    const bool mocto = kMusclesCompiled<F> && is_mocto_env(P.env_kind);
     if (epilogue && S.skip && S.skip[env] && active) {   // reset by the auto-reset pass of this env.step
         if constexpr (EPB == 1) {
             __syncthreads();                   // every thread has read the flag
-            if (tid == 0) S.skip[env] = 0;
+            if (tid == 0 && !mocto) S.skip[env] = 0;       // (mocto: the epilogue kernel clears it)
             return;
         }
         live = false;
@@ -294,10 +300,24 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
 #pragma unroll
     for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) { B.keep[j] = 1.0; B.snode[j] = -1; B.selem[j] = -1; }
     if constexpr (kMuscleArm) {
-        load_suckers<F>(P, S, N, env, B);
-        if (live) {
-            set_action_n<F, kRuntimeEnv, 1>(P, S, NR, row, lane, actions, A, B, L);
-            if (epilogue) push_store_prev_com<F, kRuntimeEnv, 1>(P, S, NR, row, lane, L, n_sub);
+        if (mocto) {
+            // every arm has its own SuckerControllers: rows [j][env * n_arm + arm]; the targets as slots of the env's block
+            const size_t NA = N * (size_t)P.n_arm, ai = (size_t)env * P.n_arm + (arm_ok ? arm : 0);
+#pragma unroll
+            for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) {
+                if (j < P.n_suckers && arm_ok) {
+                    B.keep[j] = 1.0 - S.sucker[(size_t)j * NA + ai];
+                    sucker_targets(P, S.sucker_idx[(size_t)j * NA + ai], B.snode[j], B.selem[j]);
+                    B.snode[j] += arm * P.seg;
+                    B.selem[j] += arm * P.seg;
+                }
+            }
+        } else {
+            load_suckers<F>(P, S, N, env, B);
+            if (live) {
+                set_action_n<F, kRuntimeEnv, 1>(P, S, NR, row, lane, actions, A, B, L);
+                if (epilogue) push_store_prev_com<F, kRuntimeEnv, 1>(P, S, NR, row, lane, L, n_sub);
+            }
         }
     }
     ConstN<1> C;
@@ -419,6 +439,7 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
     double hk = P.half_dt;
     auto head_step = [&]() {
         if constexpr ((SOFTROD_OCTO_DIAG & 2) != 0) return;
+        if constexpr (kMuscleArm) { if (P.head_fixed) return; }      // OneEndFixedBC: the head stays what the reset made it
         if constexpr ((SOFTROD_OCTO_BASE_MASK & 2) != 0) { if (!base) return; }
         double tot[3];
 #pragma unroll
@@ -514,6 +535,11 @@ softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __re
             S.time[env] = time;
             store_head(S, N, env, H);
         }
+    }
+    if constexpr (kMusclesCompiled<F>) {
+        // rod.kappa[0] as this launch's last force evaluation cached it: what the muscle octopus envs' get_state reads
+        if (mocto && live && n_sub > 0) S.kap[(size_t)row * kLanes + lane] = L.kap[0][0];
+        if (mocto) return;
     }
     if (!epilogue) return;
     if constexpr (kMusclesCompiled<F>) {
@@ -659,6 +685,20 @@ __device__ __forceinline__ void octo_reset_env(const RodParams& P, const StatePt
             S.sucker_idx[env] = P.sucker_index[0];
             S.sucker[env] = P.sucker_ratio0;
         }
+        if (is_mocto_env(P.env_kind)) {
+            // fresh SuckerControllers on every arm (crawl_env.py:146-155: index, reduction_ratio 1.0; turned on after
+            // finalize), a straight arm's kappa
+            const int a = tid >> P.seg_shift;
+            if (r == 0 && a < P.n_arm) {
+                const size_t NA = N * (size_t)P.n_arm, ai = (size_t)env * P.n_arm + a;
+#pragma unroll
+                for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) {
+                    S.sucker_idx[(size_t)j * NA + ai] = P.sucker_index[j];
+                    S.sucker[(size_t)j * NA + ai] = (j < P.n_suckers) ? P.sucker_ratio0 : 0.0;
+                }
+            }
+            S.kap[m] = 0.0;
+        }
     }
     const double Q0[9] = {0.0, 1.0, 0.0, -1.0, 0.0, 0.0, 0.0, 0.0, 1.0};
 #pragma unroll
@@ -669,6 +709,13 @@ __device__ __forceinline__ void octo_reset_env(const RodParams& P, const StatePt
         store_head(S, N, env, H);
         S.head[(size_t)18 * N + env] = target[0];
         S.head[(size_t)19 * N + env] = target[1];
+        if (is_mocto_env(P.env_kind)) {      // the env's target (three numbers: ReachEnv's is a point in space)
+            S.aux[(size_t)0 * N + env] = target[0];
+            S.aux[(size_t)1 * N + env] = target[1];
+            S.aux[(size_t)2 * N + env] = target[2];
+            S.aux[(size_t)3 * N + env] = H.x[0];
+            S.aux[(size_t)4 * N + env] = H.x[1];
+        }
     }
 }
 
@@ -678,7 +725,7 @@ softrod_octo_reset_kernel(const RodParams P, const StatePtrs S, const OctoResetA
     if (A.mask && !A.mask[env]) return;
     LaneN<1> L;
     HeadState H;
-    octo_reset_env(P, S, env, A.init + (size_t)env * P.n_arm * 18, A.target + 2 * (size_t)env, L, H);
+    octo_reset_env(P, S, env, A.init + (size_t)env * P.n_arm * 18, A.target + (is_mocto_env(P.env_kind) ? 3 : 2) * (size_t)env, L, H);
 }
 
 // Device-side auto-reset pass for OctoFlat (see softrod_autoreset_kernel): the queue record
@@ -697,14 +744,18 @@ softrod_octo_autoreset_kernel(const RodParams P, const StatePtrs S, float* __res
         return;
     }
     const double* in = S.queue + ((size_t)(k % S.q_depth) * N + env) * (size_t)S.q_record;
-    const double tgt[2] = {in[P.n_arm * 18], in[P.n_arm * 18 + 1]};
+    const bool mocto = is_mocto_env(P.env_kind);
+    const double tgt[3] = {in[P.n_arm * 18], in[P.n_arm * 18 + 1], mocto ? in[P.n_arm * 18 + 2] : 0.0};
     LaneN<1> L;
     HeadState H;
     octo_reset_env(P, S, env, in, tgt, L, H);
     const bool push = is_push_env(P.env_kind);
-    const int od = push ? env_obs_dim(P) : octo_obs_dim(P);
+    const int od = push ? env_obs_dim(P) : (mocto ? mocto_obs_dim(P) : octo_obs_dim(P));
     float* o = out_row(obs, env, od, pack);
-    if (push) {
+    if (mocto) {
+        __syncthreads();                       // thread 0's target rows are there (get_state reads them)
+        mocto_write_obs(P, S, env, tid, L.x[0], L.v[0], 0.0, H, o);
+    } else if (push) {
         float pa[2] = {S.prev_action[7 * (size_t)env], S.prev_action[7 * (size_t)env + 1]};
         (void)push_get_state_n<1>(P, tid & 63, L, pa, o, false);
     } else

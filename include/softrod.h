@@ -162,6 +162,12 @@ enum softrod_feature {
 #define SOFTROD_ENV_ARM_PULL_WEIGHT 7 /* octopus/arm_push_env.py:516-618 ArmPullWeightEnv (OctoArmPullWeight-v0): the same
                                         arm and step(), joined to a rigid Cylinder "weight" by FixedJoint2Rigid; with
                                         SOFTROD_FEATURES_ARM_PULL_WEIGHT (parity unpinned: COOMM)                     */
+/* The muscle octopus (octopus/build_muscle_octopus.py): n_arm tapered 20-element arms with COOMM muscle layers joined to a
+ * rigid head, SOFTROD_FEATURES_ARM_PULL_WEIGHT's feature set on several arms (parity unpinned: COOMM).  Their set_action /
+ * get_state / step live in two small kernels either side of the step kernel (csrc/softrod_mocto.hpp). */
+#define SOFTROD_ENV_CRAWL 8          /* octopus/crawl_env.py:175-318 CrawlEnv (OctoCrawl-v0): 8 arms, one sucker each      */
+#define SOFTROD_ENV_ARM_TWO 9        /* octopus/arm_two_env.py:166-343 ArmTwoEnv (OctoArmTwo-v0): 2 arms, 3 suckers each   */
+#define SOFTROD_ENV_REACH 10         /* octopus/reach_env.py:150-290 ReachEnv (OctoReach-v0): 8 arms, head held            */
 
 /* math_mode (HIP library only; the oracle always uses libm). */
 #define SOFTROD_MATH_LIBM 0 /* sqrt/sin/cos/acos/pow evaluated as written   */
@@ -273,7 +279,8 @@ typedef struct softrod_config {
                                  1 = |nu_m| like a longitudinal muscle                                      */
     int32_t arm_push_mode;    /* ArmPushEnv(mode=...): 0 "discrete" (OctoArmPush-v0), 1 "continuous" (-v1)
                                  arm_push_env.py:90-130                                                    */
-    int32_t reserved3;
+    int32_t head_fixed;       /* 1: the rigid body ALSO carries OneEndFixedBC (reach_env.py:126-130): position, directors
+                                 held at their initial values, velocities at zero — the head does not move          */
     double muscle_fl_coef[8]; /* fl(l) = sum_k coef[k] l^k, clipped at 0 from below; the cubic of the paper,
                                  max{3.06 l^3 - 13.64 l^2 + 18.01 l - 6.44, 0}: (-6.44, 18.01, -13.64, 3.06)      */
     /* ---- the rigid body of the SOFTROD_FEAT_OCTO_HEAD sets, as Cylinder(start, direction = e_z, normal = e_y,
@@ -283,7 +290,11 @@ typedef struct softrod_config {
     double head_length;       /* Cylinder base_length.  FlatEnv: 2 r0; ArmPullWeightEnv: 2 * radius_base = 0.024  */
     double joint_angle0;      /* FixedJoint2Rigid(angle=...) of arm a, degrees: joint_angle0 + a * joint_angle_step. */
     double joint_angle_step;  /* FlatEnv: 0, 360 / n_arm (octopus/build.py:73-74,117-132); ArmPullWeightEnv: 0, 0
-                                 (arm_push_env.py:585-587)                                                         */
+                                 (arm_push_env.py:585-587); build_octopus_muscles: 22.5, 45; build_two_arms: 90, 180
+                                 (build_muscle_octopus.py:85-86,202-203)                                           */
+    double damper_time_step;  /* AnalyticalLinearDamper(time_step=...) when it is NOT the stepper's dt: the muscle octopus
+                                 registers its dampers with 7e-5 (build_muscle_octopus.py:101-106,217-222) and is stepped
+                                 with 5e-5 (crawl_env.py:63).  0 = dt.                                              */
 } softrod_config;
 
 #define SOFTROD_MAX_SUCKERS 4
@@ -372,6 +383,14 @@ typedef struct softrod_state_view {
     double* material; /* [SOFTROD_MATERIAL_ROWS][lane_stride]  per-node / per-element constants of
                          a TAPERED rod (softrod_set_radius_profile), shared by all envs; NULL
                          for a uniform rod.  Read-only for the caller.                     */
+    /* ---- the muscle octopus envs (SOFTROD_ENV_CRAWL / _ARM_TWO / _REACH); NULL otherwise.  Their sucker_ratio /
+     *      sucker_index rows are [SOFTROD_MAX_SUCKERS][n_envs * n_arm] (arm a of env e at e * n_arm + a) ---- */
+    double* env_aux;  /* [8][n_envs]  rows 0-2 the env's target (crawl_env.py:172, arm_two_env.py:160: (5, 0);
+                         reach_env.py:141-143: np_random.random(3) * sum(rest_lengths)), rows 3-4 the head's x, y before
+                         the step (`xposbefore`, crawl_env.py:248).  (rod.kappa[0] of get_state, crawl_env.py:178,
+                         is row 0 of `kappa`: what the last substep's force evaluation cached; zeros after a reset)  */
+    float* prev_kappa; /* [n_envs][n_arm * (n_elem - 1)]  ArmTwoEnv._prev_kappa (arm_two_env.py:103,196-203): float32,
+                         NOT cleared by reset() — it belongs to the env object, as in the reference            */
 } softrod_state_view;
 
 /* Fill `cfg` with SoftPendulumEnv.__init__ defaults (soft_pendulum.py:59-78)
@@ -434,6 +453,16 @@ int softrod_set_muscle_layers(softrod_handle* h, const double* ratio_position, c
  * the sucker at reduction_ratio 0.9, a Cylinder of radius 0.015 / length 0.024 / density 700 joined to node 0 by
  * FixedJoint2Rigid(k = 1e6, nu = 1e-2, kt = 1, angle = 0, radius = 0.015) and held by BodyBoundaryCondition.      */
 int softrod_config_arm_pull_weight(softrod_config* cfg, int n_envs);
+
+/* The muscle octopus envs: env_kind = SOFTROD_ENV_CRAWL (CrawlEnv.__init__ / reset, crawl_env.py:61-174 over
+ * build_octopus_muscles, build_muscle_octopus.py:66-179), SOFTROD_ENV_ARM_TWO (arm_two_env.py:55-164 over build_two_arms,
+ * :182-291) or SOFTROD_ENV_REACH (reach_env.py:53-148).  Arms: 20 elements, 0.25 long, density 1000, E 1.5e4, G 1e4,
+ * radii linspace(0.013, 0.0042, n) through softrod_set_radius_profile, layers through softrod_set_muscle_layers (both
+ * once: every arm is the same rod); head Cylinder(start (0, 0, -0.026), e_z, e_y, 0.026, 0.04, 50); joints k 1e6, kt 1e2,
+ * nu 1e-3; dampers 0.2 * 1e-2 at time_step 7e-5; dt 5e-5, 800 substeps per env.step.  Resets go through softrod_reset_octo
+ * / softrod_queue_push_octo (arm frames from the caller, build_muscle_octopus.py:87-93; `target`: the first two numbers
+ * of the env's target — ReachEnv's third through softrod_state_view.env_aux row 2).                               */
+int softrod_config_muscle_octopus(softrod_config* cfg, int n_envs, int env_kind);
 
 /* Same as softrod_config_arm_single for ArmPushEnv (octopus/arm_push_env.py:65-224): the 40-element arm tapered
  * 12:1 (the radii themselves go through softrod_set_radius_profile), damper, one sucker, three muscle layers

@@ -24,6 +24,7 @@ typedef struct rigid_head {
     double mass, J[3], invJ[3];
     double f_ext[3], t_ext[3];
     double fixed_z;
+    double fixed_x[3], fixed_Q[3][3];      /* OneEndFixedBC on the rigid body (reach_env.py:126-130) */
 } rigid_head;
 
 typedef struct oracle_octo {
@@ -58,6 +59,7 @@ static void cylinder_init(rigid_head* h, const double start[3], const double dir
     h->Q[1][1] = direction[2] * normal[0] - direction[0] * normal[2];
     h->Q[1][2] = direction[0] * normal[1] - direction[1] * normal[0];
     h->fixed_z = h->x[2];
+    for (int i = 0; i < 3; ++i) { h->fixed_x[i] = h->x[i]; for (int j = 0; j < 3; ++j) h->fixed_Q[i][j] = h->Q[i][j]; }
 }
 
 static void head_kinematic(rigid_head* h, double prefac, double eps)
@@ -104,6 +106,15 @@ static void head_constrain_rates(rigid_head* h)
     h->v[2] = 0.0;
     h->w[0] = 0.0; h->w[1] = 0.0;
 }
+
+/* OneEndFixedBC(constrained_position_idx=(0,), constrained_director_idx=(0,)) registered on the rigid body AFTER its
+ * BodyBoundaryCondition (reach_env.py:126-130): position[..., 0] and directors[..., 0] back to their finalize() values,
+ * velocity[..., 0] = omega[..., 0] = 0 (pyelastica's OneEndFixedBC, recalled) */
+static void head_fixed_values(rigid_head* h)
+{
+    for (int i = 0; i < 3; ++i) { h->x[i] = h->fixed_x[i]; for (int j = 0; j < 3; ++j) h->Q[i][j] = h->fixed_Q[i][j]; }
+}
+static void head_fixed_rates(rigid_head* h) { for (int i = 0; i < 3; ++i) { h->v[i] = 0.0; h->w[i] = 0.0; } }
 
 /* FixedJoint2Rigid.apply_forces + apply_torques, joint.py:48-123,125-219, for the
  * connection (first_rod = head, idx -1 ; second_rod = arm, idx 0), octopus/build.py:117-132 */
@@ -176,6 +187,7 @@ static void octo_substep(oracle_octo* o)
     head_kinematic(&o->head, 0.5 * dt, o->cfg.eps_rot_axis);
     if (o->cfg.time_two_half_adds) o->time += 0.5 * dt;
     head_constrain_values(&o->head);
+    if (o->cfg.head_fixed) head_fixed_values(&o->head);
     for (int a = 0; a < na; ++a) { compute_internal_forces(o->arm[a]); compute_internal_torques(o->arm[a]); }
     /* synchronize: joints, gravity, contact (registration order); with the switch
      * contact_before_forcing the contact runs before the forcing group: joints, contact, gravity —
@@ -189,6 +201,7 @@ static void octo_substep(oracle_octo* o)
     for (int a = 0; a < na; ++a) dynamic_step(o->arm[a], dt);
     head_dynamic(&o->head, dt);
     head_constrain_rates(&o->head);
+    if (o->cfg.head_fixed) head_fixed_rates(&o->head);
     /* the arms' own constraints (ControllableFixConstraint of the muscle arms, arm_push_env.py:591-599; none in
      * FlatEnv) and dampers, in registration order (damp_before_constrain: dampen() is registered first there) */
     for (int a = 0; a < na; ++a) {
@@ -199,6 +212,7 @@ static void octo_substep(oracle_octo* o)
     head_kinematic(&o->head, 0.5 * dt, o->cfg.eps_rot_axis);
     o->time += o->cfg.time_two_half_adds ? 0.5 * dt : dt;
     head_constrain_values(&o->head);
+    if (o->cfg.head_fixed) head_fixed_values(&o->head);
     for (int a = 0; a < na; ++a) {
         oracle_rod* r = o->arm[a];
         for (int i = 0; i < 3; ++i) {
@@ -286,8 +300,9 @@ static void octo_get_state(const oracle_octo* o, float* individual, float* share
 oracle_octo* oracle_octo_create(const softrod_config* cfg)
 {
     if (!cfg || cfg->struct_size != sizeof(softrod_config)) return NULL;
+    const int mocto = cfg->env_kind == SOFTROD_ENV_CRAWL || cfg->env_kind == SOFTROD_ENV_ARM_TWO || cfg->env_kind == SOFTROD_ENV_REACH;
     if (cfg->n_arm < 1 || cfg->n_arm > OCTO_MAX_ARM || cfg->n_knots < 1 ||
-        cfg->n_arm * cfg->n_knots > 3 * OCTO_MAX_ARM) return NULL;
+        (!mocto && cfg->n_arm * cfg->n_knots > 3 * OCTO_MAX_ARM)) return NULL;
     oracle_octo* o = (oracle_octo*)calloc(1, sizeof(oracle_octo));
     if (!o) return NULL;
     o->cfg = *cfg;
@@ -500,4 +515,48 @@ void oracle_env_step_pull(oracle_octo* o, const float* action, float* obs, doubl
     for (int s = 0; s < o->cfg.n_substeps; ++s) octo_substep(o);
     r->time = o->time;
     push_epilogue(r, prev_cm, obs, reward, terminated, truncated);
+}
+
+
+/* ------------------------------------------------------------------------- */
+/* The muscle octopus (octopus/build_muscle_octopus.py): build_octopus_muscles  */
+/* (:66-179) / build_two_arms (:182-291) under CrawlEnv / ArmTwoEnv / ReachEnv. */
+/* The body only: set_action / get_state / step's bookkeeping are NumPy in      */
+/* tests/oracle_backend.py, line by line after the env files.  PARITY UNPINNED  */
+/* (the COOMM muscle law; softrod_oracle.c apply_muscles).                      */
+/* ------------------------------------------------------------------------- */
+/* arm_pos / arm_dir [n_arm][3]: Rot.from_euler("z", angle, degrees=True).apply(...) of :87-93, by the caller; normal e_z;
+ * Cylinder((0, 0, -2 r0), e_z, e_y, 2 r0, head_radius, head_density) (:108-114) as head_center / head_length;
+ * FixedJoint2Rigid(angle=angles[arm_i]) (:127-141): joint_angle0 + a * joint_angle_step; fresh muscle objects and
+ * SuckerControllers (crawl_env.py:146-155: index, reduction_ratio 1.0, turned on after finalize) */
+void oracle_mocto_reset(oracle_octo* o, const double* arm_pos, const double* arm_dir)
+{
+    const softrod_config* c = &o->cfg;
+    const double normal[3] = { 0.0, 0.0, 1.0 };
+    for (int a = 0; a < o->n_arm; ++a) {
+        oracle_rod* r = o->arm[a];
+        o->angle[a] = c->joint_angle0 + c->joint_angle_step * (double)a;
+        oracle_reset_straight(r, arm_pos + 3 * a, arm_dir + 3 * a, normal);
+        for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) oracle_apply_activation(r, m, 0.0);
+        for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) {
+            r->sucker_index[j] = c->sucker_index[j];
+            r->sucker_ratio[j] = (j < c->n_suckers) ? c->sucker_reduction_ratio : 0.0;
+        }
+        r->time = 0.0;
+    }
+    const double hd[3] = { 0.0, 0.0, 1.0 }, hn[3] = { 0.0, 1.0, 0.0 };
+    const double hs[3] = { c->head_center[0] - hd[0] * c->head_length / 2, c->head_center[1] - hd[1] * c->head_length / 2,
+                           c->head_center[2] - hd[2] * c->head_length / 2 };
+    cylinder_init(&o->head, hs, hd, hn, c->head_length, c->head_radius, c->head_density);
+    head_constrain_values(&o->head);
+    head_constrain_rates(&o->head);
+    if (c->head_fixed) { head_fixed_values(&o->head); head_fixed_rates(&o->head); }
+    o->time = 0.0;
+}
+
+/* one env.step's stepping (crawl_env.py:251-253): n_substeps of the whole body */
+void oracle_mocto_step(oracle_octo* o)
+{
+    for (int s = 0; s < o->cfg.n_substeps; ++s) octo_substep(o);
+    for (int a = 0; a < o->n_arm; ++a) o->arm[a]->time = o->time;
 }

@@ -106,6 +106,9 @@ def _load(omp) -> C.CDLL:
     lib.oracle_forcing_probe.argtypes = [C.c_void_p, C.c_double]
     lib.oracle_set_muscle_layers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.oracle_apply_activation.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.oracle_apply_activation_array.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.oracle_mocto_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_mocto_step.argtypes = [C.c_void_p]
     lib.oracle_muscle_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.oracle_observe_push.argtypes = [C.c_void_p, C.c_void_p]
     lib.oracle_reset_push.argtypes = [C.c_void_p, C.c_void_p]
@@ -134,7 +137,7 @@ _SHAPES = {
     "prev_action2": lambda n: (2,), "prev_action": lambda n: (1,), "fixed_pos": lambda n: (3,),
     "fixed_dir": lambda n: (3, 3), "voronoi_dilatation": lambda n: (n - 1,),
     "muscle_force": lambda n: (4, n), "muscle_length": lambda n: (4, n), "muscle_activation": lambda n: (4, n),
-    "sucker_index": lambda n: (4,), "prev_action_push": lambda n: (2,),
+    "sucker_index": lambda n: (4,), "sucker_ratio": lambda n: (4,), "prev_action_push": lambda n: (2,),
 }
 
 
@@ -381,6 +384,26 @@ class _ArmView:
     get = OracleRod.get
     set = OracleRod.set
 
+    def apply_activation(self, m: int, activation) -> None:
+        """MuscleForce.apply_activation: a scalar is broadcast, an array taken per element."""
+        if np.ndim(activation) == 0:
+            self._lib.oracle_apply_activation(self._h, int(m), float(activation))
+        else:
+            a = np.ascontiguousarray(activation, np.float64).reshape(self.n)
+            self._lib.oracle_apply_activation_array(self._h, int(m), a.ctypes.data)
+
+    def set_sucker(self, j: int, index=None, reduction_ratio=None) -> None:
+        """SuckerController j of this arm: .index and / or .reduction_ratio."""
+        if index is not None:
+            idx = self.get("sucker_index")
+            idx[j] = int(index)
+            self.set("sucker_index", idx)
+        if reduction_ratio is not None:
+            r = self.get("sucker_ratio")
+            r[j] = float(reduction_ratio)
+            a = np.ascontiguousarray(r, np.float64)
+            self._lib.oracle_set_sucker_ratio(self._h, a.ctypes.data)
+
 
 class OracleOcto:
     """OctoFlat-v0 (8 arms + rigid head) stepped by the C oracle (octoflat_oracle.inc.c)."""
@@ -481,6 +504,27 @@ class OracleOcto:
         self._lib.oracle_env_step_pull(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, term.ctypes.data,
                                        trunc.ctypes.data)
         return obs, float(rew[0]), bool(term[0]), bool(trunc[0])
+
+    # -- the muscle octopus (CrawlEnv / ArmTwoEnv / ReachEnv): the body; the env code is tests/oracle_backend.py ----
+    def mocto_setup(self, radius, ratio_position, strength) -> None:
+        """Every arm is the same rod: build_arm's radii (build_muscle_octopus.py:60-62) and create_es_muscle_layers."""
+        a = np.ascontiguousarray(radius, np.float64).reshape(self.n)
+        m = int(self.cfg.n_muscles)
+        rp = np.ascontiguousarray(ratio_position, np.float64).reshape(m, 3, self.n)
+        st = np.ascontiguousarray(strength, np.float64).reshape(m, self.n)
+        for k in range(self.n_arm):
+            arm = self._lib.oracle_octo_arm(self._h, k)
+            self._lib.oracle_set_radius_profile(arm, a.ctypes.data)
+            self._lib.oracle_set_muscle_layers(arm, rp.ctypes.data, st.ctypes.data)
+
+    def reset_mocto(self) -> None:
+        from gym_softrobot_amd import _capi
+
+        pos, dirs, _ = _capi.muscle_octopus_arm_frames(int(self.cfg.env_kind), float(self.cfg.head_radius))
+        self._lib.oracle_mocto_reset(self._h, pos.ctypes.data, dirs.ctypes.data)
+
+    def mocto_step(self) -> None:
+        self._lib.oracle_mocto_step(self._h)
 
     def set_target(self, target) -> None:
         t = np.ascontiguousarray(target, np.float64).reshape(2)

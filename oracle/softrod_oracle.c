@@ -136,6 +136,10 @@ typedef struct oracle_rod {
 /* CosseratRod.straight_rod -> elastica/rod/factory_function.py allocate()    */
 /* call site: build.py:54-61                                                   */
 /* ------------------------------------------------------------------------- */
+/* AnalyticalLinearDamper(time_step=...): the stepper's dt unless the build hands the damper another one
+ * (build_muscle_octopus.py:101-106: 7e-5 under a stepper run at 5e-5, crawl_env.py:63) */
+static double damper_dt(const softrod_config* c) { return c->damper_time_step > 0.0 ? c->damper_time_step : c->dt; }
+
 static void straight_rod(oracle_rod* r, const double start[3],
                          const double direction[3], const double normal_in[3])
 {
@@ -207,13 +211,13 @@ static void straight_rod(oracle_rod* r, const double start[3],
     }
     /* AnalyticalLinearDamper.__init__ (elastica/dissipation.py), build.py:108-113.
      * `damping_constant=` keyword -> per-unit-mass protocol. */
-    r->damp_t = exp(-c->damping_constant * c->dt);
+    r->damp_t = exp(-c->damping_constant * damper_dt(c));
     for (int k = 0; k < n; ++k) {
         double me = 0.5 * (r->mass[k + 1] + r->mass[k]);
         if (k == 0) me += 0.5 * r->mass[0];
         if (k == n - 1) me += 0.5 * r->mass[n];
         for (int i = 0; i < 3; ++i)     /* damper_protocol 1: `uniform_damping_constant=`, exp(-nu dt) on every rate */
-            r->damp_r[i][k] = c->damper_protocol == 1 ? r->damp_t : exp(-c->damping_constant * c->dt * me * r->invJ[i][k]);
+            r->damp_r[i][k] = c->damper_protocol == 1 ? r->damp_t : exp(-c->damping_constant * damper_dt(c) * me * r->invJ[i][k]);
     }
     /* constraint targets: ConstraintBase is handed position[..., idx] and
      * directors[..., idx] at finalize (build.py:81-85) */
@@ -1275,6 +1279,7 @@ int oracle_get(const oracle_rod* r, const char* name, double* out)
     if (!strcmp(name, "muscle_length")) { for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) for (int k = 0; k < n; ++k) out[m * n + k] = r->m_length[m][k]; return SOFTROD_MAX_MUSCLES * n; }
     if (!strcmp(name, "muscle_activation")) { for (int m = 0; m < SOFTROD_MAX_MUSCLES; ++m) for (int k = 0; k < n; ++k) out[m * n + k] = r->m_act[m][k]; return SOFTROD_MAX_MUSCLES * n; }
     if (!strcmp(name, "sucker_index")) { for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) out[j] = (double)r->sucker_index[j]; return SOFTROD_MAX_SUCKERS; }
+    if (!strcmp(name, "sucker_ratio")) { for (int j = 0; j < SOFTROD_MAX_SUCKERS; ++j) out[j] = r->sucker_ratio[j]; return SOFTROD_MAX_SUCKERS; }
     if (!strcmp(name, "rest_kappa")) COPY3X(rest_kappa, n - 1);
     if (!strcmp(name, "radius")) { for (int k = 0; k < n; ++k) out[k] = r->radius[k]; return n; }
     if (!strcmp(name, "f_ext")) COPY3X(f_ext, n + 1);
@@ -1476,6 +1481,11 @@ void oracle_set_muscle_layers(oracle_rod* r, const double* ratio_position, const
 void oracle_apply_activation(oracle_rod* r, int m, double activation)
 {
     for (int k = 0; k < r->n; ++k) r->m_act[m][k] = activation;
+}
+/* ... and an array is taken element by element (arm_two_env.py:246-248, reach_env.py:176-179) */
+void oracle_apply_activation_array(oracle_rod* r, int m, const double* activation)
+{
+    for (int k = 0; k < r->n; ++k) r->m_act[m][k] = activation[k];
 }
 
 /* test probe: ApplyMuscles on the current caches (sigma, kappa, radius, tangents, dilatations as last

@@ -23,11 +23,20 @@ class OracleBackend:
         self.issoftarm = cfg.env_kind == _capi.ENV_SOFT_ARM
         self.ispush = cfg.env_kind == _capi.ENV_ARM_PUSH
         self.ispull = cfg.env_kind == _capi.ENV_ARM_PULL_WEIGHT
+        self.ismocto = int(cfg.env_kind) in _capi.MUSCLE_OCTOPUS_ENVS      # CrawlEnv / ArmTwoEnv / ReachEnv (tests/oracle_mocto.py)
         # softrod_state_view.control: SoftArmTracking keeps tick and the target there
         self._ctrl = torch.zeros((4, int(cfg.n_envs)), dtype=torch.float64)
         self.action_dim = _capi.config_action_dim(cfg)
         self.obs_dim = _capi.config_obs_dim(cfg)
-        if self.isocto or self.ispull:
+        if self.ismocto:
+            try:
+                from tests.oracle_mocto import MuscleOctopusOracleEnv
+            except ImportError:                     # imported with tests/ itself on the path
+                from oracle_mocto import MuscleOctopusOracleEnv
+
+            self.rods = [MuscleOctopusOracleEnv(self.cfg) for _ in range(self.n_envs)]
+            self._octo_obs = [None] * self.n_envs
+        elif self.isocto or self.ispull:
             self.rods = [oracle_c.OracleOcto(self.cfg) for _ in range(self.n_envs)]
             self._octo_obs = [None] * self.n_envs
         else:
@@ -42,21 +51,23 @@ class OracleBackend:
 
     def set_radius_profile(self, radius):
         self._radius = np.asarray(radius, np.float64).copy()
-        if self.ispull:
+        if self.ispull or self.ismocto:
             return                      # handed over together with the layers (OracleOcto.pull_setup)
         for r in self.rods:
             r.set_radius_profile(radius)
 
     def set_muscle_layers(self, ratio_position, strength):
         for r in self.rods:
-            if self.ispull:
+            if self.ismocto:
+                r.body.mocto_setup(self._radius, ratio_position, strength)
+            elif self.ispull:
                 r.pull_setup(self._radius, ratio_position, strength)
             else:
                 r.set_muscle_layers(ratio_position, strength)
 
     def state(self):
         st = {"time": torch.tensor([r.time for r in self.rods], dtype=torch.float64), "control": self._ctrl}
-        if not self.isocto:       # softrod_state_view.bc_targets: fixed_position[3], fixed_directors[9] per env
+        if not self.isocto and not self.ismocto:       # softrod_state_view.bc_targets: fixed_position[3], fixed_directors[9] per env
             bc = np.stack([np.concatenate([r.get("fixed_pos"), r.get("fixed_dir").ravel()]) for r in self.rods], axis=1)
             st["bc_targets"] = torch.from_numpy(bc)
             if self.is3d:         # MovingBaseController position x, y; velocity x, y
@@ -120,7 +131,7 @@ class OracleBackend:
                     for i in range(self.n_envs)], counts)
 
     def queue_push_octo(self, targets, counts):
-        tg = np.asarray(targets, np.float64).reshape(self.n_envs, -1, 2)
+        tg = np.asarray(targets, np.float64).reshape(self.n_envs, -1, 3 if self.ismocto else 2)
         self._push([[("octo", t) for t in row] for row in tg], counts)
 
     def queue_status(self):
@@ -164,7 +175,7 @@ class OracleBackend:
                 s[i], d[i], nrm[i] = rec[1], rec[2], rec[3]
                 self.reset_straight(s, d, nrm, m)
             else:
-                tg = np.zeros((self.n_envs, 2))
+                tg = np.zeros((self.n_envs, 3 if self.ismocto else 2))
                 tg[i] = rec[1]
                 self.reset_octo(tg, m)
             self._need[i] = False
@@ -183,10 +194,22 @@ class OracleBackend:
     def reset_octo(self, targets, mask=None):
         for i, r in enumerate(self.rods):
             if mask is None or mask[i]:
+                if self.ismocto:
+                    self._octo_obs[i] = r.reset(np.asarray(targets[i], np.float64))
+                    if self._queue is not None:
+                        self._need[i] = False
+                    continue
                 ob = r.reset(targets[i])
                 self._octo_obs[i] = np.concatenate([ob["individual"].ravel(), ob["shared"]])
 
     def observe(self, prev_action=None):
+        if self.ismocto:    # get_state() on the current state; like the reference's it moves ArmTwoEnv's _prev_kappa
+            if prev_action is not None:
+                raise _capi.SoftrodError("the muscle octopus envs observe with their resident prev_action")
+            for i, r in enumerate(self.rods):
+                self.obs[i] = torch.from_numpy(r.get_state() if self._octo_obs[i] is None else self._octo_obs[i])
+                self._octo_obs[i] = None
+            return self.obs
         if self.isocto:     # the oracle keeps _prev_action itself (it survives reset)
             for i in range(self.n_envs):
                 self.obs[i] = torch.from_numpy(self._octo_obs[i])
@@ -229,7 +252,10 @@ class OracleBackend:
             if i in skip:
                 continue
             self._prev[i] = a[i]
-            if self.isocto:
+            if self.ismocto:
+                o, rw, te, tr = r.step(a[i])
+                self._octo_obs[i] = None
+            elif self.isocto:
                 ob, rw, te, tr = r.env_step(a[i])
                 o = np.concatenate([ob["individual"].ravel(), ob["shared"]])
                 self._octo_obs[i] = o

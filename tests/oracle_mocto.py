@@ -1,0 +1,155 @@
+"""CrawlEnv / ArmTwoEnv / ReachEnv around the C oracle's muscle-octopus body (oracle/octoflat_oracle.inc.c
+oracle_mocto_*): the env code — set_action, get_state, step's reward / termination bookkeeping — restated in NumPy
+after the reference's files, each block citing its lines.  TEST INFRASTRUCTURE ONLY (the checker of
+gym_softrobot_amd/csrc/softrod_mocto.hpp); the muscle law underneath is the restated COOMM model: PARITY UNPINNED.
+
+    CrawlEnv   gym_softrobot/envs/octopus/crawl_env.py     (OctoCrawl-v0)
+    ArmTwoEnv  gym_softrobot/envs/octopus/arm_two_env.py   (OctoArmTwo-v0)
+    ReachEnv   gym_softrobot/envs/octopus/reach_env.py     (OctoReach-v0)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from gym_softrobot_amd import _capi
+from oracle import oracle_c
+
+
+class MuscleOctopusOracleEnv:
+    def __init__(self, cfg, variant=False):
+        self.cfg = cfg.copy()
+        self.cfg.n_envs = 1
+        self.kind = int(cfg.env_kind)
+        assert self.kind in _capi.MUSCLE_OCTOPUS_ENVS
+        self.n_arm, self.n_elems, self.n_action = int(cfg.n_arm), int(cfg.n_elem), int(cfg.n_knots)
+        self.body = oracle_c.OracleOcto(self.cfg, variant=variant)
+        radii = _capi.muscle_octopus_radii(self.n_elems)
+        self.body.mocto_setup(radii, *_capi.es_muscle_layers(radii, _capi.MUSCLE_OCTOPUS["base_radius"]))
+        self.reward_range = 100.0
+        # __init__: _prev_action zeros (crawl_env.py:106-108); ArmTwoEnv also _prev_kappa (arm_two_env.py:103) —
+        # neither is touched by reset()
+        self._prev_action = np.zeros(self.n_arm * self.n_action, np.float32)
+        self._prev_kappa = np.zeros((self.n_arm, self.n_elems - 1), np.float32)
+        if self.kind == _capi.ENV_ARM_TWO:
+            _, self.sucker_location = _capi.arm_two_activation_basis(self.n_elems, 3)
+            self.control_location = [0] + self.sucker_location + [self.n_elems - 1]
+        self._target = None
+        self.final_time = float(cfg.final_time)
+
+    # -- the body --------------------------------------------------------------------------------------------------
+    def arm(self, a):
+        return self.body.arm(a)
+
+    def head(self):
+        return self.body.head()
+
+    @property
+    def time(self):
+        return self.body.time
+
+    def reset(self, target=None):
+        """reset (crawl_env.py:127-174, arm_two_env.py:115-164, reach_env.py:108-148): a fresh simulator; the target is
+        (5, 0) for Crawl / ArmTwo and np_random.random(3) * sum(rest_lengths) for Reach (handed in by the caller)."""
+        self.body.reset_mocto()
+        if self.kind == _capi.ENV_REACH:
+            self._target = np.asarray(target, np.float64).reshape(3)                # float64: random() * float64 (:141-143)
+        else:
+            self._target = np.array([5, 0], dtype=np.float32)
+        return self.get_state()
+
+    def _rows(self, name, comp):
+        return np.vstack([self.arm(a).get(name)[comp] for a in range(self.n_arm)])
+
+    def get_state(self):
+        kappa_state = self._rows("kappa", 0)
+        previous_action = self._prev_action.reshape([self.n_arm, self.n_action])
+        h = self.head()
+        if self.kind == _capi.ENV_ARM_TWO:                                              # arm_two_env.py:166-203
+            shared_state = np.concatenate([h["v"]], dtype=np.float32)
+            obs = np.hstack([kappa_state, self._prev_kappa, previous_action, np.eye(self.n_arm),
+                             np.repeat(shared_state[None, ...], self.n_arm, axis=0)]).astype(np.float32)
+            self._prev_kappa[...] = kappa_state
+            return np.nan_to_num(obs.ravel())
+        # crawl_env.py:175-218, reach_env.py:150-190
+        shared_state = np.concatenate([self._target, h["x"], h["v"], h["Q"].ravel()], dtype=np.float32)
+        obs = np.hstack([kappa_state, self._rows("x", 0), self._rows("x", 1), self._rows("v", 0), self._rows("v", 1),
+                         previous_action, np.eye(self.n_arm),
+                         np.repeat(shared_state[None, ...], self.n_arm, axis=0)]).astype(np.float32)
+        return np.nan_to_num(obs.ravel())
+
+    def set_action(self, action):
+        action = np.reshape(np.asarray(action, np.float32), [self.n_arm, self.n_action])
+        if self.kind == _capi.ENV_CRAWL:                                                # crawl_env.py:220-241
+            for i in range(self.n_arm):
+                location, activation, r_ratio = action[i, 0], action[i, 1], action[i, 2]
+                index = int(np.clip(location * self.n_elems, 0, self.n_elems - 1))
+                self.arm(i).set_sucker(0, index=index, reduction_ratio=r_ratio)
+                self.arm(i).apply_activation(2, activation)                          # 2 for TM
+        elif self.kind == _capi.ENV_ARM_TWO:                                            # arm_two_env.py:205-251
+            from scipy.interpolate import interp1d
+
+            for i in range(self.n_arm):
+                sucker_activation = action[i, :3]
+                LM_activation = action[i, 3:6]
+                TM_activation = action[i, 6:]
+                for j in range(3):
+                    self.arm(i).set_sucker(j, reduction_ratio=sucker_activation[j])
+                LM_activation = LM_activation - 0.5
+                LM1 = np.max((LM_activation, [0.0] * 3), axis=0)
+                LM2 = abs(np.min((LM_activation, [0.0] * 3), axis=0))
+                for m, act in enumerate((LM1, LM2, TM_activation)):
+                    self.arm(i).apply_activation(m, interp1d(self.control_location, [0] + list(act) + [0], kind="cubic")(range(self.n_elems)))
+        else:                                                                          # reach_env.py:192-205
+            for i in range(self.n_arm):
+                for j in range(3):
+                    self.arm(i).apply_activation(j, action[i, self.n_elems * j: self.n_elems * (j + 1)])
+        self._prev_action = action.ravel().copy()
+
+    def _invalid(self):                                                                # _isnan_check over positions + velocities
+        return any(np.isnan(self.arm(a).get(k)).any() for a in range(self.n_arm) for k in ("x", "v"))
+
+    def step(self, action, stepper=None):
+        """`stepper`: what runs in place of the substep loop (the fixture replays install the recorded post-loop state)."""
+        self.set_action(action)
+        xposbefore = self.head()["x"][0:2].copy()
+        (stepper or self.body.mocto_step)()
+        states = self.get_state()
+        terminated = truncated = False
+        survive_reward = forward_reward = 0.0
+        invalid = self._invalid()
+        if self.kind == _capi.ENV_REACH:                                                # reach_env.py:220-262
+            if invalid:
+                terminated, survive_reward = True, -5.0
+            else:
+                all_tip_pos = [self.arm(i).get("x")[:, -1] for i in range(self.n_arm)]
+                distance = np.linalg.norm(self._target - all_tip_pos, axis=1)
+                min_distance = min(distance) / 0.25
+                forward_reward = -((min_distance) ** 2)
+                if min_distance < 0.1:
+                    survive_reward, terminated = 5, True
+                if self.time > self.final_time:
+                    truncated = True
+            reward = forward_reward + survive_reward
+            if np.isnan(reward):
+                reward, terminated = -5, True
+            return states, min(self.reward_range, reward), terminated, truncated
+        if invalid:                                                                    # crawl_env.py:264-285, arm_two_env.py:290-321
+            terminated, survive_reward = True, -5.0
+        else:
+            xposafter = self.head()["x"][0:2]
+            forward_reward = (np.linalg.norm(self._target - xposbefore) - np.linalg.norm(self._target - xposafter)) * 1e2
+            if np.linalg.norm(self._target - xposafter) < 0.2:
+                survive_reward, terminated = 5, True
+        if not terminated and self.time > self.final_time:
+            if self.kind == _capi.ENV_ARM_TWO:
+                forward_reward -= np.linalg.norm(self._target - xposafter)              # arm_two_env.py:319
+            truncated = True
+        reward = forward_reward - 0.0 + survive_reward - 0.0
+        if np.isnan(reward):
+            if self.kind == _capi.ENV_ARM_TWO:
+                reward = -5                                                            # arm_two_env.py:335-338
+            else:
+                reward -= 5                                                            # crawl_env.py:294-296 (still NaN: min() below returns 100)
+            terminated = True
+        reward = min(self.reward_range, reward)
+        return states, reward, terminated, truncated
