@@ -16,7 +16,9 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
-IDS = ["OctoArmPullWeight-v0", "OctoArmPush-v0", "OctoArmPush-v1", "OctoArmSingle-v0", "OctoFlat-v0", "OctoFlatLite-v0", "SoftArmTracking-v0", "SoftPendulum-v0", "SoftPendulum3D-v0"]
+IDS = ["OctoArmPullWeight-v0", "OctoArmPush-v0", "OctoArmPush-v1", "OctoArmSingle-v0", "OctoArmTwo-v0", "OctoCrawl-v0", "OctoFlat-v0",
+       "OctoFlatLite-v0", "OctoReach-v0", "SoftArmTracking-v0", "SoftPendulum-v0", "SoftPendulum3D-v0"]
+MUSCLE_IDS = ("OctoArmPush", "OctoArmPullWeight", "OctoArmTwo", "OctoCrawl", "OctoReach")       # registered with the COOMM caveat
 
 PRELUDE = f"""
 import json, sys
@@ -61,6 +63,7 @@ print(json.dumps(out))
         "gym_softrobot_amd/OctoArmPullWeight-v0": "ArmPullWeightEnv",
         "gym_softrobot_amd/OctoArmPush-v0": "ArmPushEnv", "gym_softrobot_amd/OctoArmPush-v1": "ArmPushEnv",
         "gym_softrobot_amd/OctoArmSingle-v0": "ArmSingleEnv", "gym_softrobot_amd/OctoFlat-v0": "FlatEnv",
+        "gym_softrobot_amd/OctoArmTwo-v0": "ArmTwoEnv", "gym_softrobot_amd/OctoCrawl-v0": "CrawlEnv", "gym_softrobot_amd/OctoReach-v0": "ReachEnv",
         "gym_softrobot_amd/OctoFlatLite-v0": "FlatEnv", "gym_softrobot_amd/SoftArmTracking-v0": "SoftArmTrackingEnv",
         "gym_softrobot_amd/SoftPendulum-v0": "SoftPendulumEnv", "gym_softrobot_amd/SoftPendulum3D-v0": "SoftPendulum3DEnv"}
     # gym_softrobot/__init__.py:11-15: OctoFlatLite = FlatEnv(n_arm=1, n_action=8); the others carry no kwargs
@@ -68,12 +71,13 @@ print(json.dumps(out))
     assert res["kwargs"]["gym_softrobot_amd/OctoArmPush-v1"] == {"mode": "continuous"}     # gym_softrobot/__init__.py:42-46
     assert res["kwargs"]["gym_softrobot_amd/OctoArmPullWeight-v0"] == {"mode": "continuous"}   # gym_softrobot/__init__.py:48-52
     assert all(v == {} for k, v in res["kwargs"].items() if "Lite" not in k and "Push-v1" not in k and "PullWeight" not in k)
-    assert res["max_steps"] == [None] * 9          # no TimeLimit wrapper: truncation is the env's own (soft_pendulum.py:226-229)
+    assert res["max_steps"] == [None] * 12          # no TimeLimit wrapper: truncation is the env's own (soft_pendulum.py:226-229)
     # Gymnasium 1.0's make_vec(..., vectorization_mode="vector_entry_point") gets the batched HIP classes
     assert res["vec"] == {
         "gym_softrobot_amd/OctoArmPullWeight-v0": "VecArmPullWeightEnv",
         "gym_softrobot_amd/OctoArmPush-v0": "VecArmPushEnv", "gym_softrobot_amd/OctoArmPush-v1": "VecArmPushEnv",
         "gym_softrobot_amd/OctoArmSingle-v0": "VecArmSingleEnv", "gym_softrobot_amd/OctoFlat-v0": "VecOctoFlatEnv",
+        "gym_softrobot_amd/OctoArmTwo-v0": "VecArmTwoEnv", "gym_softrobot_amd/OctoCrawl-v0": "VecCrawlEnv", "gym_softrobot_amd/OctoReach-v0": "VecReachEnv",
         "gym_softrobot_amd/OctoFlatLite-v0": "VecOctoFlatEnv", "gym_softrobot_amd/SoftArmTracking-v0": "VecSoftArmTrackingEnv",
         "gym_softrobot_amd/SoftPendulum-v0": "VecSoftPendulumEnv", "gym_softrobot_amd/SoftPendulum3D-v0": "VecSoftPendulum3DEnv"}
 
@@ -84,7 +88,7 @@ def test_muscle_envs_are_registered_with_the_unpinned_label():
 
     for i in IDS:
         label = gsa.parity_label(i)
-        assert (label is not None and "parity-unpinned" in label and "COOMM" in label) == i.startswith(("OctoArmPush", "OctoArmPullWeight")), i
+        assert (label is not None and "parity-unpinned" in label and "COOMM" in label) == i.startswith(MUSCLE_IDS), i
     assert "parity-unpinned" in gsa.VecArmPushEnv.parity_label and "parity-unpinned" in gsa.ArmPushEnv.parity_label
 
 

@@ -20,8 +20,9 @@ def _env(**kw):
 def test_registry_lists_softpendulum():
     assert "SoftPendulum-v0" in gsa.registered()
     assert {"OctoFlat-v0", "OctoFlatLite-v0", "OctoArmSingle-v0"} <= set(gsa.registered())
+    assert {"OctoCrawl-v0", "OctoArmTwo-v0", "OctoReach-v0"} <= set(gsa.registered())       # round 6: the muscle octopus (N3)
     with pytest.raises(KeyError):
-        gsa.make("OctoCrawl-v0")   # not on the accelerated path
+        gsa.make("ContinuumSnake-v0")   # gym_softrobot/__init__.py:54-58: not on the accelerated path (out of scope)
 
 
 def test_seeding_matches_gymnasium_convention():
@@ -328,7 +329,7 @@ def test_make_vec_knows_every_registered_id(oracle_built):
     assert obs.shape == (2, 61 + 13)
     lite.close()
     with pytest.raises(KeyError):
-        gsa.make_vec("OctoReach-v0", 2)
+        gsa.make_vec("ContinuumSnake-v0", 2)
 
 
 def test_octo_action_basis_reproduces_padded_interp1d():
