@@ -104,8 +104,11 @@ CYCLES_PER_FP64_WAVE_INSTR = 4.0   # wave64 fp64 op: 16 lanes per clock per SIMD
 VALU_PEAK_GINSTR = N_SIMD * CLOCK_HZ / CYCLES_PER_FP64_WAVE_INSTR / 1e9   # 614.4
 METHODOLOGY_VERSION = 5
 AMAX = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0,
-        "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0, "OctoArmPush-v0": 1.0, "OctoArmPush-v1": 1.0, "OctoArmPullWeight-v0": 1.0}
-MUSCLE_ENVS = ("OctoArmPush-v0", "OctoArmPush-v1", "OctoArmPullWeight-v0")      # COOMM muscle arms: parity unpinned
+        "OctoFlat-v0": 22.0, "SoftArmTracking-v0": 1.0, "OctoArmPush-v0": 1.0, "OctoArmPush-v1": 1.0, "OctoArmPullWeight-v0": 1.0,
+        "OctoCrawl-v0": 1.0, "OctoArmTwo-v0": 1.0, "OctoReach-v0": 1.0}
+MUSCLE_OCTOPUS_ENVS = ("OctoCrawl-v0", "OctoArmTwo-v0", "OctoReach-v0")          # n_arm muscle arms on a rigid head
+MUSCLE_ENVS = ("OctoArmPush-v0", "OctoArmPush-v1", "OctoArmPullWeight-v0") + MUSCLE_OCTOPUS_ENVS      # COOMM muscles: parity unpinned
+HEADED_ENVS = ("OctoFlat-v0",) + MUSCLE_OCTOPUS_ENVS                             # several rods per env
 
 
 def random_actions(np, env_id: str, shape, amax: float, seed: int = 1):
@@ -113,6 +116,8 @@ def random_actions(np, env_id: str, shape, amax: float, seed: int = 1):
     (Box(0, 1), arm_push_env.py:113-115); OctoArmPush-v0: 0 / 1 (Discrete(2), :101) held for four env.steps each (an
     inchworm stroke lasts several steps; flipping every step drives the restated muscle law out of its range)."""
     rng = np.random.default_rng(seed)
+    if env_id in MUSCLE_OCTOPUS_ENVS:          # Box(0, 1) per arm; 0.6 keeps the restated cubic force-length law in its range
+        return (rng.uniform(0.0, 0.6, shape) * (1.0 if amax else 0.0)).astype(np.float32)
     if env_id in ("OctoArmPush-v1", "OctoArmPullWeight-v0"):
         return (rng.uniform(0.0, 1.0, shape) * (1.0 if amax else 0.0)).astype(np.float32)
     if env_id == "OctoArmPush-v0":
@@ -277,7 +282,7 @@ def parse_args(argv=None):
     ap.add_argument("--math-mode", choices=["fast", "libm"], default="fast")
     ap.add_argument("--env", default="SoftPendulum-v0",
                     choices=["SoftPendulum-v0", "SoftPendulum3D-v0", "OctoArmSingle-v0", "OctoFlat-v0", "SoftArmTracking-v0",
-                             "OctoArmPush-v0", "OctoArmPush-v1", "OctoArmPullWeight-v0"],
+                             "OctoArmPush-v0", "OctoArmPush-v1", "OctoArmPullWeight-v0", "OctoCrawl-v0", "OctoArmTwo-v0", "OctoReach-v0"],
                     help="headline metric is SoftPendulum-v0; the others are the widened §8 rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -522,7 +527,7 @@ def taper_profile(base_radius: float, n_elem: int):
 
 
 def workload_name(env_id: str, cfg, n_local: int, world: int = 1, taper: bool = False, libm: bool = False) -> str:
-    octo = env_id == "OctoFlat-v0"
+    octo = env_id in HEADED_ENVS
     taper = taper or env_id in MUSCLE_ENVS          # the muscle arm is tapered 12:1 by construction
     return (f"{env_id}, {n_local} envs x " + (f"{int(cfg.n_arm)} arms x " if octo else "")
             + f"{int(cfg.n_elem)} elements per GPU " + ("tapered " if taper else "") + ("libm kernel " if libm else "")
@@ -540,7 +545,7 @@ def roofline_block(env_id, cfg, n_local, kernel_ms, math_mode, lib_hash, hip, ba
     """The `roofline` object of one workload: priced against the tracked rocprofv3 tables, used only
     when they were measured on THIS env / size / build of the library."""
     nsub = int(cfg.n_substeps)
-    octo = env_id == "OctoFlat-v0"
+    octo = env_id in HEADED_ENVS
     rods_per_env = int(cfg.n_arm) if octo else 1
     rod_substeps = n_local * rods_per_env * nsub
     # OctoFlat: n_arm rods + the rigid head (x, v, Q, w = 18 doubles read and written)
@@ -585,7 +590,8 @@ def roofline_block(env_id, cfg, n_local, kernel_ms, math_mode, lib_hash, hip, ba
         # LANE-slots that advance a node
         "useful_lane_frac": lanes,
         "frac_of_lane_slots": None if frac is None else frac * lanes,
-        "kernel": "softrod_octo_step_kernel" if octo else
+        "kernel": "softrod_octo_step_kernel (muscle-arm instantiation; softrod_mocto_action / _epilogue kernels either side)"
+                  if env_id in MUSCLE_OCTOPUS_ENVS else "softrod_octo_step_kernel" if octo else
                   "softrod_octo_step_kernel (ArmPullWeight instantiation: one arm wave + the rigid weight)"
                   if env_id == "OctoArmPullWeight-v0" else
                   "softrod_step_window_kernel + softrod_step_fast_kernel (epilogue only)"
@@ -1101,7 +1107,7 @@ def main(argv=None, script=None) -> int:
         # RCCL's stream at high priority (SOFTROD_RCCL_HIGH_PRIORITY=0: normal): distributed.py says why
         init_process_group(backend, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
-    n_local = args.envs_per_gpu or (1024 if args.env == "OctoFlat-v0" else ENVS_PER_GPU)
+    n_local = args.envs_per_gpu or (1024 if args.env in HEADED_ENVS else ENVS_PER_GPU)
     if args.scaling == "strong":
         if n_local % world:
             raise SystemExit(f"--scaling strong: {n_local} envs do not split over {world} GPUs")
@@ -1238,7 +1244,7 @@ def main(argv=None, script=None) -> int:
     if rank == 0:
         cfg = local.cfg
         nsub = int(cfg.n_substeps)
-        octo = args.env == "OctoFlat-v0"
+        octo = args.env in HEADED_ENVS
         rods_per_env = int(cfg.n_arm) if octo else 1
         per_win_kernel = [float(np.mean(kt[w * K:(w + 1) * K])) for w in range(R)] if len(kt) == R * K else []
         kernel_ms = per_win_kernel[m] if per_win_kernel else float(np.mean(kt))

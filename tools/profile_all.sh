@@ -22,8 +22,11 @@ declare -A ARGS=(
   [SoftPendulum-v0_libm]="--math-mode libm"
   [OctoArmPush-v0]="--env OctoArmPush-v0"
   [OctoArmPullWeight-v0]="--env OctoArmPullWeight-v0"
+  [OctoCrawl-v0]="--env OctoCrawl-v0"
+  [OctoArmTwo-v0]="--env OctoArmTwo-v0"
+  [OctoReach-v0]="--env OctoReach-v0"
 )
-NAMES=${*:-SoftPendulum-v0 SoftPendulum3D-v0 OctoArmSingle-v0 OctoArmSingle-v0_n100 OctoArmSingle-v0_taper OctoFlat-v0 SoftArmTracking-v0 OctoArmPush-v1 SoftPendulum-v0_libm}
+NAMES=${*:-SoftPendulum-v0 SoftPendulum3D-v0 OctoArmSingle-v0 OctoArmSingle-v0_n100 OctoArmSingle-v0_taper OctoFlat-v0 SoftArmTracking-v0 OctoArmPush-v1 SoftPendulum-v0_libm OctoArmPullWeight-v0 OctoCrawl-v0}
 for NAME in $NAMES; do
   A="--no-cpu-baseline --no-secondary ${ARGS[$NAME]}"
   OUT=$ROOT/gpurun_out/prof_${TAG}_$NAME
