@@ -74,7 +74,9 @@ def test_bench_two_ranks_softpendulum(hip_lib):
     t = two["_p2p_trial"]
     assert t["returncode"] == 0 and t["transport"] == "p2p" and t["exchange_memory"] in ("uncached", "fine-grained"), t
     assert t["last_step_checksum"] == two["config"]["last_step_checksum"] and t["value"] > 0
-    assert "secondary" not in two and "secondary" in one and len(one["secondary"]) == 3
+    # configs[2], configs[4]'s share, the libm kernel, and (round 6) the muscle arm WITH its parity label
+    assert "secondary" not in two and "secondary" in one and len(one["secondary"]) == 4
+    assert "parity-unpinned" in one["secondary"][3]["parity_label"] and "OctoArmPush-v1" in one["secondary"][3]["workload"]
     for sec in one["secondary"]:
         assert sec["value"] > 0 and sec["non_finite_envs_at_end"] == 0 and sec["kernel_ms_avg"] > 0
     assert one["secondary"][2]["math_mode"] == "libm" and one["secondary"][2]["value"] < one["value"]
@@ -282,7 +284,8 @@ def test_driver_line_carries_cpu_baseline_and_parity_vs_oracle(hip_lib):
     r = line["roofline"]
     assert r["bound"] == "fp64_valu" and (r["frac"] is None or 0.5 < r["frac"] < 1.05)
     assert r["frac"] is None or (r["frac_cycle_weighted"] is not None and 0.5 < r["frac_cycle_weighted"] <= 1.0)
-    assert [s["baseline_config"][:10] for s in line["secondary"]] == ["configs[2]", "configs[4]", "configs[1]"]
+    assert [s["baseline_config"][:10] for s in line["secondary"]] == ["configs[2]", "configs[4]", "configs[1]", "none: BASE"]
+    assert "parity-unpinned" in line["secondary"][3]["parity_label"]          # the COOMM muscle arm never without its caveat
     assert line["secondary"][2]["math_mode"] == "libm"
     su = line["sustained"]
     assert su["seconds"] >= 2.0 and 0.85 < su["ratio_to_value"] < 1.1 and {"near_start", "near_end"} <= set(su["sensors"]), su

@@ -5,10 +5,12 @@
 set -eu
 TAG=$1
 cd "$(dirname "$0")/.."
+FILES=""
 for d in gpurun_out/prof_${TAG}_*; do
   name=${d#gpurun_out/prof_${TAG}_}
   cp "$d/summary.json" "profiles/${TAG}_${name}.json"
+  FILES="$FILES profiles/${TAG}_${name}.json"
   ks=$(find "$d/trace" -name "*kernel_stats.csv" | head -1)      # rocprofv3 --kernel-trace --stats summary of the bench command
   [ -n "$ks" ] && cp "$ks" "profiles/${TAG}_${name}_kernel_stats.csv"
 done
-python3 tools/update_profile_tables.py $(ls profiles/${TAG}_*.json | grep -v _bench_)
+python3 tools/update_profile_tables.py $FILES      # (only the summaries just copied: other records share the tag's prefix)
