@@ -194,8 +194,16 @@ __device__ __forceinline__ int octo_obs_dim(const RodParams& P) {
 #ifndef SOFTROD_OCTO_PRIO
 #define SOFTROD_OCTO_PRIO 1
 #endif
+// The muscle-arm instantiations (taper table, three muscle layers, suckers on top of the rod, joint and head code) want ~330
+// registers: at two waves per SIMD (256) they park 217 of them in scratch and the loop waits on it — 12 GB of HBM traffic per
+// env.step of 4096 OctoArmPullWeight envs, VALU busy 0.37.  ONE wave per SIMD (512 registers, no spills in the loop) is
+// faster in spite of half the occupancy: OctoArmPullWeight 13.7 -> 10.6 ms, OctoCrawl 12.6 -> 9.9, OctoArmTwo 5.18 -> 2.96,
+// OctoReach 21.4 -> 12.3 (profiles/README.md "Round 6").  OctoFlat's own instantiations are indifferent (8.94 / 8.97 ms) and stay.
+template <unsigned F>
+constexpr int octo_kernel_waves() { return kMusclesCompiled<F> ? 1 : SOFTROD_OCTO_WAVES; }
+
 template <unsigned F, int MAXW, int EPB = 1>
-__global__ void __launch_bounds__(kLanes * MAXW * EPB, SOFTROD_OCTO_WAVES)
+__global__ void __launch_bounds__(kLanes * MAXW * EPB, (octo_kernel_waves<F>()))
 softrod_octo_step_kernel(const RodParams P, const StatePtrs S, const float* __restrict__ actions,
                          float* __restrict__ obs, double* __restrict__ reward,
                          uint8_t* __restrict__ terminated, uint8_t* __restrict__ truncated,
