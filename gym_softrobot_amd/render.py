@@ -98,7 +98,7 @@ def _build(env) -> MatplotlibSession:
     sess = MatplotlibSession(800, 600)            # maxwidth 800, aspect 3/4 (soft_pendulum.py:261-262)
     r0 = float(cfg.base_radius)
     ne = int(cfg.n_elem)
-    if kind == _capi.ENV_OCTO_FLAT:
+    if kind == _capi.ENV_OCTO_FLAT or kind in _capi.MUSCLE_OCTOPUS_ENVS:     # arms + head (the muscle octopus: same state layout)
         na = int(cfg.n_arm)
         for a in range(na):
             sess.add_rod(lambda a=a: (vec.backend.octo_state_numpy()["x"][0, a], np.full(ne, r0)))
