@@ -200,3 +200,26 @@ def test_env_code_replays_the_executed_reference(torch_gpu, hip_lib, env_id):
     if kind == _capi.ENV_ARM_TWO:
         np.testing.assert_array_equal(st["prev_kappa"].cpu().numpy().reshape(N, na, n - 1), z[p + "step_prev_kappa_after"])
     be.close()
+
+
+@pytest.mark.parametrize("env_id,n", [("OctoCrawl-v0", 256), ("OctoArmTwo-v0", 512), ("OctoReach-v0", 128)])
+def test_a_whole_batch_one_step(torch_gpu, hip_lib, oracle_built, env_id, n):
+    """Hundreds of envs (several workgroups per CU, every XCD), one env.step each under its own random action: every
+    env's observation and reward against the oracle — a mapping bug (an env reading its neighbour's sucker row, a wave
+    its neighbour's activation row) would show as a pattern over the env index, not as noise."""
+    env, ref = _pair(env_id, n)
+    env.reset(seed=21)
+    ref.reset(seed=21)
+    a = _actions(env_id, np.random.default_rng(8), n, env.action_dim)
+    o, r, te, tr, _ = env.step(a)
+    o2, r2, te2, tr2, _ = ref.step(a)
+    torch_gpu.cuda.synchronize()
+    o, r = o.cpu().numpy(), r.cpu().numpy()
+    band = 5e-6 + RTOL * np.abs(o2)
+    per_env = (np.abs(o - o2) / band).max(axis=1)
+    assert per_env.max() <= 1.0, (int(per_env.argmax()), float(per_env.max()), np.nonzero(per_env > 1.0)[0][:10])
+    np.testing.assert_allclose(r, r2, rtol=RTOL, atol=2e-6)
+    np.testing.assert_array_equal(te.cpu().numpy(), te2)
+    np.testing.assert_array_equal(tr.cpu().numpy(), tr2)
+    env.close()
+    ref.close()
