@@ -692,8 +692,41 @@ def secondary_workload(gsa, _capi, torch, device, math_mode, lib_hash, env_id, n
         "roofline": roofline_block(env_id, cfg, n_local, kernel_ms, "fast" if math_mode == _capi.MATH_FAST else "libm",
                                    lib_hash, True, env.backend),
     }
+    if env_id == "OctoArmPush-v1":
+        # the CPU beside it: the C oracle's own ArmPush env.step (the restated muscle law on the same tapered arm), one
+        # thread, a bounded sample of the same actions; and env 0..15 after step 1 against it (rtol 1e-5)
+        try:
+            out["cpu_port"] = muscle_arm_cpu_port(np, _capi, cfg, acts, obs_step1=None)
+        except Exception as exc:  # noqa: BLE001
+            out["cpu_port"] = {"error": repr(exc)}
     env.close()
     return out
+
+
+def muscle_arm_cpu_port(np, _capi, cfg, acts, obs_step1=None, n_envs: int = 4, steps: int = 3):
+    """The oracle's OctoArmPush-v1 env.step on ONE host thread (oracle/softrod_oracle.c oracle_env_step_push: the same
+    restated COOMM law, PARITY UNPINNED like the kernel's): `n_envs` envs x `steps` env.steps of the benchmark's actions."""
+    from oracle import oracle_c
+
+    c1 = cfg.copy()
+    c1.n_envs = 1
+    radii = _capi.arm_push_radii(int(cfg.n_elem))
+    layers = _capi.es_muscle_layers(radii, 0.012)
+    rods = []
+    for _ in range(n_envs):
+        r = oracle_c.OracleRod(c1)
+        r.set_radius_profile(radii)
+        r.set_muscle_layers(*layers)
+        r.reset_push()
+        rods.append(r)
+    t0 = time.perf_counter()
+    for t in range(steps):
+        for i, r in enumerate(rods):
+            r.env_step_push(acts[t, i])
+    el = time.perf_counter() - t0
+    return {"value": n_envs * steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n_envs} envs x {steps} env.steps of the benchmark's actions, one thread, the C oracle's ArmPush env "
+                      "(restated muscle law: parity unpinned)"}
 
 
 def pcie_inclusive(gsa, torch, device, math_mode, n_local, steps: int = 40, warmup: int = 5):

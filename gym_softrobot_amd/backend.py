@@ -157,12 +157,12 @@ class HipRodBackend:
 
     def reset_octo(self, targets, mask: Optional[np.ndarray] = None) -> None:
         """FlatEnv.reset: targets (n_envs, 2); the arm frames are build_octopus's.  The muscle octopus envs: targets
-        (n_envs, 3), the frames of build_octopus_muscles / build_two_arms."""
+        (n_envs, 4) — x, y, z and the episode's final_time (0: the config's) —, the frames of build_octopus_muscles / build_two_arms."""
         na = int(self.cfg.n_arm)
         pos, dirs = self._arm_frames()
         pos = np.ascontiguousarray(np.broadcast_to(pos, (self.n_envs, na, 3)))
         dirs = np.ascontiguousarray(np.broadcast_to(dirs, (self.n_envs, na, 3)))
-        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, 3 if self.is_mocto else 2)
+        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, 4 if self.is_mocto else 2)
         m = None
         if mask is not None:
             m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.n_envs)
@@ -199,7 +199,7 @@ class HipRodBackend:
 
     def queue_push_octo(self, targets, counts) -> None:
         na = int(self.cfg.n_arm)
-        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, -1, 3 if self.is_mocto else 2)
+        tg = np.ascontiguousarray(targets, dtype=np.float64).reshape(self.n_envs, -1, 4 if self.is_mocto else 2)
         m = tg.shape[1]
         pos, dirs = self._arm_frames()
         pos = np.ascontiguousarray(np.broadcast_to(pos, (self.n_envs, m, na, 3)))

@@ -396,7 +396,7 @@ int upload_and_reset(softrod_handle* h, hipStream_t st, bool use_mask) {
         SR_HIP(h, hipMemcpyAsync(h->d_mask, h->h_mask, N, hipMemcpyHostToDevice, st));
     ResetArgs A{h->d_init, use_mask ? h->d_mask : nullptr};
     if (is_octo(h)) {
-        OctoResetArgs OA{h->d_init, h->d_init + N * (size_t)h->cfg.n_arm * 18, use_mask ? h->d_mask : nullptr};   // (targets: 2 per env, 3 for the muscle octopus)
+        OctoResetArgs OA{h->d_init, h->d_init + N * (size_t)h->cfg.n_arm * 18, use_mask ? h->d_mask : nullptr};   // (targets: 2 numbers per env, 4 for the muscle octopus)
         hipLaunchKernelGGL(softrod_octo_reset_kernel, dim3((unsigned)N), dim3(kLanes * h->nw), 0, st, h->P, h->S, OA);
     } else if (h->epl == 2)
         hipLaunchKernelGGL(softrod_reset_kernel<2>, dim3((unsigned)N), dim3(kLanes), 0, st, h->P, h->S, A);
@@ -843,7 +843,7 @@ int softrod_create(const softrod_config* cfg, int device, softrod_handle** out) 
     const size_t N = (size_t)cfg->n_envs;
     if (octo) {
         h->nw = (cfg->n_arm * h->P.seg + kLanes - 1) / kLanes;
-        h->init_stride = (size_t)cfg->n_arm * 18 + (mocto ? 3 : 2);
+        h->init_stride = (size_t)cfg->n_arm * 18 + (mocto ? 4 : 2);
     }
     // A/B switches for profiling and tests.  A product library must not change its kernel tier because of a
     // stray environment variable: they are read only when SOFTROD_DEBUG_SWITCHES=1 is set as well
@@ -981,7 +981,7 @@ int softrod_reset_octo(softrod_handle* h, const double* arm_start, const double*
     const int N = h->cfg.n_envs, na = h->cfg.n_arm;
     const double normal[3] = {0.0, 0.0, 1.0};             // octopus/build.py:82, build_muscle_octopus.py:92
     double* tgt = h->h_init + (size_t)N * na * 18;
-    const size_t td = is_mocto(h) ? 3 : 2;                // the muscle octopus: three numbers per target
+    const size_t td = is_mocto(h) ? 4 : 2;                // the muscle octopus: target x, y, z and the episode's final_time (0: the config's)
     for (int e = 0; e < N; ++e) {
         if (mask) h->h_mask[e] = mask[e];
         if (mask && !mask[e]) continue;
@@ -1182,7 +1182,7 @@ int softrod_queue_push_octo(softrod_handle* h, const double* arm_start, const do
             for (int a = 0; a < na; ++a)
                 straight_init(h->cfg, arm_start + (k * na + a) * 3, arm_direction + (k * na + a) * 3, normal,
                               rec + (size_t)a * 18);
-            const size_t td = is_mocto(h) ? 3 : 2;
+            const size_t td = is_mocto(h) ? 4 : 2;
             for (size_t i = 0; i < td; ++i) rec[(size_t)na * 18 + i] = target[td * k + i];
         }
     return queue_commit(h, (hipStream_t)stream);

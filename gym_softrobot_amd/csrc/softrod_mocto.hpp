@@ -177,6 +177,9 @@ softrod_mocto_epilogue_kernel(const RodParams P, const StatePtrs S, float* __res
     const bool invalid = __syncthreads_or(bad ? 1 : 0) != 0;
     if (tid != 0) return;
     const double time = S.time[env];
+    // CrawlEnv(config_random_final_time=True) draws its final_time per episode (crawl_env.py:135-136): aux row 5, 0 = the config's
+    const double ft_env = S.aux[5 * N + env];
+    const double final_time = ft_env > 0.0 ? ft_env : P.final_time;
     bool term = false, trunc = false;
     double survive = 0.0, forward = 0.0, rew;
     if (P.env_kind == SOFTROD_ENV_REACH) {                       // reach_env.py:220-262
@@ -187,7 +190,7 @@ softrod_mocto_epilogue_kernel(const RodParams P, const StatePtrs S, float* __res
             dmin = dmin / 0.25;
             forward = -(dmin * dmin);
             if (dmin < 0.1) { survive = 5.0; term = true; }
-            if (time > P.final_time) trunc = true;
+            if (time > final_time) trunc = true;
         }
         rew = forward + survive;
         if (isnan(rew)) { rew = -5.0; term = true; }
@@ -201,7 +204,7 @@ softrod_mocto_epilogue_kernel(const RodParams P, const StatePtrs S, float* __res
             forward = (sqrt(bx * bx + by * by) - after) * 1e2;
             if (after < 0.2) { survive = 5.0; term = true; }
         }
-        if (!term && time > P.final_time) {
+        if (!term && time > final_time) {
             if (P.env_kind == SOFTROD_ENV_ARM_TWO) forward -= after;
             trunc = true;
         }

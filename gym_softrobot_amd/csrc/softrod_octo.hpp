@@ -717,10 +717,11 @@ __device__ __forceinline__ void octo_reset_env(const RodParams& P, const StatePt
         store_head(S, N, env, H);
         S.head[(size_t)18 * N + env] = target[0];
         S.head[(size_t)19 * N + env] = target[1];
-        if (is_mocto_env(P.env_kind)) {      // the env's target (three numbers: ReachEnv's is a point in space)
-            S.aux[(size_t)0 * N + env] = target[0];
+        if (is_mocto_env(P.env_kind)) {      // the env's target (three numbers: ReachEnv's is a point in space) and, fourth,
+            S.aux[(size_t)0 * N + env] = target[0];      // the episode's own final_time (0: the config's; crawl_env.py:135-136)
             S.aux[(size_t)1 * N + env] = target[1];
             S.aux[(size_t)2 * N + env] = target[2];
+            S.aux[(size_t)5 * N + env] = target[3];
             S.aux[(size_t)3 * N + env] = H.x[0];
             S.aux[(size_t)4 * N + env] = H.x[1];
         }
@@ -733,7 +734,7 @@ softrod_octo_reset_kernel(const RodParams P, const StatePtrs S, const OctoResetA
     if (A.mask && !A.mask[env]) return;
     LaneN<1> L;
     HeadState H;
-    octo_reset_env(P, S, env, A.init + (size_t)env * P.n_arm * 18, A.target + (is_mocto_env(P.env_kind) ? 3 : 2) * (size_t)env, L, H);
+    octo_reset_env(P, S, env, A.init + (size_t)env * P.n_arm * 18, A.target + (is_mocto_env(P.env_kind) ? 4 : 2) * (size_t)env, L, H);
 }
 
 // Device-side auto-reset pass for OctoFlat (see softrod_autoreset_kernel): the queue record
@@ -753,7 +754,8 @@ softrod_octo_autoreset_kernel(const RodParams P, const StatePtrs S, float* __res
     }
     const double* in = S.queue + ((size_t)(k % S.q_depth) * N + env) * (size_t)S.q_record;
     const bool mocto = is_mocto_env(P.env_kind);
-    const double tgt[3] = {in[P.n_arm * 18], in[P.n_arm * 18 + 1], mocto ? in[P.n_arm * 18 + 2] : 0.0};
+    const double tgt[4] = {in[P.n_arm * 18], in[P.n_arm * 18 + 1], mocto ? in[P.n_arm * 18 + 2] : 0.0,
+                           mocto ? in[P.n_arm * 18 + 3] : 0.0};
     LaneN<1> L;
     HeadState H;
     octo_reset_env(P, S, env, in, tgt, L, H);

@@ -64,16 +64,17 @@ class _VecMuscleOctopusEnv(VecRodEnvBase):
         self.n_seg = n_elems - 1
         self.n_action = int(cfg.n_knots)                  # per arm, as in the reference
         self.reward_range = 100.0
-        self.targets = np.zeros((num_envs, 3), np.float64)
+        # per env: the target's x, y, z and the episode's own final_time (0: the config's; CrawlEnv's random one)
+        self.targets = np.zeros((num_envs, 4), np.float64)
         radii = _capi.muscle_octopus_radii(n_elems)
         self.backend.set_radius_profile(radii)
         self.backend.set_muscle_layers(*_capi.es_muscle_layers(radii, _capi.MUSCLE_OCTOPUS["base_radius"], **(muscle_kwargs or {})))
 
     def _draw_reset(self, i):
-        return np.array([5.0, 0.0, 0.0])                  # self._target = np.array([5, 0], dtype=np.float32) (crawl_env.py:172)
+        return np.array([5.0, 0.0, 0.0, 0.0])             # self._target = np.array([5, 0], dtype=np.float32) (crawl_env.py:172)
 
     def _queue_from_draws(self, draws, counts):
-        tg = np.zeros((self.num_envs, max(1, int(counts.max())), 3))
+        tg = np.zeros((self.num_envs, max(1, int(counts.max())), 4))
         for i, d in enumerate(draws):
             for j, v in enumerate(d):
                 tg[i, j] = v
@@ -96,11 +97,22 @@ class VecCrawlEnv(_VecMuscleOctopusEnv):
 
     def __init__(self, num_envs: int, final_time: float = 10.0, time_step: float = 5.0e-5, recording_fps: int = 25,
                  n_elems: int = 20, config_random_final_time: bool = False, render_mode: Optional[str] = None, **kw):
-        if config_random_final_time:
-            raise NotImplementedError("config_random_final_time (crawl_env.py:135-136: a per-episode final_time) is not built: "
-                                      "the default (False) only")
         super().__init__(num_envs, final_time, time_step, recording_fps, n_elems, render_mode, **kw)
-        self.config_random_final_time = False
+        self.config_random_final_time = bool(config_random_final_time)
+
+    def _draw_reset(self, i):
+        # reset (crawl_env.py:134-136): `if self.config_random_final_time: self.final_time = self.np_random.uniform(3.0, 10.0)`
+        # — the first draw of the episode; the target is the constant (5, 0)
+        ft = self._rngs[i].uniform(3.0, 10.0) if self.config_random_final_time else 0.0
+        return np.array([5.0, 0.0, 0.0, ft])
+
+    @property
+    def final_times(self):
+        """Every env's current final_time (the configured one unless config_random_final_time drew another)."""
+        return np.where(self.targets[:, 3] > 0.0, self.targets[:, 3], self.final_time)
+
+    def _infos(self, times):
+        return {"time": times, "TimeLimit.truncated": times > self.final_times}
 
     def get_env_info(self):
         return dict(n_actions=self.n_action, n_agents=8)                   # crawl_env.py:121-123
@@ -137,7 +149,7 @@ class VecReachEnv(_VecMuscleOctopusEnv):
 
     def _draw_reset(self, i):
         # reach_env.py:141-143: self._target = self.np_random.random(3) * sum(self.shearable_rods[0].rest_lengths)
-        return self._rngs[i].random(3) * self._rest_length_sum
+        return np.concatenate([self._rngs[i].random(3) * self._rest_length_sum, [0.0]])
 
     def get_env_info(self):
         return dict(n_actions=self.n_action, n_agents=8)
@@ -173,7 +185,7 @@ class _MuscleOctopusEnv(_GymEnv):
     @property
     def _target(self):
         t = self._vec.targets[0]
-        return t.copy() if self._vec.env_kind == _capi.ENV_REACH else np.array(t[:2], dtype=np.float32)
+        return t[:3].copy() if self._vec.env_kind == _capi.ENV_REACH else np.array(t[:2], dtype=np.float32)
 
     def get_env_info(self):
         return self._vec.get_env_info()
@@ -223,6 +235,11 @@ class CrawlEnv(_MuscleOctopusEnv):
                          config_random_final_time=config_random_final_time, **kw)
         self.n_agent = self.n_arm
         self.config_random_final_time = config_random_final_time
+
+    def reset(self, *, seed=None, options=None):
+        out = super().reset(seed=seed, options=options)
+        self.final_time = float(self._vec.final_times[0])          # crawl_env.py:135-136
+        return out
 
     @property
     def agent_id(self):

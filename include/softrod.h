@@ -387,7 +387,7 @@ typedef struct softrod_state_view {
      *      sucker_index rows are [SOFTROD_MAX_SUCKERS][n_envs * n_arm] (arm a of env e at e * n_arm + a) ---- */
     double* env_aux;  /* [8][n_envs]  rows 0-2 the env's target (crawl_env.py:172, arm_two_env.py:160: (5, 0);
                          reach_env.py:141-143: np_random.random(3) * sum(rest_lengths)), rows 3-4 the head's x, y before
-                         the step (`xposbefore`, crawl_env.py:248).  (rod.kappa[0] of get_state, crawl_env.py:178,
+                         the step (`xposbefore`, crawl_env.py:248), row 5 the episode's own final_time (0: the config's).  (rod.kappa[0] of get_state, crawl_env.py:178,
                          is row 0 of `kappa`: what the last substep's force evaluation cached; zeros after a reset)  */
     float* prev_kappa; /* [n_envs][n_arm * (n_elem - 1)]  ArmTwoEnv._prev_kappa (arm_two_env.py:103,196-203): float32,
                          NOT cleared by reset() — it belongs to the env object, as in the reference            */
@@ -460,8 +460,10 @@ int softrod_config_arm_pull_weight(softrod_config* cfg, int n_envs);
  * radii linspace(0.013, 0.0042, n) through softrod_set_radius_profile, layers through softrod_set_muscle_layers (both
  * once: every arm is the same rod); head Cylinder(start (0, 0, -0.026), e_z, e_y, 0.026, 0.04, 50); joints k 1e6, kt 1e2,
  * nu 1e-3; dampers 0.2 * 1e-2 at time_step 7e-5; dt 5e-5, 800 substeps per env.step.  Resets go through softrod_reset_octo
- * / softrod_queue_push_octo (arm frames from the caller, build_muscle_octopus.py:87-93; `target`: the first two numbers
- * of the env's target — ReachEnv's third through softrod_state_view.env_aux row 2).                               */
+ * / softrod_queue_push_octo (arm frames from the caller, build_muscle_octopus.py:87-93; `target`: FOUR numbers per env
+ * here — the target's x, y, z (CrawlEnv / ArmTwoEnv: 5, 0, 0; ReachEnv: its random point) and the episode's own
+ * final_time, 0 = softrod_config.final_time (CrawlEnv(config_random_final_time=True) draws one per reset,
+ * crawl_env.py:135-136)).                                                                                         */
 int softrod_config_muscle_octopus(softrod_config* cfg, int n_envs, int env_kind);
 
 /* Same as softrod_config_arm_single for ArmPushEnv (octopus/arm_push_env.py:65-224): the 40-element arm tapered

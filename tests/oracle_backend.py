@@ -131,7 +131,7 @@ class OracleBackend:
                     for i in range(self.n_envs)], counts)
 
     def queue_push_octo(self, targets, counts):
-        tg = np.asarray(targets, np.float64).reshape(self.n_envs, -1, 3 if self.ismocto else 2)
+        tg = np.asarray(targets, np.float64).reshape(self.n_envs, -1, 4 if self.ismocto else 2)
         self._push([[("octo", t) for t in row] for row in tg], counts)
 
     def queue_status(self):
@@ -175,7 +175,7 @@ class OracleBackend:
                 s[i], d[i], nrm[i] = rec[1], rec[2], rec[3]
                 self.reset_straight(s, d, nrm, m)
             else:
-                tg = np.zeros((self.n_envs, 3 if self.ismocto else 2))
+                tg = np.zeros((self.n_envs, 4 if self.ismocto else 2))
                 tg[i] = rec[1]
                 self.reset_octo(tg, m)
             self._need[i] = False
@@ -195,7 +195,8 @@ class OracleBackend:
         for i, r in enumerate(self.rods):
             if mask is None or mask[i]:
                 if self.ismocto:
-                    self._octo_obs[i] = r.reset(np.asarray(targets[i], np.float64))
+                    t4 = np.asarray(targets[i], np.float64)
+                    self._octo_obs[i] = r.reset(t4[:3], final_time=(t4[3] if t4[3] > 0 else float(self.cfg.final_time)))
                     if self._queue is not None:
                         self._need[i] = False
                     continue

@@ -47,10 +47,12 @@ class MuscleOctopusOracleEnv:
     def time(self):
         return self.body.time
 
-    def reset(self, target=None):
+    def reset(self, target=None, final_time=None):
         """reset (crawl_env.py:127-174, arm_two_env.py:115-164, reach_env.py:108-148): a fresh simulator; the target is
         (5, 0) for Crawl / ArmTwo and np_random.random(3) * sum(rest_lengths) for Reach (handed in by the caller)."""
         self.body.reset_mocto()
+        if final_time:                                      # CrawlEnv(config_random_final_time=True), crawl_env.py:135-136
+            self.final_time = float(final_time)
         if self.kind == _capi.ENV_REACH:
             self._target = np.asarray(target, np.float64).reshape(3)                # float64: random() * float64 (:141-143)
         else:

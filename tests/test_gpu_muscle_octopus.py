@@ -150,8 +150,8 @@ def test_env_code_replays_the_executed_reference(torch_gpu, hip_lib, env_id):
     radii = _capi.muscle_octopus_radii(20)
     be.set_radius_profile(radii)
     be.set_muscle_layers(*_capi.es_muscle_layers(radii, 0.013))
-    tgt = np.zeros((N, 3))
-    tgt[:] = z[p + "reset_target"] if kind == _capi.ENV_REACH else [5.0, 0.0, 0.0]
+    tgt = np.zeros((N, 4))                       # x, y, z and the episode's final_time (0: the config's)
+    tgt[:, :3] = z[p + "reset_target"] if kind == _capi.ENV_REACH else [5.0, 0.0, 0.0]
     be.reset_octo(tgt)
     torch.cuda.synchronize()
     # the reset observation is the reference's get_state on the freshly built body
@@ -223,3 +223,26 @@ def test_a_whole_batch_one_step(torch_gpu, hip_lib, oracle_built, env_id, n):
     np.testing.assert_array_equal(tr.cpu().numpy(), tr2)
     env.close()
     ref.close()
+
+
+def test_crawl_random_final_time_on_the_device(torch_gpu, hip_lib):
+    """config_random_final_time: every env's own final_time travels with its reset record (env_aux row 5) and truncation
+    follows it — one env.step (0.04 s) from a clock set just short of each env's draw."""
+    import gym_softrobot_amd as gsa
+
+    n = 4
+    env = gsa.make_vec("OctoCrawl-v0", n, config_random_final_time=True, numpy_output=True)
+    env.reset(seed=0)
+    z = np.load(__import__("pathlib").Path(__file__).resolve().parent / "golden" / "ref_muscle_octopus.npz")
+    np.testing.assert_array_equal(env.final_times[:2], z["crawl_random_final_time"][:2])
+    st = env.backend.state()
+    np.testing.assert_array_equal(st["env_aux"][5].cpu().numpy(), env.final_times)
+    back = np.array([0.02, 0.06, 0.039, 5.0])          # 0.039: 0.04 later the clock is PAST the draw by 1 ms
+    st["time"][:] = torch_gpu.from_numpy(env.final_times - back).to(env.backend.device)
+    o, r, te, tr, info = env.step(np.zeros((n, 24), np.float32))
+    assert list(tr) == [True, False, True, False] and not te.any()
+    env.close()
+    plain = gsa.make_vec("OctoCrawl-v0", 2, numpy_output=True)
+    plain.reset(seed=0)
+    np.testing.assert_array_equal(plain.backend.state()["env_aux"][5].cpu().numpy(), [0.0, 0.0])
+    plain.close()

@@ -223,3 +223,38 @@ def test_host_classes_over_the_cpu_double(oracle_built, name):
         assert o.shape == (2, vec.obs_dim) and np.isfinite(o).all()
     assert truncs[1] and not truncs[0]
     vec.close()
+
+
+def test_crawl_random_final_time_draws_like_the_reference(oracle_built):
+    """CrawlEnv(config_random_final_time=True): `self.final_time = self.np_random.uniform(3.0, 10.0)` is the first draw of
+    every reset (crawl_env.py:135-136) — seeds 0, 1, 42 and an unseeded reset continuing seed 42's stream, against the
+    executed reference; the batched env draws per env from its own stream and truncation follows the env's OWN final_time."""
+    import gym_softrobot_amd as gsa
+    from tests.oracle_backend import OracleBackend
+
+    want = np.load(GOLD / "ref_muscle_octopus.npz")["crawl_random_final_time"]
+    env = gsa.make("OctoCrawl-v0", config_random_final_time=True, backend=OracleBackend(_capi.muscle_octopus_config(_capi.ENV_CRAWL, 1)))
+    got = []
+    for seed in (0, 1, 42):
+        env.reset(seed=seed)
+        got.append(env.final_time)
+    env.reset()
+    got.append(env.final_time)
+    np.testing.assert_array_equal(got, want)
+    assert all(3.0 <= f <= 10.0 for f in got)
+    env.close()
+    vec = gsa.make_vec("OctoCrawl-v0", 3, config_random_final_time=True, numpy_output=True,
+                       backend=OracleBackend(_capi.muscle_octopus_config(_capi.ENV_CRAWL, 3)))
+    vec.reset(seed=0)
+    np.testing.assert_array_equal(vec.final_times[:2], want[:2])           # env i is seeded seed + i
+    # put env 0 one step short of ITS final_time, env 1 two steps short of its own: only env 0 truncates
+    be = vec.backend
+    for i, back in ((0, 0.02), (1, 0.06), (2, 5.0)):
+        be.rods[i].body.set_time(float(vec.final_times[i]) - back)
+    o, r, te, tr, info = vec.step(np.zeros((3, 24), np.float32))
+    assert list(tr) == [True, False, False] and not te.any()
+    vec.close()
+    plain = gsa.make_vec("OctoCrawl-v0", 2, backend=OracleBackend(_capi.muscle_octopus_config(_capi.ENV_CRAWL, 2)), numpy_output=True)
+    plain.reset(seed=0)
+    np.testing.assert_array_equal(plain.final_times, [10.0, 10.0])
+    plain.close()

@@ -232,6 +232,15 @@ def main():
             far["time"] = np.float64(ft + 1.0)
             ref_step(last, base, far, "moved_and_late")
         out.update(S.arrays(prefix + "step_"))
+        if kind == _capi.ENV_CRAWL:      # config_random_final_time (crawl_env.py:135-136): the episode's own final_time, first draw of reset()
+            env2 = getattr(mod, clsname)(config_random_final_time=True)
+            fts = []
+            for seed in (0, 1, 42):
+                env2.reset(seed=seed)
+                fts.append(float(env2.final_time))
+            env2.reset()                 # no seed: the stream goes on
+            fts.append(float(env2.final_time))
+            out[prefix + "random_final_time"] = np.array(fts)
 
     GOLD.mkdir(parents=True, exist_ok=True)
     np.savez_compressed(GOLD / "ref_muscle_octopus.npz", **out)
