@@ -32,6 +32,8 @@ def main() -> None:
     t0 = time.perf_counter()
     for k in range(args.steps):
         a = rng.uniform(lo, hi, (args.num_envs, env.action_dim)).astype(np.float32)
+        if getattr(env, "mode", None) == 0:          # OctoArmPush-v0: Discrete(2)
+            a = np.round(a)
         obs, rew, term, trunc, info = env.step(a)
         print(f"step {k + 1:4d}  time {info['time'][0]:.3f}  reward[0] {float(rew[0]):+.5f}  "
               f"terminated {int(term.sum())}  truncated {int(trunc.sum())}")
