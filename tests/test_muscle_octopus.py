@@ -258,3 +258,20 @@ def test_crawl_random_final_time_draws_like_the_reference(oracle_built):
     plain.reset(seed=0)
     np.testing.assert_array_equal(plain.final_times, [10.0, 10.0])
     plain.close()
+
+
+def test_symmetric_actuation_leaves_the_head_where_it_is(oracle_built):
+    """Known answer for the whole body (oracle; tests/test_gpu_muscle_octopus.py holds the same on the GPU): eight identical
+    arms at 45-degree spacing under the same transverse activation with their suckers released — the joint loads on the
+    head cancel, it stays put, every arm extends alike."""
+    from tests.oracle_mocto import MuscleOctopusOracleEnv
+
+    e = MuscleOctopusOracleEnv(_capi.muscle_octopus_config(_capi.ENV_CRAWL, 1))
+    e.reset()
+    a = np.tile(np.array([0.0, 0.5, 0.0], np.float32), 8)
+    for _ in range(3):
+        e.step(a)
+    h = e.head()
+    assert np.abs(h["x"][:2]).max() < 1e-9 and np.abs(h["v"][:2]).max() < 1e-7
+    reach = np.array([np.linalg.norm(e.arm(k).get("x")[:, 20] - e.arm(k).get("x")[:, 0]) for k in range(8)])
+    assert reach.min() > 0.2505 and reach.max() - reach.min() < 1e-9
