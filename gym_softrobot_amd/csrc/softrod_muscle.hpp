@@ -89,8 +89,17 @@ __device__ __forceinline__ void muscle_loads_n(const RodParams& P, const ConstN<
             else { nrm = sqrt(ss); rn = 1.0 / nrm; }
             double len = nrm;
             if (radial) len = FASTM ? fast_rsqrt(nrm) : 1.0 / sqrt(nrm);
-            double w = P.fl_coef[P.fl_degree];
-            for (int p = P.fl_degree - 1; p >= 0; --p) w = fma(w, len, P.fl_coef[p]);      // wave-uniform trip count
+            // fl(l) by Horner with COMPILE-TIME indices only: a run-time index into fl_coef[] forces the kernels that step on
+            // a local, edited copy of RodParams (the rigid-body ones: `Pk`) to keep the WHOLE struct in scratch — 1592 B per
+            // lane and a scratch load for every parameter the loop reads.  The cubic of the paper is the common case.
+            double w;
+            if (P.fl_degree == 3) {
+                w = fma(fma(fma(P.fl_coef[3], len, P.fl_coef[2]), len, P.fl_coef[1]), len, P.fl_coef[0]);
+            } else {
+                w = 0.0;
+#pragma unroll
+                for (int p = SOFTROD_MAX_FL_COEF - 1; p >= 0; --p) w = (p <= P.fl_degree) ? fma(w, len, P.fl_coef[p]) : w;
+            }
             w = (w < 0.0) ? 0.0 : w;
             const double Fm = amp[s] * w * rn;
             const double g0 = Fm * n0, g1 = Fm * n1, g2 = Fm * n2;       // F_m t_m

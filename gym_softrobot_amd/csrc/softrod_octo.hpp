@@ -199,8 +199,11 @@ __device__ __forceinline__ int octo_obs_dim(const RodParams& P) {
 // env.step of 4096 OctoArmPullWeight envs, VALU busy 0.37.  ONE wave per SIMD (512 registers, no spills in the loop) is
 // faster in spite of half the occupancy: OctoArmPullWeight 13.7 -> 10.6 ms, OctoCrawl 12.6 -> 9.9, OctoArmTwo 5.18 -> 2.96,
 // OctoReach 21.4 -> 12.3 (profiles/README.md "Round 6").  OctoFlat's own instantiations are indifferent (8.94 / 8.97 ms) and stay.
+#ifndef SOFTROD_MUSCLE_OCTO_WAVES
+#define SOFTROD_MUSCLE_OCTO_WAVES 1
+#endif
 template <unsigned F>
-constexpr int octo_kernel_waves() { return kMusclesCompiled<F> ? 1 : SOFTROD_OCTO_WAVES; }
+constexpr int octo_kernel_waves() { return kMusclesCompiled<F> ? SOFTROD_MUSCLE_OCTO_WAVES : SOFTROD_OCTO_WAVES; }
 
 template <unsigned F, int MAXW, int EPB = 1>
 __global__ void __launch_bounds__(kLanes * MAXW * EPB, (octo_kernel_waves<F>()))
