@@ -187,3 +187,36 @@ def test_config5_share_every_one_of_1024_octoflat_envs(torch_gpu, hip_lib, oracl
 
     assert _explained_by_conditioning(ro, ro["abs_dev_of_over_band_envs"], rerun, n) == [], ro
     assert ro["worst_over_band"] <= 100.0, ro          # still the same trajectory: 1e-3 of the entry at worst
+
+
+def test_muscle_arm_every_env_of_a_thousand(torch_gpu, hip_lib, oracle_built):
+    """N3 at batch scale: 1024 OctoArmPush-v1 envs (the `secondary` bench entry's workload, a quarter of its batch), one
+    env.step each under the bench's own actions, every env against the oracle's ArmPush env.  PARITY UNPINNED underneath
+    (the restated muscle law); what is held is HIP == oracle at rtol 1e-5 for every env, with the worst env's position."""
+    import gym_softrobot_amd as gsa
+
+    n = 1024
+    env = gsa.make_vec("OctoArmPush-v1", n)
+    env.reset(seed=0)
+    cfg1 = gsa._capi.arm_push_config(1, mode="continuous")
+    radii = gsa._capi.arm_push_radii(40)
+    layers = gsa._capi.es_muscle_layers(radii, 0.012)
+    rods = []
+    for _ in range(n):
+        r = oracle_built.OracleRod(cfg1)
+        r.set_radius_profile(radii)
+        r.set_muscle_layers(*layers)
+        r.reset_push()
+        rods.append(r)
+    acts = np.random.default_rng(1).uniform(0.0, 1.0, (n, 2)).astype(np.float32)
+    o, r_, te, tr, _ = env.step(acts)
+    ref = [q.env_step_push(acts[i]) for i, q in enumerate(rods)]
+    torch_gpu.cuda.synchronize()
+    o2 = np.stack([x[0] for x in ref])
+    r2 = np.array([x[1] for x in ref])
+    ro = _report("N3 OctoArmPush-v1 1024x40 step 1 obs", o.cpu().numpy(), o2, 2e-7)
+    rr = _report("N3 OctoArmPush-v1 1024x40 step 1 reward", r_.cpu().numpy(), r2, 1e-9)
+    assert ro["worst_over_band"] <= 1.0 and rr["worst_over_band"] <= 1.0, (ro, rr)
+    np.testing.assert_array_equal(te.cpu().numpy(), np.array([x[2] for x in ref]))
+    np.testing.assert_array_equal(tr.cpu().numpy(), np.array([x[3] for x in ref]))
+    env.close()
