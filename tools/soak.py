@@ -22,6 +22,7 @@ import bench  # noqa: E402
 import gym_softrobot_amd as gsa  # noqa: E402
 
 AMAX = {"SoftPendulum-v0": 22.0, "SoftPendulum3D-v0": 1.0, "OctoArmSingle-v0": 6.0, "OctoFlat-v0": 22.0}
+UNIT_BOX = ("OctoArmPush-v1", "OctoArmPullWeight-v0", "OctoCrawl-v0", "OctoArmTwo-v0", "OctoReach-v0")     # Box(0, 1) actions
 
 
 def main():
@@ -33,7 +34,13 @@ def main():
     a = ap.parse_args()
     env = gsa.make_vec(a.env, a.envs, device=0, autoreset="device")
     obs, _ = env.reset(seed=0)
-    policy = bench.make_policy(torch, env.backend.device, env.obs_dim, env.action_dim, AMAX[a.env])
+    if a.env in UNIT_BOX:          # the muscle envs: the MLP's tanh output mapped onto [0, 1]
+        raw = bench.make_policy(torch, env.backend.device, env.obs_dim, env.action_dim, 1.0)
+
+        def policy(o):
+            return 0.5 + 0.5 * raw(o)
+    else:
+        policy = bench.make_policy(torch, env.backend.device, env.obs_dim, env.action_dim, AMAX[a.env])
     dev = env.backend.device
     ended = torch.zeros(a.envs, dtype=torch.int64, device=dev)       # episodes ended per env (device-side count)
     bad_after_reset = torch.zeros((), dtype=torch.int64, device=dev)
