@@ -33,13 +33,16 @@ def function_body(asm: str, name: str):
 
 def hot_path(ins, labels):
     # the substep loop: the first of the innermost backward branches whose span holds the substep's
-    # v_rsq_f64 (the kernel has other loops: the clock fallback, epilogue reductions)
+    # v_rsq_f64 AND its DPP wave shifts (the kernel has other loops: the clock fallback, epilogue reductions, the
+    # OctoFlat epilogue's crossing count — which holds a square root of its own since round 6's builds)
     head, best = None, None
     for i, t in enumerate(ins):
         m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", t)
         if m and labels.get(m.group(1), i) < i - 60:
             lo = labels[m.group(1)]
-            if any(x.startswith("v_rsq_f64") for x in ins[lo:i]) and (best is None or i - lo < best):
+            span = ins[lo:i]
+            if (any(x.startswith("v_rsq_f64") for x in span) and any("_dpp" in x for x in span)
+                    and (best is None or i - lo < best)):
                 head, best = lo, i - lo
     if head is None:
         raise SystemExit("no loop found")
