@@ -3,6 +3,8 @@
     configs[1]        SoftPendulum-v0, 4096 envs x 50 elements, 3 env.steps            (soft_pendulum.py:176-251)
     configs[2]        OctoArmSingle-style reach, 4096 envs x 100 elements, 1 env.step  (octopus/arm_single_env.py:237-316)
     configs[4] share  OctoFlat-v0, 1024 envs x 8 arms x 10 elements, 1 env.step        (octopus/flat_env.py:315-408)
+    N3 (no config)    OctoArmPush-v1, 1024 envs x 40 elements tapered + muscles, 1 step (octopus/arm_push_env.py:276-347; parity
+                      unpinned underneath: the restated COOMM law)
 
 The reference's own shape for this is tests/envs/test_determinism.py:46-54 (reset(seed), sampled actions, three
 steps, arrays compared) — here on a population, HIP against the C oracle stepping the SAME envs with OpenMP over
