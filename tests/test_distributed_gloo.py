@@ -434,3 +434,61 @@ def test_p2p_without_overlap_warns_and_uses_the_collective(oracle_built):
     assert env.transport == "rccl" and "overlap=True" in env._p2p_error
     with pytest.raises(ValueError):
         ShardedVecEnv(local, 2, transport="carrier pigeon")
+
+
+def _muscle_worker(rank, world, port, total, q):
+    """OctoReach-v0 through the sharded env: per-env random targets (env i seeded seed + i across the shard boundary),
+    even obs_dim 1512, 480 actions per env."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from gym_softrobot_amd.distributed import ShardedVecEnv, shard_bounds
+    from tests.oracle_backend import OracleBackend
+
+    lo, hi = shard_bounds(total, world, rank)
+    cfg = _capi.muscle_octopus_config(_capi.ENV_REACH, hi - lo)
+    cfg.n_substeps = 10
+    local = gsa.VecReachEnv(hi - lo, backend=OracleBackend(cfg))
+    local.cfg.n_substeps = 10
+    env = ShardedVecEnv(local, total)
+    obs0, _ = env.reset(seed=3)
+    obs0 = obs0.clone().numpy()
+    acts = np.random.default_rng(8).uniform(0, 0.6, (total, 480)).astype(np.float32)
+    o, r, te, tr, _ = env.step(acts)
+    if rank == 0:
+        q.put((obs0, o.clone().numpy(), r.clone().numpy(), te.clone().numpy(), tr.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_muscle_octopus_matches_single_process(oracle_built):
+    """The N > 1 path for the round-6 envs: two gloo ranks, OctoReach-v0 sharded 2 + 2, against one process stepping all 4."""
+    import gym_softrobot_amd as gsa
+    from gym_softrobot_amd import _capi
+    from tests.oracle_backend import OracleBackend
+
+    total, world = 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_muscle_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = _capi.muscle_octopus_config(_capi.ENV_REACH, total)
+    cfg.n_substeps = 10
+    env = gsa.VecReachEnv(total, backend=OracleBackend(cfg), numpy_output=True)
+    env.cfg.n_substeps = 10
+    obs0, _ = env.reset(seed=3)
+    acts = np.random.default_rng(8).uniform(0, 0.6, (total, 480)).astype(np.float32)
+    ref = (obs0.copy(),) + tuple(np.asarray(x).copy() for x in env.step(acts)[:4])
+    assert got[0].shape == (total, 1512)
+    assert len({tuple(np.round(row[-18:-15], 6)) for row in got[0]}) == total      # four different targets
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
