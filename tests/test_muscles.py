@@ -296,10 +296,10 @@ def test_arm_push_env_host_logic_on_the_oracle_backend(oracle_built):
 
 # ---- the one-command pin, extended to the muscle arm ----------------------------------------------------------------
 def test_pin_tooling_covers_the_muscle_envs(tmp_path, oracle_built):
-    """tools/make_pyelastica_golden.py --muscle-envs records OctoArmPush-v0 / -v1 where pyelastica AND coomm import;
-    here the same record / replay code runs on oracle-made fixtures: exact self-replay, and a flipped recalled detail
-    is not matched — for the three switches this env can decide (it never activates a longitudinal layer, so the two
-    longitudinal-geometry details are invisible to it: OctoArmTwo / OctoReach fixtures decide those)."""
+    """tools/make_pyelastica_golden.py --muscle-envs records all six muscle envs where pyelastica AND coomm import; here
+    the same record / replay code runs on oracle-made fixtures: exact self-replay, and a flipped recalled detail is not
+    matched — three of the five switches by the envs that only ever drive the transverse layer (the push arm, the arm
+    with a weight, CrawlEnv), ALL FIVE by OctoArmTwo and OctoReach, which drive the longitudinal layers too."""
     import sys
 
     sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
@@ -310,11 +310,13 @@ def test_pin_tooling_covers_the_muscle_envs(tmp_path, oracle_built):
         gen.main(["--muscle-envs", "--out", str(tmp_path / "never")])
     assert gen.main(["--source", "oracle", "--out", str(tmp_path), "--envs", "--muscle-envs", "--seeds", "42", "--steps", "3"]) == 0
     files = pin.fixture_files(tmp_path, "oracle")
-    assert [f.name for f in files] == ["oracle_OctoArmPush-v0_seed42.npz", "oracle_OctoArmPush-v1_seed42.npz"]
+    assert [f.name for f in files] == [f"oracle_{e}_seed42.npz" for e in ("OctoArmPullWeight-v0", "OctoArmPush-v0", "OctoArmPush-v1",
+                                                                          "OctoArmTwo-v0", "OctoCrawl-v0", "OctoReach-v0")]
     for f in files:
         fx = dict(np.load(f, allow_pickle=False))
         env_id = str(fx["env_id"])
         assert "sub1_x" not in fx and "step3_x" in fx            # no raw-substep records for the unactuated arm
+        assert ("step3_head_x" in fx) == (env_id not in ("OctoArmPush-v0", "OctoArmPush-v1"))     # the rigid body's state too
         drv = pin.OracleDriver(env_id, None)
         assert pin.worst(pin.compare_case(drv, fx)) == 0.0
         drv.close()
@@ -323,8 +325,9 @@ def test_pin_tooling_covers_the_muscle_envs(tmp_path, oracle_built):
             drv = pin.OracleDriver(env_id, {k: cands[1]})
             decided[k] = pin.worst(pin.compare_case(drv, fx)) > 1e-3
             drv.close()
-        assert decided == {"muscle_equiv_load_form": True, "muscle_position_current_radius": False,
-                           "muscle_tm_length_law": True, "muscle_init_angle_rotates": False, "muscle_tm_sign": True}
+        longitudinal = env_id in ("OctoArmTwo-v0", "OctoReach-v0")          # they drive the longitudinal layers
+        assert decided == {"muscle_equiv_load_form": True, "muscle_position_current_radius": longitudinal,
+                           "muscle_tm_length_law": True, "muscle_init_angle_rotates": longitudinal, "muscle_tm_sign": True}, env_id
 
 
 def test_pull_weight_build_matches_the_executed_reference(oracle_built):

@@ -67,7 +67,7 @@ def main(argv=None) -> int:
     ap.add_argument("--prefix", default=None, help="file prefix (default: pyelastica for the reference, oracle otherwise)")
     ap.add_argument("--envs", nargs="*", default=list(pin.ENVS))
     ap.add_argument("--muscle-envs", action="store_true",
-                    help="also the COOMM muscle arm, OctoArmPush-v0 / -v1 (SURVEY 8(f) N3; needs `import coomm` as well: "
+                    help="also the six COOMM muscle envs, OctoArmPush-v0 / -v1, OctoArmPullWeight-v0, OctoCrawl-v0, OctoArmTwo-v0, OctoReach-v0 (SURVEY 8(f) N3; needs `import coomm` as well: "
                          "uv.lock:173-175).  Their fixtures are what decides pyelastica_pin.MUSCLE_SWITCHES")
     ap.add_argument("--seeds", nargs="*", type=int, default=list(pin.SEEDS))
     ap.add_argument("--steps", type=int, default=None, help="env.steps per case (default: the schedule's)")

@@ -65,7 +65,14 @@ MUSCLE_ENVS = {
                            mode="discrete"),
     "OctoArmPush-v1": dict(amax=1.0, state_steps=(1, 3, 10, 101), n_steps=102, strict_steps=3, raw=False, script="unit",
                            mode="continuous"),
+    # the arm with a rigid weight, and the muscle octopus (build_muscle_octopus.py): ArmTwo / Reach drive the
+    # longitudinal layers, so their fixtures decide the two longitudinal-geometry details the push arm cannot see
+    "OctoArmPullWeight-v0": dict(amax=1.0, state_steps=(1, 3, 10), n_steps=10, strict_steps=3, raw=False, script="unit"),
+    "OctoCrawl-v0": dict(amax=1.0, state_steps=(1, 3, 10), n_steps=10, strict_steps=3, raw=False, script="unit06"),
+    "OctoArmTwo-v0": dict(amax=1.0, state_steps=(1, 3, 10), n_steps=10, strict_steps=3, raw=False, script="unit06"),
+    "OctoReach-v0": dict(amax=1.0, state_steps=(1, 3, 10), n_steps=10, strict_steps=3, raw=False, script="unit06"),
 }
+MUSCLE_OCTOPUS_IDS = {"OctoCrawl-v0": "ENV_CRAWL", "OctoArmTwo-v0": "ENV_ARM_TWO", "OctoReach-v0": "ENV_REACH"}
 ENVS_ALL = dict(ENVS, **MUSCLE_ENVS)
 
 # The recalled COOMM details a muscle-env fixture can decide (fields of softrod_config honoured by the oracle, the
@@ -112,6 +119,8 @@ def action_script(env_id: str, seed: int, adim: int) -> np.ndarray:
         return ((np.arange(spec["n_steps"]) + int(rng.integers(0, 2))) % 2).astype(np.float32).reshape(-1, 1)
     if spec.get("script") == "unit":
         return rng.uniform(0.0, 1.0, (spec["n_steps"], adim)).astype(np.float32)
+    if spec.get("script") == "unit06":      # Box(0, 1) actions kept inside the restated force-length law's range
+        return rng.uniform(0.0, 0.6, (spec["n_steps"], adim)).astype(np.float32)
     return rng.uniform(-spec["amax"], spec["amax"], (spec["n_steps"], adim)).astype(np.float32)
 
 
@@ -160,7 +169,9 @@ class _RepoDriver:
         maker = {"SoftPendulum-v0": _capi.softpendulum_config, "SoftPendulum3D-v0": _capi.softpendulum3d_config,
                  "OctoArmSingle-v0": _capi.arm_single_config, "OctoFlat-v0": _capi.octo_flat_config,
                  "OctoArmPush-v0": lambda n: _capi.arm_push_config(n, mode="discrete"),
-                 "OctoArmPush-v1": lambda n: _capi.arm_push_config(n, mode="continuous")}[env_id]
+                 "OctoArmPush-v1": lambda n: _capi.arm_push_config(n, mode="continuous"),
+                 "OctoArmPullWeight-v0": _capi.arm_pull_weight_config,
+                 **{k: (lambda n, kind=getattr(_capi, v): _capi.muscle_octopus_config(kind, n)) for k, v in MUSCLE_OCTOPUS_IDS.items()}}[env_id]
         cfg = maker(1)
         self._apply(cfg)
         extra = {}
@@ -170,7 +181,8 @@ class _RepoDriver:
         self.env = gsa.make_vec(env_id, 1, backend=self._backend(cfg), numpy_output=True, **extra)
         self._apply(self.env.cfg)                      # the env's own copy: the host clock table reads it
         self.env._time_tab = time_table(self.env.cfg, 128)
-        self.octo = env_id == "OctoFlat-v0"
+        self.octo = env_id == "OctoFlat-v0" or env_id in MUSCLE_OCTOPUS_IDS      # several arms + a rigid head
+        self.pull = env_id == "OctoArmPullWeight-v0"                               # one arm + a rigid weight
         self.adim = self.env.action_dim
 
     def _apply(self, cfg) -> None:
@@ -222,6 +234,10 @@ class OracleDriver(_RepoDriver):
 
     def state(self) -> Dict[str, np.ndarray]:
         r = self.env.backend.rods[0]
+        if self.pull:
+            a, h = r.arm(0), r.head()
+            return {"x": a.get("x"), "v": a.get("v"), "Q": a.get("Q"), "w": a.get("w"), "head_x": h["x"].copy(),
+                    "head_v": h["v"].copy(), "head_Q": h["Q"].copy(), "head_w": h["w"].copy(), "time": np.float64(r.time)}
         if self.octo:
             arms = [r.arm(a) for a in range(r.n_arm)]
             h = r.head()
@@ -257,7 +273,11 @@ class HipDriver(_RepoDriver):
                     "head_v": s["head_v"][0], "head_Q": s["head_Q"][0], "head_w": s["head_w"][0],
                     "time": np.float64(s["time"][0])}
         s = be.state_numpy()
-        return {"x": s["x"][0], "v": s["v"][0], "Q": s["Q"][0], "w": s["w"][0], "time": np.float64(s["time"][0])}
+        out = {"x": s["x"][0], "v": s["v"][0], "Q": s["Q"][0], "w": s["w"][0], "time": np.float64(s["time"][0])}
+        if self.pull:
+            hd = be.state()["head"].cpu().numpy()[:, 0]
+            out.update(head_x=hd[0:3].copy(), head_v=hd[3:6].copy(), head_Q=hd[6:15].reshape(3, 3).copy(), head_w=hd[15:18].copy())
+        return out
 
 
 class PyElasticaDriver:
@@ -276,8 +296,13 @@ class PyElasticaDriver:
              "OctoFlat-v0": ("gym_softrobot.envs.octopus.flat_env", "FlatEnv"),
              # gym_softrobot/__init__.py:37-46
              "OctoArmPush-v0": ("gym_softrobot.envs.octopus.arm_push_env", "ArmPushEnv"),
-             "OctoArmPush-v1": ("gym_softrobot.envs.octopus.arm_push_env", "ArmPushEnv")}
-    KWARGS = {"OctoArmPush-v1": dict(mode="continuous")}
+             "OctoArmPush-v1": ("gym_softrobot.envs.octopus.arm_push_env", "ArmPushEnv"),
+             # gym_softrobot/__init__.py:17-25,32-35,48-52
+             "OctoArmPullWeight-v0": ("gym_softrobot.envs.octopus.arm_push_env", "ArmPullWeightEnv"),
+             "OctoCrawl-v0": ("gym_softrobot.envs.octopus.crawl_env", "CrawlEnv"),
+             "OctoArmTwo-v0": ("gym_softrobot.envs.octopus.arm_two_env", "ArmTwoEnv"),
+             "OctoReach-v0": ("gym_softrobot.envs.octopus.reach_env", "ReachEnv")}
+    KWARGS = {"OctoArmPush-v1": dict(mode="continuous"), "OctoArmPullWeight-v0": dict(mode="continuous")}
 
     def __init__(self, env_id: str, reference: str = "/root/reference"):
         if reference not in sys.path:
@@ -286,7 +311,8 @@ class PyElasticaDriver:
 
         self.env_id = env_id
         self.env = self._make(env_id)
-        self.octo = env_id == "OctoFlat-v0"
+        self.octo = env_id == "OctoFlat-v0" or env_id in MUSCLE_OCTOPUS_IDS
+        self.pull = env_id == "OctoArmPullWeight-v0"
         self.adim = max(1, int(np.prod(self.env.action_space.shape)))      # Discrete(2): shape () -> one number
         self.discrete = type(self.env.action_space).__name__ == "Discrete"
 
@@ -346,7 +372,11 @@ class PyElasticaDriver:
                     "head_x": hx[:, 0], "head_v": hv[:, 0], "head_Q": hq[:, :, 0], "head_w": hw[:, 0],
                     "time": np.float64(e.time)}
         x, v, q, w = rod(e.shearable_rod)
-        return {"x": x, "v": v, "Q": q, "w": w, "time": np.float64(e.time)}
+        out = {"x": x, "v": v, "Q": q, "w": w, "time": np.float64(e.time)}
+        if self.pull:
+            hx, hv, hq, hw = rod(e.rigid_rod)
+            out.update(head_x=hx[:, 0], head_v=hv[:, 0], head_Q=hq[:, :, 0], head_w=hw[:, 0])
+        return out
 
     def close(self) -> None:
         self.env.close()
